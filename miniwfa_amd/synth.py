@@ -1,0 +1,151 @@
+"""Deterministic synthetic sequence pairs.
+
+The reference ships no generator (its evaluation data lives on Zenodo, README.md:146), so the
+benchmark configs are defined on synthetic pairs: a uniform random ACGT target and a query that is
+the target mutated per base with probability P — 60 % substitutions (always to a different
+base), 20 % insertions, 20 % deletions, indel lengths geometric with continue-probability 0.3.
+
+Everything is driven by a counter-based splitmix64 hash evaluated with numpy uint64 arithmetic,
+so the sequences depend only on (seed, tl, P, ...) and not on the numpy version; the golden
+fixtures under tests/golden/ store seeds, not sequences.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+_GOLD = np.uint64(0x9E3779B97F4A7C15)
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def _mix(z: np.ndarray) -> np.ndarray:
+    """splitmix64 finaliser on a uint64 array."""
+    with np.errstate(over="ignore"):
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def _stream(seed: int, stream: int, n: int, start: int = 0) -> np.ndarray:
+    """n 64-bit words of stream `stream` for `seed`, counter = start..start+n-1."""
+    with np.errstate(over="ignore"):
+        key = _mix(np.array([(seed * 0x632BE59BD9B4E019 + stream * 0xD1B54A32D192ED03 + 0x2545F4914F6CDD1D) & 0xFFFFFFFFFFFFFFFF], dtype=np.uint64))[0]
+        ctr = np.arange(start, start + n, dtype=np.uint64)
+        return _mix(key + (ctr + np.uint64(1)) * _GOLD)
+
+
+def _unit(x: np.ndarray) -> np.ndarray:
+    """uint64 -> float64 in [0,1) using the top 53 bits."""
+    return (x >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def _geom_len(x: np.ndarray, cont: float, cap: int) -> np.ndarray:
+    """1 + Geometric(continue-prob cont), capped."""
+    u = 1.0 - _unit(x)  # (0,1]
+    n = 1 + np.floor(np.log(u) / np.log(cont)).astype(np.int64)
+    return np.clip(n, 1, cap)
+
+
+def random_seq(seed: int, n: int) -> bytes:
+    """Uniform random ACGT of length n."""
+    return _ACGT[(_stream(seed, 0, n) >> np.uint64(60)).astype(np.int64) & 3].tobytes()
+
+
+def mutate(target: bytes, seed: int, p: float, cont: float = 0.3, cap: int = 255,
+           frac_sub: float = 0.6, frac_ins: float = 0.2) -> bytes:
+    """Query = target mutated per base with probability p (see module docstring)."""
+    t = np.frombuffer(target, dtype=np.uint8)
+    n = t.size
+    if n == 0:
+        return b""
+    code = np.zeros(256, dtype=np.int64)
+    for i, c in enumerate(b"ACGT"):
+        code[c] = i
+    tc = code[t]
+    ev = _unit(_stream(seed, 1, n)) < p
+    kind = _unit(_stream(seed, 2, n))
+    is_sub = ev & (kind < frac_sub)
+    is_ins = ev & (kind >= frac_sub) & (kind < frac_sub + frac_ins)
+    is_del = ev & (kind >= frac_sub + frac_ins)
+    glen = _geom_len(_stream(seed, 3, n), cont, cap)
+    # deletions: position i starts a deletion of glen[i] target bases; anything inside a deleted
+    # run emits nothing and its own event is ignored.  A deletion start that is itself covered by
+    # an earlier deletion still extends the run (union of intervals).
+    diff = np.zeros(n + 1, dtype=np.int64)
+    ds = np.nonzero(is_del)[0]
+    np.add.at(diff, ds, 1)
+    np.add.at(diff, np.minimum(ds + glen[ds], n), -1)
+    deleted = np.cumsum(diff[:n]) > 0
+    subbase = (tc + 1 + ((_stream(seed, 4, n) >> np.uint64(40)) % np.uint64(3)).astype(np.int64)) & 3
+    first = np.where(is_sub, subbase, tc)
+    count = np.where(deleted, 0, 1 + np.where(is_ins, glen, 0))
+    total = int(count.sum())
+    if total == 0:
+        return b""
+    src = np.repeat(np.arange(n, dtype=np.int64), count)
+    begin = np.cumsum(count) - count
+    within = np.arange(total, dtype=np.int64) - begin[src]
+    with np.errstate(over="ignore"):
+        insb = (_mix(_stream(seed, 5, 1)[0] + (src.astype(np.uint64) * np.uint64(256) + within.astype(np.uint64)) * _GOLD) >> np.uint64(61)).astype(np.int64) & 3
+    out = np.where(within == 0, first[src], insb)
+    return _ACGT[out].tobytes()
+
+
+def long_indels(target: bytes, query: bytes, seed: int, n_events: int, max_len: int) -> bytes:
+    """Insert/delete a few long blocks in the query (MHC-like structural differences).
+
+    Applied to the query independently of mutate(): event j picks a query position and a length in
+    [max_len/8, max_len]; even j deletes the block, odd j inserts random sequence."""
+    q = bytearray(query)
+    r = _stream(seed, 6, 3 * max(n_events, 1))
+    for j in range(n_events):
+        if not q:
+            break
+        pos = int(r[3 * j] % np.uint64(len(q)))
+        ln = int(max_len // 8 + int(r[3 * j + 1] % np.uint64(max(1, max_len - max_len // 8))))
+        if j % 2 == 0:
+            del q[pos:pos + ln]
+        else:
+            q[pos:pos] = random_seq(int(r[3 * j + 2] & np.uint64(0x7FFFFFFF)), ln)
+    return bytes(q)
+
+
+def synth_pair(seed: int, tl: int, p: float, n_long: int = 0, long_max: int = 0) -> tuple[bytes, bytes]:
+    """(target, query) for one synthetic pair; seed = base seed + pair index by convention."""
+    t = random_seq(seed, tl)
+    q = mutate(t, seed, p)
+    if n_long > 0:
+        q = long_indels(t, q, seed, n_long, long_max)
+    return t, q
+
+
+def synth_batch(base_seed: int, n: int, tl: int, p: float) -> list[tuple[bytes, bytes]]:
+    return [synth_pair(base_seed + i, tl, p) for i in range(n)]
+
+
+class PackedBatch:
+    """Pairs packed back to back in one byte buffer (+16 bytes of slack so word-sized device
+    reads past the last sequence stay inside the allocation)."""
+
+    def __init__(self, pairs):
+        n = len(pairs)
+        self.n = n
+        self.tl = np.array([len(t) for t, _ in pairs], dtype=np.int32)
+        self.ql = np.array([len(q) for _, q in pairs], dtype=np.int32)
+        lens = np.empty(2 * n, dtype=np.int64)
+        lens[0::2] = self.tl
+        lens[1::2] = self.ql
+        off = np.zeros(2 * n + 1, dtype=np.int64)
+        np.cumsum(lens, out=off[1:])
+        self.t_off = off[0:2 * n:2].copy()
+        self.q_off = off[1:2 * n:2].copy()
+        self.total = int(off[-1])
+        buf = bytearray(self.total + 16)
+        for i, (t, q) in enumerate(pairs):
+            buf[self.t_off[i]:self.t_off[i] + len(t)] = t
+            buf[self.q_off[i]:self.q_off[i] + len(q)] = q
+        self.seqs = np.frombuffer(bytes(buf), dtype=np.uint8)
+
+    @property
+    def bases(self) -> int:
+        return int(self.tl.sum() + self.ql.sum())
