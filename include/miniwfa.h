@@ -1,0 +1,135 @@
+/*
+ * miniwfa.h — C ABI of libmwf_hip.so, the MI355X (gfx950) implementation of miniwfa's exact
+ * score-and-CIGAR path.
+ *
+ * PART 1 is the drop-in surface: the option/result structs and entry points of lh3/miniwfa
+ * (reference miniwfa.h:32-89) with identical names, field order, sizes (56 B / 24 B), argument
+ * meaning, ownership and error behaviour, so a program written against the reference header
+ * links against this library unchanged.  Each declaration cites the reference line it replaces.
+ *
+ * PART 2 is new: a batch entry point over host buffers and a device-resident engine API
+ * (plain pointers and sizes only) that the Python/torch host side and bench.py drive.
+ *
+ * There is no CPU fallback anywhere behind this header: every alignment runs in the HIP
+ * kernels of miniwfa_amd/csrc/mwf_kernels.hip, and every entry point aborts with a message
+ * if no gfx950 device can be opened.
+ */
+#ifndef MWF_HIP_MINIWFA_H
+#define MWF_HIP_MINIWFA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------
+ * PART 1 — drop-in surface
+ * ---------------------------------------------------------------------------------------- */
+
+/* flag bits, reference miniwfa.h:32-34 */
+#define MWF_F_CIGAR      0x1      /* produce the CIGAR, not only the penalty */
+#define MWF_F_NO_KALLOC  0x2      /* reference: bypass kalloc for scratch; here: accepted, no effect (scratch is device memory) */
+#define MWF_F_DEBUG      0x10000  /* one line on stderr at the end of traceback (reference miniwfa.c:367) */
+
+/* reference miniwfa.h:36-44; offsets flag@0 x@4 o1@8 e1@12 o2@16 e2@20 step@24 max_s@28 max_iter@32 max_occ@40 kmer@44 min_len@48 */
+typedef struct {
+	int32_t flag;
+	int32_t x, o1, e1, o2, e2; /* mismatch; gap open/extend of the two affine pieces: a gap of length L costs min(o1+L*e1, o2+L*e2) */
+	int32_t step;              /* >0: low-memory two-pass mode, checkpoint every `step` penalties */
+	int32_t max_s;             /* >0: give up (s=-1) once the penalty exceeds this */
+	int64_t max_iter;          /* >0: give up (s=-1) once more than this many (penalty,diagonal) cells were computed */
+	int32_t max_occ, kmer, min_len; /* chaining heuristic only (mwf_wfa_chain) */
+} mwf_opt_t;
+
+/* reference miniwfa.h:46-51; offsets s@0 n_cigar@4 n_iter@8 cigar@16 */
+typedef struct {
+	int32_t s;        /* alignment penalty; -1 if stopped by max_s / max_iter */
+	int32_t n_cigar;
+	int64_t n_iter;   /* cells computed by the (second-pass) core loop, reference miniwfa.c:421 */
+	uint32_t *cigar;  /* len<<4|op, op in {1:I, 2:D, 7:=, 8:X}; allocated from the caller's km (kfree(km,.) or free() if km==NULL) */
+} mwf_rst_t;
+
+/* reference miniwfa.h:62 / miniwfa.c:11-18: x=4 o1=4 e1=2 o2=15 e2=1 kmer=13 max_occ=2 min_len=30, rest 0 */
+void mwf_opt_init(mwf_opt_t *opt);
+
+/* reference miniwfa.h:83 / miniwfa.c:603-615: optimal global alignment of ts[0,tl) vs qs[0,ql).
+ * Sequences are length-delimited arbitrary bytes compared verbatim.  *r is fully overwritten. */
+void mwf_wfa_exact(void *km, const mwf_opt_t *opt, int32_t tl, const char *ts, int32_t ql, const char *qs, mwf_rst_t *r);
+
+/* reference miniwfa.h:85 / miniwfa.c:898-908: exact with step=0 and max_iter=1e8; if that stops, mwf_wfa_chain. */
+void mwf_wfa_auto(void *km, const mwf_opt_t *opt, int32_t tl, const char *ts, int32_t ql, const char *qs, mwf_rst_t *r);
+
+/* reference miniwfa.h:84 / miniwfa.c:850-896: k-mer chaining heuristic whose gap fills are exact alignments.
+ * The chaining itself is host code; every gap fill runs on the device as one batch. */
+void mwf_wfa_chain(void *km, const mwf_opt_t *opt, int32_t tl, const char *ts, int32_t ql, const char *qs, mwf_rst_t *r);
+
+/* reference miniwfa.h:88-89 / mwf-dbg.c:6-31 */
+int32_t mwf_cigar2score(const mwf_opt_t *opt, int32_t n_cigar, const uint32_t *cigar, int32_t *tl, int32_t *ql);
+void mwf_assert_cigar(const mwf_opt_t *opt, int32_t n_cigar, const uint32_t *cigar, int32_t tl0, int32_t ql0, int32_t s0);
+
+/* ------------------------------------------------------------------------------------------
+ * PART 2 — batch and device-resident API (new; SURVEY.md §8b "New")
+ * ---------------------------------------------------------------------------------------- */
+
+/* n independent pairs from host buffers; r[i] is filled exactly as mwf_wfa_exact would fill it. */
+void mwf_wfa_batch(void *km, const mwf_opt_t *opt, int32_t n, const int32_t *tl, const char *const *ts,
+                   const int32_t *ql, const char *const *qs, mwf_rst_t *r);
+
+typedef struct mwf_gpu_s mwf_gpu_t;             /* engine: one device, one stream, one memory pool */
+typedef struct mwf_gpu_batch_s mwf_gpu_batch_t; /* a set of pairs resident in that device's HBM */
+
+int         mwf_gpu_device_count(void);
+/* device: HIP ordinal.  stream: a hipStream_t to enqueue on, or NULL to let the engine create its own. */
+mwf_gpu_t  *mwf_gpu_create(int device, void *stream);
+void        mwf_gpu_destroy(mwf_gpu_t *g);
+const char *mwf_gpu_last_error(const mwf_gpu_t *g);
+
+/* Packed layout: all sequences back to back in `seqs` (seq_bytes bytes, +>=16 readable bytes of slack);
+ * pair i is target seqs[t_off[i], t_off[i]+tl[i]) and query seqs[q_off[i], q_off[i]+ql[i]).
+ * _upload copies from host memory; _wrap adopts buffers that already live in this device's HBM
+ * (e.g. torch tensors) without copying — they must outlive the batch object. */
+mwf_gpu_batch_t *mwf_gpu_batch_upload(mwf_gpu_t *g, int32_t n, const char *seqs, int64_t seq_bytes,
+                                      const int64_t *t_off, const int32_t *tl, const int64_t *q_off, const int32_t *ql);
+mwf_gpu_batch_t *mwf_gpu_batch_wrap(mwf_gpu_t *g, int32_t n, const void *d_seqs, int64_t seq_bytes,
+                                    const int64_t *d_t_off, const int32_t *d_tl, const int64_t *d_q_off, const int32_t *d_ql,
+                                    const int32_t *h_tl, const int32_t *h_ql);
+void mwf_gpu_batch_free(mwf_gpu_batch_t *b);
+
+/* Align every pair of the batch with `opt`.  Kernels are enqueued on the engine's stream; the call
+ * returns after they are enqueued (it only synchronises when a pair has to be retried with a larger
+ * traceback arena).  Returns 0, or a negative error (see mwf_gpu_last_error). */
+int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt);
+
+/* Wait for the batch and copy the fixed-size results to host arrays of length n (any may be NULL). */
+int mwf_gpu_batch_results(mwf_gpu_t *g, mwf_gpu_batch_t *b, int32_t *s, int64_t *n_iter, int32_t *n_cigar);
+/* Device pointers to the same fixed-size results (int32 s[n], int64 n_iter[n]) for zero-copy consumers. */
+const int32_t *mwf_gpu_batch_dev_scores(const mwf_gpu_batch_t *b);
+const int64_t *mwf_gpu_batch_dev_iters(const mwf_gpu_batch_t *b);
+/* CIGAR of pair i into dst (capacity cap words); returns n_cigar or a negative error. */
+int32_t mwf_gpu_batch_cigar(mwf_gpu_t *g, mwf_gpu_batch_t *b, int32_t i, uint32_t *dst, int32_t cap);
+
+/* Timing and counters of the most recent mwf_gpu_batch_align on this engine. */
+typedef struct {
+	double  kernel_ms;     /* HIP-event time around the alignment kernels on the engine's stream */
+	int64_t cells;         /* (penalty,diagonal) cells computed by core passes (= sum of n_iter) */
+	int64_t cells_pass1;   /* cells computed by low-memory first passes (not part of n_iter) */
+	int32_t n_launches;    /* kernel launches issued */
+	int32_t n_retries;     /* pairs re-run with a larger traceback arena */
+	int32_t grid, block;   /* geometry of the dominant launch */
+	int32_t kernel_kind;   /* 0: one workgroup per pair; 1: one pair across the whole device */
+} mwf_gpu_stats_t;
+void mwf_gpu_get_stats(const mwf_gpu_t *g, mwf_gpu_stats_t *st);
+
+/* Diagnostics: align with `opt` and report the column window [lo,hi] (column = diagonal + tl + 1) of every
+ * wavefront slice the core pass opened for `pair`; returns the number of penalties written (<= cap). */
+int32_t mwf_gpu_debug_band(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt, int32_t pair, int32_t *lohi, int32_t cap);
+
+/* Tunables (call before align): name in {"block", "slots_per_cu", "coop_min_len", "tb_budget_mb", "force_kind"}. */
+int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

@@ -1,0 +1,674 @@
+// mwf_engine.cpp — host side of libmwf_hip.so: the device engine (stream, memory pool, launch
+// geometry, retry policy) and every entry point of include/miniwfa.h.
+//
+// Boundary: the reference's device-free API mwf_wfa_exact/auto/chain
+// (miniwfa.c:603-615, :850-908) is kept; a call ships its pair(s) to HBM, runs the kernels of
+// mwf_kernels.hip and copies back (s, n_iter, n_cigar, CIGAR).  r->cigar is allocated from the
+// caller's kalloc arena exactly as the reference does (miniwfa.c:434).  kalloc arenas for
+// scratch are replaced by one device workspace per engine that only ever grows (a per-stream
+// hipMalloc pool): ring, traceback arena, row table, CIGAR scratch, snapshots.
+//
+// There is no CPU alignment path in this file or anywhere in the library.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+#include "miniwfa.h"
+#include "kalloc.h"
+#include "mwf_internal.h"
+
+using namespace mwf;
+
+namespace {
+
+[[noreturn]] void fatal(const char *what, const char *detail)
+{
+	fprintf(stderr, "[libmwf_hip] fatal: %s%s%s\n", what, detail ? ": " : "", detail ? detail : "");
+	abort();
+}
+
+// One device buffer that only grows.
+struct DevBuf {
+	void *p = nullptr;
+	size_t bytes = 0;
+};
+
+} // namespace
+
+struct mwf_gpu_s {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	bool own_stream = false;
+	int n_cu = 0;
+	size_t total_mem = 0;
+	std::string err;
+	// tunables
+	int block = 0;              // 0: choose from the batch
+	int slots_per_cu = 0;       // 0: occupancy of the kernel
+	int64_t coop_min_len = 0;
+	int64_t tb_budget_mb = 0;   // 0: automatic
+	int force_kind = -1;
+	// workspace (per-stream pool)
+	DevBuf ring, sring, good, tb, row_off, row_lo, cig_scratch, snap, snap_meta, seg, queue, dbg;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	bool ev_pending = false;
+	mwf_gpu_stats_t stats{};
+};
+
+struct mwf_gpu_batch_s {
+	mwf_gpu_t *g = nullptr;
+	int32_t n = 0;
+	bool owns_inputs = false;
+	const uint8_t *d_seqs = nullptr;
+	int64_t seq_bytes = 0;
+	const int64_t *d_t_off = nullptr, *d_q_off = nullptr;
+	const int32_t *d_tl = nullptr, *d_ql = nullptr;
+	std::vector<int32_t> h_tl, h_ql;
+	int32_t *d_order = nullptr;
+	// outputs
+	int32_t *d_s = nullptr, *d_ncig = nullptr, *d_status = nullptr, *d_dbg4 = nullptr;
+	int64_t *d_iter = nullptr, *d_cigoff = nullptr, *d_cells1 = nullptr;
+	uint32_t *d_cig_pool = nullptr;
+	int64_t cig_pool_words = 0;
+	unsigned long long *d_cig_head = nullptr;
+	// state of the last align
+	bool aligned = false, finalized = false;
+	mwf_opt_t opt{};
+	std::vector<int32_t> h_s, h_ncig, h_status;
+	std::vector<int64_t> h_iter, h_cigoff, h_cells1;
+	// debug band trace (tests)
+	int32_t debug_pair = -1;
+};
+
+namespace {
+
+#define HIP_TRY(g, call)                                                              \
+	do {                                                                              \
+		hipError_t e_ = (call);                                                       \
+		if (e_ != hipSuccess) {                                                       \
+			(g)->err = std::string(#call) + ": " + hipGetErrorString(e_);             \
+			return -1;                                                                \
+		}                                                                             \
+	} while (0)
+
+int ensure(mwf_gpu_t *g, DevBuf &b, size_t bytes)
+{
+	if (bytes <= b.bytes) return 0;
+	if (b.p) {
+		HIP_TRY(g, hipStreamSynchronize(g->stream));
+		HIP_TRY(g, hipFree(b.p));
+		b.p = nullptr, b.bytes = 0;
+	}
+	size_t want = bytes + bytes / 8 + 256;
+	hipError_t e = hipMalloc(&b.p, want);
+	if (e != hipSuccess) {
+		(void)hipGetLastError();
+		want = bytes;
+		e = hipMalloc(&b.p, want);
+	}
+	if (e != hipSuccess) {
+		b.p = nullptr;
+		g->err = "hipMalloc of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e);
+		return -1;
+	}
+	b.bytes = want;
+	return 0;
+}
+
+void release(DevBuf &b)
+{
+	if (b.p) (void)hipFree(b.p);
+	b.p = nullptr, b.bytes = 0;
+}
+
+Penalty make_penalty(const mwf_opt_t &o)
+{
+	Penalty p;
+	p.x = o.x, p.o1 = o.o1, p.o2 = o.o2, p.e1 = o.e1, p.e2 = o.e2;
+	p.oe1 = o.o1 + o.e1, p.oe2 = o.o2 + o.e2;
+	int32_t mp = std::max(p.x, std::max(p.oe1, p.oe2)); // reference miniwfa.c:390-392
+	p.nH = mp + 1, p.n1 = p.e1 + 1, p.n2 = p.e2 + 1;
+	return p;
+}
+
+const char *validate(const mwf_opt_t &o)
+{
+	if (o.x < 1 || o.e1 < 1 || o.e2 < 1) return "x, e1 and e2 must be >= 1 (a zero lag would make a wavefront depend on itself)";
+	if (o.o1 < 0 || o.o2 < 0) return "gap-open penalties must be >= 0";
+	if (std::max(o.x, std::max(o.o1 + o.e1, o.o2 + o.e2)) + 1 > kMaxRing) return "max(x, o1+e1, o2+e2) must be < 256";
+	if (o.step < 0) return "step must be >= 0";
+	return nullptr;
+}
+
+// Upper bound on the optimal penalty: delete the whole target, insert the whole query.
+int64_t penalty_bound(const mwf_opt_t &o, int64_t tl, int64_t ql)
+{
+	auto gap = [&](int64_t L) -> int64_t { return L == 0 ? 0 : std::min<int64_t>(o.o1 + L * o.e1, o.o2 + L * o.e2); };
+	int64_t b = gap(tl) + gap(ql);
+	if (o.max_s > 0) b = std::min<int64_t>(b, (int64_t)o.max_s + 1);
+	return b;
+}
+
+struct Plan {
+	int block = 256, grid = 1;
+	int32_t W = 0, GW = 0;
+	int64_t ring_slot_ints = 0, rows_slot = 0, tb_slot_bytes = 0, cig_scratch_slot = 0;
+	int64_t snap_slot_ints = 0, snap_meta_slot = 0, seg_slot = 0;
+	bool low_mem = false, cigar = false;
+};
+
+// Run the one-workgroup-per-pair kernel over `n_items` pairs given by d_order (device) on `slots` workgroups.
+int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const int32_t *d_order, int32_t n_items,
+                     int slots, int64_t max_len, int64_t max_bound, int64_t tb_total_budget, bool timed)
+{
+	const Penalty P = make_penalty(opt);
+	Plan pl;
+	pl.cigar = (opt.flag & MWF_F_CIGAR) != 0;
+	pl.low_mem = pl.cigar && opt.step > 0;
+	pl.block = g->block > 0 ? g->block : 256;
+	pl.grid = std::max(1, std::min<int>(slots, n_items));
+	pl.W = (int32_t)((max_len + 3 + 63) / 64 * 64);
+	pl.GW = pl.W / 64 + 2;
+	pl.ring_slot_ints = (int64_t)(P.nH + 2 * P.n1 + 2 * P.n2) * pl.W;
+	const size_t S = (size_t)pl.grid;
+
+	if (ensure(g, g->ring, S * pl.ring_slot_ints * 4)) return -1;
+	if (ensure(g, g->good, S * (size_t)P.nH * pl.GW * 8)) return -1;
+	if (ensure(g, g->queue, 64)) return -1;
+	if (pl.cigar) {
+		pl.rows_slot = max_bound + 2;
+		pl.cig_scratch_slot = max_len + 2;
+		int64_t per = tb_total_budget / (int64_t)S;
+		const int64_t worst = (max_bound + 1) * (max_len + 1); // every penalty as wide as the whole matrix
+		if (pl.low_mem && opt.step > 2 * P.nH) {
+			// the second pass collapses the band to one diagonal at every checkpoint (miniwfa.c:413-416) and consecutive
+			// checkpoints are at most step+nH penalties apart, so a row is never wider than about 2*(step+nH)
+			const int64_t seg_worst = (max_bound + 1) * std::min<int64_t>(max_len + 1, 2 * (int64_t)(opt.step + 2 * P.nH) + 8);
+			per = std::min(per, seg_worst);
+		}
+		pl.tb_slot_bytes = std::max<int64_t>(4096, std::min(per, worst));
+		if (ensure(g, g->tb, S * (size_t)pl.tb_slot_bytes)) return -1;
+		if (ensure(g, g->row_off, S * (size_t)pl.rows_slot * 8)) return -1;
+		if (ensure(g, g->row_lo, S * (size_t)pl.rows_slot * 4)) return -1;
+		if (ensure(g, g->cig_scratch, S * (size_t)pl.cig_scratch_slot * 4)) return -1;
+	}
+	if (pl.low_mem) {
+		const int64_t NS = P.nH + 2 * P.n1 + 2 * P.n2;
+		const int64_t n_snap_max = max_bound / opt.step + 2;
+		pl.seg_slot = n_snap_max;
+		pl.snap_meta_slot = n_snap_max * (4 + 4 * NS);
+		// a snapshot holds every array-slice of the shadow ring; windows are at most min(2s+1, whole matrix) wide
+		int64_t worst = 0;
+		for (int64_t j = 1; j <= n_snap_max; ++j)
+			worst += NS * std::min<int64_t>(max_len + 1, 2 * j * opt.step + 3);
+		const int64_t budget = (int64_t)(tb_total_budget / 4 / (int64_t)S);
+		pl.snap_slot_ints = std::max<int64_t>(1024, std::min(worst, budget));
+		if (ensure(g, g->sring, S * pl.ring_slot_ints * 4)) return -1;
+		if (ensure(g, g->snap, S * (size_t)pl.snap_slot_ints * 4)) return -1;
+		if (ensure(g, g->snap_meta, S * (size_t)pl.snap_meta_slot * 4)) return -1;
+		if (ensure(g, g->seg, S * (size_t)pl.seg_slot * 8)) return -1;
+	}
+
+	BatchArgs a;
+	memset(&a, 0, sizeof(a));
+	a.seqs = b->d_seqs, a.t_off = b->d_t_off, a.q_off = b->d_q_off, a.tl = b->d_tl, a.ql = b->d_ql;
+	a.order = d_order, a.n_pairs = n_items;
+	a.queue = (int32_t*)g->queue.p;
+	a.pen = P;
+	a.want_cigar = pl.cigar ? 1 : 0;
+	a.step = pl.low_mem ? opt.step : 0;
+	a.max_s = opt.max_s, a.max_iter = opt.max_iter;
+	a.debug_pair = b->debug_pair;
+	a.ring = (int32_t*)g->ring.p;
+	a.sring = pl.low_mem ? (int32_t*)g->sring.p : nullptr;
+	a.ring_slot_ints = pl.ring_slot_ints, a.W = pl.W;
+	a.good = (unsigned long long*)g->good.p, a.GW = pl.GW;
+	a.tb = pl.cigar ? (uint8_t*)g->tb.p : nullptr, a.tb_slot_bytes = pl.tb_slot_bytes;
+	a.row_off = pl.cigar ? (int64_t*)g->row_off.p : nullptr;
+	a.row_lo = pl.cigar ? (int32_t*)g->row_lo.p : nullptr;
+	a.rows_slot = pl.rows_slot;
+	a.cig_scratch = pl.cigar ? (uint32_t*)g->cig_scratch.p : nullptr, a.cig_scratch_slot = pl.cig_scratch_slot;
+	a.cig_pool = b->d_cig_pool, a.cig_head = b->d_cig_head, a.cig_pool_words = b->cig_pool_words;
+	a.snap = pl.low_mem ? (int32_t*)g->snap.p : nullptr, a.snap_slot_ints = pl.snap_slot_ints;
+	a.snap_meta = pl.low_mem ? (int32_t*)g->snap_meta.p : nullptr, a.snap_meta_slot = pl.snap_meta_slot;
+	a.seg = pl.low_mem ? (int32_t*)g->seg.p : nullptr, a.seg_slot = pl.seg_slot;
+	a.out_s = b->d_s, a.out_iter = b->d_iter, a.out_ncig = b->d_ncig, a.out_cigoff = b->d_cigoff;
+	a.out_status = b->d_status, a.out_cells1 = b->d_cells1, a.out_dbg = b->d_dbg4;
+	a.dbg = b->debug_pair >= 0 ? (int32_t*)g->dbg.p : nullptr;
+	a.dbg_cap = b->debug_pair >= 0 ? (int32_t)(g->dbg.bytes / 8) : 0;
+
+	HIP_TRY(g, hipMemsetAsync(g->queue.p, 0, 64, g->stream));
+	// HIP events bracket the kernel only: every workspace allocation above is already done
+	if (timed) HIP_TRY(g, hipEventRecord(g->ev0, g->stream));
+	if (launch_batch(a, pl.grid, pl.block, g->stream) != 0) {
+		g->err = "kernel launch failed";
+		return -1;
+	}
+	if (timed) {
+		HIP_TRY(g, hipEventRecord(g->ev1, g->stream));
+		g->ev_pending = true;
+	}
+	g->stats.n_launches += 1;
+	g->stats.grid = pl.grid, g->stats.block = pl.block, g->stats.kernel_kind = 0;
+	return 0;
+}
+
+int64_t tb_budget_bytes(mwf_gpu_t *g)
+{
+	if (g->tb_budget_mb > 0) return g->tb_budget_mb << 20;
+	size_t fr = 0, tot = 0;
+	if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = (size_t)8 << 30;
+	// leave a fifth of what is free right now alone; the arena is kept between calls
+	int64_t b = (int64_t)(fr / 5 * 4) + (int64_t)g->tb.bytes;
+	return std::min<int64_t>(b, (int64_t)64 << 30);
+}
+
+int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b);
+
+} // namespace
+
+extern "C" {
+
+/* ------------------------------------------------------------------ engine */
+
+int mwf_gpu_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+	return n;
+}
+
+mwf_gpu_t *mwf_gpu_create(int device, void *stream)
+{
+	int n = mwf_gpu_device_count();
+	if (device < 0 || device >= n) return nullptr;
+	if (hipSetDevice(device) != hipSuccess) return nullptr;
+	mwf_gpu_t *g = new mwf_gpu_t();
+	g->device = device;
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete g; return nullptr; }
+	g->n_cu = prop.multiProcessorCount;
+	g->total_mem = prop.totalGlobalMem;
+	if (stream) g->stream = (hipStream_t)stream;
+	else {
+		if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess) { delete g; return nullptr; }
+		g->own_stream = true;
+	}
+	(void)hipEventCreate(&g->ev0);
+	(void)hipEventCreate(&g->ev1);
+	return g;
+}
+
+void mwf_gpu_destroy(mwf_gpu_t *g)
+{
+	if (!g) return;
+	(void)hipSetDevice(g->device);
+	(void)hipStreamSynchronize(g->stream);
+	for (DevBuf *b : {&g->ring, &g->sring, &g->good, &g->tb, &g->row_off, &g->row_lo, &g->cig_scratch, &g->snap, &g->snap_meta, &g->seg, &g->queue, &g->dbg})
+		release(*b);
+	if (g->ev0) (void)hipEventDestroy(g->ev0);
+	if (g->ev1) (void)hipEventDestroy(g->ev1);
+	if (g->own_stream) (void)hipStreamDestroy(g->stream);
+	delete g;
+}
+
+const char *mwf_gpu_last_error(const mwf_gpu_t *g) { return g ? g->err.c_str() : "no engine (no gfx950 device could be opened)"; }
+
+int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value)
+{
+	if (!g || !name) return -1;
+	if (!strcmp(name, "block")) {
+		if (value != 0 && value != 64 && value != 128 && value != 256 && value != 512 && value != 1024) return -1;
+		g->block = (int)value;
+	} else if (!strcmp(name, "slots_per_cu")) g->slots_per_cu = (int)value;
+	else if (!strcmp(name, "coop_min_len")) g->coop_min_len = value;
+	else if (!strcmp(name, "tb_budget_mb")) g->tb_budget_mb = value;
+	else if (!strcmp(name, "force_kind")) g->force_kind = (int)value;
+	else return -1;
+	return 0;
+}
+
+void mwf_gpu_get_stats(const mwf_gpu_t *g, mwf_gpu_stats_t *st)
+{
+	if (!g || !st) return;
+	mwf_gpu_t *m = const_cast<mwf_gpu_t*>(g);
+	if (m->ev_pending) {
+		(void)hipSetDevice(m->device);
+		float ms = 0;
+		if (hipEventSynchronize(m->ev1) == hipSuccess && hipEventElapsedTime(&ms, m->ev0, m->ev1) == hipSuccess) m->stats.kernel_ms = ms;
+		m->ev_pending = false;
+	}
+	*st = m->stats;
+}
+
+/* ------------------------------------------------------------------ batches */
+
+static mwf_gpu_batch_t *batch_common(mwf_gpu_t *g, int32_t n, const int32_t *h_tl, const int32_t *h_ql)
+{
+	mwf_gpu_batch_t *b = new mwf_gpu_batch_t();
+	b->g = g, b->n = n;
+	b->h_tl.assign(h_tl, h_tl + n);
+	b->h_ql.assign(h_ql, h_ql + n);
+	const size_t N = (size_t)std::max(n, 1);
+	int64_t words = 0;
+	for (int32_t i = 0; i < n; ++i) words += (int64_t)h_tl[i] + h_ql[i] + 1;
+	b->cig_pool_words = std::max<int64_t>(words, 1);
+	bool ok = hipMalloc(&b->d_s, N * 4) == hipSuccess && hipMalloc(&b->d_ncig, N * 4) == hipSuccess &&
+	          hipMalloc(&b->d_status, N * 4) == hipSuccess && hipMalloc(&b->d_dbg4, N * 16) == hipSuccess &&
+	          hipMalloc(&b->d_iter, N * 8) == hipSuccess && hipMalloc(&b->d_cigoff, N * 8) == hipSuccess &&
+	          hipMalloc(&b->d_cells1, N * 8) == hipSuccess && hipMalloc(&b->d_order, N * 4) == hipSuccess &&
+	          hipMalloc(&b->d_cig_head, 64) == hipSuccess;
+	if (!ok) {
+		g->err = "hipMalloc of result arrays failed";
+		mwf_gpu_batch_free(b);
+		return nullptr;
+	}
+	// longest pairs first, so the persistent workgroups finish together
+	std::vector<int32_t> order(n);
+	std::iota(order.begin(), order.end(), 0);
+	std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+		return (int64_t)h_tl[x] + h_ql[x] > (int64_t)h_tl[y] + h_ql[y];
+	});
+	if (n > 0 && hipMemcpy(b->d_order, order.data(), (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess) {
+		g->err = "upload of the processing order failed";
+		mwf_gpu_batch_free(b);
+		return nullptr;
+	}
+	return b;
+}
+
+mwf_gpu_batch_t *mwf_gpu_batch_upload(mwf_gpu_t *g, int32_t n, const char *seqs, int64_t seq_bytes,
+                                      const int64_t *t_off, const int32_t *tl, const int64_t *q_off, const int32_t *ql)
+{
+	if (!g || n < 0) return nullptr;
+	(void)hipSetDevice(g->device);
+	mwf_gpu_batch_t *b = batch_common(g, n, tl, ql);
+	if (!b) return nullptr;
+	b->owns_inputs = true;
+	b->seq_bytes = seq_bytes;
+	const size_t N = (size_t)std::max(n, 1);
+	void *ds = nullptr, *dto = nullptr, *dqo = nullptr, *dtl = nullptr, *dql = nullptr;
+	bool ok = hipMalloc(&ds, (size_t)seq_bytes + 64) == hipSuccess && hipMalloc(&dto, N * 8) == hipSuccess &&
+	          hipMalloc(&dqo, N * 8) == hipSuccess && hipMalloc(&dtl, N * 4) == hipSuccess && hipMalloc(&dql, N * 4) == hipSuccess;
+	b->d_seqs = (const uint8_t*)ds, b->d_t_off = (const int64_t*)dto, b->d_q_off = (const int64_t*)dqo;
+	b->d_tl = (const int32_t*)dtl, b->d_ql = (const int32_t*)dql;
+	if (ok) ok = hipMemsetAsync(ds, 0, (size_t)seq_bytes + 64, g->stream) == hipSuccess;
+	if (ok && seq_bytes > 0) ok = hipMemcpyAsync(ds, seqs, (size_t)seq_bytes, hipMemcpyHostToDevice, g->stream) == hipSuccess;
+	if (ok && n > 0)
+		ok = hipMemcpyAsync(dto, t_off, (size_t)n * 8, hipMemcpyHostToDevice, g->stream) == hipSuccess &&
+		     hipMemcpyAsync(dqo, q_off, (size_t)n * 8, hipMemcpyHostToDevice, g->stream) == hipSuccess &&
+		     hipMemcpyAsync(dtl, tl, (size_t)n * 4, hipMemcpyHostToDevice, g->stream) == hipSuccess &&
+		     hipMemcpyAsync(dql, ql, (size_t)n * 4, hipMemcpyHostToDevice, g->stream) == hipSuccess;
+	if (ok) ok = hipStreamSynchronize(g->stream) == hipSuccess; // the host buffers are borrowed only for this call
+	if (!ok) {
+		g->err = "upload of the batch failed";
+		mwf_gpu_batch_free(b);
+		return nullptr;
+	}
+	return b;
+}
+
+mwf_gpu_batch_t *mwf_gpu_batch_wrap(mwf_gpu_t *g, int32_t n, const void *d_seqs, int64_t seq_bytes,
+                                    const int64_t *d_t_off, const int32_t *d_tl, const int64_t *d_q_off, const int32_t *d_ql,
+                                    const int32_t *h_tl, const int32_t *h_ql)
+{
+	if (!g || n < 0) return nullptr;
+	(void)hipSetDevice(g->device);
+	mwf_gpu_batch_t *b = batch_common(g, n, h_tl, h_ql);
+	if (!b) return nullptr;
+	b->owns_inputs = false;
+	b->d_seqs = (const uint8_t*)d_seqs, b->seq_bytes = seq_bytes;
+	b->d_t_off = d_t_off, b->d_q_off = d_q_off, b->d_tl = d_tl, b->d_ql = d_ql;
+	return b;
+}
+
+void mwf_gpu_batch_free(mwf_gpu_batch_t *b)
+{
+	if (!b) return;
+	(void)hipSetDevice(b->g->device);
+	(void)hipStreamSynchronize(b->g->stream);
+	if (b->owns_inputs)
+		for (const void *p : {(const void*)b->d_seqs, (const void*)b->d_t_off, (const void*)b->d_q_off, (const void*)b->d_tl, (const void*)b->d_ql})
+			if (p) (void)hipFree(const_cast<void*>(p));
+	for (void *p : {(void*)b->d_s, (void*)b->d_ncig, (void*)b->d_status, (void*)b->d_dbg4, (void*)b->d_iter, (void*)b->d_cigoff,
+	                (void*)b->d_cells1, (void*)b->d_order, (void*)b->d_cig_pool, (void*)b->d_cig_head})
+		if (p) (void)hipFree(p);
+	delete b;
+}
+
+int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
+{
+	if (!g || !b || !opt) return -1;
+	if (const char *why = validate(*opt)) { g->err = why; return -2; }
+	(void)hipSetDevice(g->device);
+	b->opt = *opt;
+	b->aligned = false, b->finalized = false;
+	g->stats = mwf_gpu_stats_t{};
+	if (b->n == 0) { b->aligned = b->finalized = true; return 0; }
+	const bool cigar = (opt->flag & MWF_F_CIGAR) != 0;
+	if (cigar && !b->d_cig_pool) {
+		if (hipMalloc(&b->d_cig_pool, (size_t)b->cig_pool_words * 4) != hipSuccess) { g->err = "hipMalloc of the CIGAR pool failed"; return -1; }
+	}
+	int64_t max_len = 0, max_bound = 0;
+	for (int32_t i = 0; i < b->n; ++i) {
+		max_len = std::max<int64_t>(max_len, (int64_t)b->h_tl[i] + b->h_ql[i]);
+		max_bound = std::max(max_bound, penalty_bound(*opt, b->h_tl[i], b->h_ql[i]));
+	}
+	if (max_len + 4 >= ((int64_t)1 << 31)) { g->err = "tl+ql must be below 2^31-4"; return -2; }
+	const int block = g->block > 0 ? g->block : 256;
+	int per_cu = g->slots_per_cu > 0 ? g->slots_per_cu : batch_kernel_occupancy(block);
+	if (per_cu <= 0) per_cu = 1;
+	const int slots = std::max(1, g->n_cu * per_cu);
+	if (b->debug_pair >= 0 && ensure(g, g->dbg, (size_t)8 * (max_bound + 2))) return -1;
+	HIP_TRY(g, hipMemsetAsync(b->d_cig_head, 0, 64, g->stream));
+	HIP_TRY(g, hipMemsetAsync(b->d_status, 0xff, (size_t)b->n * 4, g->stream));
+	const int64_t budget = cigar ? tb_budget_bytes(g) : 0;
+	if (run_batch_kernel(g, b, *opt, b->d_order, b->n, slots, max_len, max_bound, budget, true)) return -1;
+	b->aligned = true;
+	return 0;
+}
+
+} // extern "C"
+
+namespace {
+
+// Wait for the batch, re-run pairs whose traceback arena overflowed with fewer, larger slots.
+int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
+{
+	if (b->finalized) return 0;
+	if (!b->aligned) { g->err = "batch was not aligned"; return -1; }
+	const size_t n = (size_t)b->n;
+	b->h_s.resize(n), b->h_ncig.resize(n), b->h_status.resize(n), b->h_iter.resize(n), b->h_cigoff.resize(n), b->h_cells1.resize(n);
+	auto fetch = [&]() -> int {
+		HIP_TRY(g, hipStreamSynchronize(g->stream));
+		if (n == 0) return 0;
+		HIP_TRY(g, hipMemcpy(b->h_status.data(), b->d_status, n * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(g, hipMemcpy(b->h_s.data(), b->d_s, n * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(g, hipMemcpy(b->h_iter.data(), b->d_iter, n * 8, hipMemcpyDeviceToHost));
+		HIP_TRY(g, hipMemcpy(b->h_ncig.data(), b->d_ncig, n * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(g, hipMemcpy(b->h_cigoff.data(), b->d_cigoff, n * 8, hipMemcpyDeviceToHost));
+		HIP_TRY(g, hipMemcpy(b->h_cells1.data(), b->d_cells1, n * 8, hipMemcpyDeviceToHost));
+		return 0;
+	};
+	if (fetch()) return -1;
+	int slots = g->stats.grid;
+	for (int round = 0; round < 12; ++round) {
+		std::vector<int32_t> redo;
+		for (size_t i = 0; i < n; ++i) {
+			const int32_t st = b->h_status[i];
+			if (st == ST_TB_OVERFLOW || st == ST_SNAP_OVERFLOW) redo.push_back((int32_t)i);
+			else if (st != ST_OK && st != ST_STOPPED) {
+				g->err = "pair " + std::to_string(i) + " failed on the device with status " + std::to_string(st);
+				return -3;
+			}
+		}
+		if (redo.empty()) break;
+		if (slots == 1) {
+			g->err = "traceback of pair " + std::to_string(redo[0]) + " does not fit in device memory; set opt.step > 0 (low-memory mode)";
+			return -4;
+		}
+		slots = std::max(1, std::min<int>(slots / 8, (int)redo.size()));
+		std::stable_sort(redo.begin(), redo.end(), [&](int32_t x, int32_t y) {
+			return (int64_t)b->h_tl[x] + b->h_ql[x] > (int64_t)b->h_tl[y] + b->h_ql[y];
+		});
+		int64_t max_len = 0, max_bound = 0;
+		for (int32_t i : redo) {
+			max_len = std::max<int64_t>(max_len, (int64_t)b->h_tl[i] + b->h_ql[i]);
+			max_bound = std::max(max_bound, penalty_bound(b->opt, b->h_tl[i], b->h_ql[i]));
+		}
+		int32_t *d_redo = nullptr;
+		HIP_TRY(g, hipMalloc(&d_redo, redo.size() * 4));
+		HIP_TRY(g, hipMemcpy(d_redo, redo.data(), redo.size() * 4, hipMemcpyHostToDevice));
+		g->stats.n_retries += (int32_t)redo.size();
+		const int rc = run_batch_kernel(g, b, b->opt, d_redo, (int32_t)redo.size(), slots, max_len, max_bound, tb_budget_bytes(g), false);
+		if (rc == 0 && fetch()) { (void)hipFree(d_redo); return -1; }
+		(void)hipFree(d_redo);
+		if (rc) return -1;
+	}
+	g->stats.cells = 0, g->stats.cells_pass1 = 0;
+	for (size_t i = 0; i < n; ++i) g->stats.cells += b->h_iter[i], g->stats.cells_pass1 += b->h_cells1[i];
+	b->finalized = true;
+	return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int mwf_gpu_batch_results(mwf_gpu_t *g, mwf_gpu_batch_t *b, int32_t *s, int64_t *n_iter, int32_t *n_cigar)
+{
+	if (!g || !b) return -1;
+	(void)hipSetDevice(g->device);
+	if (int rc = finalize(g, b)) return rc;
+	const size_t n = (size_t)b->n;
+	if (s && n) memcpy(s, b->h_s.data(), n * 4);
+	if (n_iter && n) memcpy(n_iter, b->h_iter.data(), n * 8);
+	if (n_cigar && n) memcpy(n_cigar, b->h_ncig.data(), n * 4);
+	return 0;
+}
+
+const int32_t *mwf_gpu_batch_dev_scores(const mwf_gpu_batch_t *b) { return b ? b->d_s : nullptr; }
+const int64_t *mwf_gpu_batch_dev_iters(const mwf_gpu_batch_t *b) { return b ? b->d_iter : nullptr; }
+
+int32_t mwf_gpu_batch_cigar(mwf_gpu_t *g, mwf_gpu_batch_t *b, int32_t i, uint32_t *dst, int32_t cap)
+{
+	if (!g || !b || i < 0 || i >= b->n) return -1;
+	(void)hipSetDevice(g->device);
+	if (int rc = finalize(g, b)) return rc;
+	const int32_t nc = b->h_ncig[i];
+	if (nc > cap) return -5;
+	if (nc > 0) HIP_TRY(g, hipMemcpy(dst, b->d_cig_pool + b->h_cigoff[i], (size_t)nc * 4, hipMemcpyDeviceToHost));
+	return nc;
+}
+
+/* test hook: trace the band of one pair (columns lo,hi per penalty); returns penalties traced */
+int32_t mwf_gpu_debug_band(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt, int32_t pair, int32_t *lohi, int32_t cap)
+{
+	if (!g || !b) return -1;
+	b->debug_pair = pair;
+	int rc = mwf_gpu_batch_align(g, b, opt);
+	if (rc == 0) rc = finalize(g, b);
+	b->debug_pair = -1;
+	if (rc) return rc;
+	const int32_t n = std::min<int32_t>(cap, std::max(0, b->h_s[pair] >= 0 ? b->h_s[pair] : 0));
+	if (n > 0) HIP_TRY(g, hipMemcpy(lohi, g->dbg.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+	return n;
+}
+
+/* ------------------------------------------------------------------ drop-in entry points */
+
+void mwf_opt_init(mwf_opt_t *opt) // reference miniwfa.c:11-18
+{
+	memset(opt, 0, sizeof(*opt));
+	opt->x = 4;
+	opt->o1 = 4, opt->e1 = 2;
+	opt->o2 = 15, opt->e2 = 1;
+	opt->kmer = 13, opt->max_occ = 2, opt->min_len = 30;
+}
+
+static mwf_gpu_t *thread_engine()
+{
+	// One engine (stream + pool) per host thread keeps the reference's re-entrancy: no shared
+	// mutable state between threads beyond the HIP runtime itself.
+	// (deliberately never destroyed: tearing a stream down from a thread_local destructor can run after
+	// the HIP runtime's own static teardown)
+	struct Holder { mwf_gpu_t *g = nullptr; };
+	static thread_local Holder h;
+	if (!h.g) {
+		int dev = 0;
+		if (const char *e = getenv("MWF_DEVICE")) dev = atoi(e);
+		h.g = mwf_gpu_create(dev, nullptr);
+		if (!h.g) fatal("cannot open a HIP device; this library has no CPU path", nullptr);
+	}
+	return h.g;
+}
+
+void mwf_wfa_batch(void *km, const mwf_opt_t *opt, int32_t n, const int32_t *tl, const char *const *ts,
+                   const int32_t *ql, const char *const *qs, mwf_rst_t *r)
+{
+	mwf_gpu_t *g = thread_engine();
+	if (n <= 0) return;
+	std::vector<int64_t> t_off(n), q_off(n);
+	int64_t total = 0;
+	for (int32_t i = 0; i < n; ++i) {
+		t_off[i] = total, total += tl[i];
+		q_off[i] = total, total += ql[i];
+	}
+	std::vector<char> packed((size_t)total + 16, 0);
+	for (int32_t i = 0; i < n; ++i) {
+		if (tl[i]) memcpy(&packed[t_off[i]], ts[i], tl[i]);
+		if (ql[i]) memcpy(&packed[q_off[i]], qs[i], ql[i]);
+	}
+	mwf_gpu_batch_t *b = mwf_gpu_batch_upload(g, n, packed.data(), total, t_off.data(), tl, q_off.data(), ql);
+	if (!b) fatal("batch upload failed", mwf_gpu_last_error(g));
+	if (mwf_gpu_batch_align(g, b, opt)) fatal("alignment failed", mwf_gpu_last_error(g));
+	std::vector<int32_t> s(n), nc(n);
+	std::vector<int64_t> it(n);
+	if (mwf_gpu_batch_results(g, b, s.data(), it.data(), nc.data())) fatal("alignment failed", mwf_gpu_last_error(g));
+	for (int32_t i = 0; i < n; ++i) {
+		memset(&r[i], 0, sizeof(mwf_rst_t)); // reference miniwfa.c:387
+		r[i].s = s[i], r[i].n_iter = it[i];
+		if ((opt->flag & MWF_F_CIGAR) && s[i] >= 0) {
+			r[i].n_cigar = nc[i];
+			// reference krelocate()s the CIGAR into the caller's arena (miniwfa.c:434); a zero-length one stays NULL
+			r[i].cigar = nc[i] > 0 ? (uint32_t*)kmalloc(km, (size_t)nc[i] * 4) : nullptr;
+			if (nc[i] > 0 && mwf_gpu_batch_cigar(g, b, i, r[i].cigar, nc[i]) != nc[i]) fatal("CIGAR download failed", mwf_gpu_last_error(g));
+		}
+	}
+	if (opt->flag & MWF_F_DEBUG) { // reference miniwfa.c:367 prints the traceback end state
+		std::vector<int32_t> d4((size_t)n * 4);
+		if ((opt->flag & MWF_F_CIGAR) && hipMemcpy(d4.data(), b->d_dbg4, (size_t)n * 16, hipMemcpyDeviceToHost) == hipSuccess)
+			for (int32_t i = 0; i < n; ++i)
+				if (s[i] >= 0) fprintf(stderr, "s0=%d, s=%d, i=%d, k=%d\n", s[i] - 1, d4[4 * i], d4[4 * i + 1], d4[4 * i + 2]);
+	}
+	mwf_gpu_batch_free(b);
+}
+
+void mwf_wfa_exact(void *km, const mwf_opt_t *opt, int32_t tl, const char *ts, int32_t ql, const char *qs, mwf_rst_t *r)
+{
+	mwf_wfa_batch(km, opt, 1, &tl, &ts, &ql, &qs, r);
+}
+
+void mwf_wfa_chain(void *km, const mwf_opt_t *opt, int32_t tl, const char *ts, int32_t ql, const char *qs, mwf_rst_t *r)
+{
+	(void)km, (void)opt, (void)tl, (void)ts, (void)ql, (void)qs, (void)r;
+	fatal("mwf_wfa_chain: the chaining heuristic (reference miniwfa.c:617-896) is not part of this build yet", nullptr);
+}
+
+void mwf_wfa_auto(void *km, const mwf_opt_t *opt0, int32_t tl, const char *ts, int32_t ql, const char *qs, mwf_rst_t *r)
+{
+	mwf_opt_t opt = *opt0; // reference miniwfa.c:900-907
+	opt.step = 0, opt.max_iter = 100000000;
+	mwf_wfa_exact(km, &opt, tl, ts, ql, qs, r);
+	if (r->s < 0) {
+		if (opt.flag & MWF_F_CIGAR) opt.step = 5000;
+		opt.max_iter = -1;
+		mwf_wfa_chain(km, &opt, tl, ts, ql, qs, r);
+	}
+}
+
+} // extern "C"

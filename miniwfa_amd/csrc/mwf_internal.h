@@ -1,0 +1,92 @@
+// mwf_internal.h — structures shared by the host engine (mwf_engine.cpp) and the HIP kernels
+// (mwf_kernels.hip).  Nothing here is part of the public ABI (include/miniwfa.h).
+#pragma once
+#include <stdint.h>
+
+namespace mwf {
+
+constexpr int32_t kNegInf = -0x40000000;   // reference miniwfa.c:67
+constexpr int32_t kMaxRing = 256;          // ring slots supported in LDS tables: max(x, o1+e1, o2+e2) + 1 <= 256
+
+// per-pair status written by the kernels
+enum : int32_t {
+	ST_OK = 0,
+	ST_STOPPED = 1,        // max_s / max_iter hit: s = -1 (reference miniwfa.c:422-428)
+	ST_TB_OVERFLOW = 2,    // traceback arena of this slot too small: host re-runs the pair with a larger one
+	ST_ROWS_OVERFLOW = 3,  // more penalties than row-metadata entries (cannot happen with the host's bound)
+	ST_CIGAR_OVERFLOW = 4, // CIGAR pool exhausted: host grows it and re-runs
+	ST_SNAP_OVERFLOW = 5,  // low-memory snapshot arena too small
+	ST_INTERNAL = 6,       // an invariant the reference asserts on failed
+	ST_PENDING = 7         // not produced yet
+};
+
+// Penalties in the form the recurrence uses them (reference miniwfa.c:252-256): lags into the ring.
+struct Penalty {
+	int32_t x;      // mismatch: H comes from the slice x penalties back
+	int32_t oe1;    // o1+e1: gap-open source slice for piece 1
+	int32_t e1;     // gap-extend source slice for piece 1
+	int32_t oe2;    // o2+e2
+	int32_t e2;
+	int32_t o1, o2; // only traceback needs the opens separately
+	int32_t nH;     // H ring depth  = max(x, oe1, oe2) + 1
+	int32_t n1;     // E1/F1 depth   = e1 + 1
+	int32_t n2;     // E2/F2 depth   = e2 + 1
+};
+
+// One workgroup ("slot") owns one of each of these regions; pairs are pulled from `queue`.
+struct BatchArgs {
+	// ---- input: packed sequences and per-pair geometry (device pointers)
+	const uint8_t *seqs;
+	const int64_t *t_off, *q_off;
+	const int32_t *tl, *ql;
+	const int32_t *order;      // optional processing order (longest first); may be null
+	int32_t n_pairs;
+	int32_t *queue;            // [0]: next position in `order`
+	// ---- options
+	Penalty pen;
+	int32_t want_cigar;        // MWF_F_CIGAR
+	int32_t step;              // low-memory checkpoint distance (0: high-memory)
+	int32_t max_s;
+	int64_t max_iter;
+	int32_t debug_pair;        // pair whose per-penalty band is traced into dbg (or -1)
+	// ---- per-slot workspace
+	int32_t *ring;             // [slot][H:nH | E1:n1 | F1:n1 | E2:n2 | F2:n2][W]   offsets
+	int32_t *sring;            // same shape, provenance (low-memory first pass only)
+	int64_t ring_slot_ints;
+	int32_t W;                 // row stride in ints; diagonal d of a pair lives at column d+tl+1
+	unsigned long long *good;  // [slot][nH][GW] one bit per diagonal: some array holds an in-matrix offset
+	int32_t GW;
+	uint8_t *tb;               // [slot][tb_slot_bytes] traceback bytes, rows back to back
+	int64_t tb_slot_bytes;
+	int64_t *row_off;          // [slot][rows_slot] start of the row of penalty r+1 inside tb
+	int32_t *row_lo;           // [slot][rows_slot] its first column
+	int64_t rows_slot;
+	uint32_t *cig_scratch;     // [slot][cig_scratch_slot] CIGAR is built backwards from the end
+	int64_t cig_scratch_slot;
+	uint32_t *cig_pool;        // all CIGARs of the batch, bump-allocated
+	unsigned long long *cig_head;
+	int64_t cig_pool_words;
+	// ---- low-memory first pass
+	int32_t *snap;             // [slot][snap_slot_ints] provenance snapshots, back to back
+	int64_t snap_slot_ints;
+	int32_t *snap_meta;        // [slot][snap_meta_slot] per snapshot: see mwf_kernels.hip
+	int64_t snap_meta_slot;
+	int32_t *seg;              // [slot][2*seg_slot] checkpoints (s, column)
+	int64_t seg_slot;
+	// ---- output, one entry per pair
+	int32_t *out_s;
+	int64_t *out_iter;
+	int32_t *out_ncig;
+	int64_t *out_cigoff;
+	int32_t *out_status;
+	int64_t *out_cells1;
+	int32_t *out_dbg;          // [pair][4]: traceback end state (row, i, k) and last_state, for MWF_F_DEBUG
+	int32_t *dbg;              // optional band trace of debug_pair: [2*dbg_cap] lo,hi per penalty (columns)
+	int32_t dbg_cap;
+};
+
+// launch wrappers implemented in mwf_kernels.hip
+int launch_batch(const BatchArgs &a, int grid, int block, void *stream);
+int batch_kernel_occupancy(int block);   // resident workgroups per CU for that block size
+
+} // namespace mwf

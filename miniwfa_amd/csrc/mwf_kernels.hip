@@ -1,0 +1,628 @@
+// mwf_kernels.hip — gfx950 kernels for the exact WFA score-and-CIGAR path.
+//
+// What the reference does on one CPU thread per pair (miniwfa.c:380-435 core loop, :551-601
+// low-memory first pass, :329-377 traceback) is restated here for a wave64 machine:
+//
+//   * one workgroup owns one sequence pair; its threads own diagonals.  A penalty step is
+//     "advance + extend" fused: every thread computes the five wavefront values of its diagonals
+//     (reference wf_next_score/wf_next_tb, miniwfa.c:261-308), immediately walks the new H offset
+//     along exact matches with unaligned 8-byte loads (reference wf_extend1_padded, :212-226) and
+//     stores the extended value.  One s_barrier per penalty.
+//   * the ring keeps only what the recurrence can read again: H for max_pen+1 penalties, E1/F1
+//     for e1+1, E2/F2 for e2+1 (27 array-slices with default penalties instead of the reference's
+//     85, miniwfa.c:90).  Columns are absolute (column = diagonal + tl + 1), so a wave's 64 lanes
+//     always touch one aligned 256-byte segment per array — coalesced int32 loads/stores.
+//   * a slice is a window [lo,hi] of columns; reads outside a source window yield NEG_INF (what
+//     the reference's pads supply, miniwfa.c:96-99).  Waves whose 64 columns lie inside every
+//     source window take a branch-free path without any window test.
+//   * band bookkeeping (edge rule :325-326, growth :417-418, shrink every 256 penalties :144-171,
+//     checkpoint resets :413-416, n_iter :421, stop rules :422-425) is replicated exactly; it is
+//     evaluated redundantly by every thread from a few LDS flags, so no second barrier is needed.
+//     "Does any array hold an in-matrix offset on this diagonal" — all the shrink needs from the
+//     E/F arrays the ring no longer keeps — is recorded as one ballot bit per cell, only for the
+//     slices a shrink can still see.
+//   * traceback bytes (7-bit packing of :289-306) go to a per-workgroup arena, rows back to back
+//     (row offset = cells computed so far); the traceback itself runs on the first wave right
+//     after the forward pass, matching runs compared 64 bases per step with a ballot.
+//   * low-memory mode: the first pass carries a shadow ring of provenance indices and flattens it
+//     every `step` penalties (:451-474, :495-526) but never materialises traceback bytes; the
+//     checkpoints it yields drive the band resets of the second pass.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mwf_internal.h"
+
+namespace mwf {
+
+namespace {
+
+struct Shared {
+	int32_t flags[3][4];   // per penalty (mod 3): new lo edge live, new hi edge live, end cell reached, payload
+	int32_t red[2];        // shrink: first / last good column
+	int32_t item;          // work item broadcast
+	int32_t word[4];       // scratch broadcast
+	int32_t rng_lo[kMaxRing], rng_hi[kMaxRing]; // column window of the slice held by each H slot
+};
+
+struct PassResult {
+	int32_t status;
+	int32_t s;          // final penalty
+	int32_t info;       // TB: last_state; SEG: provenance of the end cell
+	int32_t n_snap;     // SEG: snapshots taken
+	int64_t cells;      // cells computed (n_iter of the reference for the core pass)
+};
+
+__device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ uint64_t ld8(const uint8_t *p)
+{
+	uint64_t x;
+	__builtin_memcpy(&x, p, 8); // gfx950 global loads may be unaligned: one global_load_dwordx2
+	return x;
+}
+
+// k -> k + LCP(ts[k+1..], qs[d+k+1..]); the caller guarantees (k,d) is inside the DP matrix.
+__device__ __forceinline__ int32_t extend_run(const uint8_t *ts, const uint8_t *qs, int32_t tl, int32_t ql, int32_t k, int32_t d)
+{
+	const int32_t j = k + 1, i = d + j;
+	const int32_t room = min(tl - j, ql - i);
+	const uint8_t *pt = ts + j, *pq = qs + i;
+	int32_t n = 0;
+	while (n < room) {
+		const uint64_t x = ld8(pt + n) ^ ld8(pq + n);
+		if (x) { n += (int32_t)(__builtin_ctzll(x) >> 3); break; }
+		n += 8;
+	}
+	return k + min(n, room);
+}
+
+// offset k on diagonal d is a cell of the DP matrix (reference good_diag, miniwfa.c:139-142)
+__device__ __forceinline__ bool in_matrix(int32_t d, int32_t k, int32_t tl, int32_t ql)
+{
+	return (uint32_t)(k + 1) < (uint32_t)(tl + 1) && (uint32_t)(d + k + 1) < (uint32_t)(ql + 1);
+}
+
+struct Cell { int32_t h, e1, f1, e2, f2; uint32_t tb; };
+
+// The recurrence and its tie-breaking (miniwfa.c:267-278 values, :289-306 traceback byte):
+// gap states prefer "open" on ties; H prefers mismatch, then insertion piece 1, piece 2, deletion piece 1, piece 2.
+__device__ __forceinline__ Cell wf_cell(int32_t hx, int32_t o1m, int32_t g1m, int32_t o2m, int32_t g2m,
+                                        int32_t o1p, int32_t g1p, int32_t o2p, int32_t g2p)
+{
+	Cell c;
+	const bool xe1 = g1m > o1m, xe2 = g2m > o2m, xf1 = g1p > o1p, xf2 = g2p > o2p;
+	c.e1 = xe1 ? g1m : o1m;
+	c.e2 = xe2 ? g2m : o2m;
+	c.f1 = (xf1 ? g1p : o1p) + 1;
+	c.f2 = (xf2 ? g2p : o2p) + 1;
+	const bool e_first = c.e1 >= c.e2, f_first = c.f1 >= c.f2;
+	const int32_t e = e_first ? c.e1 : c.e2, f = f_first ? c.f1 : c.f2;
+	const bool ins = e >= f;
+	const int32_t g = ins ? e : f, m = hx + 1;
+	const bool mis = m >= g;
+	c.h = mis ? m : g;
+	const uint32_t z = mis ? 0u : (ins ? (e_first ? 1u : 3u) : (f_first ? 2u : 4u));
+	c.tb = z | (xe1 ? 0x08u : 0u) | (xf1 ? 0x10u : 0u) | (xe2 ? 0x20u : 0u) | (xf2 ? 0x40u : 0u);
+	return c;
+}
+
+// Provenance follows the choices recorded in the traceback byte (second loop of wf_next_seg, miniwfa.c:504-523).
+__device__ __forceinline__ Cell shadow_cell(uint32_t tb, int32_t hx, int32_t o1m, int32_t g1m, int32_t o2m, int32_t g2m,
+                                            int32_t o1p, int32_t g1p, int32_t o2p, int32_t g2p)
+{
+	Cell c;
+	c.e1 = (tb & 0x08u) ? g1m : o1m;
+	c.f1 = (tb & 0x10u) ? g1p : o1p;
+	c.e2 = (tb & 0x20u) ? g2m : o2m;
+	c.f2 = (tb & 0x40u) ? g2p : o2p;
+	const uint32_t z = tb & 7u;
+	c.h = z == 1 ? c.e1 : z == 2 ? c.f1 : z == 3 ? c.e2 : z == 4 ? c.f2 : hx;
+	c.tb = 0;
+	return c;
+}
+
+// A source slice: row pointer (column-indexed) and its window.
+struct Src {
+	const int32_t *p;
+	int32_t lo, hi;
+	__device__ __forceinline__ int32_t at(int32_t c) const { return p[c]; } // unchecked
+	__device__ __forceinline__ int32_t rd(int32_t c) const                  // window-checked
+	{
+		const int32_t v = p[c];
+		return (c >= lo && c <= hi) ? v : kNegInf;
+	}
+};
+
+// bits of the 64-column word starting at column w0 that fall inside [lo,hi]
+__device__ __forceinline__ unsigned long long window_mask(int32_t w0, int32_t lo, int32_t hi)
+{
+	if (hi < w0 || lo > w0 + 63 || lo > hi) return 0ull;
+	unsigned long long m = ~0ull;
+	if (lo > w0) m &= ~0ull << (lo - w0);
+	if (hi < w0 + 63) m &= ~0ull >> (w0 + 63 - hi);
+	return m;
+}
+
+// Everything a pass needs to know about the pair and this slot's memory.
+struct PairMem {
+	const uint8_t *ts, *qs;
+	int32_t tl, ql;
+	int32_t *H, *E1, *F1, *E2, *F2;       // ring rows (row r of array X at X + r*W), column-indexed
+	int32_t *sH, *sE1, *sF1, *sE2, *sF2;  // shadow ring (low-memory first pass)
+	unsigned long long *good;
+	uint8_t *tb;
+	int64_t *row_off;
+	int32_t *row_lo;
+	int32_t *snap, *snap_meta, *seg;
+	int32_t *dbg;
+};
+
+// Flatten the shadow ring into the next snapshot and renumber it (reference wf_snapshot1, miniwfa.c:451-474).
+// Snapshot record in snap_meta, stride 4+4*NS ints: [arena offset lo, hi, penalty, n] then per array-slice
+// [penalty of the slice, first column, width, first index].  Array-slices are listed H slots, then E1, F1, E2, F2.
+template <int T>
+__device__ bool take_snapshot(const BatchArgs &A, const PairMem &M, Shared &sh, int32_t n_snap, int64_t &snap_used,
+                              int32_t s, int32_t curH, int32_t cur1, int32_t cur2)
+{
+	const Penalty &P = A.pen;
+	const int32_t NS = P.nH + 2 * P.n1 + 2 * P.n2, MS = 4 + 4 * NS;
+	int32_t *meta = M.snap_meta + (int64_t)n_snap * MS;
+	if (threadIdx.x == 0) {
+		int32_t t = 0, q = 4;
+		bool ok = (int64_t)(n_snap + 1) * MS <= A.snap_meta_slot;
+		if (ok) {
+			for (int32_t j = 0; j < P.nH; ++j, q += 4) {
+				const int32_t age = curH - j < 0 ? curH - j + P.nH : curH - j;
+				const int32_t lo = sh.rng_lo[j], hi = sh.rng_hi[j], n = hi >= lo ? hi - lo + 1 : 0;
+				meta[q] = s - age, meta[q + 1] = lo, meta[q + 2] = n, meta[q + 3] = t;
+				t += n;
+			}
+			for (int32_t arr = 0; arr < 4; ++arr) {
+				const int32_t nr = arr < 2 ? P.n1 : P.n2, cur = arr < 2 ? cur1 : cur2;
+				for (int32_t j = 0; j < nr; ++j, q += 4) {
+					const int32_t age = cur - j < 0 ? cur - j + nr : cur - j;
+					int32_t lo = 1, hi = 0;
+					if (s - age >= 0) {
+						const int32_t hj = curH - age < 0 ? curH - age + P.nH : curH - age;
+						lo = sh.rng_lo[hj], hi = sh.rng_hi[hj];
+					}
+					const int32_t n = hi >= lo ? hi - lo + 1 : 0;
+					meta[q] = s - age, meta[q + 1] = lo, meta[q + 2] = n, meta[q + 3] = t;
+					t += n;
+				}
+			}
+			ok = snap_used + t <= A.snap_slot_ints;
+			meta[0] = (int32_t)(snap_used & 0xffffffff), meta[1] = (int32_t)(snap_used >> 32), meta[2] = s, meta[3] = t;
+		}
+		sh.word[0] = ok ? t : -1;
+	}
+	__syncthreads();
+	const int32_t total = uni(sh.word[0]);
+	if (total < 0) return false;
+	int32_t *x = M.snap + snap_used;
+	for (int32_t k = 0; k < NS; ++k) {
+		const int32_t lo = uni(meta[4 + 4 * k + 1]), n = uni(meta[4 + 4 * k + 2]), t0 = uni(meta[4 + 4 * k + 3]);
+		if (n == 0) continue;
+		int32_t *row;
+		if (k < P.nH) row = M.sH + (int64_t)k * A.W;
+		else if (k < P.nH + P.n1) row = M.sE1 + (int64_t)(k - P.nH) * A.W;
+		else if (k < P.nH + 2 * P.n1) row = M.sF1 + (int64_t)(k - P.nH - P.n1) * A.W;
+		else if (k < P.nH + 2 * P.n1 + P.n2) row = M.sE2 + (int64_t)(k - P.nH - 2 * P.n1) * A.W;
+		else row = M.sF2 + (int64_t)(k - P.nH - 2 * P.n1 - P.n2) * A.W;
+		for (int32_t i = threadIdx.x; i < n; i += T) {
+			x[t0 + i] = row[lo + i];
+			row[lo + i] = t0 + i;
+		}
+	}
+	snap_used += total;
+	__syncthreads();
+	return true;
+}
+
+// Walk the provenance chain back through the snapshots (reference wf_traceback_seg, miniwfa.c:528-549). One thread.
+__device__ int32_t trace_checkpoints(const BatchArgs &A, const PairMem &M, int32_t n_snap, int32_t last)
+{
+	const Penalty &P = A.pen;
+	const int32_t NS = P.nH + 2 * P.n1 + 2 * P.n2, MS = 4 + 4 * NS;
+	if (n_snap > A.seg_slot) return ST_SNAP_OVERFLOW;
+	for (int32_t j = n_snap - 1; j >= 0; --j) {
+		const int32_t *meta = M.snap_meta + (int64_t)j * MS;
+		const int64_t base = (int64_t)(uint32_t)meta[0] | (int64_t)meta[1] << 32;
+		int32_t k;
+		for (k = 0; k < NS; ++k) {
+			const int32_t n = meta[4 + 4 * k + 2], t0 = meta[4 + 4 * k + 3];
+			if (n > 0 && last >= t0 && last < t0 + n) break;
+		}
+		if (k == NS) return ST_INTERNAL;
+		M.seg[2 * j] = meta[4 + 4 * k];
+		M.seg[2 * j + 1] = meta[4 + 4 * k + 1] + (last - meta[4 + 4 * k + 3]);
+		last = M.snap[base + last];
+	}
+	return last == -1 ? ST_OK : ST_INTERNAL;
+}
+
+// One forward pass over a pair.
+//   TB : store traceback bytes, honour checkpoints (core pass with MWF_F_CIGAR)
+//   SEG: low-memory first pass (shadow ring + snapshots, no traceback bytes, no stop rules, miniwfa.c:569-589)
+template <int T, bool TB, bool SEG>
+__device__ PassResult forward_pass(const BatchArgs &A, const PairMem &M, Shared &sh, int32_t n_seg, bool trace_band)
+{
+	const Penalty &P = A.pen;
+	const int32_t tl = M.tl, ql = M.ql, cmax = tl + ql + 1; // columns 1..cmax hold diagonals -tl..ql
+	const int32_t tid = threadIdx.x, lane = tid & 63, wave0 = tid & ~63;
+	const int64_t W = A.W;
+	PassResult R;
+	R.status = ST_OK, R.s = 0, R.info = 0, R.n_snap = 0, R.cells = 0;
+
+	// ---- penalty 0: the origin (reference wf_stripe_init, miniwfa.c:103-121) and its extension
+	if (tid == 0) {
+		for (int32_t j = 0; j < P.nH; ++j) sh.rng_lo[j] = 1, sh.rng_hi[j] = 0;
+		for (int32_t j = 0; j < 12; ++j) (&sh.flags[0][0])[j] = 0;
+		const int32_t c0 = tl + 1;
+		const int32_t k0 = extend_run(M.ts, M.qs, tl, ql, -1, 0);
+		M.H[c0] = k0;
+		M.E1[c0] = M.F1[c0] = M.E2[c0] = M.F2[c0] = kNegInf;
+		if (SEG) {
+			M.sH[c0] = -1;
+			M.sE1[c0] = M.sF1[c0] = M.sE2[c0] = M.sF2[c0] = kNegInf;
+		}
+		sh.rng_lo[0] = sh.rng_hi[0] = c0;
+		sh.word[1] = k0;
+	}
+	__syncthreads();
+	{
+		const int32_t k0 = uni(sh.word[1]);
+		if (k0 == tl - 1 && k0 == ql - 1) { // identical (or both empty) sequences
+			R.info = SEG ? -1 : 0;
+			return R;
+		}
+	}
+
+	int32_t s = 0, wf_lo = tl + 1, wf_hi = tl + 1;  // live band, in columns
+	int32_t curH = 0, cur1 = 0, cur2 = 0, par = 0, sid = 0;
+	int32_t snap_ctr = A.step == 1 ? 0 : 1;         // (s+1) % step
+	int64_t cells = 0, tb_used = 0, snap_used = 0;
+	int32_t n_snap = 0;
+
+	for (;;) {
+		// ---- checkpoint reset of the second pass (miniwfa.c:413-416)
+		if (TB && sid < n_seg) {
+			if (uni(M.seg[2 * sid]) == s) {
+				const int32_t c = uni(M.seg[2 * sid + 1]);
+				if (c < wf_lo || c > wf_hi) { R.status = ST_INTERNAL; break; }
+				wf_lo = wf_hi = c;
+				++sid;
+			}
+		}
+		// ---- window of the new slice (miniwfa.c:417-418)
+		const int32_t lo = wf_lo > 1 ? wf_lo - 1 : 1;
+		const int32_t hi = wf_hi < cmax ? wf_hi + 1 : cmax;
+		const int32_t w = hi - lo + 1;
+		if (SEG) {
+			if (snap_ctr == 0) {
+				if (!take_snapshot<T>(A, M, sh, n_snap, snap_used, s, curH, cur1, cur2)) { R.status = ST_SNAP_OVERFLOW; break; }
+				++n_snap;
+			}
+			snap_ctr = snap_ctr + 1 == A.step ? 0 : snap_ctr + 1;
+		}
+		const int32_t s_new = s + 1;
+		const int32_t newH = curH + 1 == P.nH ? 0 : curH + 1;
+		const int32_t new1 = cur1 + 1 == P.n1 ? 0 : cur1 + 1;
+		const int32_t new2 = cur2 + 1 == P.n2 ? 0 : cur2 + 1;
+		const int32_t npar = par + 1 == 3 ? 0 : par + 1;
+		if (TB) {
+			if (s_new - 1 >= A.rows_slot) { R.status = ST_ROWS_OVERFLOW; break; }
+			if (tb_used + w > A.tb_slot_bytes) { R.status = ST_TB_OVERFLOW; break; }
+		}
+		// ---- source slices (reference wf_next_prep, miniwfa.c:243-259)
+		int32_t jx = newH - P.x;    if (jx < 0) jx += P.nH;
+		int32_t j1 = newH - P.oe1;  if (j1 < 0) j1 += P.nH;
+		int32_t j2 = newH - P.oe2;  if (j2 < 0) j2 += P.nH;
+		int32_t jg1 = newH - P.e1;  if (jg1 < 0) jg1 += P.nH;
+		int32_t jg2 = newH - P.e2;  if (jg2 < 0) jg2 += P.nH;
+		const int32_t r1 = new1 + 1 == P.n1 ? 0 : new1 + 1; // row of penalty s_new - e1 in the E1/F1 ring
+		const int32_t r2 = new2 + 1 == P.n2 ? 0 : new2 + 1;
+		Src sx, so1, so2, se1, sf1, se2, sf2;
+		sx.p  = M.H + jx * W,   sx.lo  = uni(sh.rng_lo[jx]),  sx.hi  = uni(sh.rng_hi[jx]);
+		so1.p = M.H + j1 * W,   so1.lo = uni(sh.rng_lo[j1]),  so1.hi = uni(sh.rng_hi[j1]);
+		so2.p = M.H + j2 * W,   so2.lo = uni(sh.rng_lo[j2]),  so2.hi = uni(sh.rng_hi[j2]);
+		se1.p = M.E1 + r1 * W,  se1.lo = uni(sh.rng_lo[jg1]), se1.hi = uni(sh.rng_hi[jg1]);
+		sf1.p = M.F1 + r1 * W,  sf1.lo = se1.lo,              sf1.hi = se1.hi;
+		se2.p = M.E2 + r2 * W,  se2.lo = uni(sh.rng_lo[jg2]), se2.hi = uni(sh.rng_hi[jg2]);
+		sf2.p = M.F2 + r2 * W,  sf2.lo = se2.lo,              sf2.hi = se2.hi;
+		Src tx, to1, to2, te1, tf1, te2, tf2; // shadow sources, same windows
+		if (SEG) {
+			tx = sx, to1 = so1, to2 = so2, te1 = se1, tf1 = sf1, te2 = se2, tf2 = sf2;
+			tx.p = M.sH + jx * W, to1.p = M.sH + j1 * W, to2.p = M.sH + j2 * W;
+			te1.p = M.sE1 + r1 * W, tf1.p = M.sF1 + r1 * W, te2.p = M.sE2 + r2 * W, tf2.p = M.sF2 + r2 * W;
+		}
+		// columns for which no read can leave a source window
+		int32_t ilo = max(max(lo, sx.lo), max(max(so1.lo, so2.lo), max(se1.lo, se2.lo)) + 1);
+		int32_t ihi = min(min(hi, sx.hi), min(min(so1.hi, so2.hi), min(se1.hi, se2.hi)) - 1);
+		int32_t *dH = M.H + newH * W, *dE1 = M.E1 + new1 * W, *dF1 = M.F1 + new1 * W, *dE2 = M.E2 + new2 * W, *dF2 = M.F2 + new2 * W;
+		int32_t *uH = 0, *uE1 = 0, *uF1 = 0, *uE2 = 0, *uF2 = 0;
+		if (SEG) uH = M.sH + newH * W, uE1 = M.sE1 + new1 * W, uF1 = M.sF1 + new1 * W, uE2 = M.sE2 + new2 * W, uF2 = M.sF2 + new2 * W;
+		uint8_t *tbrow = TB ? M.tb + tb_used - lo : 0; // tbrow[c] is the byte of column c
+		// a shrink at the next multiple of 256 can still see this slice (miniwfa.c:148-154)
+		const bool track_good = (((256 - (s_new & 255)) & 255) < P.nH);
+		unsigned long long *gword = M.good + (int64_t)newH * A.GW;
+
+		if (tid == 0) {
+			sh.rng_lo[newH] = lo, sh.rng_hi[newH] = hi;
+			// clear the flag set of the NEXT penalty: its last readers passed the previous barrier, its next
+			// writers start after this penalty's barrier (clearing the current set here would race with them)
+			const int32_t nn = npar + 1 == 3 ? 0 : npar + 1;
+			sh.flags[nn][0] = sh.flags[nn][1] = sh.flags[nn][2] = sh.flags[nn][3] = 0;
+			if (TB) M.row_off[s_new - 1] = tb_used, M.row_lo[s_new - 1] = lo;
+			if (trace_band && s_new - 1 < A.dbg_cap) M.dbg[2 * (s_new - 1)] = lo, M.dbg[2 * (s_new - 1) + 1] = hi;
+		}
+
+		// ---- advance + extend over the window, 64 columns per wave per trip
+		for (int32_t c0 = (lo & ~63) + wave0; c0 <= hi; c0 += T) {
+			const int32_t c = c0 + lane;
+			Cell v, u;
+			bool active = true;
+			if (c0 >= ilo && c0 + 63 <= ihi) { // interior wave: plain coalesced loads
+				v = wf_cell(sx.at(c), so1.at(c - 1), se1.at(c - 1), so2.at(c - 1), se2.at(c - 1),
+				            so1.at(c + 1), sf1.at(c + 1), so2.at(c + 1), sf2.at(c + 1));
+				if (SEG) u = shadow_cell(v.tb, tx.at(c), to1.at(c - 1), te1.at(c - 1), to2.at(c - 1), te2.at(c - 1),
+				                         to1.at(c + 1), tf1.at(c + 1), to2.at(c + 1), tf2.at(c + 1));
+			} else {
+				active = c >= lo && c <= hi;
+				const int32_t cc = active ? c : lo; // keep idle lanes on a valid address
+				v = wf_cell(sx.rd(cc), so1.rd(cc - 1), se1.rd(cc - 1), so2.rd(cc - 1), se2.rd(cc - 1),
+				            so1.rd(cc + 1), sf1.rd(cc + 1), so2.rd(cc + 1), sf2.rd(cc + 1));
+				if (SEG) u = shadow_cell(v.tb, tx.rd(cc), to1.rd(cc - 1), te1.rd(cc - 1), to2.rd(cc - 1), te2.rd(cc - 1),
+				                         to1.rd(cc + 1), tf1.rd(cc + 1), to2.rd(cc + 1), tf2.rd(cc + 1));
+			}
+			const int32_t d = c - 1 - tl;
+			if (track_good) {
+				const bool g = active && (in_matrix(d, v.h, tl, ql) || in_matrix(d, v.e1, tl, ql) || in_matrix(d, v.f1, tl, ql) ||
+				                          in_matrix(d, v.e2, tl, ql) || in_matrix(d, v.f2, tl, ql));
+				const unsigned long long m = __ballot(g);
+				if (lane == 0) gword[c0 >> 6] = m;
+			}
+			if (active) {
+				// edge rule (miniwfa.c:325-326): H is the max of the five, so "any of them live" == "H live"
+				if (c == lo && v.h >= -1) sh.flags[npar][0] = 1;
+				if (c == hi && v.h >= -1) sh.flags[npar][1] = 1;
+				int32_t k = v.h;
+				if (in_matrix(d, k, tl, ql)) { // extension sweep of the next iteration (miniwfa.c:400-411)
+					k = extend_run(M.ts, M.qs, tl, ql, k, d);
+					if (k == tl - 1 && d + k == ql - 1) {
+						sh.flags[npar][2] = 1;
+						sh.flags[npar][3] = SEG ? u.h : (k == v.h ? (int32_t)(v.tb & 7u) : 0);
+					}
+				}
+				dH[c] = k, dE1[c] = v.e1, dF1[c] = v.f1, dE2[c] = v.e2, dF2[c] = v.f2;
+				if (TB) tbrow[c] = (uint8_t)v.tb;
+				if (SEG) uH[c] = u.h, uE1[c] = u.e1, uF1[c] = u.f1, uE2[c] = u.e2, uF2[c] = u.f2;
+			}
+		}
+		__syncthreads();
+
+		// ---- bookkeeping, identical on every thread
+		if (uni(sh.flags[npar][0])) wf_lo = lo;
+		if (uni(sh.flags[npar][1])) wf_hi = hi;
+		const int32_t done = uni(sh.flags[npar][2]), payload = uni(sh.flags[npar][3]);
+		s = s_new, curH = newH, cur1 = new1, cur2 = new2, par = npar;
+		if (TB) tb_used += w;
+		if ((s & 0xff) == 0) { // shrink (reference wf_stripe_shrink, miniwfa.c:144-171)
+			if (tid == 0) sh.red[0] = 0x7fffffff, sh.red[1] = -1;
+			__syncthreads();
+			const int32_t wfirst = wf_lo >> 6, wlast = wf_hi >> 6;
+			for (int32_t wi = wfirst + tid; wi <= wlast; wi += T) {
+				unsigned long long m = 0;
+				for (int32_t j = 0; j < P.nH; ++j)
+					m |= M.good[(int64_t)j * A.GW + wi] & window_mask(wi << 6, sh.rng_lo[j], sh.rng_hi[j]);
+				m &= window_mask(wi << 6, wf_lo, wf_hi);
+				if (m) {
+					atomicMin(&sh.red[0], (wi << 6) + (int32_t)__builtin_ctzll(m));
+					atomicMax(&sh.red[1], (wi << 6) + 63 - (int32_t)__builtin_clzll(m));
+				}
+			}
+			__syncthreads();
+			const int32_t glo = uni(sh.red[0]), ghi = uni(sh.red[1]);
+			if (ghi < 0) { R.status = ST_INTERNAL; break; } // reference asserts this cannot happen (:157,169)
+			wf_lo = glo, wf_hi = ghi;
+		}
+		cells += w;
+		if (!SEG && ((A.max_iter > 0 && cells > A.max_iter) || (A.max_s > 0 && s > A.max_s))) { // miniwfa.c:422-425
+			R.status = ST_STOPPED;
+			break;
+		}
+		if (done) {
+			R.info = payload;
+			break;
+		}
+	}
+	R.s = s, R.cells = cells, R.n_snap = n_snap;
+	return R;
+}
+
+// Traceback on one wave (reference wf_traceback, miniwfa.c:329-377).  Ops are emitted from the end of
+// the alignment to its start, so writing them backwards from the end of the scratch buffer leaves the
+// CIGAR in input order.  Returns n_cigar (>= 0) or -1 when the scratch buffer is too small.
+__device__ int32_t traceback_wave(const BatchArgs &A, const PairMem &M, uint32_t *scratch, int64_t cap,
+                                  int32_t s_final, int32_t last, int32_t *end_state)
+{
+	const Penalty &P = A.pen;
+	const int32_t lane = threadIdx.x & 63;
+	int32_t i = M.ql - 1, k = M.tl - 1, row = s_final - 1;
+	int64_t pos = cap;
+	int32_t run_op = -1, run_len = 0;
+	bool overflow = false;
+	auto push = [&](int32_t op, int32_t len) { // reference wf_cigar_push1, miniwfa.c:51-62
+		if (op == run_op) { run_len += len; return; }
+		if (run_op >= 0) {
+			if (pos == 0) { overflow = true; return; }
+			--pos;
+			if (lane == 0) scratch[pos] = (uint32_t)run_len << 4 | (uint32_t)run_op;
+		}
+		run_op = op, run_len = len;
+	};
+	while (i >= 0 && k >= 0 && !overflow) {
+		if (last == 0) { // greedy back-match, 64 bases per trip (miniwfa.c:335-341)
+			int32_t run = 0;
+			for (;;) {
+				const int32_t ii = i - run - lane, kk = k - run - lane;
+				const bool eq = ii >= 0 && kk >= 0 && M.qs[ii] == M.ts[kk];
+				const unsigned long long m = __ballot(eq);
+				const int32_t n = m == ~0ull ? 64 : (int32_t)__builtin_ctzll(~m);
+				run += n;
+				if (n < 64) break;
+			}
+			if (run > 0) push(7, run);
+			i -= run, k -= run;
+			if (i < 0 || k < 0) break;
+		}
+		if (row < 0) { overflow = true; break; }
+		const int32_t col = i - k + M.tl + 1;
+		const uint32_t x = M.tb[M.row_off[row] + (col - M.row_lo[row])];
+		const int32_t state = last == 0 ? (int32_t)(x & 7u) : last;           // :346
+		const int32_t ext = state > 0 ? (int32_t)(x >> (state + 2)) & 1 : 0;  // :347
+		if (state == 0) { push(8, 1); --i, --k; row -= P.x; }
+		else if (state == 1) { push(1, 1); --i; row -= ext ? P.e1 : P.oe1; }
+		else if (state == 3) { push(1, 1); --i; row -= ext ? P.e2 : P.oe2; }
+		else if (state == 2) { push(2, 1); --k; row -= ext ? P.e1 : P.oe1; }
+		else { push(2, 1); --k; row -= ext ? P.e2 : P.oe2; }
+		last = (state > 0 && ext) ? state : 0;                                // :365
+	}
+	end_state[0] = row, end_state[1] = i, end_state[2] = k;
+	if (i >= 0) push(1, i + 1);          // :368-369
+	else if (k >= 0) push(2, k + 1);
+	push(-2, 0);                         // flush the pending run
+	if (overflow) return -1;
+	return (int32_t)(cap - pos);
+}
+
+template <int T>
+__device__ void align_pair(const BatchArgs &A, Shared &sh, int32_t slot, int32_t pair)
+{
+	const Penalty &P = A.pen;
+	PairMem M;
+	M.tl = A.tl[pair], M.ql = A.ql[pair];
+	M.ts = A.seqs + A.t_off[pair], M.qs = A.seqs + A.q_off[pair];
+	const int64_t W = A.W;
+	int32_t *ring = A.ring + (int64_t)slot * A.ring_slot_ints;
+	M.H = ring, M.E1 = M.H + P.nH * W, M.F1 = M.E1 + P.n1 * W, M.E2 = M.F1 + P.n1 * W, M.F2 = M.E2 + P.n2 * W;
+	M.sH = M.sE1 = M.sF1 = M.sE2 = M.sF2 = 0;
+	if (A.sring) {
+		int32_t *sr = A.sring + (int64_t)slot * A.ring_slot_ints;
+		M.sH = sr, M.sE1 = M.sH + P.nH * W, M.sF1 = M.sE1 + P.n1 * W, M.sE2 = M.sF1 + P.n1 * W, M.sF2 = M.sE2 + P.n2 * W;
+	}
+	M.good = A.good + (int64_t)slot * P.nH * A.GW;
+	M.tb = A.tb ? A.tb + (int64_t)slot * A.tb_slot_bytes : 0;
+	M.row_off = A.row_off ? A.row_off + (int64_t)slot * A.rows_slot : 0;
+	M.row_lo = A.row_lo ? A.row_lo + (int64_t)slot * A.rows_slot : 0;
+	M.snap = A.snap ? A.snap + (int64_t)slot * A.snap_slot_ints : 0;
+	M.snap_meta = A.snap_meta ? A.snap_meta + (int64_t)slot * A.snap_meta_slot : 0;
+	M.seg = A.seg ? A.seg + (int64_t)slot * 2 * A.seg_slot : 0;
+	M.dbg = A.dbg;
+	const bool trace = A.dbg && pair == A.debug_pair;
+
+	int32_t n_seg = 0, status = ST_OK;
+	int64_t cells1 = 0;
+	PassResult R;
+	R.status = ST_OK, R.s = 0, R.info = 0, R.n_snap = 0, R.cells = 0;
+	if (A.step > 0 && A.want_cigar) { // low-memory first pass (reference mwf_wfa_exact, miniwfa.c:610-611)
+		PassResult R1 = forward_pass<T, false, true>(A, M, sh, 0, false);
+		cells1 = R1.cells;
+		status = R1.status;
+		if (status == ST_OK) {
+			if (threadIdx.x == 0) sh.word[2] = trace_checkpoints(A, M, R1.n_snap, R1.info);
+			__syncthreads();
+			status = uni(sh.word[2]);
+			n_seg = R1.n_snap;
+		}
+		__syncthreads();
+	}
+	if (status == ST_OK) {
+		if (A.want_cigar) R = forward_pass<T, true, false>(A, M, sh, n_seg, trace);
+		else R = forward_pass<T, false, false>(A, M, sh, 0, trace);
+		status = R.status;
+	}
+	int32_t n_cigar = 0;
+	int64_t cig_off = 0;
+	if (A.want_cigar && status == ST_OK) {
+		__syncthreads();
+		if (threadIdx.x < 64) {
+			uint32_t *scratch = A.cig_scratch + (int64_t)slot * A.cig_scratch_slot;
+			int32_t end_state[3];
+			n_cigar = traceback_wave(A, M, scratch, A.cig_scratch_slot, R.s, R.info, end_state);
+			if (n_cigar < 0) status = ST_INTERNAL, n_cigar = 0;
+			else {
+				unsigned long long off = 0;
+				if (threadIdx.x == 0) off = atomicAdd(A.cig_head, (unsigned long long)n_cigar);
+				off = ((unsigned long long)(uint32_t)uni((int32_t)(off >> 32)) << 32) | (uint32_t)uni((int32_t)(off & 0xffffffffu));
+				if ((int64_t)off + n_cigar > A.cig_pool_words) status = ST_CIGAR_OVERFLOW, n_cigar = 0;
+				else {
+					cig_off = (int64_t)off;
+					const uint32_t *src = scratch + (A.cig_scratch_slot - n_cigar);
+					for (int32_t j = threadIdx.x; j < n_cigar; j += 64) A.cig_pool[off + j] = src[j];
+				}
+			}
+			if (threadIdx.x == 0 && A.out_dbg) {
+				A.out_dbg[4 * pair] = end_state[0], A.out_dbg[4 * pair + 1] = end_state[1];
+				A.out_dbg[4 * pair + 2] = end_state[2], A.out_dbg[4 * pair + 3] = R.info;
+			}
+		}
+	}
+	if (threadIdx.x == 0) {
+		A.out_s[pair] = (status == ST_OK) ? R.s : -1;
+		A.out_iter[pair] = R.cells;
+		A.out_ncig[pair] = n_cigar;
+		A.out_cigoff[pair] = cig_off;
+		A.out_cells1[pair] = cells1;
+		A.out_status[pair] = status;
+	}
+	__syncthreads();
+}
+
+// Persistent workgroups: each pulls pairs from a shared counter until the batch is drained.
+template <int T>
+__global__ __launch_bounds__(T) void wfa_batch_kernel(const BatchArgs A)
+{
+	__shared__ Shared sh;
+	for (;;) {
+		if (threadIdx.x == 0) sh.item = (int32_t)atomicAdd(A.queue, 1);
+		__syncthreads();
+		const int32_t item = uni(sh.item);
+		__syncthreads();
+		if (item >= A.n_pairs) break;
+		const int32_t pair = A.order ? A.order[item] : item;
+		align_pair<T>(A, sh, (int32_t)blockIdx.x, pair);
+	}
+}
+
+} // namespace
+
+int launch_batch(const BatchArgs &a, int grid, int block, void *stream)
+{
+	hipStream_t st = (hipStream_t)stream;
+	switch (block) {
+	case 64:   hipLaunchKernelGGL(wfa_batch_kernel<64>,   dim3(grid), dim3(64),   0, st, a); break;
+	case 128:  hipLaunchKernelGGL(wfa_batch_kernel<128>,  dim3(grid), dim3(128),  0, st, a); break;
+	case 256:  hipLaunchKernelGGL(wfa_batch_kernel<256>,  dim3(grid), dim3(256),  0, st, a); break;
+	case 512:  hipLaunchKernelGGL(wfa_batch_kernel<512>,  dim3(grid), dim3(512),  0, st, a); break;
+	case 1024: hipLaunchKernelGGL(wfa_batch_kernel<1024>, dim3(grid), dim3(1024), 0, st, a); break;
+	default: return -1;
+	}
+	return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int batch_kernel_occupancy(int block)
+{
+	int n = 0;
+	hipError_t e = hipErrorInvalidValue;
+	switch (block) {
+	case 64:   e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<64>, 64, 0); break;
+	case 128:  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<128>, 128, 0); break;
+	case 256:  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<256>, 256, 0); break;
+	case 512:  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<512>, 512, 0); break;
+	case 1024: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<1024>, 1024, 0); break;
+	default: break;
+	}
+	return e == hipSuccess ? n : 0;
+}
+
+} // namespace mwf

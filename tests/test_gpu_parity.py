@@ -1,0 +1,199 @@
+"""Parity of the HIP path (through the C ABI) with the oracle and the reference's golden vectors.
+
+Bar: bit-exact s, n_iter and CIGAR (integer/byte work — no tolerance).  Inputs are the committed
+golden fixtures (answers produced by the real lh3/miniwfa) plus seeded synthetic pairs checked
+against oracle/mwf_oracle.c at sizes the oracle finishes in seconds."""
+import numpy as np
+import pytest
+
+import miniwfa_amd as mw
+from miniwfa_amd.synth import synth_pair, PackedBatch
+from conftest import load_golden, golden_inputs
+from oracle.pyoracle import make_opt, cigar_str as ocig
+
+pytestmark = pytest.mark.gpu
+
+OPT_KEYS = ("flag", "x", "o1", "e1", "o2", "e2", "step", "max_s", "max_iter")
+
+
+def gpu_opt(v_opt):
+    return mw.opt_init(**{k: v_opt[k] for k in OPT_KEYS})
+
+
+def explain_band(t, q, o, oracle):
+    """On a mismatch: first penalty at which the device band leaves the oracle's."""
+    try:
+        eng = mw.Engine(0)
+        b = eng.upload(PackedBatch([(t, q)]))
+        dev = b.debug_band(o, 0) - 1 - len(t)
+        ref = np.array(oracle.band_trace(t, q, make_opt(**{k: getattr(o, k) for k in OPT_KEYS})), dtype=np.int32).reshape(-1, 2)
+        n = min(len(dev), len(ref))
+        bad = np.nonzero((dev[:n] != ref[:n]).any(axis=1))[0]
+        if len(bad):
+            j = int(bad[0])
+            return f"band diverges at penalty {j + 1}: device {dev[j].tolist()} oracle {ref[j].tolist()} (lens {len(dev)}/{len(ref)})"
+        return f"bands agree for {n} penalties (lens {len(dev)}/{len(ref)})"
+    except Exception as e:  # diagnostics only
+        return f"(band trace unavailable: {e})"
+
+
+@pytest.fixture(scope="module")
+def engine():
+    e = mw.Engine(0)
+    yield e
+    e.close()
+
+
+def run_vectors(engine, oracle, vecs):
+    """Group vectors by option set, run each group as one device batch, compare with the stored answers."""
+    groups = {}
+    for v in vecs:
+        groups.setdefault(tuple(v["opt"][k] for k in OPT_KEYS), []).append(v)
+    for key, vs in groups.items():
+        o = gpu_opt(dict(zip(OPT_KEYS, key)))
+        pairs = [golden_inputs(v) for v in vs]
+        b = engine.upload(PackedBatch(pairs))
+        b.align(o)
+        s, it, nc = b.results()
+        for i, v in enumerate(vs):
+            exp = v["expect"]
+            why = ""
+            if s[i] != exp["s"] or it[i] != exp["n_iter"]:
+                why = explain_band(pairs[i][0], pairs[i][1], o, oracle)
+            assert s[i] == exp["s"], (v["id"], int(s[i]), exp["s"], why)
+            assert it[i] == exp["n_iter"], (v["id"], int(it[i]), exp["n_iter"], why)
+            if exp["cigar"] is None:
+                assert nc[i] == 0, v["id"]
+            else:
+                assert ocig(b.cigar(i, int(nc[i]))) == exp["cigar"], v["id"]
+        b.free()
+
+
+def test_t3_known_answer_through_drop_in_api():
+    v = load_golden("exact_small.jsonl")[0]
+    t, q = golden_inputs(v)
+    s, n_iter, cig = mw.wfa_exact(t, q, mw.opt_init(flag=mw.MWF_F_CIGAR))
+    assert s == 155 and mw.cigar_str(cig) == "1X16=1X14=128I4=1X24="
+    s2, n_iter2, cig2 = mw.wfa_exact(t, q, mw.opt_init())
+    assert (s2, cig2) == (155, None) and n_iter2 == n_iter == 16875
+
+
+def test_small_golden_vectors(engine, oracle):
+    vecs = [v for v in load_golden("exact_small.jsonl") if v["entry"] == "exact"]
+    assert len(vecs) > 600
+    run_vectors(engine, oracle, vecs)
+
+
+def test_bench_shaped_golden_vectors(engine, oracle):
+    run_vectors(engine, oracle, [v for v in load_golden("bench_shaped.jsonl") if v["entry"] == "exact"])
+
+
+def test_auto_exact_branch_matches_reference():
+    for v in load_golden("exact_small.jsonl") + load_golden("bench_shaped.jsonl"):
+        if v["entry"] != "auto":
+            continue
+        t, q = golden_inputs(v)
+        s, n_iter, cig = mw.wfa_auto(t, q, gpu_opt(v["opt"]))
+        assert (s, n_iter) == (v["expect"]["s"], v["expect"]["n_iter"]), v["id"]
+        assert (None if cig is None else mw.cigar_str(cig)) == v["expect"]["cigar"], v["id"]
+
+
+def test_empty_and_degenerate_inputs(engine, oracle):
+    # ("","") with MWF_F_CIGAR crashes the reference (miniwfa.c:406-407); here it is defined as s=0, no CIGAR
+    assert mw.wfa_exact(b"", b"", mw.opt_init(flag=mw.MWF_F_CIGAR)) == (0, 0, None)
+    assert mw.wfa_exact(b"", b"", mw.opt_init()) == (0, 0, None)
+    for t, q in ((b"A", b""), (b"", b"ACGTA"), (b"ACGT", b"ACGT"), (b"A" * 5000, b"A" * 5000), (b"A" * 700, b"C" * 650)):
+        for o in (make_opt(), make_opt(flag=1), make_opt(flag=1, step=3)):
+            exp = oracle.align(t, q, o)
+            got = mw.wfa_exact(t, q, mw.opt_init(flag=o.flag, step=o.step))
+            assert got == exp, (t[:8], q[:8], o.flag, o.step)
+
+
+def test_ragged_batch_against_oracle(engine, oracle):
+    """One launch, pairs of very different size and divergence (and a few identical / empty ones)."""
+    pairs = [synth_pair(81000 + i, (5, 40, 333, 1200, 2500, 4000)[i % 6], (0.0, 0.03, 0.12, 0.3)[i % 4]) for i in range(96)]
+    pairs += [(b"", b"ACGT"), (b"ACGT", b""), (b"GATTACA", b"GATTACA")]
+    for o in (make_opt(), make_opt(flag=1), make_opt(flag=1, step=64), make_opt(flag=1, x=2, o1=3, e1=1, o2=9, e2=2)):
+        go = mw.opt_init(**{k: getattr(o, k) for k in OPT_KEYS})
+        b = engine.upload(PackedBatch(pairs))
+        b.align(go)
+        s, it, nc = b.results()
+        for i, (t, q) in enumerate(pairs):
+            es, eit, ecig = oracle.align(t, q, o)
+            why = explain_band(t, q, go, oracle) if (s[i], it[i]) != (es, eit) else ""
+            assert (s[i], it[i]) == (es, eit), (i, len(t), len(q), o.flag, o.step, why)
+            if ecig is not None:
+                assert b.cigar(i, int(nc[i])).tolist() == ecig, (i, o.step)
+        b.free()
+
+
+@pytest.mark.parametrize("block", [64, 128, 256, 512, 1024])
+def test_every_block_size_gives_identical_results(block, oracle):
+    eng = mw.Engine(0)
+    eng.set("block", block)
+    pairs = [synth_pair(82000 + i, 1500, 0.08) for i in range(12)]
+    for o in (make_opt(), make_opt(flag=1), make_opt(flag=1, step=50)):
+        b = eng.upload(PackedBatch(pairs))
+        b.align(mw.opt_init(flag=o.flag, step=o.step))
+        s, it, nc = b.results()
+        for i, (t, q) in enumerate(pairs):
+            es, eit, ecig = oracle.align(t, q, o)
+            assert (s[i], it[i]) == (es, eit), (block, i)
+            if ecig is not None:
+                assert b.cigar(i, int(nc[i])).tolist() == ecig
+        b.free()
+    eng.close()
+
+
+def test_stop_rules(engine, oracle):
+    t, q = synth_pair(83000, 2000, 0.1)
+    full = oracle.align(t, q, make_opt())
+    for kw in (dict(max_s=full[0] - 1), dict(max_s=full[0]), dict(max_iter=full[1] - 1), dict(max_iter=full[1]), dict(max_iter=1000), dict(max_s=300)):
+        for flag, step in ((0, 0), (1, 0), (1, 100)):
+            o = make_opt(flag=flag, step=step, **kw)
+            assert mw.wfa_exact(t, q, mw.opt_init(flag=flag, step=step, **kw)) == oracle.align(t, q, o), (kw, flag, step)
+
+
+def test_traceback_arena_retry(oracle):
+    """A tiny traceback budget forces the overflow -> fewer/larger slots retry path."""
+    eng = mw.Engine(0)
+    eng.set("tb_budget_mb", 8)
+    pairs = [synth_pair(84000 + i, 1500, 0.1) for i in range(40)]
+    b = eng.upload(PackedBatch(pairs))
+    b.align(mw.opt_init(flag=mw.MWF_F_CIGAR))
+    s, it, nc = b.results()
+    assert eng.stats().n_retries > 0
+    for i, (t, q) in enumerate(pairs):
+        es, eit, ecig = oracle.align(t, q, make_opt(flag=1))
+        assert (s[i], it[i]) == (es, eit) and b.cigar(i, int(nc[i])).tolist() == ecig
+    b.free()
+    eng.close()
+
+
+def test_kalloc_arena_owns_the_cigar():
+    L = mw.lib()
+    km = L.km_init()
+    t, q = synth_pair(85000, 800, 0.1)
+    s, n_iter, cig = mw.wfa_exact(t, q, mw.opt_init(flag=mw.MWF_F_CIGAR), km=km)   # _take() kfree()s into km
+    assert s > 0 and mw.cigar2score(mw.opt_init(), cig) == (s, len(t), len(q))
+    L.km_destroy(km)
+
+
+def test_full_size_batch_properties(engine, oracle):
+    """BASELINE config 3 at full size (1024 x 10 kb, 5 %): spot-check against the oracle, and check the
+    size-independent properties on every pair: CIGAR re-scores to s and consumes both sequences."""
+    pairs = [synth_pair(50000 + i, 10000, 0.05) for i in range(1024)]
+    pk = PackedBatch(pairs)
+    b = engine.upload(pk)
+    b.align(mw.opt_init())
+    s0, it0, _ = b.results()
+    b.align(mw.opt_init(flag=mw.MWF_F_CIGAR))
+    s1, it1, nc = b.results()
+    assert (s0 == s1).all() and (it0 == it1).all() and (s0 > 0).all()
+    for i in range(0, 1024, 97):
+        assert (int(s0[i]), int(it0[i])) == oracle.align(pairs[i][0], pairs[i][1], make_opt())[:2], i
+    o = mw.opt_init()
+    for i in range(0, 1024, 8):
+        cig = b.cigar(i, int(nc[i])).tolist()
+        assert mw.cigar2score(o, cig) == (int(s1[i]), len(pairs[i][0]), len(pairs[i][1])), i
+    b.free()
