@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py — aligned Gbp/s of the exact WFA hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[2], the batch the metric is quoted on): per GPU, 1024 synthetic pairs,
+10 kb target, query = target mutated at 5 % (60/20/20 sub/ins/del, geometric indels), score-only
+mwf_wfa_exact semantics, default penalties.  One "step" = one pass of the hot path over that batch, with
+the packed sequences already resident in HBM (torch tensors wrapped zero-copy by the C ABI).  Pairs are
+independent, so ranks shard them with no data-path collective (weak scaling); the only collective is the
+final RCCL all_gather of the fixed 12-byte (s, n_iter) records, inside the timed region.
+
+Printed JSON (one line, rank 0): the driver contract fields plus
+  roofline     — 48 algorithmic bytes per (penalty,diagonal) cell (7 int32 loads + 5 stores, reference
+                 miniwfa.c:269-276) x cells per launch / HIP-event kernel time, against 8 TB/s
+  cpu_baseline — the compiled reference (oracle/_ref, kind "reference") or our C restatement (kind "port")
+                 on the host cores, bounded sample of the same batch (rank 0, N=1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_CELL = 48          # score-only; 49 with traceback, 97 in the low-memory first pass
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+class _DevPtr:
+    """Zero-copy torch view of a device buffer owned by the C library."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=1024, help="pairs per GPU")
+    ap.add_argument("--len", type=int, default=10000, dest="tl")
+    ap.add_argument("--div", type=float, default=0.05)
+    ap.add_argument("--cigar", action="store_true", help="score+CIGAR (high-memory) instead of score-only")
+    ap.add_argument("--block", type=int, default=0)
+    ap.add_argument("--slots-per-cu", type=int, default=0)
+    ap.add_argument("--cpu-sample", type=int, default=256, help="pairs in the cpu_baseline sample (0: skip)")
+    ap.add_argument("--seed", type=int, default=50000)
+    args = ap.parse_args()
+
+    import torch
+    import miniwfa_amd as mw
+    from miniwfa_amd.synth import synth_pair, PackedBatch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+
+    # ---- synthetic batch of this rank, resident in HBM before anything is timed
+    pairs = [synth_pair(args.seed + rank * args.pairs + i, args.tl, args.div) for i in range(args.pairs)]
+    pk = PackedBatch(pairs)
+    d_seqs = torch.from_numpy(pk.seqs.copy()).to(dev)
+    d_toff, d_qoff = torch.from_numpy(pk.t_off).to(dev), torch.from_numpy(pk.q_off).to(dev)
+    d_tl, d_ql = torch.from_numpy(pk.tl).to(dev), torch.from_numpy(pk.ql).to(dev)
+    stream = torch.cuda.current_stream(dev)
+    eng = mw.Engine(local_rank, stream.cuda_stream)
+    if args.block:
+        eng.set("block", args.block)
+    if args.slots_per_cu:
+        eng.set("slots_per_cu", args.slots_per_cu)
+    batch = eng.wrap(pk.n, d_seqs.data_ptr(), pk.total, d_toff.data_ptr(), d_tl.data_ptr(), d_qoff.data_ptr(), d_ql.data_ptr(),
+                     pk.tl, pk.ql, keep=(d_seqs, d_toff, d_qoff, d_tl, d_ql))
+    opt = mw.opt_init(flag=mw.MWF_F_CIGAR if args.cigar else 0)
+    d_s = torch.as_tensor(_DevPtr(batch.dev_scores_ptr(), pk.n, "<i4"), device=dev)
+    d_it = torch.as_tensor(_DevPtr(batch.dev_iters_ptr(), pk.n, "<i8"), device=dev)
+    gather_s = [torch.empty_like(d_s) for _ in range(world)] if world > 1 else None
+    gather_it = [torch.empty_like(d_it) for _ in range(world)] if world > 1 else None
+
+    kernel_ms = []
+
+    def step(record: bool):
+        batch.align(opt)                       # kernels enqueued on torch's current stream
+        if args.cigar:
+            batch.results()                    # CIGAR mode may have to retry pairs: needs the host in the loop
+        if world > 1:                          # the result gather of the multi-GPU job (RCCL over xGMI)
+            dist.all_gather(gather_s, d_s)
+            dist.all_gather(gather_it, d_it)
+        if record:
+            torch.cuda.synchronize(dev)
+            kernel_ms.append(eng.stats().kernel_ms)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(False)
+    fence()
+    elapsed = time.perf_counter() - t0
+    # kernel-only timing (HIP events on the launch stream), outside the wall-clock region so the per-step
+    # event sync does not perturb it
+    for _ in range(max(3, min(args.steps, 10))):
+        step(True)
+    s, n_iter, _ = batch.results()
+    cells = int(n_iter.sum())
+    assert (s >= 0).all(), "some pairs did not finish"
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        tot = torch.tensor([pk.bases, cells], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_bases, total_cells = int(tot[0].item()), int(tot[1].item())
+    else:
+        total_bases, total_cells = pk.bases, cells
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    k_ms = float(np.mean(kernel_ms))
+    bytes_per_cell = 49 if args.cigar else ALGO_BYTES_PER_CELL
+    achieved = bytes_per_cell * cells / (k_ms * 1e-3) / 1e9
+    out = {
+        "metric": "aligned Gbp/s (q+t)",
+        "value": total_bases * args.steps / elapsed / 1e9,
+        "unit": "Gbp/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int32", "data": "synthetic",
+        "config": {
+            "workload": f"{args.pairs} pairs/GPU x {args.tl} bp, {args.div:g} divergence, "
+                        f"{'score+CIGAR high-mem' if args.cigar else 'score-only'} mwf_wfa_exact, default penalties (BASELINE configs[2])",
+            "pairs_per_gpu": args.pairs, "target_len": args.tl, "divergence": args.div,
+            "bases_per_gpu": pk.bases, "cells_per_gpu": cells, "mean_s": float(s.mean()),
+            "kernel": "wfa_batch_kernel (one workgroup per pair)", "grid": eng.stats().grid, "block": eng.stats().block,
+            "parallelism": f"pairs sharded over {world} GPU(s), RCCL all_gather of (s,n_iter)",
+        },
+        "gcells_per_s": total_cells * args.steps / elapsed / 1e9,
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None, "bytes_per_cell": bytes_per_cell, "cells_per_launch": cells, "kernel_ms": k_ms,
+        },
+    }
+    traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(traffic_file):
+        try:
+            tr = json.load(open(traffic_file))
+            key = f"{args.pairs}x{args.tl}@{args.div:g}{'c' if args.cigar else 's'}"
+            if key in tr:
+                out["roofline"]["traffic"] = tr[key]["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = tr[key].get("source")
+        except Exception:
+            pass
+
+    # ---- PCIe-inclusive rate (host buffers in, host results out) — reported beside, never as `value`
+    t1 = time.perf_counter()
+    b2 = eng.upload(pk)
+    b2.align(opt)
+    b2.results()
+    out["pcie_inclusive_gbps"] = pk.bases / (time.perf_counter() - t1) / 1e9
+    b2.free()
+
+    # ---- CPU baseline: same pairs (a bounded sample), host cores of this box
+    if world == 1 and args.cpu_sample > 0:
+        from oracle.pyoracle import Oracle, Reference, make_opt
+        n = min(args.cpu_sample, pk.n)
+        cores = os.cpu_count() or 1
+        o = make_opt(flag=1 if args.cigar else 0)
+        if Reference.available():
+            cpu, kind = Reference(), "reference"
+        else:
+            cpu, kind = Oracle(), "port"
+        res, sec = cpu.align_many(pairs[:n], o, threads=cores)
+        ok = all(int(s[i]) == res[i][0] and int(n_iter[i]) == res[i][1] for i in range(n))
+        sb = int(pk.tl[:n].sum() + pk.ql[:n].sum())
+        out["cpu_baseline"] = {
+            "value": sb / sec / 1e9, "unit": "Gbp/s", "cores": cores, "kind": kind,
+            "sample": f"first {n} of the {pk.n} pairs, one pair per thread on {cores} threads, "
+                      f"{'lh3/miniwfa compiled -O3 -msse4.2 (oracle/_ref)' if kind == 'reference' else 'oracle/mwf_oracle.c'}, {sec:.2f} s wall",
+            "gcells_per_s": float(n_iter[:n].sum()) / sec / 1e9,
+            "gpu_matches_cpu_on_sample": ok,
+        }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from typing import Iterable, Sequence
 
 import numpy as np
@@ -196,9 +197,12 @@ class Engine:
         if not self.h:
             raise RuntimeError(f"libmwf_hip: cannot open device {device}")
         self.device = device
+        self._batches = weakref.WeakSet()
 
     def close(self):
         if self.h:
+            for b in list(self._batches):  # a batch must not outlive its engine
+                b.free()
             lib().mwf_gpu_destroy(self.h)
             self.h = None
 
@@ -244,11 +248,12 @@ class Batch:
 
     def __init__(self, eng: Engine, handle, n: int, keep=()):
         self.eng, self.h, self.n, self._keep = eng, handle, n, keep
+        eng._batches.add(self)
 
     def free(self):
-        if self.h:
+        if self.h and self.eng.h:
             lib().mwf_gpu_batch_free(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:

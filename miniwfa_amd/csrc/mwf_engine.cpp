@@ -145,11 +145,12 @@ const char *validate(const mwf_opt_t &o)
 }
 
 // Upper bound on the optimal penalty: delete the whole target, insert the whole query.
-int64_t penalty_bound(const mwf_opt_t &o, int64_t tl, int64_t ql)
+int64_t penalty_bound(const mwf_opt_t &o, int64_t tl, int64_t ql, bool honour_max_s)
 {
 	auto gap = [&](int64_t L) -> int64_t { return L == 0 ? 0 : std::min<int64_t>(o.o1 + L * o.e1, o.o2 + L * o.e2); };
 	int64_t b = gap(tl) + gap(ql);
-	if (o.max_s > 0) b = std::min<int64_t>(b, (int64_t)o.max_s + 1);
+	// the core pass stops one penalty after max_s (miniwfa.c:422); the low-memory first pass never stops (:569-589)
+	if (honour_max_s && o.max_s > 0) b = std::min<int64_t>(b, (int64_t)o.max_s + 1);
 	return b;
 }
 
@@ -163,7 +164,7 @@ struct Plan {
 
 // Run the one-workgroup-per-pair kernel over `n_items` pairs given by d_order (device) on `slots` workgroups.
 int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const int32_t *d_order, int32_t n_items,
-                     int slots, int64_t max_len, int64_t max_bound, int64_t tb_total_budget, bool timed)
+                     int slots, int64_t max_len, int64_t max_bound, int64_t max_bound1, int64_t tb_total_budget, bool timed)
 {
 	const Penalty P = make_penalty(opt);
 	Plan pl;
@@ -198,7 +199,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	}
 	if (pl.low_mem) {
 		const int64_t NS = P.nH + 2 * P.n1 + 2 * P.n2;
-		const int64_t n_snap_max = max_bound / opt.step + 2;
+		const int64_t n_snap_max = max_bound1 / opt.step + 2; // first pass: bound without max_s
 		pl.seg_slot = n_snap_max;
 		pl.snap_meta_slot = n_snap_max * (4 + 4 * NS);
 		// a snapshot holds every array-slice of the shadow ring; windows are at most min(2s+1, whole matrix) wide
@@ -453,10 +454,11 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	if (cigar && !b->d_cig_pool) {
 		if (hipMalloc(&b->d_cig_pool, (size_t)b->cig_pool_words * 4) != hipSuccess) { g->err = "hipMalloc of the CIGAR pool failed"; return -1; }
 	}
-	int64_t max_len = 0, max_bound = 0;
+	int64_t max_len = 0, max_bound = 0, max_bound1 = 0;
 	for (int32_t i = 0; i < b->n; ++i) {
 		max_len = std::max<int64_t>(max_len, (int64_t)b->h_tl[i] + b->h_ql[i]);
-		max_bound = std::max(max_bound, penalty_bound(*opt, b->h_tl[i], b->h_ql[i]));
+		max_bound = std::max(max_bound, penalty_bound(*opt, b->h_tl[i], b->h_ql[i], true));
+		max_bound1 = std::max(max_bound1, penalty_bound(*opt, b->h_tl[i], b->h_ql[i], false));
 	}
 	if (max_len + 4 >= ((int64_t)1 << 31)) { g->err = "tl+ql must be below 2^31-4"; return -2; }
 	const int block = g->block > 0 ? g->block : 256;
@@ -467,7 +469,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	HIP_TRY(g, hipMemsetAsync(b->d_cig_head, 0, 64, g->stream));
 	HIP_TRY(g, hipMemsetAsync(b->d_status, 0xff, (size_t)b->n * 4, g->stream));
 	const int64_t budget = cigar ? tb_budget_bytes(g) : 0;
-	if (run_batch_kernel(g, b, *opt, b->d_order, b->n, slots, max_len, max_bound, budget, true)) return -1;
+	if (run_batch_kernel(g, b, *opt, b->d_order, b->n, slots, max_len, max_bound, max_bound1, budget, true)) return -1;
 	b->aligned = true;
 	return 0;
 }
@@ -508,23 +510,26 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 		}
 		if (redo.empty()) break;
 		if (slots == 1) {
-			g->err = "traceback of pair " + std::to_string(redo[0]) + " does not fit in device memory; set opt.step > 0 (low-memory mode)";
+			g->err = std::string(b->h_status[redo[0]] == ST_TB_OVERFLOW ? "traceback" : "low-memory snapshots") + " of pair " + std::to_string(redo[0]) +
+			         " (tl=" + std::to_string(b->h_tl[redo[0]]) + ", ql=" + std::to_string(b->h_ql[redo[0]]) + ") do not fit in device memory" +
+			         (b->opt.step > 0 ? "" : "; set opt.step > 0 (low-memory mode)");
 			return -4;
 		}
 		slots = std::max(1, std::min<int>(slots / 8, (int)redo.size()));
 		std::stable_sort(redo.begin(), redo.end(), [&](int32_t x, int32_t y) {
 			return (int64_t)b->h_tl[x] + b->h_ql[x] > (int64_t)b->h_tl[y] + b->h_ql[y];
 		});
-		int64_t max_len = 0, max_bound = 0;
+		int64_t max_len = 0, max_bound = 0, max_bound1 = 0;
 		for (int32_t i : redo) {
 			max_len = std::max<int64_t>(max_len, (int64_t)b->h_tl[i] + b->h_ql[i]);
-			max_bound = std::max(max_bound, penalty_bound(b->opt, b->h_tl[i], b->h_ql[i]));
+			max_bound = std::max(max_bound, penalty_bound(b->opt, b->h_tl[i], b->h_ql[i], true));
+			max_bound1 = std::max(max_bound1, penalty_bound(b->opt, b->h_tl[i], b->h_ql[i], false));
 		}
 		int32_t *d_redo = nullptr;
 		HIP_TRY(g, hipMalloc(&d_redo, redo.size() * 4));
 		HIP_TRY(g, hipMemcpy(d_redo, redo.data(), redo.size() * 4, hipMemcpyHostToDevice));
 		g->stats.n_retries += (int32_t)redo.size();
-		const int rc = run_batch_kernel(g, b, b->opt, d_redo, (int32_t)redo.size(), slots, max_len, max_bound, tb_budget_bytes(g), false);
+		const int rc = run_batch_kernel(g, b, b->opt, d_redo, (int32_t)redo.size(), slots, max_len, max_bound, max_bound1, tb_budget_bytes(g), false);
 		if (rc == 0 && fetch()) { (void)hipFree(d_redo); return -1; }
 		(void)hipFree(d_redo);
 		if (rc) return -1;
