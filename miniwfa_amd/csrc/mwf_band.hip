@@ -1,0 +1,438 @@
+// mwf_band.hip — register-resident band kernel (the fast path for batches of short/medium pairs).
+//
+// Same arithmetic and bookkeeping as the generic kernel (mwf_kernels.hip), different data placement,
+// chosen from the rocprof profile of the generic kernel (83 % of wave-cycles waiting on memory, every
+// one of the 5 stores per cell going out to HBM):
+//
+//   * The E1/F1/E2/F2 wavefronts are only ever read e1 resp. e2 penalties later (reference
+//     miniwfa.c:255-257), so they never leave the chip: every thread OWNS fixed columns and keeps their
+//     last e1 (e2) values in VGPRs.  A wave owns 256 consecutive columns per slot (4 per lane, 2 slots);
+//     the d-1 / d+1 neighbours the recurrence needs (:269-273) come from the adjacent lane through a DPP
+//     wave shift, and across wave boundaries through a 2 KB LDS edge table written once per penalty.
+//     Columns outside the current window push NEG_INF, which is exactly what the reference's pads yield.
+//   * Only H goes to HBM (it is read again x, o1+e1 and o2+e2 penalties later): one 16-byte store and
+//     three 16-byte loads per lane per 4 cells — the wide coalesced pattern — instead of 9 dword loads
+//     and 5 dword stores per cell.  16 algorithmic bytes per cell instead of 48.
+//   * The three H rows of penalty s+1 were final at least one penalty earlier (every H lag >= 2 here), so
+//     their loads are issued BEFORE the barrier that ends penalty s and stay in flight across it
+//     (raw s_barrier behind a counted s_waitcnt vmcnt): HBM/L2 latency is off the critical path.
+//   * Both sequences are copied to LDS once per pair; match extension reads two aligned dwords and
+//     v_alignbyte's them, so the per-cell probe never leaves the CU.
+//
+// Column -> owner mapping.  Columns are cut in 256-column chunks; chunk g belongs to (wave, slot) with
+// g mod (waves*2) == wave + waves*slot.  A workgroup therefore holds any window narrower than
+// (waves*2 - 1) chunks; one chunk is always spare, which is what makes the mapping change safe (a chunk
+// that becomes mapped has been outside every window for hundreds of penalties, so its registers already
+// hold NEG_INF).  A pair whose window outgrows that span is reported ST_BAND_OVERFLOW and re-run by the
+// host on the generic kernel.
+#include "mwf_device.h"
+
+namespace mwf {
+
+using namespace dev;
+
+namespace {
+
+extern __shared__ __attribute__((aligned(16))) uint8_t lds_dyn[];
+
+constexpr int kSlots = 2;      // 256-column chunks per wave
+constexpr int kChunk = 256;
+
+// lane i <- lane i-1 (lane 0 keeps `fill`); lane i <- lane i+1 (lane 63 keeps `fill`).  All 64 lanes must be active.
+__device__ __forceinline__ int32_t from_left(int32_t v, int32_t fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int32_t from_right(int32_t v, int32_t fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false); }
+
+// four bytes at an arbitrary byte offset of an LDS array
+__device__ __forceinline__ uint32_t lds_ld4(const uint8_t *base, int32_t off)
+{
+	const uint32_t *p = (const uint32_t*)(base + (off & ~3));
+	return __builtin_amdgcn_alignbyte(p[1], p[0], (uint32_t)off & 3u);
+}
+
+template <bool LSEQ>
+__device__ __forceinline__ int32_t extend_cell(const PairMem &M, const uint8_t *lt, const uint8_t *lq, int32_t k, int32_t d)
+{
+	if (!LSEQ) return extend_run(M.ts, M.qs, M.tl, M.ql, k, d);
+	const int32_t j = k + 1, i = d + j;
+	const int32_t room = min(M.tl - j, M.ql - i);
+	int32_t n = 0;
+	while (n < room) {
+		const uint32_t x = lds_ld4(lt, j + n) ^ lds_ld4(lq, i + n);
+		if (x) { n += (int32_t)(__builtin_ctz(x) >> 3); break; }
+		n += 4;
+	}
+	return k + min(n, room);
+}
+
+// lanes l of interleaved word k (column = base + 4*l + k) whose column lies in [a,b]
+__device__ __forceinline__ unsigned long long lane_mask(int32_t base, int32_t k, int32_t a, int32_t b)
+{
+	int32_t lmin = a - base - k, lmax = b - base - k;
+	if (lmax < 0) return 0ull;
+	lmin = lmin <= 0 ? 0 : (lmin + 3) >> 2;
+	lmax = min(lmax >> 2, 63);
+	if (lmin > lmax) return 0ull;
+	return (~0ull >> (63 - lmax)) & (~0ull << lmin);
+}
+
+template <int T, int E1, int E2, bool TB, bool LSEQ>
+__device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh,
+                                int32_t (*edge)[(T / 64) * kSlots][4], const uint8_t *lt, const uint8_t *lq,
+                                int32_t n_seg, bool trace_band)
+{
+	constexpr int K = kSlots, NW = T / 64, NWK = NW * K, D = (E1 > E2 ? E1 : E2) + 1;
+	static_assert((NWK & (NWK - 1)) == 0, "chunk table size must be a power of two");
+	const Penalty &P = A.pen;
+	const int32_t tl = M.tl, ql = M.ql, cmax = tl + ql + 1;
+	const int32_t tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+	const int64_t W = A.W;
+	PassResult R;
+	R.status = ST_OK, R.s = 0, R.info = 0, R.n_snap = 0, R.cells = 0;
+
+	// per-thread wavefront state: [age][slot][column-in-lane]; age 0 is the previous penalty
+	int32_t e1h[E1][K][4], f1h[E1][K][4], e2h[E2][K][4], f2h[E2][K][4];
+#pragma unroll
+	for (int k = 0; k < K; ++k)
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+#pragma unroll
+			for (int a = 0; a < E1; ++a) e1h[a][k][i] = f1h[a][k][i] = kNegInf;
+#pragma unroll
+			for (int a = 0; a < E2; ++a) e2h[a][k][i] = f2h[a][k][i] = kNegInf;
+		}
+	int4 phx[K], po1[K], po2[K];   // prefetched H rows of the next penalty: lags x, o1+e1, o2+e2
+	int32_t pe1[K], pe2[K];        // lane 0: column to the left of the chunk, lane 63: column to its right
+#pragma unroll
+	for (int k = 0; k < K; ++k) phx[k] = po1[k] = po2[k] = make_int4(0, 0, 0, 0), pe1[k] = pe2[k] = 0;
+
+	// ---- penalty 0 (reference wf_stripe_init, miniwfa.c:103-121) and its extension
+	for (int32_t j = tid; j < D * NWK * 4; j += T) (&edge[0][0][0])[j] = kNegInf;
+	if (tid == 0) {
+		for (int32_t j = 0; j < P.nH; ++j) sh.rng_lo[j] = 1, sh.rng_hi[j] = 0;
+		for (int32_t j = 0; j < 12; ++j) (&sh.flags[0][0])[j] = 0;
+		const int32_t c0 = tl + 1;
+		const int32_t k0 = extend_cell<LSEQ>(M, lt, lq, -1, 0);
+		M.H[c0] = k0;
+		sh.rng_lo[0] = sh.rng_hi[0] = c0;
+		sh.word[1] = k0;
+	}
+	__syncthreads();
+	{
+		const int32_t k0 = uni(sh.word[1]);
+		if (k0 == tl - 1 && k0 == ql - 1) return R;
+	}
+
+	int32_t s = 0, wf_lo = tl + 1, wf_hi = tl + 1;
+	int32_t curH = 0, par = 0, sid = 0, dcur = 0;
+	int64_t cells = 0, tb_used = 0;
+	int32_t gl = 0; // lowest chunk of the mapping the prefetched registers were loaded under
+
+	// issue the H loads of the penalty whose ring slot is `slotH`, for every chunk of [plo,phi]
+	auto prefetch = [&](int32_t slotH, int32_t plo, int32_t phi, int32_t g_lo) -> int32_t {
+		int32_t n_chunks = 0;
+		int32_t jx = slotH - P.x;   if (jx < 0) jx += P.nH;
+		int32_t j1 = slotH - P.oe1; if (j1 < 0) j1 += P.nH;
+		int32_t j2 = slotH - P.oe2; if (j2 < 0) j2 += P.nH;
+		const int32_t *rx = M.H + jx * W, *r1 = M.H + j1 * W, *r2 = M.H + j2 * W;
+		const int32_t g_hi = phi >> 8;
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			const int32_t r = wave + NW * k;
+			int32_t g = (g_lo & ~(NWK - 1)) + r;
+			if (g < g_lo) g += NWK;
+			if (g <= g_hi) { // uniform per wave
+				++n_chunks;
+				const int32_t c0 = g * kChunk + 4 * lane;
+				phx[k] = *(const int4*)(rx + c0);
+				po1[k] = *(const int4*)(r1 + c0);
+				po2[k] = *(const int4*)(r2 + c0);
+				if (lane == 0 || lane == 63) {
+					const int32_t ce = lane == 0 ? max(c0 - 1, 0) : c0 + 4; // column 0 is a pad no window contains
+					pe1[k] = r1[ce], pe2[k] = r2[ce];
+				}
+			}
+		}
+		return n_chunks;
+	};
+	{
+		const int32_t lo1 = wf_lo > 1 ? wf_lo - 1 : 1, hi1 = wf_hi < cmax ? wf_hi + 1 : cmax;
+		gl = lo1 >> 8;
+		(void)prefetch(P.nH > 1 ? 1 : 0, lo1, hi1, gl);
+	}
+
+	for (;;) {
+		if (TB && sid < n_seg) { // checkpoint reset of the second pass (miniwfa.c:413-416)
+			if (uni(M.seg[2 * sid]) == s) {
+				const int32_t c = uni(M.seg[2 * sid + 1]);
+				if (c < wf_lo || c > wf_hi) { R.status = ST_INTERNAL; break; }
+				wf_lo = wf_hi = c;
+				++sid;
+			}
+		}
+		const int32_t lo = wf_lo > 1 ? wf_lo - 1 : 1;       // miniwfa.c:417-418
+		const int32_t hi = wf_hi < cmax ? wf_hi + 1 : cmax;
+		const int32_t w = hi - lo + 1;
+		const int32_t s_new = s + 1;
+		const int32_t newH = curH + 1 == P.nH ? 0 : curH + 1;
+		const int32_t npar = par + 1 == 3 ? 0 : par + 1;
+		const int32_t dnew = dcur + 1 == D ? 0 : dcur + 1;
+		const int32_t origin = lo & ~3;
+		const int32_t row_bytes = (hi | 3) - origin + 1;
+		if (TB) {
+			if (s_new - 1 >= A.rows_slot) { R.status = ST_ROWS_OVERFLOW; break; }
+			if (tb_used + row_bytes > A.tb_slot_bytes) { R.status = ST_TB_OVERFLOW; break; }
+		}
+		// windows of the three H source slices (reference wf_next_prep, miniwfa.c:252-254)
+		int32_t jx = newH - P.x;   if (jx < 0) jx += P.nH;
+		int32_t j1 = newH - P.oe1; if (j1 < 0) j1 += P.nH;
+		int32_t j2 = newH - P.oe2; if (j2 < 0) j2 += P.nH;
+		const int32_t xlo = uni(sh.rng_lo[jx]), xhi = uni(sh.rng_hi[jx]);
+		const int32_t alo = uni(sh.rng_lo[j1]), ahi = uni(sh.rng_hi[j1]);
+		const int32_t blo = uni(sh.rng_lo[j2]), bhi = uni(sh.rng_hi[j2]);
+		int32_t *dH = M.H + newH * W;
+		uint8_t *tbrow = TB ? M.tb + tb_used - origin : 0;
+		const bool track_good = (((256 - (s_new & 255)) & 255) < P.nH);
+		unsigned long long *gword = M.good + (int64_t)newH * A.GW;
+		// ages of the LDS edge table to read: penalty s_new-E1 and s_new-E2
+		int32_t d1 = dnew - E1; if (d1 < 0) d1 += D;
+		int32_t d2 = dnew - E2; if (d2 < 0) d2 += D;
+
+		if (tid == 0) {
+			sh.rng_lo[newH] = lo, sh.rng_hi[newH] = hi;
+			const int32_t nn = npar + 1 == 3 ? 0 : npar + 1; // flags of the NEXT penalty (see mwf_kernels.hip)
+			sh.flags[nn][0] = sh.flags[nn][1] = sh.flags[nn][2] = sh.flags[nn][3] = 0;
+			if (TB) M.row_off[s_new - 1] = tb_used, M.row_lo[s_new - 1] = origin;
+			if (trace_band && s_new - 1 < A.dbg_cap) M.dbg[2 * (s_new - 1)] = lo, M.dbg[2 * (s_new - 1) + 1] = hi;
+		}
+
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			const int32_t r = wave + NW * k;
+			int32_t g = (gl & ~(NWK - 1)) + r;
+			if (g < gl) g += NWK;
+			const int32_t cb = g * kChunk;
+			int32_t ne1[4], nf1[4], ne2[4], nf2[4];
+			if (cb <= hi && cb + kChunk - 1 >= lo) { // this wave's chunk meets the window (uniform)
+				const int32_t c0 = cb + 4 * lane;
+				const int32_t hxv[4] = {phx[k].x, phx[k].y, phx[k].z, phx[k].w};
+				const int32_t a1v[4] = {po1[k].x, po1[k].y, po1[k].z, po1[k].w};
+				const int32_t a2v[4] = {po2[k].x, po2[k].y, po2[k].z, po2[k].w};
+				int32_t hx[4], o1[6], o2[6]; // o1[i+1] is column c0+i; o1[0], o1[5] the neighbours
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					const int32_t c = c0 + i;
+					hx[i] = (c >= xlo && c <= xhi) ? hxv[i] : kNegInf;
+					o1[i + 1] = (c >= alo && c <= ahi) ? a1v[i] : kNegInf;
+					o2[i + 1] = (c >= blo && c <= bhi) ? a2v[i] : kNegInf;
+				}
+				{
+					const int32_t ce = lane == 0 ? c0 - 1 : c0 + 4;
+					const int32_t v1 = (ce >= alo && ce <= ahi) ? pe1[k] : kNegInf;
+					const int32_t v2 = (ce >= blo && ce <= bhi) ? pe2[k] : kNegInf;
+					o1[0] = from_left(o1[4], v1), o1[5] = from_right(o1[1], v1);
+					o2[0] = from_left(o2[4], v2), o2[5] = from_right(o2[1], v2);
+				}
+				// gap-extension sources: E of column c-1, F of column c+1, e1 (e2) penalties ago
+				int32_t g1m[4], g1p[4], g2m[4], g2p[4];
+				{
+					const int32_t rl = (r + NWK - 1) & (NWK - 1), rr = (r + 1) & (NWK - 1);
+					const int32_t le1 = edge[d1][rl][0], le2 = edge[d2][rl][1], rf1 = edge[d1][rr][2], rf2 = edge[d2][rr][3];
+					g1m[0] = from_left(e1h[E1 - 1][k][3], le1);
+					g2m[0] = from_left(e2h[E2 - 1][k][3], le2);
+					g1p[3] = from_right(f1h[E1 - 1][k][0], rf1);
+					g2p[3] = from_right(f2h[E2 - 1][k][0], rf2);
+#pragma unroll
+					for (int i = 1; i < 4; ++i) g1m[i] = e1h[E1 - 1][k][i - 1], g2m[i] = e2h[E2 - 1][k][i - 1];
+#pragma unroll
+					for (int i = 0; i < 3; ++i) g1p[i] = f1h[E1 - 1][k][i + 1], g2p[i] = f2h[E2 - 1][k][i + 1];
+				}
+				int32_t hout[4];
+				uint32_t tbw = 0;
+				bool gbit[4];
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					const int32_t c = c0 + i, d = c - 1 - tl;
+					const bool act = c >= lo && c <= hi;
+					const Cell v = wf_cell(hx[i], o1[i], g1m[i], o2[i], g2m[i], o1[i + 2], g1p[i], o2[i + 2], g2p[i]);
+					ne1[i] = act ? v.e1 : kNegInf, nf1[i] = act ? v.f1 : kNegInf;
+					ne2[i] = act ? v.e2 : kNegInf, nf2[i] = act ? v.f2 : kNegInf;
+					gbit[i] = act && (in_matrix(d, v.h, tl, ql) || in_matrix(d, v.e1, tl, ql) || in_matrix(d, v.f1, tl, ql) ||
+					                  in_matrix(d, v.e2, tl, ql) || in_matrix(d, v.f2, tl, ql));
+					int32_t kk = v.h;
+					if (act) {
+						if (c == lo && v.h >= -1) sh.flags[npar][0] = 1; // edge rule, miniwfa.c:325-326
+						if (c == hi && v.h >= -1) sh.flags[npar][1] = 1;
+						if (in_matrix(d, kk, tl, ql)) {                  // extension sweep, miniwfa.c:400-411
+							kk = extend_cell<LSEQ>(M, lt, lq, kk, d);
+							if (kk == tl - 1 && d + kk == ql - 1) {
+								sh.flags[npar][2] = 1;
+								sh.flags[npar][3] = kk == v.h ? (int32_t)(v.tb & 7u) : 0;
+							}
+						}
+					}
+					hout[i] = kk;
+					tbw |= v.tb << (8 * i);
+				}
+				*(int4*)(dH + c0) = make_int4(hout[0], hout[1], hout[2], hout[3]);
+				if (TB && c0 >= origin && c0 <= hi) *(uint32_t*)(tbrow + c0) = tbw;
+				if (track_good) {
+#pragma unroll
+					for (int i = 0; i < 4; ++i) {
+						const unsigned long long m = __ballot(gbit[i]);
+						if (lane == 0) gword[g * 4 + i] = m;
+					}
+				}
+			} else {
+#pragma unroll
+				for (int i = 0; i < 4; ++i) ne1[i] = nf1[i] = ne2[i] = nf2[i] = kNegInf;
+			}
+			// publish this chunk's outer columns for the neighbouring waves, then age the registers
+			if (lane == 63) edge[dnew][r][0] = ne1[3], edge[dnew][r][1] = ne2[3];
+			if (lane == 0) edge[dnew][r][2] = nf1[0], edge[dnew][r][3] = nf2[0];
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+#pragma unroll
+				for (int a = E1 - 1; a > 0; --a) e1h[a][k][i] = e1h[a - 1][k][i], f1h[a][k][i] = f1h[a - 1][k][i];
+#pragma unroll
+				for (int a = E2 - 1; a > 0; --a) e2h[a][k][i] = e2h[a - 1][k][i], f2h[a][k][i] = f2h[a - 1][k][i];
+				e1h[0][k][i] = ne1[i], f1h[0][k][i] = nf1[i], e2h[0][k][i] = ne2[i], f2h[0][k][i] = nf2[i];
+			}
+		}
+
+		// ---- H rows of penalty s_new+1: its window is inside [lo-1, hi+1] whatever the flags say
+		const int32_t plo = lo > 1 ? lo - 1 : 1, phi = hi < cmax ? hi + 1 : cmax;
+		const int32_t gl_next = plo >> 8;
+		if ((phi >> 8) - gl_next + 1 > NWK - 1) { R.status = ST_BAND_OVERFLOW; break; }
+		const int32_t n_pref = prefetch(newH + 1 == P.nH ? 0 : newH + 1, plo, phi, gl_next);
+		// Everything older than those loads (this penalty's H/traceback stores included) must be complete before
+		// another wave may load it; the prefetch loads themselves (5 per chunk: three 16-byte rows + the two
+		// edge columns) stay in flight across the barrier.  vmcnt retires in issue order on gfx9-family parts.
+		if (n_pref == 2) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+		else if (n_pref == 1) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+		else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+		__builtin_amdgcn_s_barrier();
+		asm volatile("" ::: "memory");
+
+		// ---- bookkeeping, identical on every thread
+		if (uni(sh.flags[npar][0])) wf_lo = lo;
+		if (uni(sh.flags[npar][1])) wf_hi = hi;
+		const int32_t done = uni(sh.flags[npar][2]), payload = uni(sh.flags[npar][3]);
+		s = s_new, curH = newH, par = npar, dcur = dnew, gl = gl_next;
+		if (TB) tb_used += row_bytes;
+		if ((s & 0xff) == 0) { // shrink (reference wf_stripe_shrink, miniwfa.c:144-171) on the interleaved good bits
+			if (tid == 0) sh.red[0] = 0x7fffffff, sh.red[1] = -1;
+			__syncthreads();
+			const int32_t gfirst = wf_lo >> 8, n_words = ((wf_hi >> 8) - gfirst + 1) * 4;
+			for (int32_t q = tid; q < n_words; q += T) {
+				const int32_t gg = gfirst + (q >> 2), kq = q & 3, base = gg * kChunk;
+				unsigned long long m = 0;
+				for (int32_t j = 0; j < P.nH; ++j)
+					if (sh.rng_lo[j] <= sh.rng_hi[j] && sh.rng_lo[j] <= base + kChunk - 1 && sh.rng_hi[j] >= base) m |= M.good[(int64_t)j * A.GW + gg * 4 + kq];
+				m &= lane_mask(base, kq, wf_lo, wf_hi);
+				if (m) {
+					atomicMin(&sh.red[0], base + 4 * (int32_t)__builtin_ctzll(m) + kq);
+					atomicMax(&sh.red[1], base + 4 * (63 - (int32_t)__builtin_clzll(m)) + kq);
+				}
+			}
+			__syncthreads();
+			const int32_t glo = uni(sh.red[0]), ghi = uni(sh.red[1]);
+			if (ghi < 0) { R.status = ST_INTERNAL; break; }
+			wf_lo = glo, wf_hi = ghi;
+		}
+		cells += w;
+		if ((A.max_iter > 0 && cells > A.max_iter) || (A.max_s > 0 && s > A.max_s)) { // miniwfa.c:422-425
+			R.status = ST_STOPPED;
+			break;
+		}
+		if (done) {
+			R.info = payload;
+			break;
+		}
+	}
+	R.s = s, R.cells = cells;
+	return R;
+}
+
+template <int T, int E1, int E2, bool LSEQ>
+__global__ __launch_bounds__(T) void wfa_band_kernel(const BatchArgs A)
+{
+	constexpr int NWK = (T / 64) * kSlots, D = (E1 > E2 ? E1 : E2) + 1;
+	__shared__ Shared sh;
+	__shared__ int32_t edge[D][NWK][4];
+	for (;;) {
+		if (threadIdx.x == 0) sh.item = (int32_t)atomicAdd(A.queue, 1);
+		__syncthreads();
+		const int32_t item = uni(sh.item);
+		__syncthreads();
+		if (item >= A.n_pairs) break;
+		const int32_t pair = A.order ? A.order[item] : item;
+		PairMem M;
+		pair_mem(A, (int32_t)blockIdx.x, pair, M);
+		const uint8_t *lt = lds_dyn, *lq = lds_dyn;
+		if (LSEQ) { // both sequences into LDS, each starting on a dword
+			const int32_t qoff = ((M.tl + 3) & ~3) + 8;
+			lq = lds_dyn + qoff;
+			for (int32_t j = threadIdx.x; j < M.tl; j += T) lds_dyn[j] = M.ts[j];
+			for (int32_t j = threadIdx.x; j < M.ql; j += T) lds_dyn[qoff + j] = M.qs[j];
+			__syncthreads();
+		}
+		const bool trace = A.dbg && pair == A.debug_pair;
+		PassResult R;
+		if (A.want_cigar) R = band_pass<T, E1, E2, true, LSEQ>(A, M, sh, edge, lt, lq, 0, trace);
+		else R = band_pass<T, E1, E2, false, LSEQ>(A, M, sh, edge, lt, lq, 0, trace);
+		finish_pair(A, M, (int32_t)blockIdx.x, pair, R, R.status, 0);
+	}
+}
+
+template <int T, int E1, int E2>
+int launch_one(const BatchArgs &a, int grid, int lds, hipStream_t st)
+{
+	if (lds > 0) hipLaunchKernelGGL((wfa_band_kernel<T, E1, E2, true>), dim3(grid), dim3(T), lds, st, a);
+	else hipLaunchKernelGGL((wfa_band_kernel<T, E1, E2, false>), dim3(grid), dim3(T), 0, st, a);
+	return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+template <int T, int E1, int E2>
+int occ_one(int lds)
+{
+	int n = 0;
+	hipError_t e = lds > 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band_kernel<T, E1, E2, true>, T, lds)
+	                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band_kernel<T, E1, E2, false>, T, 0);
+	return e == hipSuccess ? n : 0;
+}
+
+} // namespace
+
+bool band_supported(const Penalty &p)
+{
+	const bool inst = (p.e1 == 2 && p.e2 == 1) || (p.e1 == 2 && p.e2 == 2);
+	// the prefetch reads H rows that are at least two penalties old
+	return inst && p.x >= 2 && p.oe1 >= 2 && p.oe2 >= 2;
+}
+
+#define MWF_BAND_DISPATCH(FN, ...)                                                    \
+	do {                                                                              \
+		if (g.block == 1024) {                                                        \
+			if (a_e1 == 2 && a_e2 == 1) return FN<1024, 2, 1>(__VA_ARGS__);           \
+			if (a_e1 == 2 && a_e2 == 2) return FN<1024, 2, 2>(__VA_ARGS__);           \
+		} else if (g.block == 256) {                                                  \
+			if (a_e1 == 2 && a_e2 == 1) return FN<256, 2, 1>(__VA_ARGS__);            \
+			if (a_e1 == 2 && a_e2 == 2) return FN<256, 2, 2>(__VA_ARGS__);            \
+		}                                                                             \
+	} while (0)
+
+int launch_band(const BatchArgs &a, int grid, const BandGeom &g, void *stream)
+{
+	const int a_e1 = a.pen.e1, a_e2 = a.pen.e2;
+	MWF_BAND_DISPATCH(launch_one, a, grid, g.lds_bytes, (hipStream_t)stream);
+	return -1;
+}
+
+int band_kernel_occupancy(const Penalty &p, const BandGeom &g, bool)
+{
+	const int a_e1 = p.e1, a_e2 = p.e2;
+	MWF_BAND_DISPATCH(occ_one, g.lds_bytes);
+	return 0;
+}
+
+} // namespace mwf

@@ -1,0 +1,255 @@
+// mwf_device.h — device-side helpers shared by the two alignment kernels
+// (mwf_kernels.hip: generic ring-in-HBM kernel; mwf_band.hip: register-resident band kernel).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mwf_internal.h"
+
+namespace mwf {
+namespace dev {
+
+struct Shared {
+	int32_t flags[3][4];   // per penalty (mod 3): new lo edge live, new hi edge live, end cell reached, payload
+	int32_t red[2];        // shrink: first / last good column
+	int32_t item;          // work item broadcast
+	int32_t word[4];       // scratch broadcast
+	int32_t rng_lo[kMaxRing], rng_hi[kMaxRing]; // column window of the slice held by each H slot
+};
+
+struct PassResult {
+	int32_t status;
+	int32_t s;          // final penalty
+	int32_t info;       // TB: last_state; SEG: provenance of the end cell
+	int32_t n_snap;     // SEG: snapshots taken
+	int64_t cells;      // cells computed (n_iter of the reference for the core pass)
+};
+
+__device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ uint64_t ld8(const uint8_t *p)
+{
+	uint64_t x;
+	__builtin_memcpy(&x, p, 8); // gfx950 global loads may be unaligned: one global_load_dwordx2
+	return x;
+}
+
+// k -> k + LCP(ts[k+1..], qs[d+k+1..]); the caller guarantees (k,d) is inside the DP matrix.
+__device__ __forceinline__ int32_t extend_run(const uint8_t *ts, const uint8_t *qs, int32_t tl, int32_t ql, int32_t k, int32_t d)
+{
+	const int32_t j = k + 1, i = d + j;
+	const int32_t room = min(tl - j, ql - i);
+	const uint8_t *pt = ts + j, *pq = qs + i;
+	int32_t n = 0;
+	while (n < room) {
+		const uint64_t x = ld8(pt + n) ^ ld8(pq + n);
+		if (x) { n += (int32_t)(__builtin_ctzll(x) >> 3); break; }
+		n += 8;
+	}
+	return k + min(n, room);
+}
+
+// offset k on diagonal d is a cell of the DP matrix (reference good_diag, miniwfa.c:139-142)
+__device__ __forceinline__ bool in_matrix(int32_t d, int32_t k, int32_t tl, int32_t ql)
+{
+	return (uint32_t)(k + 1) < (uint32_t)(tl + 1) && (uint32_t)(d + k + 1) < (uint32_t)(ql + 1);
+}
+
+struct Cell { int32_t h, e1, f1, e2, f2; uint32_t tb; };
+
+// The recurrence and its tie-breaking (miniwfa.c:267-278 values, :289-306 traceback byte):
+// gap states prefer "open" on ties; H prefers mismatch, then insertion piece 1, piece 2, deletion piece 1, piece 2.
+__device__ __forceinline__ Cell wf_cell(int32_t hx, int32_t o1m, int32_t g1m, int32_t o2m, int32_t g2m,
+                                        int32_t o1p, int32_t g1p, int32_t o2p, int32_t g2p)
+{
+	Cell c;
+	const bool xe1 = g1m > o1m, xe2 = g2m > o2m, xf1 = g1p > o1p, xf2 = g2p > o2p;
+	c.e1 = xe1 ? g1m : o1m;
+	c.e2 = xe2 ? g2m : o2m;
+	c.f1 = (xf1 ? g1p : o1p) + 1;
+	c.f2 = (xf2 ? g2p : o2p) + 1;
+	const bool e_first = c.e1 >= c.e2, f_first = c.f1 >= c.f2;
+	const int32_t e = e_first ? c.e1 : c.e2, f = f_first ? c.f1 : c.f2;
+	const bool ins = e >= f;
+	const int32_t g = ins ? e : f, m = hx + 1;
+	const bool mis = m >= g;
+	c.h = mis ? m : g;
+	const uint32_t z = mis ? 0u : (ins ? (e_first ? 1u : 3u) : (f_first ? 2u : 4u));
+	c.tb = z | (xe1 ? 0x08u : 0u) | (xf1 ? 0x10u : 0u) | (xe2 ? 0x20u : 0u) | (xf2 ? 0x40u : 0u);
+	return c;
+}
+
+// Provenance follows the choices recorded in the traceback byte (second loop of wf_next_seg, miniwfa.c:504-523).
+__device__ __forceinline__ Cell shadow_cell(uint32_t tb, int32_t hx, int32_t o1m, int32_t g1m, int32_t o2m, int32_t g2m,
+                                            int32_t o1p, int32_t g1p, int32_t o2p, int32_t g2p)
+{
+	Cell c;
+	c.e1 = (tb & 0x08u) ? g1m : o1m;
+	c.f1 = (tb & 0x10u) ? g1p : o1p;
+	c.e2 = (tb & 0x20u) ? g2m : o2m;
+	c.f2 = (tb & 0x40u) ? g2p : o2p;
+	const uint32_t z = tb & 7u;
+	c.h = z == 1 ? c.e1 : z == 2 ? c.f1 : z == 3 ? c.e2 : z == 4 ? c.f2 : hx;
+	c.tb = 0;
+	return c;
+}
+
+// A source slice: row pointer (column-indexed) and its window.
+struct Src {
+	const int32_t *p;
+	int32_t lo, hi;
+	__device__ __forceinline__ int32_t at(int32_t c) const { return p[c]; } // unchecked
+	__device__ __forceinline__ int32_t rd(int32_t c) const                  // window-checked
+	{
+		const int32_t v = p[c];
+		return (c >= lo && c <= hi) ? v : kNegInf;
+	}
+};
+
+// bits of the 64-column word starting at column w0 that fall inside [lo,hi]
+__device__ __forceinline__ unsigned long long window_mask(int32_t w0, int32_t lo, int32_t hi)
+{
+	if (hi < w0 || lo > w0 + 63 || lo > hi) return 0ull;
+	unsigned long long m = ~0ull;
+	if (lo > w0) m &= ~0ull << (lo - w0);
+	if (hi < w0 + 63) m &= ~0ull >> (w0 + 63 - hi);
+	return m;
+}
+
+// Everything a pass needs to know about the pair and this slot's memory.
+struct PairMem {
+	const uint8_t *ts, *qs;
+	int32_t tl, ql;
+	int32_t *H, *E1, *F1, *E2, *F2;       // ring rows (row r of array X at X + r*W), column-indexed
+	int32_t *sH, *sE1, *sF1, *sE2, *sF2;  // shadow ring (low-memory first pass)
+	unsigned long long *good;
+	uint8_t *tb;
+	int64_t *row_off;
+	int32_t *row_lo;
+	int32_t *snap, *snap_meta, *seg;
+	int32_t *dbg;
+};
+
+// Traceback on one wave (reference wf_traceback, miniwfa.c:329-377).  Ops are emitted from the end of
+// the alignment to its start, so writing them backwards from the end of the scratch buffer leaves the
+// CIGAR in input order.  Returns n_cigar (>= 0) or -1 when the scratch buffer is too small.
+static __device__ int32_t traceback_wave(const BatchArgs &A, const PairMem &M, uint32_t *scratch, int64_t cap,
+                                  int32_t s_final, int32_t last, int32_t *end_state)
+{
+	const Penalty &P = A.pen;
+	const int32_t lane = threadIdx.x & 63;
+	int32_t i = M.ql - 1, k = M.tl - 1, row = s_final - 1;
+	int64_t pos = cap;
+	int32_t run_op = -1, run_len = 0;
+	bool overflow = false;
+	auto push = [&](int32_t op, int32_t len) { // reference wf_cigar_push1, miniwfa.c:51-62
+		if (op == run_op) { run_len += len; return; }
+		if (run_op >= 0) {
+			if (pos == 0) { overflow = true; return; }
+			--pos;
+			if (lane == 0) scratch[pos] = (uint32_t)run_len << 4 | (uint32_t)run_op;
+		}
+		run_op = op, run_len = len;
+	};
+	while (i >= 0 && k >= 0 && !overflow) {
+		if (last == 0) { // greedy back-match, 64 bases per trip (miniwfa.c:335-341)
+			int32_t run = 0;
+			for (;;) {
+				const int32_t ii = i - run - lane, kk = k - run - lane;
+				const bool eq = ii >= 0 && kk >= 0 && M.qs[ii] == M.ts[kk];
+				const unsigned long long m = __ballot(eq);
+				const int32_t n = m == ~0ull ? 64 : (int32_t)__builtin_ctzll(~m);
+				run += n;
+				if (n < 64) break;
+			}
+			if (run > 0) push(7, run);
+			i -= run, k -= run;
+			if (i < 0 || k < 0) break;
+		}
+		if (row < 0) { overflow = true; break; }
+		const int32_t col = i - k + M.tl + 1;
+		const uint32_t x = M.tb[M.row_off[row] + (col - M.row_lo[row])];
+		const int32_t state = last == 0 ? (int32_t)(x & 7u) : last;           // :346
+		const int32_t ext = state > 0 ? (int32_t)(x >> (state + 2)) & 1 : 0;  // :347
+		if (state == 0) { push(8, 1); --i, --k; row -= P.x; }
+		else if (state == 1) { push(1, 1); --i; row -= ext ? P.e1 : P.oe1; }
+		else if (state == 3) { push(1, 1); --i; row -= ext ? P.e2 : P.oe2; }
+		else if (state == 2) { push(2, 1); --k; row -= ext ? P.e1 : P.oe1; }
+		else { push(2, 1); --k; row -= ext ? P.e2 : P.oe2; }
+		last = (state > 0 && ext) ? state : 0;                                // :365
+	}
+	end_state[0] = row, end_state[1] = i, end_state[2] = k;
+	if (i >= 0) push(1, i + 1);          // :368-369
+	else if (k >= 0) push(2, k + 1);
+	push(-2, 0);                         // flush the pending run
+	if (overflow) return -1;
+	return (int32_t)(cap - pos);
+}
+
+
+// Set up the per-slot memory views of one pair.
+__device__ __forceinline__ void pair_mem(const BatchArgs &A, int32_t slot, int32_t pair, PairMem &M)
+{
+	const Penalty &P = A.pen;
+	M.tl = A.tl[pair], M.ql = A.ql[pair];
+	M.ts = A.seqs + A.t_off[pair], M.qs = A.seqs + A.q_off[pair];
+	const int64_t W = A.W;
+	int32_t *ring = A.ring + (int64_t)slot * A.ring_slot_ints;
+	M.H = ring, M.E1 = M.H + P.nH * W, M.F1 = M.E1 + P.n1 * W, M.E2 = M.F1 + P.n1 * W, M.F2 = M.E2 + P.n2 * W;
+	M.sH = M.sE1 = M.sF1 = M.sE2 = M.sF2 = 0;
+	if (A.sring) {
+		int32_t *sr = A.sring + (int64_t)slot * A.ring_slot_ints;
+		M.sH = sr, M.sE1 = M.sH + P.nH * W, M.sF1 = M.sE1 + P.n1 * W, M.sE2 = M.sF1 + P.n1 * W, M.sF2 = M.sE2 + P.n2 * W;
+	}
+	M.good = A.good + (int64_t)slot * P.nH * A.GW;
+	M.tb = A.tb ? A.tb + (int64_t)slot * A.tb_slot_bytes : 0;
+	M.row_off = A.row_off ? A.row_off + (int64_t)slot * A.rows_slot : 0;
+	M.row_lo = A.row_lo ? A.row_lo + (int64_t)slot * A.rows_slot : 0;
+	M.snap = A.snap ? A.snap + (int64_t)slot * A.snap_slot_ints : 0;
+	M.snap_meta = A.snap_meta ? A.snap_meta + (int64_t)slot * A.snap_meta_slot : 0;
+	M.seg = A.seg ? A.seg + (int64_t)slot * 2 * A.seg_slot : 0;
+	M.dbg = A.dbg;
+}
+
+// After the forward pass(es): traceback on the first wave, CIGAR into the pool, per-pair outputs.
+__device__ __forceinline__ void finish_pair(const BatchArgs &A, const PairMem &M, int32_t slot, int32_t pair,
+                                            const PassResult &R, int32_t status, int64_t cells1)
+{
+	int32_t n_cigar = 0;
+	int64_t cig_off = 0;
+	if (A.want_cigar && status == ST_OK) {
+		__syncthreads();
+		if (threadIdx.x < 64) {
+			uint32_t *scratch = A.cig_scratch + (int64_t)slot * A.cig_scratch_slot;
+			int32_t end_state[3];
+			n_cigar = traceback_wave(A, M, scratch, A.cig_scratch_slot, R.s, R.info, end_state);
+			if (n_cigar < 0) status = ST_INTERNAL, n_cigar = 0;
+			else {
+				unsigned long long off = 0;
+				if (threadIdx.x == 0) off = atomicAdd(A.cig_head, (unsigned long long)n_cigar);
+				off = ((unsigned long long)(uint32_t)uni((int32_t)(off >> 32)) << 32) | (uint32_t)uni((int32_t)(off & 0xffffffffu));
+				if ((int64_t)off + n_cigar > A.cig_pool_words) status = ST_CIGAR_OVERFLOW, n_cigar = 0;
+				else {
+					cig_off = (int64_t)off;
+					const uint32_t *src = scratch + (A.cig_scratch_slot - n_cigar);
+					for (int32_t j = threadIdx.x; j < n_cigar; j += 64) A.cig_pool[off + j] = src[j];
+				}
+			}
+			if (threadIdx.x == 0 && A.out_dbg) {
+				A.out_dbg[4 * pair] = end_state[0], A.out_dbg[4 * pair + 1] = end_state[1];
+				A.out_dbg[4 * pair + 2] = end_state[2], A.out_dbg[4 * pair + 3] = R.info;
+			}
+		}
+	}
+	if (threadIdx.x == 0) {
+		A.out_s[pair] = (status == ST_OK) ? R.s : -1;
+		A.out_iter[pair] = R.cells;
+		A.out_ncig[pair] = n_cigar;
+		A.out_cigoff[pair] = cig_off;
+		A.out_cells1[pair] = cells1;
+		A.out_status[pair] = status;
+	}
+	__syncthreads();
+}
+
+} // namespace dev
+} // namespace mwf

@@ -68,6 +68,7 @@ struct mwf_gpu_batch_s {
 	const int64_t *d_t_off = nullptr, *d_q_off = nullptr;
 	const int32_t *d_tl = nullptr, *d_ql = nullptr;
 	std::vector<int32_t> h_tl, h_ql;
+	int64_t max_seq_lds = 0;   // LDS bytes the band kernel needs to hold the longest pair's sequences
 	int32_t *d_order = nullptr;
 	// outputs
 	int32_t *d_s = nullptr, *d_ncig = nullptr, *d_status = nullptr, *d_dbg4 = nullptr;
@@ -155,6 +156,8 @@ int64_t penalty_bound(const mwf_opt_t &o, int64_t tl, int64_t ql, bool honour_ma
 }
 
 struct Plan {
+	int kind = 0;              // 0: generic kernel, 2: band kernel
+	BandGeom band{0, 0, 0};
 	int block = 256, grid = 1;
 	int32_t W = 0, GW = 0;
 	int64_t ring_slot_ints = 0, rows_slot = 0, tb_slot_bytes = 0, cig_scratch_slot = 0;
@@ -163,16 +166,43 @@ struct Plan {
 };
 
 // Run the one-workgroup-per-pair kernel over `n_items` pairs given by d_order (device) on `slots` workgroups.
+// Which kernel serves a set of pairs.  The band kernel keeps E/F in registers and therefore only holds windows up to
+// its span; it has no low-memory first pass.  kind: -1 automatic, 0 generic, 2 band.
+void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, int64_t max_len, int64_t max_bound,
+                   int64_t max_seq_lds, int want_kind, Plan &pl)
+{
+	pl.kind = 0;
+	const bool low_mem = (opt.flag & MWF_F_CIGAR) && opt.step > 0;
+	if (want_kind == 0 || low_mem || !band_supported(P)) return;
+	const int64_t max_window = std::min<int64_t>(max_len + 1, 2 * max_bound + 3);
+	BandGeom bg;
+	bg.block = max_window <= 8 * 256 - 256 - 64 ? 256 : 1024;
+	if (g->block == 256 || g->block == 1024) bg.block = g->block;
+	bg.span = bg.block / 64 * 2 * 256;
+	if (want_kind != 2 && max_len + 1 > 3 * (int64_t)bg.span) return; // windows will mostly outgrow the span: go generic at once
+	const int64_t lds_cap = bg.block == 1024 ? 140 * 1024 : 36 * 1024;
+	bg.lds_bytes = max_seq_lds <= lds_cap ? (int)((max_seq_lds + 15) / 16 * 16) : 0;
+	pl.kind = 2, pl.band = bg;
+}
+
 int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const int32_t *d_order, int32_t n_items,
-                     int slots, int64_t max_len, int64_t max_bound, int64_t max_bound1, int64_t tb_total_budget, bool timed)
+                     int slots, int64_t max_len, int64_t max_bound, int64_t max_bound1, int64_t tb_total_budget, bool timed,
+                     int want_kind = -1)
 {
 	const Penalty P = make_penalty(opt);
 	Plan pl;
 	pl.cigar = (opt.flag & MWF_F_CIGAR) != 0;
 	pl.low_mem = pl.cigar && opt.step > 0;
 	pl.block = g->block > 0 ? g->block : 256;
+	choose_kernel(g, opt, P, max_len, max_bound, b->max_seq_lds, want_kind >= 0 ? want_kind : g->force_kind, pl);
+	if (pl.kind == 2) {
+		pl.block = pl.band.block;
+		int per_cu = g->slots_per_cu > 0 ? g->slots_per_cu : band_kernel_occupancy(P, pl.band, pl.cigar);
+		slots = std::max(1, std::min(slots, g->n_cu * std::max(1, per_cu)));
+	}
 	pl.grid = std::max(1, std::min<int>(slots, n_items));
-	pl.W = (int32_t)((max_len + 3 + 63) / 64 * 64);
+	// row stride: whole 256-column chunks plus room for the band kernel's neighbour loads past the last chunk
+	pl.W = (int32_t)((max_len + 3 + 255) / 256 * 256 + 512);
 	pl.GW = pl.W / 64 + 2;
 	pl.ring_slot_ints = (int64_t)(P.nH + 2 * P.n1 + 2 * P.n2) * pl.W;
 	const size_t S = (size_t)pl.grid;
@@ -191,7 +221,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 			const int64_t seg_worst = (max_bound + 1) * std::min<int64_t>(max_len + 1, 2 * (int64_t)(opt.step + 2 * P.nH) + 8);
 			per = std::min(per, seg_worst);
 		}
-		pl.tb_slot_bytes = std::max<int64_t>(4096, std::min(per, worst));
+		pl.tb_slot_bytes = std::max<int64_t>(4096, std::min(per, worst + 8 * (max_bound + 2))) / 4 * 4; // rows are padded to dwords
 		if (ensure(g, g->tb, S * (size_t)pl.tb_slot_bytes)) return -1;
 		if (ensure(g, g->row_off, S * (size_t)pl.rows_slot * 8)) return -1;
 		if (ensure(g, g->row_lo, S * (size_t)pl.rows_slot * 4)) return -1;
@@ -245,7 +275,8 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	HIP_TRY(g, hipMemsetAsync(g->queue.p, 0, 64, g->stream));
 	// HIP events bracket the kernel only: every workspace allocation above is already done
 	if (timed) HIP_TRY(g, hipEventRecord(g->ev0, g->stream));
-	if (launch_batch(a, pl.grid, pl.block, g->stream) != 0) {
+	const int lrc = pl.kind == 2 ? launch_band(a, pl.grid, pl.band, g->stream) : launch_batch(a, pl.grid, pl.block, g->stream);
+	if (lrc != 0) {
 		g->err = "kernel launch failed";
 		return -1;
 	}
@@ -254,7 +285,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 		g->ev_pending = true;
 	}
 	g->stats.n_launches += 1;
-	g->stats.grid = pl.grid, g->stats.block = pl.block, g->stats.kernel_kind = 0;
+	g->stats.grid = pl.grid, g->stats.block = pl.block, g->stats.kernel_kind = pl.kind;
 	return 0;
 }
 
@@ -356,7 +387,10 @@ static mwf_gpu_batch_t *batch_common(mwf_gpu_t *g, int32_t n, const int32_t *h_t
 	b->h_ql.assign(h_ql, h_ql + n);
 	const size_t N = (size_t)std::max(n, 1);
 	int64_t words = 0;
-	for (int32_t i = 0; i < n; ++i) words += (int64_t)h_tl[i] + h_ql[i] + 1;
+	for (int32_t i = 0; i < n; ++i) {
+		words += (int64_t)h_tl[i] + h_ql[i] + 1;
+		b->max_seq_lds = std::max<int64_t>(b->max_seq_lds, (((int64_t)h_tl[i] + 3) & ~3LL) + 8 + (((int64_t)h_ql[i] + 3) & ~3LL) + 16);
+	}
 	b->cig_pool_words = std::max<int64_t>(words, 1);
 	bool ok = hipMalloc(&b->d_s, N * 4) == hipSuccess && hipMalloc(&b->d_ncig, N * 4) == hipSuccess &&
 	          hipMalloc(&b->d_status, N * 4) == hipSuccess && hipMalloc(&b->d_dbg4, N * 16) == hipSuccess &&
@@ -497,25 +531,28 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 		return 0;
 	};
 	if (fetch()) return -1;
-	int slots = g->stats.grid;
-	for (int round = 0; round < 12; ++round) {
+	int slots = g->stats.grid, redo_kind = g->stats.kernel_kind == 2 ? 2 : 0;
+	for (int round = 0; round < 14; ++round) {
 		std::vector<int32_t> redo;
+		bool band_overflow = false;
 		for (size_t i = 0; i < n; ++i) {
 			const int32_t st = b->h_status[i];
-			if (st == ST_TB_OVERFLOW || st == ST_SNAP_OVERFLOW) redo.push_back((int32_t)i);
+			if (st == ST_BAND_OVERFLOW) band_overflow = true, redo.push_back((int32_t)i);
+			else if (st == ST_TB_OVERFLOW || st == ST_SNAP_OVERFLOW) redo.push_back((int32_t)i);
 			else if (st != ST_OK && st != ST_STOPPED) {
 				g->err = "pair " + std::to_string(i) + " failed on the device with status " + std::to_string(st);
 				return -3;
 			}
 		}
 		if (redo.empty()) break;
-		if (slots == 1) {
+		if (band_overflow) redo_kind = 0; // the window outgrew the register-resident span: generic kernel, same slots
+		else if (slots == 1) {
 			g->err = std::string(b->h_status[redo[0]] == ST_TB_OVERFLOW ? "traceback" : "low-memory snapshots") + " of pair " + std::to_string(redo[0]) +
 			         " (tl=" + std::to_string(b->h_tl[redo[0]]) + ", ql=" + std::to_string(b->h_ql[redo[0]]) + ") do not fit in device memory" +
 			         (b->opt.step > 0 ? "" : "; set opt.step > 0 (low-memory mode)");
 			return -4;
 		}
-		slots = std::max(1, std::min<int>(slots / 8, (int)redo.size()));
+		if (!band_overflow) slots = std::max(1, std::min<int>(slots / 8, (int)redo.size()));
 		std::stable_sort(redo.begin(), redo.end(), [&](int32_t x, int32_t y) {
 			return (int64_t)b->h_tl[x] + b->h_ql[x] > (int64_t)b->h_tl[y] + b->h_ql[y];
 		});
@@ -529,7 +566,7 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 		HIP_TRY(g, hipMalloc(&d_redo, redo.size() * 4));
 		HIP_TRY(g, hipMemcpy(d_redo, redo.data(), redo.size() * 4, hipMemcpyHostToDevice));
 		g->stats.n_retries += (int32_t)redo.size();
-		const int rc = run_batch_kernel(g, b, b->opt, d_redo, (int32_t)redo.size(), slots, max_len, max_bound, max_bound1, tb_budget_bytes(g), false);
+		const int rc = run_batch_kernel(g, b, b->opt, d_redo, (int32_t)redo.size(), slots, max_len, max_bound, max_bound1, tb_budget_bytes(g), false, redo_kind);
 		if (rc == 0 && fetch()) { (void)hipFree(d_redo); return -1; }
 		(void)hipFree(d_redo);
 		if (rc) return -1;

@@ -17,7 +17,8 @@ enum : int32_t {
 	ST_CIGAR_OVERFLOW = 4, // CIGAR pool exhausted: host grows it and re-runs
 	ST_SNAP_OVERFLOW = 5,  // low-memory snapshot arena too small
 	ST_INTERNAL = 6,       // an invariant the reference asserts on failed
-	ST_PENDING = 7         // not produced yet
+	ST_PENDING = 7,        // not produced yet
+	ST_BAND_OVERFLOW = 8   // band kernel: window outgrew the register-resident span; host re-runs on the generic kernel
 };
 
 // Penalties in the form the recurrence uses them (reference miniwfa.c:252-256): lags into the ring.
@@ -85,8 +86,18 @@ struct BatchArgs {
 	int32_t dbg_cap;
 };
 
-// launch wrappers implemented in mwf_kernels.hip
+// launch wrappers implemented in mwf_kernels.hip (generic kernel: any penalties, any band, low-memory mode)
 int launch_batch(const BatchArgs &a, int grid, int block, void *stream);
 int batch_kernel_occupancy(int block);   // resident workgroups per CU for that block size
+
+// launch wrappers implemented in mwf_band.hip (band kernel: E/F wavefronts live in registers)
+struct BandGeom {
+	int block;        // threads per workgroup (256 or 1024)
+	int span;         // columns the workgroup can hold: (block/64) * 2 * 256
+	int lds_bytes;    // dynamic LDS for the sequence copy (0: read sequences from global memory)
+};
+bool band_supported(const Penalty &p);                       // (e1,e2) instantiated and every H lag >= 2
+int  launch_band(const BatchArgs &a, int grid, const BandGeom &g, void *stream);
+int  band_kernel_occupancy(const Penalty &p, const BandGeom &g, bool cigar);
 
 } // namespace mwf

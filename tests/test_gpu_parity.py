@@ -129,7 +129,9 @@ def test_ragged_batch_against_oracle(engine, oracle):
 
 @pytest.mark.parametrize("block", [64, 128, 256, 512, 1024])
 def test_every_block_size_gives_identical_results(block, oracle):
+    """Generic kernel (ring in HBM), every workgroup size."""
     eng = mw.Engine(0)
+    eng.set("force_kind", 0)
     eng.set("block", block)
     pairs = [synth_pair(82000 + i, 1500, 0.08) for i in range(12)]
     for o in (make_opt(), make_opt(flag=1), make_opt(flag=1, step=50)):
@@ -142,6 +144,54 @@ def test_every_block_size_gives_identical_results(block, oracle):
             if ecig is not None:
                 assert b.cigar(i, int(nc[i])).tolist() == ecig
         b.free()
+    eng.close()
+
+
+@pytest.mark.parametrize("block", [256, 1024])
+def test_band_kernel_against_oracle(block, oracle):
+    """Register-resident band kernel forced on, both geometries: ragged sizes, both penalty sets it is instantiated
+    for, score and CIGAR.  Pairs whose window outgrows the span (block 256 holds < 1800 columns) must come back
+    through the generic kernel with identical results."""
+    eng = mw.Engine(0)
+    eng.set("force_kind", 2)
+    eng.set("block", block)
+    pairs = [synth_pair(86000 + i, (3, 60, 500, 1800, 3000, 5000)[i % 6], (0.0, 0.02, 0.1, 0.3)[i % 4]) for i in range(48)]
+    pairs += [(b"", b"ACGT"), (b"ACGT", b""), (b"GATTACA", b"GATTACA"), (b"A" * 3000, b"A" * 3000), (b"A" * 900, b"C" * 800)]
+    for o in (make_opt(), make_opt(flag=1), make_opt(flag=1, o2=4, e2=2), make_opt(flag=0, x=6, o1=2, e1=2, o2=20, e2=1)):
+        go = mw.opt_init(**{k: getattr(o, k) for k in OPT_KEYS})
+        b = eng.upload(PackedBatch(pairs))
+        b.align(go)
+        assert eng.stats().kernel_kind == 2
+        s, it, nc = b.results()
+        for i, (t, q) in enumerate(pairs):
+            es, eit, ecig = oracle.align(t, q, o)
+            why = explain_band(t, q, go, oracle) if (s[i], it[i]) != (es, eit) else ""
+            assert (s[i], it[i]) == (es, eit), (block, i, len(t), len(q), o.flag, o.o2, why)
+            if ecig is not None:
+                assert b.cigar(i, int(nc[i])).tolist() == ecig, (block, i)
+        if block == 256:
+            assert eng.stats().n_retries > 0   # the 3000/5000 bp pairs at 30 % do not fit 2048 columns
+        b.free()
+    eng.close()
+
+
+def test_band_kernel_stop_rules_and_shrink(oracle):
+    """Long enough for several shrinks (every 256 penalties) plus the max_s / max_iter exits, band kernel forced."""
+    eng = mw.Engine(0)
+    eng.set("force_kind", 2)
+    t, q = synth_pair(87000, 4000, 0.12)
+    full = oracle.align(t, q, make_opt())
+    assert full[0] > 1000
+    for kw in (dict(), dict(max_s=full[0] - 1), dict(max_s=full[0]), dict(max_iter=full[1] - 1), dict(max_iter=full[1]), dict(max_s=700)):
+        for flag in (0, 1):
+            b = eng.upload(PackedBatch([(t, q)]))
+            b.align(mw.opt_init(flag=flag, **kw))
+            s, it, nc = b.results()
+            es, eit, ecig = oracle.align(t, q, make_opt(flag=flag, **kw))
+            assert (int(s[0]), int(it[0])) == (es, eit), (kw, flag)
+            if ecig is not None:
+                assert b.cigar(0, int(nc[0])).tolist() == ecig
+            b.free()
     eng.close()
 
 
