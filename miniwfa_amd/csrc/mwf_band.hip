@@ -35,7 +35,6 @@ namespace {
 
 extern __shared__ __attribute__((aligned(16))) uint8_t lds_dyn[];
 
-constexpr int kSlots = 2;      // 256-column chunks per wave
 constexpr int kChunk = 256;
 
 // lane i <- lane i-1 (lane 0 keeps `fill`); lane i <- lane i+1 (lane 63 keeps `fill`).  All 64 lanes must be active.
@@ -64,6 +63,17 @@ __device__ __forceinline__ int32_t extend_cell(const PairMem &M, const uint8_t *
 	return k + min(n, room);
 }
 
+// four sequence bytes at t[j..] and q[i..] XORed (0 bits = equal bytes)
+template <bool LSEQ>
+__device__ __forceinline__ uint32_t probe4(const PairMem &M, const uint8_t *lt, const uint8_t *lq, int32_t j, int32_t i)
+{
+	if (LSEQ) return lds_ld4(lt, j) ^ lds_ld4(lq, i);
+	uint32_t a, b;
+	__builtin_memcpy(&a, M.ts + j, 4);
+	__builtin_memcpy(&b, M.qs + i, 4);
+	return a ^ b;
+}
+
 // lanes l of interleaved word k (column = base + 4*l + k) whose column lies in [a,b]
 __device__ __forceinline__ unsigned long long lane_mask(int32_t base, int32_t k, int32_t a, int32_t b)
 {
@@ -75,17 +85,30 @@ __device__ __forceinline__ unsigned long long lane_mask(int32_t base, int32_t k,
 	return (~0ull >> (63 - lmax)) & (~0ull << lmin);
 }
 
-template <int T, int E1, int E2, bool TB, bool LSEQ>
+__device__ __forceinline__ int32_t pick4(int32_t i, int32_t a0, int32_t a1, int32_t a2, int32_t a3)
+{
+	return i == 0 ? a0 : i == 1 ? a1 : i == 2 ? a2 : a3;
+}
+
+// in_matrix() without short-circuit control flow
+__device__ __forceinline__ uint32_t inm_bit(int32_t d, int32_t k, int32_t tl, int32_t ql)
+{
+	return (uint32_t)((uint32_t)(k + 1) < (uint32_t)(tl + 1)) & (uint32_t)((uint32_t)(d + k + 1) < (uint32_t)(ql + 1));
+}
+
+template <int T, int K, int E1, int E2, bool TB, bool LSEQ>
 __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh,
-                                int32_t (*edge)[(T / 64) * kSlots][4], const uint8_t *lt, const uint8_t *lq,
+                                int32_t (*edge)[(T / 64) * K][4], const uint8_t *lt, const uint8_t *lq,
                                 int32_t n_seg, bool trace_band)
 {
-	constexpr int K = kSlots, NW = T / 64, NWK = NW * K, D = (E1 > E2 ? E1 : E2) + 1;
-	static_assert((NWK & (NWK - 1)) == 0, "chunk table size must be a power of two");
-	const Penalty &P = A.pen;
+	constexpr int NW = T / 64, NWK = NW * K, D = (E1 > E2 ? E1 : E2) + 1;
 	const int32_t tl = M.tl, ql = M.ql, cmax = tl + ql + 1;
 	const int32_t tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
-	const int64_t W = A.W;
+	const int32_t W = A.W, nH = A.pen.nH, lagx = A.pen.x, lag1 = A.pen.oe1, lag2 = A.pen.oe2;
+	int32_t *const H = M.H; // every H access below is H[row * W + column] with a 32-bit index (band kernel rows are short)
+	// H rows written at penalty s are loaded again, at the earliest, by the prefetch issued at the start of penalty
+	// s + lag - 1.  With every lag >= 3 the stores of a penalty may therefore stay in flight across its barrier.
+	const bool relaxed_stores = min(lagx, min(lag1, lag2)) >= 3;
 	PassResult R;
 	R.status = ST_OK, R.s = 0, R.info = 0, R.n_snap = 0, R.cells = 0;
 
@@ -102,17 +125,15 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 		}
 	int4 phx[K], po1[K], po2[K];   // prefetched H rows of the next penalty: lags x, o1+e1, o2+e2
 	int32_t pe1[K], pe2[K];        // lane 0: column to the left of the chunk, lane 63: column to its right
-#pragma unroll
-	for (int k = 0; k < K; ++k) phx[k] = po1[k] = po2[k] = make_int4(0, 0, 0, 0), pe1[k] = pe2[k] = 0;
 
 	// ---- penalty 0 (reference wf_stripe_init, miniwfa.c:103-121) and its extension
 	for (int32_t j = tid; j < D * NWK * 4; j += T) (&edge[0][0][0])[j] = kNegInf;
 	if (tid == 0) {
-		for (int32_t j = 0; j < P.nH; ++j) sh.rng_lo[j] = 1, sh.rng_hi[j] = 0;
+		for (int32_t j = 0; j < nH; ++j) sh.rng_lo[j] = 1, sh.rng_hi[j] = 0;
 		for (int32_t j = 0; j < 12; ++j) (&sh.flags[0][0])[j] = 0;
 		const int32_t c0 = tl + 1;
 		const int32_t k0 = extend_cell<LSEQ>(M, lt, lq, -1, 0);
-		M.H[c0] = k0;
+		H[c0] = k0;
 		sh.rng_lo[0] = sh.rng_hi[0] = c0;
 		sh.word[1] = k0;
 	}
@@ -125,39 +146,29 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 	int32_t s = 0, wf_lo = tl + 1, wf_hi = tl + 1;
 	int32_t curH = 0, par = 0, sid = 0, dcur = 0;
 	int64_t cells = 0, tb_used = 0;
-	int32_t gl = 0; // lowest chunk of the mapping the prefetched registers were loaded under
 
-	// issue the H loads of the penalty whose ring slot is `slotH`, for every chunk of [plo,phi]
-	auto prefetch = [&](int32_t slotH, int32_t plo, int32_t phi, int32_t g_lo) -> int32_t {
-		int32_t n_chunks = 0;
-		int32_t jx = slotH - P.x;   if (jx < 0) jx += P.nH;
-		int32_t j1 = slotH - P.oe1; if (j1 < 0) j1 += P.nH;
-		int32_t j2 = slotH - P.oe2; if (j2 < 0) j2 += P.nH;
-		const int32_t *rx = M.H + jx * W, *r1 = M.H + j1 * W, *r2 = M.H + j2 * W;
-		const int32_t g_hi = phi >> 8;
-#pragma unroll
-		for (int k = 0; k < K; ++k) {
-			const int32_t r = wave + NW * k;
-			int32_t g = (g_lo & ~(NWK - 1)) + r;
-			if (g < g_lo) g += NWK;
-			if (g <= g_hi) { // uniform per wave
-				++n_chunks;
-				const int32_t c0 = g * kChunk + 4 * lane;
-				phx[k] = *(const int4*)(rx + c0);
-				po1[k] = *(const int4*)(r1 + c0);
-				po2[k] = *(const int4*)(r2 + c0);
-				if (lane == 0 || lane == 63) {
-					const int32_t ce = lane == 0 ? max(c0 - 1, 0) : c0 + 4; // column 0 is a pad no window contains
-					pe1[k] = r1[ce], pe2[k] = r2[ce];
-				}
-			}
-		}
-		return n_chunks;
+	// Loads of the three H rows penalty `slotH` reads, for this wave's chunk of slot k under the mapping that starts at
+	// chunk g_lo.  ALWAYS exactly five loads: a chunk beyond column phi loads columns 0..3 instead, so that the
+	// s_waitcnt before the barrier can use a fixed count.
+	auto prefetch = [&](int k, int32_t slotH, int32_t phi, int32_t g_lo) {
+		int32_t jx = slotH - lagx; if (jx < 0) jx += nH;
+		int32_t j1 = slotH - lag1; if (j1 < 0) j1 += nH;
+		int32_t j2 = slotH - lag2; if (j2 < 0) j2 += nH;
+		int32_t g = g_lo - g_lo % NWK + wave + NW * k;
+		if (g < g_lo) g += NWK;
+		const int32_t c0 = g * kChunk <= phi ? g * kChunk + 4 * lane : 0;
+		phx[k] = *(const int4*)(H + (jx * W + c0));
+		po1[k] = *(const int4*)(H + (j1 * W + c0));
+		po2[k] = *(const int4*)(H + (j2 * W + c0));
+		const int32_t ce = lane == 0 ? max(c0 - 1, 0) : c0 + 4; // only lanes 0 and 63 use it; column 0 is a pad
+		pe1[k] = H[j1 * W + ce], pe2[k] = H[j2 * W + ce];
 	};
+	int32_t gl; // lowest chunk of the mapping the prefetched registers were loaded under
 	{
 		const int32_t lo1 = wf_lo > 1 ? wf_lo - 1 : 1, hi1 = wf_hi < cmax ? wf_hi + 1 : cmax;
 		gl = lo1 >> 8;
-		(void)prefetch(P.nH > 1 ? 1 : 0, lo1, hi1, gl);
+#pragma unroll
+		for (int k = 0; k < K; ++k) prefetch(k, 1, hi1, gl);
 	}
 
 	for (;;) {
@@ -171,9 +182,8 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 		}
 		const int32_t lo = wf_lo > 1 ? wf_lo - 1 : 1;       // miniwfa.c:417-418
 		const int32_t hi = wf_hi < cmax ? wf_hi + 1 : cmax;
-		const int32_t w = hi - lo + 1;
 		const int32_t s_new = s + 1;
-		const int32_t newH = curH + 1 == P.nH ? 0 : curH + 1;
+		const int32_t newH = curH + 1 == nH ? 0 : curH + 1;
 		const int32_t npar = par + 1 == 3 ? 0 : par + 1;
 		const int32_t dnew = dcur + 1 == D ? 0 : dcur + 1;
 		const int32_t origin = lo & ~3;
@@ -182,17 +192,21 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 			if (s_new - 1 >= A.rows_slot) { R.status = ST_ROWS_OVERFLOW; break; }
 			if (tb_used + row_bytes > A.tb_slot_bytes) { R.status = ST_TB_OVERFLOW; break; }
 		}
+		// the window of penalty s_new+1 lies inside [lo-1, hi+1] whatever the flags say; it must fit the register span
+		const int32_t plo = lo > 1 ? lo - 1 : 1, phi = hi < cmax ? hi + 1 : cmax;
+		const int32_t gl_next = plo >> 8;
+		if ((phi >> 8) - gl_next + 1 > NWK - 1) { R.status = ST_BAND_OVERFLOW; break; }
+		const int32_t nextH = newH + 1 == nH ? 0 : newH + 1;
 		// windows of the three H source slices (reference wf_next_prep, miniwfa.c:252-254)
-		int32_t jx = newH - P.x;   if (jx < 0) jx += P.nH;
-		int32_t j1 = newH - P.oe1; if (j1 < 0) j1 += P.nH;
-		int32_t j2 = newH - P.oe2; if (j2 < 0) j2 += P.nH;
+		int32_t jx = newH - lagx; if (jx < 0) jx += nH;
+		int32_t j1 = newH - lag1; if (j1 < 0) j1 += nH;
+		int32_t j2 = newH - lag2; if (j2 < 0) j2 += nH;
 		const int32_t xlo = uni(sh.rng_lo[jx]), xhi = uni(sh.rng_hi[jx]);
 		const int32_t alo = uni(sh.rng_lo[j1]), ahi = uni(sh.rng_hi[j1]);
 		const int32_t blo = uni(sh.rng_lo[j2]), bhi = uni(sh.rng_hi[j2]);
-		int32_t *dH = M.H + newH * W;
-		uint8_t *tbrow = TB ? M.tb + tb_used - origin : 0;
-		const bool track_good = (((256 - (s_new & 255)) & 255) < P.nH);
-		unsigned long long *gword = M.good + (int64_t)newH * A.GW;
+		// columns whose every H read (c and c+-1) falls inside its source window and that are inside [lo,hi]
+		const int32_t ilo = max(max(lo, xlo), max(alo, blo) + 1), ihi = min(min(hi, xhi), min(ahi, bhi) - 1);
+		const bool track_good = (((256 - (s_new & 255)) & 255) < nH);
 		// ages of the LDS edge table to read: penalty s_new-E1 and s_new-E2
 		int32_t d1 = dnew - E1; if (d1 < 0) d1 += D;
 		int32_t d2 = dnew - E2; if (d2 < 0) d2 += D;
@@ -205,37 +219,42 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 			if (trace_band && s_new - 1 < A.dbg_cap) M.dbg[2 * (s_new - 1)] = lo, M.dbg[2 * (s_new - 1) + 1] = hi;
 		}
 
+		const int32_t gbase = gl - gl % NWK;
 #pragma unroll
 		for (int k = 0; k < K; ++k) {
 			const int32_t r = wave + NW * k;
-			int32_t g = (gl & ~(NWK - 1)) + r;
+			int32_t g = gbase + r;
 			if (g < gl) g += NWK;
 			const int32_t cb = g * kChunk;
+			const bool active = cb <= hi && cb + kChunk - 1 >= lo; // this wave's chunk meets the window (uniform)
 			int32_t ne1[4], nf1[4], ne2[4], nf2[4];
-			if (cb <= hi && cb + kChunk - 1 >= lo) { // this wave's chunk meets the window (uniform)
+			if (active) {
 				const int32_t c0 = cb + 4 * lane;
-				const int32_t hxv[4] = {phx[k].x, phx[k].y, phx[k].z, phx[k].w};
-				const int32_t a1v[4] = {po1[k].x, po1[k].y, po1[k].z, po1[k].w};
-				const int32_t a2v[4] = {po2[k].x, po2[k].y, po2[k].z, po2[k].w};
-				int32_t hx[4], o1[6], o2[6]; // o1[i+1] is column c0+i; o1[0], o1[5] the neighbours
+				const bool inner = cb >= ilo && cb + kChunk - 1 <= ihi; // uniform: no window test needed anywhere
+				int32_t hx[4] = {phx[k].x, phx[k].y, phx[k].z, phx[k].w};
+				int32_t o1[6], o2[6]; // o1[i+1] is column c0+i; o1[0], o1[5] the neighbours
+				o1[1] = po1[k].x, o1[2] = po1[k].y, o1[3] = po1[k].z, o1[4] = po1[k].w;
+				o2[1] = po2[k].x, o2[2] = po2[k].y, o2[3] = po2[k].z, o2[4] = po2[k].w;
+				int32_t v1 = pe1[k], v2 = pe2[k];
+				prefetch(k, nextH, phi, gl_next); // the registers just read are free: refill them for penalty s_new+1 now
+				if (!inner) {
 #pragma unroll
-				for (int i = 0; i < 4; ++i) {
-					const int32_t c = c0 + i;
-					hx[i] = (c >= xlo && c <= xhi) ? hxv[i] : kNegInf;
-					o1[i + 1] = (c >= alo && c <= ahi) ? a1v[i] : kNegInf;
-					o2[i + 1] = (c >= blo && c <= bhi) ? a2v[i] : kNegInf;
-				}
-				{
+					for (int i = 0; i < 4; ++i) {
+						const int32_t c = c0 + i;
+						hx[i] = (c >= xlo) & (c <= xhi) ? hx[i] : kNegInf;
+						o1[i + 1] = (c >= alo) & (c <= ahi) ? o1[i + 1] : kNegInf;
+						o2[i + 1] = (c >= blo) & (c <= bhi) ? o2[i + 1] : kNegInf;
+					}
 					const int32_t ce = lane == 0 ? c0 - 1 : c0 + 4;
-					const int32_t v1 = (ce >= alo && ce <= ahi) ? pe1[k] : kNegInf;
-					const int32_t v2 = (ce >= blo && ce <= bhi) ? pe2[k] : kNegInf;
-					o1[0] = from_left(o1[4], v1), o1[5] = from_right(o1[1], v1);
-					o2[0] = from_left(o2[4], v2), o2[5] = from_right(o2[1], v2);
+					v1 = (ce >= alo) & (ce <= ahi) ? v1 : kNegInf;
+					v2 = (ce >= blo) & (ce <= bhi) ? v2 : kNegInf;
 				}
+				o1[0] = from_left(o1[4], v1), o1[5] = from_right(o1[1], v1);
+				o2[0] = from_left(o2[4], v2), o2[5] = from_right(o2[1], v2);
 				// gap-extension sources: E of column c-1, F of column c+1, e1 (e2) penalties ago
 				int32_t g1m[4], g1p[4], g2m[4], g2p[4];
 				{
-					const int32_t rl = (r + NWK - 1) & (NWK - 1), rr = (r + 1) & (NWK - 1);
+					const int32_t rl = r == 0 ? NWK - 1 : r - 1, rr = r + 1 == NWK ? 0 : r + 1;
 					const int32_t le1 = edge[d1][rl][0], le2 = edge[d2][rl][1], rf1 = edge[d1][rr][2], rf2 = edge[d2][rr][3];
 					g1m[0] = from_left(e1h[E1 - 1][k][3], le1);
 					g2m[0] = from_left(e2h[E2 - 1][k][3], le2);
@@ -246,43 +265,75 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 #pragma unroll
 					for (int i = 0; i < 3; ++i) g1p[i] = f1h[E1 - 1][k][i + 1], g2p[i] = f2h[E2 - 1][k][i + 1];
 				}
-				int32_t hout[4];
-				uint32_t tbw = 0;
-				bool gbit[4];
+				// ---- the recurrence, then the first 4-byte probe of the match extension, branch-free for all 4 columns
+				int32_t hv[4], room[4], nmat[4];
+				uint32_t tbw = 0, pend = 0, live = 0, fin = 0, gbits = 0;
 #pragma unroll
 				for (int i = 0; i < 4; ++i) {
 					const int32_t c = c0 + i, d = c - 1 - tl;
-					const bool act = c >= lo && c <= hi;
-					const Cell v = wf_cell(hx[i], o1[i], g1m[i], o2[i], g2m[i], o1[i + 2], g1p[i], o2[i + 2], g2p[i]);
+					const uint32_t act = inner ? 1u : (uint32_t)((c >= lo) & (c <= hi));
+					const Cell v = wf_cell<TB>(hx[i], o1[i], g1m[i], o2[i], g2m[i], o1[i + 2], g1p[i], o2[i + 2], g2p[i]);
 					ne1[i] = act ? v.e1 : kNegInf, nf1[i] = act ? v.f1 : kNegInf;
 					ne2[i] = act ? v.e2 : kNegInf, nf2[i] = act ? v.f2 : kNegInf;
-					gbit[i] = act && (in_matrix(d, v.h, tl, ql) || in_matrix(d, v.e1, tl, ql) || in_matrix(d, v.f1, tl, ql) ||
-					                  in_matrix(d, v.e2, tl, ql) || in_matrix(d, v.f2, tl, ql));
-					int32_t kk = v.h;
-					if (act) {
-						if (c == lo && v.h >= -1) sh.flags[npar][0] = 1; // edge rule, miniwfa.c:325-326
-						if (c == hi && v.h >= -1) sh.flags[npar][1] = 1;
-						if (in_matrix(d, kk, tl, ql)) {                  // extension sweep, miniwfa.c:400-411
-							kk = extend_cell<LSEQ>(M, lt, lq, kk, d);
-							if (kk == tl - 1 && d + kk == ql - 1) {
-								sh.flags[npar][2] = 1;
-								sh.flags[npar][3] = kk == v.h ? (int32_t)(v.tb & 7u) : 0;
-							}
-						}
-					}
-					hout[i] = kk;
+					const uint32_t inm = act & inm_bit(d, v.h, tl, ql);
+					if (track_good) // uniform
+						gbits |= (act & (inm | inm_bit(d, v.e1, tl, ql) | inm_bit(d, v.f1, tl, ql) | inm_bit(d, v.e2, tl, ql) | inm_bit(d, v.f2, tl, ql))) << i;
+					// edge rule (miniwfa.c:325-326): H is the max of the five, so "any live" == "H live"
+					const uint32_t lv = act & (uint32_t)(v.h >= -1);
+					live |= (lv & (uint32_t)(c == lo)) | ((lv & (uint32_t)(c == hi)) << 1);
+					const int32_t j = inm ? v.h + 1 : 0, q = inm ? d + v.h + 1 : 0;
+					room[i] = inm ? min(tl - j, ql - q) : 0;
+					const uint32_t x = probe4<LSEQ>(M, lt, lq, j, q);
+					nmat[i] = min(x ? (int32_t)(__builtin_ctz(x) >> 3) : 4, room[i]);
+					pend |= ((uint32_t)(x == 0) & (uint32_t)(room[i] > 4)) << i;
+					hv[i] = v.h;
 					tbw |= v.tb << (8 * i);
 				}
-				*(int4*)(dH + c0) = make_int4(hout[0], hout[1], hout[2], hout[3]);
-				if (TB && c0 >= origin && c0 <= hi) *(uint32_t*)(tbrow + c0) = tbw;
-				if (track_good) {
+				if (__ballot(pend != 0)) { // rare: a run of >= 4 matches continues; one shared loop for the four columns
+					while (pend) {
+						const int32_t ii = __builtin_ctz(pend);
+						const int32_t hh = pick4(ii, hv[0], hv[1], hv[2], hv[3]);
+						const int32_t rm = pick4(ii, room[0], room[1], room[2], room[3]);
+						int32_t n = pick4(ii, nmat[0], nmat[1], nmat[2], nmat[3]);
+						const int32_t j = hh + 1, q = c0 + ii - 1 - tl + j;
+						while (n < rm) {
+							const uint32_t x = probe4<LSEQ>(M, lt, lq, j + n, q + n);
+							if (x) { n += (int32_t)(__builtin_ctz(x) >> 3); break; }
+							n += 4;
+						}
+						n = min(n, rm);
 #pragma unroll
-					for (int i = 0; i < 4; ++i) {
-						const unsigned long long m = __ballot(gbit[i]);
-						if (lane == 0) gword[g * 4 + i] = m;
+						for (int i = 0; i < 4; ++i) nmat[i] = ii == i ? n : nmat[i];
+						pend &= pend - 1;
 					}
 				}
+				int32_t done_info = 0;
+#pragma unroll
+				for (int i = 0; i < 4; ++i) { // termination test of the extension sweep (miniwfa.c:405-409); only in-matrix cells have room or extend
+					const int32_t d = c0 + i - 1 - tl, kk = hv[i] + nmat[i];
+					const uint32_t act = inner ? 1u : (uint32_t)((c0 + i >= lo) & (c0 + i <= hi));
+					const uint32_t f = act & inm_bit(d, hv[i], tl, ql) & (uint32_t)(kk == tl - 1) & (uint32_t)(d + kk == ql - 1);
+					fin |= f;
+					done_info = f ? (nmat[i] == 0 ? (int32_t)((tbw >> (8 * i)) & 7u) : 0) : done_info;
+					hv[i] = kk;
+				}
+				*(int4*)(H + (newH * W + c0)) = make_int4(hv[0], hv[1], hv[2], hv[3]);
+				if (TB && c0 >= origin && c0 <= hi) *(uint32_t*)(M.tb + tb_used - origin + c0) = tbw;
+				if (track_good) {
+					unsigned long long *gword = M.good + (int64_t)newH * A.GW + g * 4;
+#pragma unroll
+					for (int i = 0; i < 4; ++i) {
+						const unsigned long long m = __ballot((gbits >> i) & 1u);
+						if (lane == 0) gword[i] = m;
+					}
+				}
+				if (__ballot(live & 1u)) sh.flags[npar][0] = 1;   // uniform branches; every lane stores the same word
+				if (__ballot(live & 2u)) sh.flags[npar][1] = 1;
+				if (__ballot(fin)) {
+					if (fin) sh.flags[npar][2] = 1, sh.flags[npar][3] = done_info;
+				}
 			} else {
+				prefetch(k, nextH, phi, gl_next);
 #pragma unroll
 				for (int i = 0; i < 4; ++i) ne1[i] = nf1[i] = ne2[i] = nf2[i] = kNegInf;
 			}
@@ -299,16 +350,11 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 			}
 		}
 
-		// ---- H rows of penalty s_new+1: its window is inside [lo-1, hi+1] whatever the flags say
-		const int32_t plo = lo > 1 ? lo - 1 : 1, phi = hi < cmax ? hi + 1 : cmax;
-		const int32_t gl_next = plo >> 8;
-		if ((phi >> 8) - gl_next + 1 > NWK - 1) { R.status = ST_BAND_OVERFLOW; break; }
-		const int32_t n_pref = prefetch(newH + 1 == P.nH ? 0 : newH + 1, plo, phi, gl_next);
-		// Everything older than those loads (this penalty's H/traceback stores included) must be complete before
-		// another wave may load it; the prefetch loads themselves (5 per chunk: three 16-byte rows + the two
-		// edge columns) stay in flight across the barrier.  vmcnt retires in issue order on gfx9-family parts.
-		if (n_pref == 2) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
-		else if (n_pref == 1) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+		// Everything issued before this penalty must be complete before another wave may load it (vmcnt retires in issue
+		// order).  This penalty issued exactly 5*K loads, all before its stores; letting the youngest 5*K operations stay in
+		// flight therefore never leaves an older penalty's store pending, and keeps this penalty's own stores in flight when
+		// every H lag is >= 3.  Otherwise wait for everything.
+		if (relaxed_stores) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(5 * K) : "memory");
 		else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 		__builtin_amdgcn_s_barrier();
 		asm volatile("" ::: "memory");
@@ -326,7 +372,7 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 			for (int32_t q = tid; q < n_words; q += T) {
 				const int32_t gg = gfirst + (q >> 2), kq = q & 3, base = gg * kChunk;
 				unsigned long long m = 0;
-				for (int32_t j = 0; j < P.nH; ++j)
+				for (int32_t j = 0; j < nH; ++j)
 					if (sh.rng_lo[j] <= sh.rng_hi[j] && sh.rng_lo[j] <= base + kChunk - 1 && sh.rng_hi[j] >= base) m |= M.good[(int64_t)j * A.GW + gg * 4 + kq];
 				m &= lane_mask(base, kq, wf_lo, wf_hi);
 				if (m) {
@@ -339,7 +385,7 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 			if (ghi < 0) { R.status = ST_INTERNAL; break; }
 			wf_lo = glo, wf_hi = ghi;
 		}
-		cells += w;
+		cells += hi - lo + 1;
 		if ((A.max_iter > 0 && cells > A.max_iter) || (A.max_s > 0 && s > A.max_s)) { // miniwfa.c:422-425
 			R.status = ST_STOPPED;
 			break;
@@ -353,10 +399,10 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 	return R;
 }
 
-template <int T, int E1, int E2, bool LSEQ>
+template <int T, int K, int E1, int E2, bool TB, bool LSEQ>
 __global__ __launch_bounds__(T) void wfa_band_kernel(const BatchArgs A)
 {
-	constexpr int NWK = (T / 64) * kSlots, D = (E1 > E2 ? E1 : E2) + 1;
+	constexpr int NWK = (T / 64) * K, D = (E1 > E2 ? E1 : E2) + 1;
 	__shared__ Shared sh;
 	__shared__ int32_t edge[D][NWK][4];
 	for (;;) {
@@ -377,27 +423,31 @@ __global__ __launch_bounds__(T) void wfa_band_kernel(const BatchArgs A)
 			__syncthreads();
 		}
 		const bool trace = A.dbg && pair == A.debug_pair;
-		PassResult R;
-		if (A.want_cigar) R = band_pass<T, E1, E2, true, LSEQ>(A, M, sh, edge, lt, lq, 0, trace);
-		else R = band_pass<T, E1, E2, false, LSEQ>(A, M, sh, edge, lt, lq, 0, trace);
+		const PassResult R = band_pass<T, K, E1, E2, TB, LSEQ>(A, M, sh, edge, lt, lq, 0, trace);
 		finish_pair(A, M, (int32_t)blockIdx.x, pair, R, R.status, 0);
 	}
 }
 
-template <int T, int E1, int E2>
+template <int T, int K, int E1, int E2>
 int launch_one(const BatchArgs &a, int grid, int lds, hipStream_t st)
 {
-	if (lds > 0) hipLaunchKernelGGL((wfa_band_kernel<T, E1, E2, true>), dim3(grid), dim3(T), lds, st, a);
-	else hipLaunchKernelGGL((wfa_band_kernel<T, E1, E2, false>), dim3(grid), dim3(T), 0, st, a);
+	const bool tb = a.want_cigar != 0;
+	if (lds > 0 && tb) hipLaunchKernelGGL((wfa_band_kernel<T, K, E1, E2, true, true>), dim3(grid), dim3(T), lds, st, a);
+	else if (lds > 0) hipLaunchKernelGGL((wfa_band_kernel<T, K, E1, E2, false, true>), dim3(grid), dim3(T), lds, st, a);
+	else if (tb) hipLaunchKernelGGL((wfa_band_kernel<T, K, E1, E2, true, false>), dim3(grid), dim3(T), 0, st, a);
+	else hipLaunchKernelGGL((wfa_band_kernel<T, K, E1, E2, false, false>), dim3(grid), dim3(T), 0, st, a);
 	return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-template <int T, int E1, int E2>
-int occ_one(int lds)
+template <int T, int K, int E1, int E2>
+int occ_one(int lds, bool tb)
 {
 	int n = 0;
-	hipError_t e = lds > 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band_kernel<T, E1, E2, true>, T, lds)
-	                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band_kernel<T, E1, E2, false>, T, 0);
+	hipError_t e;
+	if (lds > 0 && tb) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band_kernel<T, K, E1, E2, true, true>, T, lds);
+	else if (lds > 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band_kernel<T, K, E1, E2, false, true>, T, lds);
+	else if (tb) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band_kernel<T, K, E1, E2, true, false>, T, 0);
+	else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band_kernel<T, K, E1, E2, false, false>, T, 0);
 	return e == hipSuccess ? n : 0;
 }
 
@@ -412,12 +462,12 @@ bool band_supported(const Penalty &p)
 
 #define MWF_BAND_DISPATCH(FN, ...)                                                    \
 	do {                                                                              \
-		if (g.block == 1024) {                                                        \
-			if (a_e1 == 2 && a_e2 == 1) return FN<1024, 2, 1>(__VA_ARGS__);           \
-			if (a_e1 == 2 && a_e2 == 2) return FN<1024, 2, 2>(__VA_ARGS__);           \
+		if (g.block == 768) {                                                         \
+			if (a_e1 == 2 && a_e2 == 1) return FN<768, 2, 2, 1>(__VA_ARGS__);         \
+			if (a_e1 == 2 && a_e2 == 2) return FN<768, 2, 2, 2>(__VA_ARGS__);         \
 		} else if (g.block == 256) {                                                  \
-			if (a_e1 == 2 && a_e2 == 1) return FN<256, 2, 1>(__VA_ARGS__);            \
-			if (a_e1 == 2 && a_e2 == 2) return FN<256, 2, 2>(__VA_ARGS__);            \
+			if (a_e1 == 2 && a_e2 == 1) return FN<256, 2, 2, 1>(__VA_ARGS__);         \
+			if (a_e1 == 2 && a_e2 == 2) return FN<256, 2, 2, 2>(__VA_ARGS__);         \
 		}                                                                             \
 	} while (0)
 
@@ -428,10 +478,10 @@ int launch_band(const BatchArgs &a, int grid, const BandGeom &g, void *stream)
 	return -1;
 }
 
-int band_kernel_occupancy(const Penalty &p, const BandGeom &g, bool)
+int band_kernel_occupancy(const Penalty &p, const BandGeom &g, bool cigar)
 {
 	const int a_e1 = p.e1, a_e2 = p.e2;
-	MWF_BAND_DISPATCH(occ_one, g.lds_bytes);
+	MWF_BAND_DISPATCH(occ_one, g.lds_bytes, cigar);
 	return 0;
 }
 

@@ -58,23 +58,27 @@ struct Cell { int32_t h, e1, f1, e2, f2; uint32_t tb; };
 
 // The recurrence and its tie-breaking (miniwfa.c:267-278 values, :289-306 traceback byte):
 // gap states prefer "open" on ties; H prefers mismatch, then insertion piece 1, piece 2, deletion piece 1, piece 2.
+// Written with selects and arithmetic only, so that it compiles to straight-line code; WANT_TB=false drops the byte.
+template <bool WANT_TB = true>
 __device__ __forceinline__ Cell wf_cell(int32_t hx, int32_t o1m, int32_t g1m, int32_t o2m, int32_t g2m,
                                         int32_t o1p, int32_t g1p, int32_t o2p, int32_t g2p)
 {
 	Cell c;
-	const bool xe1 = g1m > o1m, xe2 = g2m > o2m, xf1 = g1p > o1p, xf2 = g2p > o2p;
-	c.e1 = xe1 ? g1m : o1m;
-	c.e2 = xe2 ? g2m : o2m;
-	c.f1 = (xf1 ? g1p : o1p) + 1;
-	c.f2 = (xf2 ? g2p : o2p) + 1;
-	const bool e_first = c.e1 >= c.e2, f_first = c.f1 >= c.f2;
-	const int32_t e = e_first ? c.e1 : c.e2, f = f_first ? c.f1 : c.f2;
-	const bool ins = e >= f;
-	const int32_t g = ins ? e : f, m = hx + 1;
-	const bool mis = m >= g;
-	c.h = mis ? m : g;
-	const uint32_t z = mis ? 0u : (ins ? (e_first ? 1u : 3u) : (f_first ? 2u : 4u));
-	c.tb = z | (xe1 ? 0x08u : 0u) | (xf1 ? 0x10u : 0u) | (xe2 ? 0x20u : 0u) | (xf2 ? 0x40u : 0u);
+	c.e1 = max(o1m, g1m);
+	c.e2 = max(o2m, g2m);
+	c.f1 = max(o1p, g1p) + 1;
+	c.f2 = max(o2p, g2p) + 1;
+	const int32_t e = max(c.e1, c.e2), f = max(c.f1, c.f2), g = max(e, f), m = hx + 1;
+	c.h = max(m, g);
+	c.tb = 0;
+	if (WANT_TB) {
+		const uint32_t xe1 = (uint32_t)(g1m > o1m), xe2 = (uint32_t)(g2m > o2m), xf1 = (uint32_t)(g1p > o1p), xf2 = (uint32_t)(g2p > o2p);
+		const uint32_t ze = 1u + ((uint32_t)(c.e1 < c.e2) << 1);  // 1: E1, 3: E2 (ties -> E1)
+		const uint32_t zf = 2u + ((uint32_t)(c.f1 < c.f2) << 1);  // 2: F1, 4: F2 (ties -> F1)
+		uint32_t z = e >= f ? ze : zf;                            // ties -> insertion
+		z = m >= g ? 0u : z;                                      // ties -> mismatch
+		c.tb = z | (xe1 << 3) | (xf1 << 4) | (xe2 << 5) | (xf2 << 6);
+	}
 	return c;
 }
 

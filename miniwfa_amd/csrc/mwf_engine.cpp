@@ -176,11 +176,11 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 	if (want_kind == 0 || low_mem || !band_supported(P)) return;
 	const int64_t max_window = std::min<int64_t>(max_len + 1, 2 * max_bound + 3);
 	BandGeom bg;
-	bg.block = max_window <= 8 * 256 - 256 - 64 ? 256 : 1024;
-	if (g->block == 256 || g->block == 1024) bg.block = g->block;
+	bg.block = max_window <= 8 * 256 - 256 - 64 ? 256 : 768;
+	if (g->block == 256 || g->block == 768) bg.block = g->block;
 	bg.span = bg.block / 64 * 2 * 256;
-	if (want_kind != 2 && max_len + 1 > 3 * (int64_t)bg.span) return; // windows will mostly outgrow the span: go generic at once
-	const int64_t lds_cap = bg.block == 1024 ? 140 * 1024 : 36 * 1024;
+	if (want_kind != 2 && max_len + 1 > 4 * (int64_t)bg.span) return; // windows will mostly outgrow the span: go generic at once
+	const int64_t lds_cap = bg.block == 768 ? 140 * 1024 : 36 * 1024;
 	bg.lds_bytes = max_seq_lds <= lds_cap ? (int)((max_seq_lds + 15) / 16 * 16) : 0;
 	pl.kind = 2, pl.band = bg;
 }
@@ -193,7 +193,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	Plan pl;
 	pl.cigar = (opt.flag & MWF_F_CIGAR) != 0;
 	pl.low_mem = pl.cigar && opt.step > 0;
-	pl.block = g->block > 0 ? g->block : 256;
+	pl.block = g->block > 0 && g->block != 768 ? g->block : 256;
 	choose_kernel(g, opt, P, max_len, max_bound, b->max_seq_lds, want_kind >= 0 ? want_kind : g->force_kind, pl);
 	if (pl.kind == 2) {
 		pl.block = pl.band.block;
@@ -354,7 +354,7 @@ int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value)
 {
 	if (!g || !name) return -1;
 	if (!strcmp(name, "block")) {
-		if (value != 0 && value != 64 && value != 128 && value != 256 && value != 512 && value != 1024) return -1;
+		if (value != 0 && value != 64 && value != 128 && value != 256 && value != 512 && value != 768 && value != 1024) return -1;
 		g->block = (int)value;
 	} else if (!strcmp(name, "slots_per_cu")) g->slots_per_cu = (int)value;
 	else if (!strcmp(name, "coop_min_len")) g->coop_min_len = value;

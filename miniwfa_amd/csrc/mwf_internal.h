@@ -92,7 +92,7 @@ int batch_kernel_occupancy(int block);   // resident workgroups per CU for that 
 
 // launch wrappers implemented in mwf_band.hip (band kernel: E/F wavefronts live in registers)
 struct BandGeom {
-	int block;        // threads per workgroup (256 or 1024)
+	int block;        // threads per workgroup (256 or 768)
 	int span;         // columns the workgroup can hold: (block/64) * 2 * 256
 	int lds_bytes;    // dynamic LDS for the sequence copy (0: read sequences from global memory)
 };

@@ -14,6 +14,6 @@ for PMC in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUS
   NAME=$(echo "$PMC" | tr ' ' '_' | cut -c1-40)
   rocprofv3 --kernel-trace --pmc $PMC -d "$OUT/pmc_$NAME" -o p -- $BENCH > /dev/null 2> "$OUT/pmc_$NAME.err" || echo "pmc pass $NAME failed" >> "$OUT/errors.txt"
 done
-find "$OUT" -name "*.csv" | head -50 > "$OUT/files.txt"
+find "$OUT" -name "*.db" | head -50 > "$OUT/files.txt"
 python profiles/summarize.py "$OUT" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"

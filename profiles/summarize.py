@@ -1,28 +1,23 @@
 #!/usr/bin/env python3
-"""Condense a profiles/run_profile.sh output directory: kernel stats and per-launch PMC sums."""
-import csv
+"""Condense a profiles/run_profile.sh output directory (rocprofv3 sqlite output): kernel stats and per-launch PMC means."""
 import glob
 import os
+import sqlite3
 import sys
-from collections import defaultdict
 
 root = sys.argv[1]
-for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
-    print("== kernel stats", f)
-    for row in csv.DictReader(open(f)):
-        print({k: row[k] for k in row if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
+for f in sorted(glob.glob(os.path.join(root, "trace", "*.db"))):
+    cur = sqlite3.connect(f).cursor()
+    print("== kernel stats (rocprofv3 --kernel-trace --stats):", os.path.relpath(f, root))
+    print("name | calls | total_ns | avg_ns | pct")
+    for r in cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
+        print(" | ".join(str(x) for x in r))
 for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
     if not os.path.isdir(d):
         continue
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-        acc = defaultdict(lambda: defaultdict(float))
-        cnt = defaultdict(set)
-        for row in csv.DictReader(open(f)):
-            k = row.get("Kernel_Name", "?")
-            if "wfa" not in k:
-                continue
-            acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
-            cnt[k].add(row.get("Dispatch_Id"))
-        for k in acc:
-            n = max(1, len(cnt[k]))
-            print("== pmc", os.path.basename(d), k[:60], "launches", n, {c: v / n for c, v in acc[k].items()})
+    for f in glob.glob(os.path.join(d, "*.db")):
+        cur = sqlite3.connect(f).cursor()
+        rows = list(cur.execute("select kernel_name, counter_name, sum(value), count(distinct dispatch_id) from counters_collection group by kernel_name, counter_name"))
+        for k, c, v, n in rows:
+            if "wfa" in k:
+                print(f"== pmc {c} = {v / max(1, n):.6g} per launch ({n} launches) [{k[:70]}]")
