@@ -92,8 +92,7 @@ def main():
     opt = mw.opt_init(flag=mw.MWF_F_CIGAR if args.cigar else 0)
     d_s = torch.as_tensor(_DevPtr(batch.dev_scores_ptr(), pk.n, "<i4"), device=dev)
     d_it = torch.as_tensor(_DevPtr(batch.dev_iters_ptr(), pk.n, "<i8"), device=dev)
-    gather_s = [torch.empty_like(d_s) for _ in range(world)] if world > 1 else None
-    gather_it = [torch.empty_like(d_it) for _ in range(world)] if world > 1 else None
+    from miniwfa_amd.shard import gather_records
 
     kernel_ms = []
 
@@ -101,9 +100,8 @@ def main():
         batch.align(opt)                       # kernels enqueued on torch's current stream
         if args.cigar:
             batch.results()                    # CIGAR mode may have to retry pairs: needs the host in the loop
-        if world > 1:                          # the result gather of the multi-GPU job (RCCL over xGMI)
-            dist.all_gather(gather_s, d_s)
-            dist.all_gather(gather_it, d_it)
+        if world > 1:                          # the result gather of the multi-GPU job (RCCL all_gather over xGMI)
+            gather_records(dist, d_s, d_it, world * pk.n, device=dev)
         if record:
             torch.cuda.synchronize(dev)
             kernel_ms.append(eng.stats().kernel_ms)

@@ -241,13 +241,13 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 #pragma unroll
 					for (int i = 0; i < 4; ++i) {
 						const int32_t c = c0 + i;
-						hx[i] = (c >= xlo) & (c <= xhi) ? hx[i] : kNegInf;
-						o1[i + 1] = (c >= alo) & (c <= ahi) ? o1[i + 1] : kNegInf;
-						o2[i + 1] = (c >= blo) & (c <= bhi) ? o2[i + 1] : kNegInf;
+						hx[i] = ((c >= xlo) & (c <= xhi)) ? hx[i] : kNegInf;
+						o1[i + 1] = ((c >= alo) & (c <= ahi)) ? o1[i + 1] : kNegInf;
+						o2[i + 1] = ((c >= blo) & (c <= bhi)) ? o2[i + 1] : kNegInf;
 					}
 					const int32_t ce = lane == 0 ? c0 - 1 : c0 + 4;
-					v1 = (ce >= alo) & (ce <= ahi) ? v1 : kNegInf;
-					v2 = (ce >= blo) & (ce <= bhi) ? v2 : kNegInf;
+					v1 = ((ce >= alo) & (ce <= ahi)) ? v1 : kNegInf;
+					v2 = ((ce >= blo) & (ce <= bhi)) ? v2 : kNegInf;
 				}
 				o1[0] = from_left(o1[4], v1), o1[5] = from_right(o1[1], v1);
 				o2[0] = from_left(o2[4], v2), o2[5] = from_right(o2[1], v2);

@@ -1,0 +1,567 @@
+// mwf_coop.hip — one sequence pair across the whole device (BASELINE configs 2 and 4: a 150 kb pair, a 5 Mb pair).
+//
+// A single pair is a strictly sequential chain of penalties (reference miniwfa.c:397-426), so the only
+// parallelism is across the diagonals of one wavefront — tens to hundreds of thousands of them for these
+// pairs.  This kernel is the band kernel (mwf_band.hip) stretched over every CU:
+//
+//   * all waves of all workgroups form one wave array; 256-column chunk g belongs to wave (g mod waves),
+//     slot (g / waves) mod 2 — for ever, so the H rows of a chunk are only ever touched by one CU and can
+//     use ordinary cached 16-byte loads/stores, and the E/F wavefronts stay in that wave's registers;
+//   * what crosses waves — the outer columns of each chunk (E1/E2 of the last, F1/F2 of the first, and the
+//     H of both for the three lags) — goes through two small tables in HBM that are written and read with
+//     agent-scope (sc1) accesses only, as do the three flags per penalty (new low/high edge live, end cell
+//     reached).  No fences are needed: nothing else is shared inside a pass;
+//   * one grid barrier per penalty: every wave drains its stores, each workgroup arrives on a device-scope
+//     counter and polls it (relaxed, s_sleep) — bounded, so a lost workgroup yields an error, not a hang;
+//   * long exact-match runs (these pairs are ~99 % identical) are walked by the whole wave: 64 lanes x
+//     4 bytes per trip for the lane that owns the diagonal, instead of one lane 4 bytes at a time;
+//   * low-memory mode (opt.step > 0, reference miniwfa.c:437-601): with 288 GB of HBM the full 1-byte-per-
+//     cell traceback of the first pass fits on the device (50.6 GB for the MHC pair), so the checkpoints
+//     are read off it by walking the recorded choices back from the end cell — the same (penalty, diagonal)
+//     chain the reference's provenance stripe reports — and the second pass with band resets runs exactly
+//     as the reference's does (same n_iter, same CIGAR).  See checkpoint_walk().
+//
+// A pass is one launch; pass results travel to the next launch (walk, second pass, traceback) through
+// coop_state in HBM, so the host never synchronises in between.
+#include "mwf_device.h"
+
+namespace mwf {
+
+using namespace dev;
+
+namespace {
+
+constexpr int kT = 512;          // threads per workgroup: 8 waves, up to 256 VGPRs each
+constexpr int kNW = kT / 64;
+constexpr int kK = 2;            // chunks per wave
+constexpr int kChunk = 256;
+constexpr unsigned kSpinLimit = 1u << 26;
+
+__device__ __forceinline__ int32_t from_left(int32_t v, int32_t fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int32_t from_right(int32_t v, int32_t fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false); }
+
+__device__ __forceinline__ int32_t ld_ag(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_ag(int32_t *p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ uint32_t probe4g(const PairMem &M, int32_t j, int32_t i)
+{
+	uint32_t a, b;
+	__builtin_memcpy(&a, M.ts + j, 4);
+	__builtin_memcpy(&b, M.qs + i, 4);
+	return a ^ b;
+}
+
+__device__ __forceinline__ uint32_t inm_bit(int32_t d, int32_t k, int32_t tl, int32_t ql)
+{
+	return (uint32_t)((uint32_t)(k + 1) < (uint32_t)(tl + 1)) & (uint32_t)((uint32_t)(d + k + 1) < (uint32_t)(ql + 1));
+}
+
+__device__ __forceinline__ int32_t pick4(int32_t i, int32_t a0, int32_t a1, int32_t a2, int32_t a3)
+{
+	return i == 0 ? a0 : i == 1 ? a1 : i == 2 ? a2 : a3;
+}
+
+__device__ __forceinline__ unsigned long long lane_mask(int32_t base, int32_t k, int32_t a, int32_t b)
+{
+	int32_t lmin = a - base - k, lmax = b - base - k;
+	if (lmax < 0) return 0ull;
+	lmin = lmin <= 0 ? 0 : (lmin + 3) >> 2;
+	lmax = min(lmax >> 2, 63);
+	if (lmin > lmax) return 0ull;
+	return (~0ull >> (63 - lmax)) & (~0ull << lmin);
+}
+
+// The whole wave walks one diagonal: t[j+n..] vs q[i+n..], up to `room` bytes, starting after n0 matched bytes.
+// Every argument is wave-uniform; returns the total number of matching bytes (<= room).
+__device__ __forceinline__ int32_t lcp_wave(const PairMem &M, int32_t j, int32_t i, int32_t room, int32_t n0)
+{
+	const int32_t lane = threadIdx.x & 63;
+	int32_t n = n0;
+	while (n < room) {
+		const int32_t off = n + 4 * lane;
+		int32_t m = 0;
+		if (off < room) {
+			const uint32_t x = probe4g(M, j + off, i + off);
+			m = min(x ? (int32_t)(__builtin_ctz(x) >> 3) : 4, room - off);
+		}
+		const unsigned long long stop = __ballot(m < 4); // lanes beyond `room` have m == 0 and stop the scan too
+		if (stop == 0) { n += 256; continue; }
+		const int32_t first = (int32_t)__builtin_ctzll(stop);
+		n += 4 * first + __builtin_amdgcn_readlane(m, first);
+		break;
+	}
+	return min(n, room);
+}
+
+// Device-wide barrier: all agent-scope stores of every wave are complete before its workgroup arrives.
+// FENCE adds the release/acquire pair that also publishes data written with ORDINARY stores (one lane per workgroup
+// fences, the __syncthreads() around it extend that to the workgroup) — only the shrink needs it.
+template <bool FENCE>
+__device__ __forceinline__ bool grid_sync(const BatchArgs &A, Shared &sh, unsigned &epoch, unsigned n_groups)
+{
+	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+	__syncthreads();
+	++epoch;
+	if (threadIdx.x == 0) {
+		if (FENCE) {
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		}
+		__hip_atomic_fetch_add(&A.coop_sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const unsigned target = epoch * n_groups;
+		unsigned spins = 0;
+		int32_t ok = 1;
+		while (__hip_atomic_load(&A.coop_sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+			__builtin_amdgcn_s_sleep(1);
+			if (++spins > kSpinLimit) { ok = 0; break; }
+		}
+		if (FENCE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+		sh.word[3] = ok;
+	}
+	__syncthreads();
+	return uni(sh.word[3]) != 0;
+}
+
+template <int E1, int E2, bool TB>
+__device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh, int32_t n_seg)
+{
+	constexpr int D = 3;
+	const int32_t G = (int32_t)gridDim.x, NWt = G * kNW, TC = NWt * kK;
+	const int32_t tl = M.tl, ql = M.ql, cmax = tl + ql + 1;
+	const int32_t tid = threadIdx.x, lane = tid & 63, gw = uni((int32_t)blockIdx.x * kNW + (tid >> 6));
+	const bool lead = blockIdx.x == 0 && tid == 0;
+	const int64_t W = A.W;
+	const int32_t nH = A.pen.nH, lagx = A.pen.x, lag1 = A.pen.oe1, lag2 = A.pen.oe2;
+	int32_t *const H = M.H;
+	int32_t *const eedge = A.coop_edge;                    // [D][TC][4]
+	int32_t *const hedge = A.coop_edge + (int64_t)D * TC * 4; // [nH][TC][2]: H of a chunk's first / last column
+	int32_t *const gflags = A.coop_flags;                  // [3][4]
+	PassResult R;
+	R.status = ST_OK, R.s = 0, R.info = 0, R.n_snap = 0, R.cells = 0;
+	unsigned epoch = 0; // the host zeroes the arrival counter before every pass
+
+	int32_t e1h[E1][kK][4], f1h[E1][kK][4], e2h[E2][kK][4], f2h[E2][kK][4];
+#pragma unroll
+	for (int k = 0; k < kK; ++k)
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+#pragma unroll
+			for (int a = 0; a < E1; ++a) e1h[a][k][i] = f1h[a][k][i] = kNegInf;
+#pragma unroll
+			for (int a = 0; a < E2; ++a) e2h[a][k][i] = f2h[a][k][i] = kNegInf;
+		}
+	int4 phx[kK], po1[kK], po2[kK];
+	int32_t pe1[kK], pe2[kK];
+
+	// ---- penalty 0: origin and its extension (the first wave of workgroup 0 walks it cooperatively)
+	if (tid == 0) {
+		for (int32_t j = 0; j < nH; ++j) sh.rng_lo[j] = 1, sh.rng_hi[j] = 0;
+		sh.rng_lo[0] = sh.rng_hi[0] = tl + 1;
+	}
+	if (blockIdx.x == 0 && tid < 64) {
+		const int32_t k0 = lcp_wave(M, 0, 0, min(tl, ql), 0) - 1;
+		if (tid == 0) {
+			const int32_t c0 = tl + 1;
+			st_ag(&H[c0], k0); // its owner is some other workgroup's wave: write through
+			for (int32_t j = 0; j < 12; ++j) st_ag(&gflags[j], 0);
+			st_ag(&gflags[12], k0);
+			// the origin's chunk edges for the first lagged reads
+			const int32_t r0 = (c0 >> 8) % TC;
+			if ((c0 & 255) == 0) st_ag(&hedge[(0 * TC + r0) * 2 + 0], k0);
+			if ((c0 & 255) == 255) st_ag(&hedge[(0 * TC + r0) * 2 + 1], k0);
+		}
+	}
+	if (!grid_sync<false>(A, sh, epoch, G)) { R.status = ST_INTERNAL; return R; }
+	{
+		const int32_t k0 = uni(ld_ag(&gflags[12]));
+		if (k0 == tl - 1 && k0 == ql - 1) { R.cells = 0; return R; }
+	}
+
+	int32_t s = 0, wf_lo = tl + 1, wf_hi = tl + 1;
+	int32_t curH = 0, par = 0, sid = 0, dcur = 0;
+	int64_t cells = 0, tb_used = 0;
+
+	auto prefetch = [&](int k, int32_t slotH, int32_t phi, int32_t g_lo) {
+		int32_t jx = slotH - lagx; if (jx < 0) jx += nH;
+		int32_t j1 = slotH - lag1; if (j1 < 0) j1 += nH;
+		int32_t j2 = slotH - lag2; if (j2 < 0) j2 += nH;
+		const int32_t r = gw + NWt * k;
+		int32_t g = g_lo - g_lo % TC + r;
+		if (g < g_lo) g += TC;
+		const bool in = g * kChunk <= phi;
+		const int32_t c0 = in ? g * kChunk + 4 * lane : 0;
+		phx[k] = *(const int4*)(H + (jx * W + c0));
+		po1[k] = *(const int4*)(H + (j1 * W + c0));
+		po2[k] = *(const int4*)(H + (j2 * W + c0));
+		// neighbours' outer columns: lane 0 wants the LAST column of the chunk to the left, lane 63 the FIRST of the one to the right
+		const int32_t rn = lane == 0 ? (r == 0 ? TC - 1 : r - 1) : (r + 1 == TC ? 0 : r + 1);
+		const int32_t which = lane == 0 ? 1 : 0;
+		pe1[k] = ld_ag(&hedge[((int64_t)j1 * TC + rn) * 2 + which]);
+		pe2[k] = ld_ag(&hedge[((int64_t)j2 * TC + rn) * 2 + which]);
+	};
+	int32_t gl;
+	{
+		const int32_t lo1 = wf_lo > 1 ? wf_lo - 1 : 1, hi1 = wf_hi < cmax ? wf_hi + 1 : cmax;
+		gl = lo1 >> 8;
+#pragma unroll
+		for (int k = 0; k < kK; ++k) prefetch(k, 1, hi1, gl);
+	}
+
+	for (;;) {
+		if (TB && sid < n_seg) { // checkpoint reset of the second pass (miniwfa.c:413-416)
+			if (uni(M.seg[2 * sid]) == s) {
+				const int32_t c = uni(M.seg[2 * sid + 1]);
+				if (c < wf_lo || c > wf_hi) { R.status = ST_INTERNAL; break; }
+				wf_lo = wf_hi = c;
+				++sid;
+			}
+		}
+		const int32_t lo = wf_lo > 1 ? wf_lo - 1 : 1;
+		const int32_t hi = wf_hi < cmax ? wf_hi + 1 : cmax;
+		const int32_t s_new = s + 1;
+		const int32_t newH = curH + 1 == nH ? 0 : curH + 1;
+		const int32_t npar = par + 1 == 3 ? 0 : par + 1;
+		const int32_t dnew = dcur + 1 == D ? 0 : dcur + 1;
+		const int32_t origin = lo & ~3;
+		const int32_t row_bytes = (hi | 3) - origin + 1;
+		if (TB) {
+			if (s_new - 1 >= A.rows_slot) { R.status = ST_ROWS_OVERFLOW; break; }
+			if (tb_used + row_bytes > A.tb_slot_bytes) { R.status = ST_TB_OVERFLOW; break; }
+		}
+		const int32_t plo = lo > 1 ? lo - 1 : 1, phi = hi < cmax ? hi + 1 : cmax;
+		const int32_t gl_next = plo >> 8;
+		if ((phi >> 8) - gl_next + 1 > TC - 1) { R.status = ST_BAND_OVERFLOW; break; }
+		const int32_t nextH = newH + 1 == nH ? 0 : newH + 1;
+		int32_t jx = newH - lagx; if (jx < 0) jx += nH;
+		int32_t j1 = newH - lag1; if (j1 < 0) j1 += nH;
+		int32_t j2 = newH - lag2; if (j2 < 0) j2 += nH;
+		int32_t jg1 = newH - E1;  if (jg1 < 0) jg1 += nH;
+		int32_t jg2 = newH - E2;  if (jg2 < 0) jg2 += nH;
+		const int32_t xlo = uni(sh.rng_lo[jx]), xhi = uni(sh.rng_hi[jx]);
+		const int32_t alo = uni(sh.rng_lo[j1]), ahi = uni(sh.rng_hi[j1]);
+		const int32_t blo = uni(sh.rng_lo[j2]), bhi = uni(sh.rng_hi[j2]);
+		const int32_t p1lo = uni(sh.rng_lo[jg1]), p1hi = uni(sh.rng_hi[jg1]); // window of penalty s_new-e1 (E1/F1 sources)
+		const int32_t p2lo = uni(sh.rng_lo[jg2]), p2hi = uni(sh.rng_hi[jg2]);
+		const int32_t ilo = max(max(lo, xlo), max(alo, blo) + 1), ihi = min(min(hi, xhi), min(ahi, bhi) - 1);
+		const bool track_good = (((256 - (s_new & 255)) & 255) < nH);
+		int32_t d1 = dnew - E1; if (d1 < 0) d1 += D;
+		int32_t d2 = dnew - E2; if (d2 < 0) d2 += D;
+
+		if (tid == 0) sh.rng_lo[newH] = lo, sh.rng_hi[newH] = hi;
+		if (lead) {
+			const int32_t nn = npar + 1 == 3 ? 0 : npar + 1;
+			st_ag(&gflags[nn * 4 + 0], 0), st_ag(&gflags[nn * 4 + 1], 0), st_ag(&gflags[nn * 4 + 2], 0), st_ag(&gflags[nn * 4 + 3], 0);
+			if (TB) M.row_off[s_new - 1] = tb_used, M.row_lo[s_new - 1] = origin;
+			if (A.dbg && s_new - 1 < A.dbg_cap) M.dbg[2 * (s_new - 1)] = lo, M.dbg[2 * (s_new - 1) + 1] = hi;
+		}
+
+		const int32_t gbase = gl - gl % TC;
+#pragma unroll
+		for (int k = 0; k < kK; ++k) {
+			const int32_t r = gw + NWt * k;
+			int32_t g = gbase + r;
+			if (g < gl) g += TC;
+			const int32_t cb = g * kChunk;
+			const bool active = cb <= hi && cb + kChunk - 1 >= lo;
+			int32_t ne1[4], nf1[4], ne2[4], nf2[4];
+			if (active) {
+				const int32_t c0 = cb + 4 * lane;
+				const bool inner = cb >= ilo && cb + kChunk - 1 <= ihi;
+				int32_t hx[4] = {phx[k].x, phx[k].y, phx[k].z, phx[k].w};
+				int32_t o1[6], o2[6];
+				o1[1] = po1[k].x, o1[2] = po1[k].y, o1[3] = po1[k].z, o1[4] = po1[k].w;
+				o2[1] = po2[k].x, o2[2] = po2[k].y, o2[3] = po2[k].z, o2[4] = po2[k].w;
+				int32_t v1 = pe1[k], v2 = pe2[k];
+				prefetch(k, nextH, phi, gl_next);
+				// E/F of the neighbouring chunks' outer columns, written one (two) penalties ago
+				const int32_t rl = r == 0 ? TC - 1 : r - 1, rr = r + 1 == TC ? 0 : r + 1;
+				int32_t le1 = ld_ag(&eedge[((int64_t)d1 * TC + rl) * 4 + 0]), le2 = ld_ag(&eedge[((int64_t)d2 * TC + rl) * 4 + 1]);
+				int32_t rf1 = ld_ag(&eedge[((int64_t)d1 * TC + rr) * 4 + 2]), rf2 = ld_ag(&eedge[((int64_t)d2 * TC + rr) * 4 + 3]);
+				{ // a neighbour that was outside the source window never published: read NEG_INF instead
+					const int32_t cl = cb - 1, cr = cb + kChunk;
+					le1 = ((cl >= p1lo) & (cl <= p1hi)) ? le1 : kNegInf, rf1 = ((cr >= p1lo) & (cr <= p1hi)) ? rf1 : kNegInf;
+					le2 = ((cl >= p2lo) & (cl <= p2hi)) ? le2 : kNegInf, rf2 = ((cr >= p2lo) & (cr <= p2hi)) ? rf2 : kNegInf;
+				}
+				if (!inner) {
+#pragma unroll
+					for (int i = 0; i < 4; ++i) {
+						const int32_t c = c0 + i;
+						hx[i] = ((c >= xlo) & (c <= xhi)) ? hx[i] : kNegInf;
+						o1[i + 1] = ((c >= alo) & (c <= ahi)) ? o1[i + 1] : kNegInf;
+						o2[i + 1] = ((c >= blo) & (c <= bhi)) ? o2[i + 1] : kNegInf;
+					}
+				}
+				{
+					const int32_t ce = lane == 0 ? c0 - 1 : c0 + 4;
+					v1 = ((ce >= alo) & (ce <= ahi)) ? v1 : kNegInf;
+					v2 = ((ce >= blo) & (ce <= bhi)) ? v2 : kNegInf;
+				}
+				o1[0] = from_left(o1[4], v1), o1[5] = from_right(o1[1], v1);
+				o2[0] = from_left(o2[4], v2), o2[5] = from_right(o2[1], v2);
+				int32_t g1m[4], g1p[4], g2m[4], g2p[4];
+				g1m[0] = from_left(e1h[E1 - 1][k][3], le1);
+				g2m[0] = from_left(e2h[E2 - 1][k][3], le2);
+				g1p[3] = from_right(f1h[E1 - 1][k][0], rf1);
+				g2p[3] = from_right(f2h[E2 - 1][k][0], rf2);
+#pragma unroll
+				for (int i = 1; i < 4; ++i) g1m[i] = e1h[E1 - 1][k][i - 1], g2m[i] = e2h[E2 - 1][k][i - 1];
+#pragma unroll
+				for (int i = 0; i < 3; ++i) g1p[i] = f1h[E1 - 1][k][i + 1], g2p[i] = f2h[E2 - 1][k][i + 1];
+
+				int32_t hv[4], room[4], nmat[4];
+				uint32_t tbw = 0, pend = 0, live = 0, fin = 0, gbits = 0;
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					const int32_t c = c0 + i, d = c - 1 - tl;
+					const uint32_t act = inner ? 1u : (uint32_t)((c >= lo) & (c <= hi));
+					const Cell v = wf_cell<TB>(hx[i], o1[i], g1m[i], o2[i], g2m[i], o1[i + 2], g1p[i], o2[i + 2], g2p[i]);
+					ne1[i] = act ? v.e1 : kNegInf, nf1[i] = act ? v.f1 : kNegInf;
+					ne2[i] = act ? v.e2 : kNegInf, nf2[i] = act ? v.f2 : kNegInf;
+					const uint32_t inm = act & inm_bit(d, v.h, tl, ql);
+					if (track_good)
+						gbits |= (act & (inm | inm_bit(d, v.e1, tl, ql) | inm_bit(d, v.f1, tl, ql) | inm_bit(d, v.e2, tl, ql) | inm_bit(d, v.f2, tl, ql))) << i;
+					const uint32_t lv = act & (uint32_t)(v.h >= -1);
+					live |= (lv & (uint32_t)(c == lo)) | ((lv & (uint32_t)(c == hi)) << 1);
+					const int32_t j = inm ? v.h + 1 : 0, q = inm ? d + v.h + 1 : 0;
+					room[i] = inm ? min(tl - j, ql - q) : 0;
+					const uint32_t x = probe4g(M, j, q);
+					nmat[i] = min(x ? (int32_t)(__builtin_ctz(x) >> 3) : 4, room[i]);
+					pend |= ((uint32_t)(x == 0) & (uint32_t)(room[i] > 4)) << i;
+					hv[i] = v.h;
+					tbw |= v.tb << (8 * i);
+				}
+				// a run of >= 4 matches continues: the wave walks it together, one owning lane and column at a time
+				unsigned long long owners = __ballot(pend != 0);
+				while (owners) {
+					const int32_t src = (int32_t)__builtin_ctzll(owners);
+					owners &= owners - 1;
+					uint32_t bits = (uint32_t)__builtin_amdgcn_readlane((int32_t)pend, src);
+					const int32_t c0s = __builtin_amdgcn_readlane(c0, src);
+					while (bits) {
+						const int32_t ii = (int32_t)__builtin_ctz(bits);
+						bits &= bits - 1;
+						const int32_t hh = __builtin_amdgcn_readlane(pick4(ii, hv[0], hv[1], hv[2], hv[3]), src);
+						const int32_t rm = __builtin_amdgcn_readlane(pick4(ii, room[0], room[1], room[2], room[3]), src);
+						const int32_t j = hh + 1, q = c0s + ii - 1 - tl + j;
+						const int32_t n = lcp_wave(M, j, q, rm, 4);
+#pragma unroll
+						for (int i = 0; i < 4; ++i) nmat[i] = (ii == i && lane == src) ? n : nmat[i];
+					}
+				}
+				int32_t done_info = 0;
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					const int32_t d = c0 + i - 1 - tl, kk = hv[i] + nmat[i];
+					const uint32_t act = inner ? 1u : (uint32_t)((c0 + i >= lo) & (c0 + i <= hi));
+					const uint32_t f = act & inm_bit(d, hv[i], tl, ql) & (uint32_t)(kk == tl - 1) & (uint32_t)(d + kk == ql - 1);
+					fin |= f;
+					done_info = f ? (nmat[i] == 0 ? (int32_t)((tbw >> (8 * i)) & 7u) : 0) : done_info;
+					hv[i] = kk;
+				}
+				*(int4*)(H + (newH * W + c0)) = make_int4(hv[0], hv[1], hv[2], hv[3]);
+				if (TB && c0 >= origin && c0 <= hi) *(uint32_t*)(M.tb + tb_used - origin + c0) = tbw;
+				if (track_good) {
+					unsigned long long *gword = M.good + (int64_t)newH * A.GW + (int64_t)g * 4;
+#pragma unroll
+					for (int i = 0; i < 4; ++i) {
+						const unsigned long long m = __ballot((gbits >> i) & 1u);
+						if (lane == 0) gword[i] = m;
+					}
+				}
+				// outer columns for the neighbouring waves (any workgroup): agent scope
+				if (lane == 63) {
+					st_ag(&eedge[((int64_t)dnew * TC + r) * 4 + 0], ne1[3]), st_ag(&eedge[((int64_t)dnew * TC + r) * 4 + 1], ne2[3]);
+					st_ag(&hedge[((int64_t)newH * TC + r) * 2 + 1], hv[3]);
+				}
+				if (lane == 0) {
+					st_ag(&eedge[((int64_t)dnew * TC + r) * 4 + 2], nf1[0]), st_ag(&eedge[((int64_t)dnew * TC + r) * 4 + 3], nf2[0]);
+					st_ag(&hedge[((int64_t)newH * TC + r) * 2 + 0], hv[0]);
+				}
+				if (__ballot(live & 1u)) { if (lane == 0) st_ag(&gflags[npar * 4 + 0], 1); }
+				if (__ballot(live & 2u)) { if (lane == 0) st_ag(&gflags[npar * 4 + 1], 1); }
+				if (fin) st_ag(&gflags[npar * 4 + 3], done_info), st_ag(&gflags[npar * 4 + 2], 1);
+			} else {
+				prefetch(k, nextH, phi, gl_next);
+#pragma unroll
+				for (int i = 0; i < 4; ++i) ne1[i] = nf1[i] = ne2[i] = nf2[i] = kNegInf;
+			}
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+#pragma unroll
+				for (int a = E1 - 1; a > 0; --a) e1h[a][k][i] = e1h[a - 1][k][i], f1h[a][k][i] = f1h[a - 1][k][i];
+#pragma unroll
+				for (int a = E2 - 1; a > 0; --a) e2h[a][k][i] = e2h[a - 1][k][i], f2h[a][k][i] = f2h[a - 1][k][i];
+				e1h[0][k][i] = ne1[i], f1h[0][k][i] = nf1[i], e2h[0][k][i] = ne2[i], f2h[0][k][i] = nf2[i];
+			}
+		}
+
+		if (!grid_sync<false>(A, sh, epoch, G)) { R.status = ST_INTERNAL; break; }
+
+		// ---- bookkeeping, identical on every thread of every workgroup
+		if (uni(ld_ag(&gflags[npar * 4 + 0]))) wf_lo = lo;
+		if (uni(ld_ag(&gflags[npar * 4 + 1]))) wf_hi = hi;
+		const int32_t done = uni(ld_ag(&gflags[npar * 4 + 2])), payload = uni(ld_ag(&gflags[npar * 4 + 3]));
+		s = s_new, curH = newH, par = npar, dcur = dnew, gl = gl_next;
+		if (TB) tb_used += row_bytes;
+		if ((s & 0xff) == 0) { // shrink (miniwfa.c:144-171): the good bits were written with ordinary stores by every CU
+			if (lead) st_ag(&gflags[13], 0x7fffffff), st_ag(&gflags[14], -1);
+			if (!grid_sync<true>(A, sh, epoch, G)) { R.status = ST_INTERNAL; break; }
+			const int32_t gfirst = wf_lo >> 8, n_words = ((wf_hi >> 8) - gfirst + 1) * 4;
+			int32_t mylo = 0x7fffffff, myhi = -1;
+			for (int32_t q = (int32_t)blockIdx.x * kT + tid; q < n_words; q += G * kT) {
+				const int32_t gg = gfirst + (q >> 2), kq = q & 3, base = gg * kChunk;
+				unsigned long long m = 0;
+				for (int32_t j = 0; j < nH; ++j)
+					if (sh.rng_lo[j] <= sh.rng_hi[j] && sh.rng_lo[j] <= base + kChunk - 1 && sh.rng_hi[j] >= base) m |= M.good[(int64_t)j * A.GW + (int64_t)gg * 4 + kq];
+				m &= lane_mask(base, kq, wf_lo, wf_hi);
+				if (m) {
+					mylo = min(mylo, base + 4 * (int32_t)__builtin_ctzll(m) + kq);
+					myhi = max(myhi, base + 4 * (63 - (int32_t)__builtin_clzll(m)) + kq);
+				}
+			}
+			if (myhi >= 0) {
+				__hip_atomic_fetch_min(&gflags[13], mylo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_fetch_max(&gflags[14], myhi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+			if (!grid_sync<false>(A, sh, epoch, G)) { R.status = ST_INTERNAL; break; }
+			const int32_t glo = uni(ld_ag(&gflags[13])), ghi = uni(ld_ag(&gflags[14]));
+			if (ghi < 0) { R.status = ST_INTERNAL; break; }
+			wf_lo = glo, wf_hi = ghi;
+		}
+		cells += hi - lo + 1;
+		if ((A.max_iter > 0 && cells > A.max_iter) || (A.max_s > 0 && s > A.max_s)) {
+			R.status = ST_STOPPED;
+			break;
+		}
+		if (done) {
+			R.info = payload;
+			break;
+		}
+	}
+	R.s = s, R.cells = cells;
+	return R;
+}
+
+template <int E1, int E2>
+__global__ __launch_bounds__(kT) void wfa_coop_kernel(const BatchArgs A)
+{
+	__shared__ Shared sh;
+	const int32_t pair = A.coop_pair;
+	PairMem M;
+	pair_mem(A, 0, pair, M);
+	int32_t n_seg = 0;
+	if (A.coop_pass == 2) { // second pass of the low-memory mode: checkpoints left by the walk
+		if (A.coop_state[0] != ST_OK) return; // first pass failed: nothing to do, the finish kernel reports it
+		n_seg = A.coop_state[3];
+	}
+	PassResult R;
+	if (A.want_cigar) R = coop_pass<E1, E2, true>(A, M, sh, n_seg);
+	else R = coop_pass<E1, E2, false>(A, M, sh, 0);
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		int32_t *st = A.coop_state + (A.coop_pass == 2 ? 8 : 0);
+		st[0] = R.status, st[1] = R.s, st[2] = R.info;
+		st[4] = (int32_t)(R.cells & 0xffffffff), st[5] = (int32_t)(R.cells >> 32);
+	}
+}
+
+// Checkpoints of the low-memory mode from the full traceback matrix of a first pass.
+//
+// The reference's first pass (miniwfa.c:495-549) gives every cell the index of the ring cell its optimal predecessor
+// chain went through at the last snapshot; chasing those indices from the end cell through all snapshots yields, for the
+// snapshot taken when the newest slice had penalty S_j = (j+1)*step-1, the (penalty, diagonal) of the LAST cell of that
+// chain with penalty <= S_j.  The chain itself is dictated by the traceback bits (:506-522): H follows its 3-bit source
+// state, a gap state follows its own "extended" bit to either the same gap state e penalties back or H o+e back, one
+// diagonal over.  Walking those bits here reproduces the same chain, hence the same checkpoints.
+__global__ void coop_walk_kernel(const BatchArgs A)
+{
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	int32_t *st = A.coop_state;
+	st[3] = 0;
+	if (st[0] != ST_OK) return;
+	const Penalty &P = A.pen;
+	PairMem M;
+	pair_mem(A, 0, A.coop_pair, M);
+	const int32_t s_final = st[1], step = A.step;
+	const int32_t n_seg = s_final / step;
+	if (n_seg > A.seg_slot) { st[0] = ST_SNAP_OVERFLOW; return; }
+	int32_t arr = 0, s = s_final, col = M.ql - M.tl + M.tl + 1; // array 0=H 1=E1 2=F1 3=E2 4=F2; the end cell is on diagonal ql-tl
+	int32_t j = n_seg - 1;
+	while (j >= 0) {
+		const int32_t Sj = (j + 1) * step - 1;
+		if (s <= Sj) { // first cell of the chain that already existed at snapshot j
+			M.seg[2 * j] = s, M.seg[2 * j + 1] = col;
+			--j;
+			continue;
+		}
+		if (s <= 0) { st[0] = ST_INTERNAL; return; }
+		const uint32_t x = M.tb[M.row_off[s - 1] + (col - M.row_lo[s - 1])];
+		if (arr == 0) {
+			const uint32_t z = x & 7u;
+			if (z == 0) s -= P.x;
+			else arr = (int32_t)z == 1 ? 1 : (int32_t)z == 2 ? 2 : (int32_t)z == 3 ? 3 : 4;
+		} else if (arr == 1) { if (x & 0x08u) s -= P.e1; else s -= P.oe1, arr = 0; col -= 1; }
+		else if (arr == 2) { if (x & 0x10u) s -= P.e1; else s -= P.oe1, arr = 0; col += 1; }
+		else if (arr == 3) { if (x & 0x20u) s -= P.e2; else s -= P.oe2, arr = 0; col -= 1; }
+		else { if (x & 0x40u) s -= P.e2; else s -= P.oe2, arr = 0; col += 1; }
+	}
+	st[3] = n_seg;
+}
+
+__global__ __launch_bounds__(64) void coop_finish_kernel(const BatchArgs A)
+{
+	const int32_t pair = A.coop_pair;
+	PairMem M;
+	pair_mem(A, 0, pair, M);
+	const int32_t *st1 = A.coop_state, *st = A.step > 0 && A.want_cigar ? A.coop_state + 8 : A.coop_state;
+	PassResult R;
+	int32_t status = st1[0] != ST_OK ? st1[0] : st[0];
+	R.status = status, R.s = st[1], R.info = st[2], R.n_snap = 0;
+	R.cells = (int64_t)(uint32_t)st[4] | (int64_t)st[5] << 32;
+	const int64_t cells1 = A.step > 0 && A.want_cigar ? ((int64_t)(uint32_t)st1[4] | (int64_t)st1[5] << 32) : 0;
+	finish_pair(A, M, 0, pair, R, status, cells1);
+}
+
+template <int E1, int E2>
+int launch_pass(const BatchArgs &a, int grid, hipStream_t st)
+{
+	hipLaunchKernelGGL((wfa_coop_kernel<E1, E2>), dim3(grid), dim3(kT), 0, st, a);
+	return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+} // namespace
+
+bool coop_supported(const Penalty &p)
+{
+	const bool inst = (p.e1 == 2 && p.e2 == 1) || (p.e1 == 2 && p.e2 == 2);
+	return inst && p.x >= 2 && p.oe1 >= 2 && p.oe2 >= 2;
+}
+
+int coop_max_grid(bool)
+{
+	int dev = 0, n_cu = 0, per = 0;
+	if (hipGetDevice(&dev) != hipSuccess) return 0;
+	if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, wfa_coop_kernel<2, 1>, kT, 0) != hipSuccess || per < 1) return 0;
+	return n_cu; // one workgroup per CU: every one of them is resident, which the grid barrier relies on
+}
+
+int launch_coop_pass(const BatchArgs &a, int grid, void *stream)
+{
+	if (a.pen.e1 == 2 && a.pen.e2 == 1) return launch_pass<2, 1>(a, grid, (hipStream_t)stream);
+	if (a.pen.e1 == 2 && a.pen.e2 == 2) return launch_pass<2, 2>(a, grid, (hipStream_t)stream);
+	return -1;
+}
+
+int launch_coop_walk(const BatchArgs &a, void *stream)
+{
+	hipLaunchKernelGGL(coop_walk_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
+	return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_coop_finish(const BatchArgs &a, void *stream)
+{
+	hipLaunchKernelGGL(coop_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
+	return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+} // namespace mwf

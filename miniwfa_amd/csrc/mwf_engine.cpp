@@ -53,7 +53,7 @@ struct mwf_gpu_s {
 	int64_t tb_budget_mb = 0;   // 0: automatic
 	int force_kind = -1;
 	// workspace (per-stream pool)
-	DevBuf ring, sring, good, tb, row_off, row_lo, cig_scratch, snap, snap_meta, seg, queue, dbg;
+	DevBuf ring, sring, good, tb, row_off, row_lo, cig_scratch, snap, snap_meta, seg, queue, dbg, coop_edge, coop_misc;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	bool ev_pending = false;
 	mwf_gpu_stats_t stats{};
@@ -289,6 +289,93 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	return 0;
 }
 
+
+// One pair across the whole device (mwf_coop.hip).  Everything is enqueued on the stream: first pass, and in low-memory
+// mode the checkpoint walk over its traceback matrix and the second pass, then traceback + outputs.
+int run_coop_pair(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, int32_t pair, bool first, bool last)
+{
+	const Penalty P = make_penalty(opt);
+	const bool cigar = (opt.flag & MWF_F_CIGAR) != 0, low_mem = cigar && opt.step > 0;
+	const int G = std::min(coop_max_grid(cigar), g->n_cu);
+	if (G < 1) { g->err = "whole-device kernel cannot be made resident"; return -1; }
+	const int64_t len = (int64_t)b->h_tl[pair] + b->h_ql[pair];
+	const int64_t bound = penalty_bound(opt, b->h_tl[pair], b->h_ql[pair], true);
+	const int64_t bound1 = penalty_bound(opt, b->h_tl[pair], b->h_ql[pair], false);
+	const int32_t W = (int32_t)((len + 3 + 255) / 256 * 256 + 512), GW = W / 64 + 2;
+	const int64_t TC = (int64_t)G * 8 * 2;
+	if (ensure(g, g->ring, (size_t)P.nH * W * 4 + 4096)) return -1;
+	if (ensure(g, g->good, (size_t)P.nH * GW * 8)) return -1;
+	if (ensure(g, g->coop_edge, (size_t)(3 * TC * 4 + (int64_t)P.nH * TC * 2) * 4)) return -1;
+	if (ensure(g, g->coop_misc, 4096)) return -1;
+	int64_t rows_slot = 0, tb_bytes = 0, cig_scratch = 0, seg_slot = 0;
+	if (cigar) {
+		rows_slot = std::max(bound, bound1) + 2;
+		cig_scratch = len + 2;
+		size_t fr = 0, tot = 0;
+		if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = (size_t)8 << 30;
+		int64_t budget = g->tb_budget_mb > 0 ? (g->tb_budget_mb << 20) : (int64_t)(fr / 10 * 9) + (int64_t)g->tb.bytes;
+		const int64_t worst = (rows_slot + 1) * (len + 8);
+		tb_bytes = std::max<int64_t>(4096, std::min(budget, worst)) / 4 * 4;
+		if (ensure(g, g->row_off, (size_t)rows_slot * 8)) return -1;
+		if (ensure(g, g->row_lo, (size_t)rows_slot * 4)) return -1;
+		if (ensure(g, g->cig_scratch, (size_t)cig_scratch * 4)) return -1;
+		if (low_mem) {
+			seg_slot = bound1 / opt.step + 2;
+			if (ensure(g, g->seg, (size_t)seg_slot * 8)) return -1;
+		}
+		if (ensure(g, g->tb, (size_t)tb_bytes)) return -1;
+	}
+	if (b->debug_pair == pair && ensure(g, g->dbg, (size_t)8 * (bound + 2))) return -1;
+
+	BatchArgs a;
+	memset(&a, 0, sizeof(a));
+	a.seqs = b->d_seqs, a.t_off = b->d_t_off, a.q_off = b->d_q_off, a.tl = b->d_tl, a.ql = b->d_ql;
+	a.n_pairs = b->n;
+	a.pen = P;
+	a.want_cigar = cigar ? 1 : 0;
+	a.step = low_mem ? opt.step : 0;
+	a.max_s = opt.max_s, a.max_iter = opt.max_iter;
+	a.debug_pair = b->debug_pair;
+	a.ring = (int32_t*)g->ring.p, a.ring_slot_ints = (int64_t)P.nH * W, a.W = W;
+	a.good = (unsigned long long*)g->good.p, a.GW = GW;
+	a.tb = cigar ? (uint8_t*)g->tb.p : nullptr, a.tb_slot_bytes = tb_bytes;
+	a.row_off = cigar ? (int64_t*)g->row_off.p : nullptr, a.row_lo = cigar ? (int32_t*)g->row_lo.p : nullptr, a.rows_slot = rows_slot;
+	a.cig_scratch = cigar ? (uint32_t*)g->cig_scratch.p : nullptr, a.cig_scratch_slot = cig_scratch;
+	a.cig_pool = b->d_cig_pool, a.cig_head = b->d_cig_head, a.cig_pool_words = b->cig_pool_words;
+	a.seg = low_mem ? (int32_t*)g->seg.p : nullptr, a.seg_slot = seg_slot;
+	a.out_s = b->d_s, a.out_iter = b->d_iter, a.out_ncig = b->d_ncig, a.out_cigoff = b->d_cigoff;
+	a.out_status = b->d_status, a.out_cells1 = b->d_cells1, a.out_dbg = b->d_dbg4;
+	a.dbg = b->debug_pair == pair ? (int32_t*)g->dbg.p : nullptr;
+	a.dbg_cap = b->debug_pair == pair ? (int32_t)(g->dbg.bytes / 8) : 0;
+	a.coop_pair = pair;
+	a.coop_edge = (int32_t*)g->coop_edge.p;
+	a.coop_flags = (int32_t*)g->coop_misc.p;                       // 64 ints
+	a.coop_sync = (unsigned int*)((char*)g->coop_misc.p + 1024);   // 64 uints
+	a.coop_state = (int32_t*)((char*)g->coop_misc.p + 2048);       // 16 ints
+
+	HIP_TRY(g, hipMemsetAsync(g->coop_misc.p, 0, 4096, g->stream));
+	if (first) HIP_TRY(g, hipEventRecord(g->ev0, g->stream));
+	a.coop_pass = low_mem ? 1 : 0;
+	if (launch_coop_pass(a, G, g->stream)) { g->err = "kernel launch failed (whole-device pass)"; return -1; }
+	g->stats.n_launches += 1;
+	if (low_mem) {
+		if (launch_coop_walk(a, g->stream)) { g->err = "kernel launch failed (checkpoint walk)"; return -1; }
+		HIP_TRY(g, hipMemsetAsync((char*)g->coop_misc.p + 1024, 0, 1024, g->stream)); // barrier counter of the second pass
+		a.coop_pass = 2;
+		// the second pass is not traced: the band trace of a low-memory run is that of its second pass, traced below
+		if (launch_coop_pass(a, G, g->stream)) { g->err = "kernel launch failed (second pass)"; return -1; }
+		g->stats.n_launches += 2;
+	}
+	if (launch_coop_finish(a, g->stream)) { g->err = "kernel launch failed (traceback)"; return -1; }
+	g->stats.n_launches += 1;
+	if (last) {
+		HIP_TRY(g, hipEventRecord(g->ev1, g->stream));
+		g->ev_pending = true;
+	}
+	g->stats.grid = G, g->stats.block = 512, g->stats.kernel_kind = 1;
+	return 0;
+}
+
 int64_t tb_budget_bytes(mwf_gpu_t *g)
 {
 	if (g->tb_budget_mb > 0) return g->tb_budget_mb << 20;
@@ -340,7 +427,7 @@ void mwf_gpu_destroy(mwf_gpu_t *g)
 	if (!g) return;
 	(void)hipSetDevice(g->device);
 	(void)hipStreamSynchronize(g->stream);
-	for (DevBuf *b : {&g->ring, &g->sring, &g->good, &g->tb, &g->row_off, &g->row_lo, &g->cig_scratch, &g->snap, &g->snap_meta, &g->seg, &g->queue, &g->dbg})
+	for (DevBuf *b : {&g->ring, &g->sring, &g->good, &g->tb, &g->row_off, &g->row_lo, &g->cig_scratch, &g->snap, &g->snap_meta, &g->seg, &g->queue, &g->dbg, &g->coop_edge, &g->coop_misc})
 		release(*b);
 	if (g->ev0) (void)hipEventDestroy(g->ev0);
 	if (g->ev1) (void)hipEventDestroy(g->ev1);
@@ -502,6 +589,17 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	if (b->debug_pair >= 0 && ensure(g, g->dbg, (size_t)8 * (max_bound + 2))) return -1;
 	HIP_TRY(g, hipMemsetAsync(b->d_cig_head, 0, 64, g->stream));
 	HIP_TRY(g, hipMemsetAsync(b->d_status, 0xff, (size_t)b->n * 4, g->stream));
+	// a few long pairs: each one gets the whole device in turn
+	const Penalty P0 = make_penalty(*opt);
+	const int64_t coop_len = g->coop_min_len > 0 ? g->coop_min_len : 65536;
+	const bool coop = g->force_kind == 1 || (g->force_kind < 0 && coop_supported(P0) && b->n <= 8 && max_len >= coop_len);
+	if (coop) {
+		if (!coop_supported(P0)) { g->err = "whole-device kernel does not support these penalties"; return -2; }
+		for (int32_t i = 0; i < b->n; ++i)
+			if (run_coop_pair(g, b, *opt, i, i == 0, i == b->n - 1)) return -1;
+		b->aligned = true;
+		return 0;
+	}
 	const int64_t budget = cigar ? tb_budget_bytes(g) : 0;
 	if (run_batch_kernel(g, b, *opt, b->d_order, b->n, slots, max_len, max_bound, max_bound1, budget, true)) return -1;
 	b->aligned = true;
@@ -546,7 +644,10 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 		}
 		if (redo.empty()) break;
 		if (band_overflow) redo_kind = 0; // the window outgrew the register-resident span: generic kernel, same slots
-		else if (slots == 1) {
+		else if (g->stats.kernel_kind == 1 && b->opt.step > 0 && round == 0) {
+			// whole-device low-memory run whose first-pass traceback does not fit: the generic kernel's true two-pass mode
+			redo_kind = 0, slots = (int)redo.size(), band_overflow = true;
+		} else if (slots == 1) {
 			g->err = std::string(b->h_status[redo[0]] == ST_TB_OVERFLOW ? "traceback" : "low-memory snapshots") + " of pair " + std::to_string(redo[0]) +
 			         " (tl=" + std::to_string(b->h_tl[redo[0]]) + ", ql=" + std::to_string(b->h_ql[redo[0]]) + ") do not fit in device memory" +
 			         (b->opt.step > 0 ? "" : "; set opt.step > 0 (low-memory mode)");

@@ -84,6 +84,13 @@ struct BatchArgs {
 	int32_t *out_dbg;          // [pair][4]: traceback end state (row, i, k) and last_state, for MWF_F_DEBUG
 	int32_t *dbg;              // optional band trace of debug_pair: [2*dbg_cap] lo,hi per penalty (columns)
 	int32_t dbg_cap;
+	// ---- whole-device (cooperative) kernel only: cross-workgroup state, all accessed at agent scope
+	int32_t coop_pair;         // the one pair this launch aligns
+	int32_t coop_pass;         // 0: plain pass; 1: pass whose traceback feeds the checkpoint walk; 2: second pass (uses seg)
+	int32_t *coop_edge;        // [3][waves*2][4] E1/E2 of a chunk's last column, F1/F2 of its first column
+	int32_t *coop_flags;       // [3][4] edge-live / end-cell flags per penalty (mod 3), + [16..] barrier counters etc.
+	unsigned int *coop_sync;   // [0]: arrivals, [1..8]: per-group arrivals, [9..16]: per-group generation, [32]: timeout
+	int32_t *coop_state;       // results of a pass handed to the next launch: [0]=status [1]=s [2]=info [3]=n_seg [4..5]=cells
 };
 
 // launch wrappers implemented in mwf_kernels.hip (generic kernel: any penalties, any band, low-memory mode)
@@ -96,6 +103,13 @@ struct BandGeom {
 	int span;         // columns the workgroup can hold: (block/64) * 2 * 256
 	int lds_bytes;    // dynamic LDS for the sequence copy (0: read sequences from global memory)
 };
+// launch wrappers implemented in mwf_coop.hip (one pair across the whole device)
+bool coop_supported(const Penalty &p);
+int  coop_max_grid(bool cigar);                      // co-resident workgroups the kernel may be launched with
+int  launch_coop_pass(const BatchArgs &a, int grid, void *stream);       // forward pass (score / traceback bytes)
+int  launch_coop_walk(const BatchArgs &a, void *stream);                 // checkpoints from the traceback matrix
+int  launch_coop_finish(const BatchArgs &a, void *stream);               // traceback + per-pair outputs
+
 bool band_supported(const Penalty &p);                       // (e1,e2) instantiated and every H lag >= 2
 int  launch_band(const BatchArgs &a, int grid, const BandGeom &g, void *stream);
 int  band_kernel_occupancy(const Penalty &p, const BandGeom &g, bool cigar);

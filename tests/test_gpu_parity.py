@@ -195,6 +195,44 @@ def test_band_kernel_stop_rules_and_shrink(oracle):
     eng.close()
 
 
+def test_whole_device_kernel_against_oracle(oracle):
+    """mwf_coop.hip forced on (it is chosen automatically only for a few long pairs): score, CIGAR, low-memory mode
+    (checkpoints read off the first pass's traceback matrix must give the reference's second-pass n_iter and CIGAR),
+    stop rules, degenerate inputs.  Sizes reach several shrinks and tens of 256-column chunks."""
+    eng = mw.Engine(0)
+    eng.set("force_kind", 1)
+    cases = [synth_pair(88000, 300, 0.1), synth_pair(88001, 3000, 0.05), synth_pair(88002, 20000, 0.04),
+             synth_pair(88003, 9000, 0.2), synth_pair(88004, 15000, 0.01, 3, 2000),
+             (b"", b"ACGT"), (b"ACGT", b""), (b"A" * 7000, b"A" * 7000), (b"A" * 1200, b"C" * 1100)]
+    opts = [make_opt(), make_opt(flag=1), make_opt(flag=1, step=100), make_opt(flag=1, step=1000), make_opt(flag=1, step=5000),
+            make_opt(flag=1, o2=4, e2=2), make_opt(flag=1, o2=4, e2=2, step=300)]
+    for o in opts:
+        go = mw.opt_init(**{k: getattr(o, k) for k in OPT_KEYS})
+        for lo in range(0, len(cases), 3):
+            pairs = cases[lo:lo + 3]
+            b = eng.upload(PackedBatch(pairs))
+            b.align(go)
+            assert eng.stats().kernel_kind == 1
+            s, it, nc = b.results()
+            for i, (t, q) in enumerate(pairs):
+                es, eit, ecig = oracle.align(t, q, o)
+                why = explain_band(t, q, go, oracle) if (s[i], it[i]) != (es, eit) and o.step == 0 else ""
+                assert (int(s[i]), int(it[i])) == (es, eit), (lo + i, len(t), len(q), o.flag, o.step, o.o2, why)
+                if ecig is not None:
+                    assert b.cigar(i, int(nc[i])).tolist() == ecig, (lo + i, o.step)
+            b.free()
+    t, q = cases[2]
+    full = oracle.align(t, q, make_opt())
+    for kw in (dict(max_s=full[0] - 1), dict(max_s=full[0]), dict(max_iter=full[1] - 1), dict(max_iter=full[1]), dict(max_s=500)):
+        for flag, step in ((0, 0), (1, 0), (1, 700)):
+            b = eng.upload(PackedBatch([(t, q)]))
+            b.align(mw.opt_init(flag=flag, step=step, **kw))
+            s, it, nc = b.results()
+            assert (int(s[0]), int(it[0])) == oracle.align(t, q, make_opt(flag=flag, step=step, **kw))[:2], (kw, flag, step)
+            b.free()
+    eng.close()
+
+
 def test_stop_rules(engine, oracle):
     t, q = synth_pair(83000, 2000, 0.1)
     full = oracle.align(t, q, make_opt())
