@@ -429,7 +429,8 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 			wf_lo = glo, wf_hi = ghi;
 		}
 		cells += hi - lo + 1;
-		if ((A.max_iter > 0 && cells > A.max_iter) || (A.max_s > 0 && s > A.max_s)) {
+		// the low-memory first pass has no stop rules and is not counted in n_iter (miniwfa.c:569-589)
+		if (A.coop_pass != 1 && ((A.max_iter > 0 && cells > A.max_iter) || (A.max_s > 0 && s > A.max_s))) {
 			R.status = ST_STOPPED;
 			break;
 		}

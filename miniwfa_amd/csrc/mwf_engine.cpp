@@ -643,7 +643,11 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 			}
 		}
 		if (redo.empty()) break;
-		if (band_overflow) redo_kind = 0; // the window outgrew the register-resident span: generic kernel, same slots
+		if (band_overflow) {
+			redo_kind = 0; // the window outgrew the register-resident span: generic kernel, same slots
+			if (g->stats.kernel_kind == 1)
+				fprintf(stderr, "[libmwf_hip] warning: wavefront of pair %d outgrew the whole-device kernel's span; re-running it on one workgroup (slow)\n", redo[0]);
+		}
 		else if (g->stats.kernel_kind == 1 && b->opt.step > 0 && round == 0) {
 			// whole-device low-memory run whose first-pass traceback does not fit: the generic kernel's true two-pass mode
 			redo_kind = 0, slots = (int)redo.size(), band_overflow = true;
