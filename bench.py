@@ -52,7 +52,8 @@ def main():
     ap.add_argument("--cigar", action="store_true", help="score+CIGAR (high-memory) instead of score-only")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--slots-per-cu", type=int, default=0)
-    ap.add_argument("--cpu-sample", type=int, default=256, help="pairs in the cpu_baseline sample (0: skip)")
+    ap.add_argument("--cpu-sample", type=int, default=512, help="pairs in the cpu_baseline sample (0: skip)")
+    ap.add_argument("--long-pairs", type=int, default=1, help="also time the single-pair configs (C4-like 150 kb, MHC-like 5 Mb) on rank 0 at N=1")
     ap.add_argument("--seed", type=int, default=50000)
     args = ap.parse_args()
 
@@ -158,7 +159,9 @@ def main():
                         f"{'score+CIGAR high-mem' if args.cigar else 'score-only'} mwf_wfa_exact, default penalties (BASELINE configs[2])",
             "pairs_per_gpu": args.pairs, "target_len": args.tl, "divergence": args.div,
             "bases_per_gpu": pk.bases, "cells_per_gpu": cells, "mean_s": float(s.mean()),
-            "kernel": "wfa_batch_kernel (one workgroup per pair)", "grid": eng.stats().grid, "block": eng.stats().block,
+            "kernel": {0: "wfa_batch_kernel (generic: one workgroup per pair, ring in HBM)", 1: "wfa_coop_kernel (one pair across the device)",
+                       2: "wfa_band_kernel (one workgroup per pair, E/F in registers, H rows prefetched)"}.get(eng.stats().kernel_kind, "?"),
+            "grid": eng.stats().grid, "block": eng.stats().block,
             "parallelism": f"pairs sharded over {world} GPU(s), RCCL all_gather of (s,n_iter)",
         },
         "gcells_per_s": total_cells * args.steps / elapsed / 1e9,
@@ -206,6 +209,33 @@ def main():
             "gcells_per_s": float(n_iter[:n].sum()) / sec / 1e9,
             "gpu_matches_cpu_on_sample": ok,
         }
+    # ---- the single-pair configs of BASELINE.json (configs[1] and configs[3]); stand-ins, see SURVEY.md §8d
+    if world == 1 and args.long_pairs:
+        lp = {}
+        try:
+            batch.free()
+            for name, seed, tl_, p_, nl, lm, modes in (
+                    ("c4_like_150kb", 2001, 150000, 0.035, 0, 0, (("score", {}), ("cigar_highmem", {"flag": 1}))),
+                    ("mhc_like_5Mb", 2002, 5000000, 0.008, 3, 15000, (("cigar_lowmem_p5000", {"flag": 1, "step": 5000}),))):
+                t_, q_ = synth_pair(seed, tl_, p_, nl, lm)
+                bb = eng.upload(PackedBatch([(t_, q_)]))
+                for label, kw in modes:
+                    o_ = mw.opt_init(**kw)
+                    bb.align(o_)
+                    bb.results()               # first call also sizes the workspace (55 GB traceback arena for the 5 Mb pair)
+                    bb.align(o_)
+                    s_, it_, nc_ = bb.results()
+                    st_ = eng.stats()
+                    rec = {"s": int(s_[0]), "n_iter": int(it_[0]), "kernel_s": st_.kernel_ms * 1e-3, "cells_pass1": int(st_.cells_pass1),
+                           "gbp_s": (len(t_) + len(q_)) / (st_.kernel_ms * 1e-3) / 1e9}
+                    if kw.get("flag"):
+                        cg = bb.cigar(0, int(nc_[0])).tolist()
+                        rec["cigar_rescored_ok"] = mw.cigar2score(mw.opt_init(), cg) == (int(s_[0]), len(t_), len(q_))
+                    lp.setdefault(name, {"tl": len(t_), "ql": len(q_)})[label] = rec
+                bb.free()
+        except Exception as e:  # never lose the headline line over the extras
+            lp["error"] = repr(e)
+        out["long_pairs"] = lp
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

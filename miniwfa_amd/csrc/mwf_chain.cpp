@@ -1,0 +1,234 @@
+// mwf_chain.cpp — mwf_wfa_chain(): the chaining heuristic of miniwfa (reference miniwfa.c:617-896) on top of the
+// GPU exact path.
+//
+// The heuristic itself is small host-side integer work and stays on the host: collect every forward k-mer of both
+// sequences, pair the ones that occur at most max_occ times on each side, keep a longest colinear subset, drop anchors
+// sitting on gapless runs shorter than min_len, then walk the anchors.  What the reference does one at a time inside
+// that walk — an exact alignment of every gap between anchors (miniwfa.c:877) — is collected here and run as ONE device
+// batch (mwf_wfa_batch), which is the only expensive part.  Results (penalty and CIGAR) are the reference's:
+// tests/test_gpu_parity.py checks them against vectors produced by the reference's own chain mode.
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "miniwfa.h"
+#include "kalloc.h"
+
+namespace {
+
+// A/a C/c G/g T/t U/u -> 0..3, anything else breaks the k-mer (reference seq_nt4_table, miniwfa.c:699-716)
+inline int base_code(unsigned char c)
+{
+	switch (c) {
+	case 'A': case 'a': return 0;
+	case 'C': case 'c': return 1;
+	case 'G': case 'g': return 2;
+	case 'T': case 't': case 'U': case 'u': return 3;
+	default: return 4;
+	}
+}
+
+// every k-mer of seq as (kmer << 1 | rid) << 32 | end position  (reference mg_fc_kmer, miniwfa.c:718-730)
+void collect_kmers(int32_t len, const char *seq, int rid, int k, std::vector<uint64_t> &out)
+{
+	const uint64_t mask = (1ULL << (2 * k)) - 1;
+	uint64_t x = 0;
+	int32_t run = 0;
+	for (int32_t i = 0; i < len; ++i) {
+		const int c = base_code((unsigned char)seq[i]);
+		if (c < 4) {
+			x = (x << 2 | (uint64_t)c) & mask;
+			if (++run >= k) out.push_back((x << 1 | (uint64_t)rid) << 32 | (uint32_t)i);
+		} else run = 0, x = 0;
+	}
+}
+
+// Longest strictly increasing subsequence, patience sorting with predecessor links (reference mg_lis_64,
+// miniwfa.c:678-697).  Among equally long answers the one this construction yields is the one the reference returns.
+std::vector<int32_t> longest_increasing(const std::vector<uint64_t> &a)
+{
+	const int32_t n = (int32_t)a.size();
+	std::vector<int32_t> tail(n + 1, 0), pred(n, 0);
+	int32_t L = 0;
+	for (int32_t i = 0; i < n; ++i) {
+		int32_t lo = 1, hi = L;
+		while (lo <= hi) {
+			const int32_t mid = (lo + hi + 1) >> 1;
+			if (a[tail[mid]] < a[i]) lo = mid + 1;
+			else hi = mid - 1;
+		}
+		pred[i] = tail[lo - 1];
+		tail[lo] = i;
+		if (lo > L) L = lo;
+	}
+	std::vector<int32_t> out(L);
+	for (int32_t i = L - 1, k = L ? tail[L] : 0; i >= 0; --i) out[i] = k, k = pred[k];
+	return out;
+}
+
+// Colinear anchors (target end << 32 | query end), reference mg_chain, miniwfa.c:732-784
+std::vector<uint64_t> chain_anchors(int32_t tl, const char *ts, int32_t ql, const char *qs, int k, int max_occ)
+{
+	std::vector<uint64_t> anchors;
+	if (tl < k || ql < k) return anchors;
+	if (k < 2 || k > 15) { fprintf(stderr, "[libmwf_hip] mwf_wfa_chain: kmer must be in [2,15]\n"); abort(); }
+	std::vector<uint64_t> a;
+	a.reserve((size_t)tl + ql);
+	collect_kmers(tl, ts, 0, k, a);
+	collect_kmers(ql, qs, 1, k, a);
+	std::sort(a.begin(), a.end()); // keys are unique, so any correct sort gives the reference's order
+	std::vector<uint64_t> b;
+	for (size_t i0 = 0, i = 1; i <= a.size(); ++i) {
+		if (i == a.size() || (a[i0] >> 33) != (a[i] >> 33)) {
+			size_t j = i0;
+			while (j < i && ((a[j] >> 32) & 1) == 0) ++j; // target occurrences sort first
+			if (j > i0 && j < i && (int64_t)(j - i0) <= max_occ && (int64_t)(i - j) <= max_occ)
+				for (size_t s = i0; s < j; ++s)
+					for (size_t t = j; t < i; ++t)
+						b.push_back(a[s] << 32 | (uint32_t)a[t]);
+			i0 = i;
+		}
+	}
+	std::sort(b.begin(), b.end());
+	for (uint64_t &v : b) v = v >> 32 | v << 32; // order by target position, compare by query position
+	const std::vector<int32_t> lis = longest_increasing(b);
+	anchors.reserve(lis.size());
+	for (int32_t idx : lis) anchors.push_back(b[idx] >> 32 | b[idx] << 32);
+	return anchors;
+}
+
+// Drop anchors that sit on a gapless run shorter than min_len (reference wf_anchor_filter, miniwfa.c:829-848)
+void filter_anchors(std::vector<uint64_t> &a, int32_t tl, int32_t ql, int32_t k, int32_t min_len)
+{
+	const int32_t n = (int32_t)a.size();
+	int32_t x0 = 0, y0 = 0, x1 = 0, start = -1, run = 0;
+	for (int32_t i = 0; i <= n; ++i) {
+		int32_t x, y;
+		if (i == n) x = tl, y = ql;
+		else x = (int32_t)(a[i] >> 32) + 1, y = (int32_t)a[i] + 1;
+		if (x - x0 != y - y0) {
+			if (run < min_len)
+				for (int32_t j = start > 0 ? start : 0; j < i; ++j) a[j] = 0;
+			x0 = x, y0 = y, start = i, run = k;
+		} else run += x - x1;
+		x1 = x;
+	}
+	a.erase(std::remove(a.begin(), a.end(), (uint64_t)0), a.end());
+}
+
+// fraction of shared k-mers, the larger of the two directions (reference mwf_ksim, miniwfa.c:786-812)
+double kmer_similarity(int32_t l1, const char *s1, int32_t l2, const char *s2, int k)
+{
+	if (l1 < k || l2 < k) return 0;
+	std::vector<uint64_t> a;
+	collect_kmers(l1, s1, 0, k, a);
+	collect_kmers(l2, s2, 1, k, a);
+	std::sort(a.begin(), a.end());
+	int64_t n1 = 0, n2 = 0, shared = 0;
+	for (size_t i0 = 0, i = 1; i <= a.size(); ++i) {
+		if (i == a.size() || (a[i0] >> 33) != (a[i] >> 33)) {
+			size_t j = i0;
+			while (j < i && ((a[j] >> 32) & 1) == 0) ++j;
+			const int64_t m1 = (int64_t)(j - i0), m2 = (int64_t)(i - j);
+			n1 += m1, n2 += m2;
+			if (m1 > 0 && m2 > 0) shared += std::min(m1, m2);
+			i0 = i;
+		}
+	}
+	const double p1 = (double)shared / n1, p2 = (double)shared / n2;
+	return p1 > p2 ? p1 : p2;
+}
+
+struct CigarBuf {
+	std::vector<uint32_t> w;
+	void push(uint32_t op, int32_t len) // reference wf_cigar_push1, miniwfa.c:51-62
+	{
+		if (!w.empty() && (w.back() & 0xf) == op) w.back() += (uint32_t)len << 4;
+		else w.push_back((uint32_t)len << 4 | op);
+	}
+	void append(int32_t n, const uint32_t *c) // reference wf_cigar_push, miniwfa.c:816-827: only the first op may merge
+	{
+		if (n == 0) return;
+		push(c[0] & 0xf, (int32_t)(c[0] >> 4));
+		w.insert(w.end(), c + 1, c + n);
+	}
+};
+
+struct Segment {       // one step of the walk over the anchors
+	int kind;          // 0 '=' run, 1 exact gap fill, 2 too-diverged block (D then I), 3 pure deletion, 4 pure insertion
+	int32_t x0, y0, dx, dy;
+	int32_t fill;      // index into the gap-fill batch (kind 1)
+};
+
+inline int32_t gap_cost(const mwf_opt_t *o, int32_t len)
+{
+	const int32_t a = o->o2 + len * o->e2, b = o->o1 + len * o->e1;
+	return a < b ? a : b;
+}
+
+} // namespace
+
+extern "C" void mwf_wfa_chain(void *km, const mwf_opt_t *opt, int32_t tl, const char *ts, int32_t ql, const char *qs, mwf_rst_t *r)
+{
+	std::vector<uint64_t> anchors = chain_anchors(tl, ts, ql, qs, opt->kmer, opt->max_occ);
+	filter_anchors(anchors, tl, ql, opt->kmer, opt->min_len);
+	const int32_t n_a = (int32_t)anchors.size();
+	const bool want_cigar = (opt->flag & MWF_F_CIGAR) != 0;
+
+	// ---- walk the anchors (reference miniwfa.c:861-891) and collect the gaps that need an exact alignment
+	std::vector<Segment> segs;
+	std::vector<int32_t> ftl, fql;
+	std::vector<const char*> fts, fqs;
+	int32_t x0 = 0, y0 = 0;
+	for (int32_t i = 0; i <= n_a; ++i) {
+		int32_t x1, y1;
+		if (i == n_a) x1 = tl, y1 = ql;
+		else x1 = (int32_t)(anchors[i] >> 32) + 1, y1 = (int32_t)anchors[i] + 1;
+		Segment sg{-1, x0, y0, x1 - x0, y1 - y0, -1};
+		if (i < n_a && x1 - x0 == y1 - y0 && x1 - x0 <= opt->kmer) sg.kind = 0;
+		else if (x0 < x1 && y0 < y1) {
+			if (x1 - x0 >= 10000 && y1 - y0 >= 10000 && kmer_similarity(x1 - x0, ts + x0, y1 - y0, qs + y0, opt->kmer) < 0.02) sg.kind = 2;
+			else {
+				sg.kind = 1, sg.fill = (int32_t)ftl.size();
+				ftl.push_back(x1 - x0), fql.push_back(y1 - y0), fts.push_back(ts + x0), fqs.push_back(qs + y0);
+			}
+		} else if (x0 < x1) sg.kind = 3;
+		else if (y0 < y1) sg.kind = 4;
+		if (sg.kind >= 0) segs.push_back(sg);
+		x0 = x1, y0 = y1;
+	}
+
+	// ---- every gap fill in one device batch (the reference calls mwf_wfa_exact per gap, miniwfa.c:877)
+	std::vector<mwf_rst_t> fills(ftl.size());
+	if (!ftl.empty())
+		mwf_wfa_batch(nullptr, opt, (int32_t)ftl.size(), ftl.data(), fts.data(), fql.data(), fqs.data(), fills.data());
+
+	// ---- stitch
+	CigarBuf c;
+	int32_t score = 0;
+	for (const Segment &sg : segs) {
+		switch (sg.kind) {
+		case 0: if (want_cigar) c.push(7, sg.dx); break;
+		case 1:
+			if (want_cigar) c.append(fills[sg.fill].n_cigar, fills[sg.fill].cigar);
+			score += fills[sg.fill].s;
+			break;
+		case 2:
+			if (want_cigar) c.push(2, sg.dx), c.push(1, sg.dy);
+			score += opt->o2 * 2 + opt->e2 * (sg.dx + sg.dy);
+			break;
+		case 3: c.push(2, sg.dx), score += gap_cost(opt, sg.dx); break; // pushed even without MWF_F_CIGAR (miniwfa.c:883-885)
+		case 4: c.push(1, sg.dy), score += gap_cost(opt, sg.dy); break;
+		}
+	}
+	for (mwf_rst_t &f : fills) free(f.cigar);
+	r->s = score; // n_iter is left as the caller had it (miniwfa.c:850-896 never writes it)
+	r->n_cigar = (int32_t)c.w.size();
+	r->cigar = nullptr;
+	if (!c.w.empty()) {
+		r->cigar = (uint32_t*)kmalloc(km, c.w.size() * sizeof(uint32_t));
+		memcpy(r->cigar, c.w.data(), c.w.size() * sizeof(uint32_t));
+	}
+}

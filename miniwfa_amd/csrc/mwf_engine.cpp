@@ -800,11 +800,7 @@ void mwf_wfa_exact(void *km, const mwf_opt_t *opt, int32_t tl, const char *ts, i
 	mwf_wfa_batch(km, opt, 1, &tl, &ts, &ql, &qs, r);
 }
 
-void mwf_wfa_chain(void *km, const mwf_opt_t *opt, int32_t tl, const char *ts, int32_t ql, const char *qs, mwf_rst_t *r)
-{
-	(void)km, (void)opt, (void)tl, (void)ts, (void)ql, (void)qs, (void)r;
-	fatal("mwf_wfa_chain: the chaining heuristic (reference miniwfa.c:617-896) is not part of this build yet", nullptr);
-}
+// mwf_wfa_chain lives in mwf_chain.cpp
 
 void mwf_wfa_auto(void *km, const mwf_opt_t *opt0, int32_t tl, const char *ts, int32_t ql, const char *qs, mwf_rst_t *r)
 {

@@ -233,6 +233,37 @@ def test_whole_device_kernel_against_oracle(oracle):
     eng.close()
 
 
+def test_chain_and_auto_against_reference():
+    """mwf_wfa_chain (reference miniwfa.c:850-896): host chaining + one GPU batch of gap fills must give the reference's
+    penalty and CIGAR — on the stored chain-mode vectors and, when the compiled reference travelled with the snapshot,
+    on fresh pairs; mwf_wfa_auto must switch to it exactly when the exact branch stops at 1e8 cells."""
+    from oracle.pyoracle import Reference
+    for v in load_golden("exact_small.jsonl") + load_golden("bench_shaped.jsonl"):
+        if v["entry"] != "chain":
+            continue
+        t, q = golden_inputs(v)
+        s, _, cig = mw.wfa_chain(t, q, gpu_opt(v["opt"]))
+        assert s == v["expect"]["s"], v["id"]
+        assert (None if cig is None else mw.cigar_str(cig)) == v["expect"]["cigar"], v["id"]
+    if not Reference.available():
+        pytest.skip("oracle/_ref/libmwf_ref.so not present")
+    ref = Reference()
+    for j in range(10):
+        t, q = synth_pair(89000 + j, (400, 3000, 12000, 30000)[j % 4], (0.02, 0.06, 0.15)[j % 3], j % 3, 700)
+        for kw in (dict(flag=1), dict(flag=0), dict(flag=1, kmer=11, max_occ=3, min_len=20), dict(flag=1, step=200)):
+            es, _, ecig = ref.chain(t, q, make_opt(**kw))
+            s, _, cig = mw.wfa_chain(t, q, mw.opt_init(**kw))
+            assert (s, cig) == (es, ecig), (j, kw)
+    # auto: a pair whose exact alignment needs > 1e8 cells falls through to the chain (miniwfa.c:901-907)
+    t, q = synth_pair(89100, 60000, 0.06)
+    es, eit, ecig = ref.auto(t, q, make_opt(flag=1))
+    s, it, cig = mw.wfa_auto(t, q, mw.opt_init(flag=1))
+    assert (s, it, cig) == (es, eit, ecig)
+    assert it > 100000000
+    t, q = synth_pair(89101, 8000, 0.03)
+    assert mw.wfa_auto(t, q, mw.opt_init(flag=1)) == ref.auto(t, q, make_opt(flag=1))
+
+
 def test_stop_rules(engine, oracle):
     t, q = synth_pair(83000, 2000, 0.1)
     full = oracle.align(t, q, make_opt())
