@@ -108,6 +108,8 @@ class Oracle(_Aligner):
         L.mwfo_batch.argtypes = [C.POINTER(Opt), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_int32, C.c_void_p, C.c_void_p]
         L.mwfo_batch.restype = C.c_double
+        L.mwfo_batch_with.argtypes = [C.c_void_p] + L.mwfo_batch.argtypes
+        L.mwfo_batch_with.restype = C.c_double
         self._exact = L.mwfo_exact
         self._free = lambda p: L.mwfo_free(C.cast(p, C.c_void_p))
 
@@ -152,14 +154,17 @@ class Oracle(_Aligner):
         n = self.lib.mwfo_band_trace(C.byref(opt), len(t), t, len(q), q, buf, cap)
         return [(buf[2 * i], buf[2 * i + 1]) for i in range(min(n, cap))]
 
-    def batch(self, packed, opt: Opt, threads: int):
-        """Score-only threaded batch over a miniwfa_amd.synth.PackedBatch; returns (s[], n_iter[], seconds)."""
+    def batch(self, packed, opt: Opt, threads: int, exact_fn=None, n=None):
+        """Threaded (pthreads, one pair per thread at a time) batch over the first n pairs of a miniwfa_amd.synth.PackedBatch;
+        returns (s[], n_iter[], wall seconds).  exact_fn: address of a function with mwf_wfa_exact's signature to time instead
+        of the restatement (e.g. Reference().exact_addr())."""
         import numpy as np
-        s = np.zeros(packed.n, dtype=np.int32)
-        it = np.zeros(packed.n, dtype=np.int64)
-        sec = self.lib.mwfo_batch(C.byref(opt), packed.n, packed.seqs.ctypes.data, packed.t_off.ctypes.data,
-                                  packed.tl.ctypes.data, packed.q_off.ctypes.data, packed.ql.ctypes.data,
-                                  threads, s.ctypes.data, it.ctypes.data)
+        n = packed.n if n is None else min(n, packed.n)
+        s = np.zeros(n, dtype=np.int32)
+        it = np.zeros(n, dtype=np.int64)
+        sec = self.lib.mwfo_batch_with(exact_fn, C.byref(opt), n, packed.seqs.ctypes.data, packed.t_off.ctypes.data,
+                                       packed.tl.ctypes.data, packed.q_off.ctypes.data, packed.ql.ctypes.data,
+                                       threads, s.ctypes.data, it.ctypes.data)
         return s, it, sec
 
 
@@ -198,6 +203,10 @@ class Reference(_Aligner):
         o = Opt()
         self.lib.mwf_opt_init(C.byref(o))
         return o
+
+    def exact_addr(self) -> int:
+        """Address of the reference's mwf_wfa_exact, for Oracle.batch(exact_fn=...)."""
+        return C.cast(self.lib.mwf_wfa_exact, C.c_void_p).value
 
     def _call(self, fn, t, q, opt):
         r = Rst()
