@@ -46,5 +46,24 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+CLI = os.path.join(ROOT, "tools", "test-mwf")
+
+
+def build_cli(force: bool = False) -> str:
+    """tools/test-mwf: the reference's command line (main.c) on top of libmwf_hip.so; gzip input when zlib.h is there."""
+    src = os.path.join(ROOT, "tools", "test-mwf.cpp")
+    if not force and os.path.exists(CLI) and os.path.getmtime(CLI) >= max(os.path.getmtime(src), os.path.getmtime(LIB)):
+        return CLI
+    zl = ["-DMWF_HAVE_ZLIB", "-lz"] if os.path.exists("/usr/include/zlib.h") else []
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-o", CLI,
+           "-L", CSRC, "-lmwf_hip", "-Wl,-rpath," + CSRC] + zl
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("g++ failed building tools/test-mwf")
+    return CLI
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_cli(force="--force" in sys.argv))

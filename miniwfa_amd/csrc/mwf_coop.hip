@@ -107,13 +107,28 @@ __device__ __forceinline__ bool grid_sync(const BatchArgs &A, Shared &sh, unsign
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		}
-		__hip_atomic_fetch_add(&A.coop_sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		const unsigned target = epoch * n_groups;
+		// Two levels: workgroups with the same (blockIdx mod 8) — which the dispatcher is observed to place on one XCD, though
+		// nothing here depends on it — count on their own word; the last of a group to arrive counts on the top word, waits for
+		// all groups there and then releases its group through the group's generation word.  Pollers of a word are at most
+		// one group, and (usually) sit behind one L2.
+		unsigned *const sync = A.coop_sync;
+		const unsigned grp = blockIdx.x & 7u, n_grp = n_groups < 8u ? n_groups : 8u;
+		const unsigned gsize = (n_groups - grp + 7u) / 8u;
 		unsigned spins = 0;
 		int32_t ok = 1;
-		while (__hip_atomic_load(&A.coop_sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-			__builtin_amdgcn_s_sleep(1);
-			if (++spins > kSpinLimit) { ok = 0; break; }
+		const unsigned old = __hip_atomic_fetch_add(&sync[8 * (1 + grp)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (old + 1 == gsize * epoch) {
+			__hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_grp * epoch) {
+				__builtin_amdgcn_s_sleep(1);
+				if (++spins > kSpinLimit) { ok = 0; break; }
+			}
+			__hip_atomic_store(&sync[8 * (9 + grp)], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		} else {
+			while (__hip_atomic_load(&sync[8 * (9 + grp)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+				__builtin_amdgcn_s_sleep(1);
+				if (++spins > kSpinLimit) { ok = 0; break; }
+			}
 		}
 		if (FENCE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 		sh.word[3] = ok;
