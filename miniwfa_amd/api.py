@@ -65,9 +65,11 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB
-    if not os.path.exists(path) or _build.stale():
-        path = _build.build()
+    path = os.environ.get("MWF_HIP_LIB")   # experiments only (e.g. an instrumented build); default: the in-tree library
+    if not path:
+        path = _build.LIB
+        if not os.path.exists(path) or _build.stale():
+            path = _build.build()
     L = C.CDLL(path)
     P = C.POINTER
     sig = [C.c_void_p, P(MwfOpt), C.c_int32, C.c_char_p, C.c_int32, C.c_char_p, P(MwfRst)]

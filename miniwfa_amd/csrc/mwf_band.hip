@@ -171,7 +171,13 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 		for (int k = 0; k < K; ++k) prefetch(k, 1, hi1, gl);
 	}
 
+#ifdef MWF_BAND_TIMING
+	unsigned long long t_acc[4] = {0, 0, 0, 0}, t_steps = 0, t_active = 0;
+#endif
 	for (;;) {
+#ifdef MWF_BAND_TIMING
+		const unsigned long long t_a = __builtin_readcyclecounter();
+#endif
 		if (TB && sid < n_seg) { // checkpoint reset of the second pass (miniwfa.c:413-416)
 			if (uni(M.seg[2 * sid]) == s) {
 				const int32_t c = uni(M.seg[2 * sid + 1]);
@@ -219,6 +225,10 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 			if (trace_band && s_new - 1 < A.dbg_cap) M.dbg[2 * (s_new - 1)] = lo, M.dbg[2 * (s_new - 1) + 1] = hi;
 		}
 
+#ifdef MWF_BAND_TIMING
+		const unsigned long long t_b = __builtin_readcyclecounter();
+		int32_t t_nact = 0;
+#endif
 		const int32_t gbase = gl - gl % NWK;
 #pragma unroll
 		for (int k = 0; k < K; ++k) {
@@ -229,6 +239,9 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 			const bool active = cb <= hi && cb + kChunk - 1 >= lo; // this wave's chunk meets the window (uniform)
 			int32_t ne1[4], nf1[4], ne2[4], nf2[4];
 			if (active) {
+#ifdef MWF_BAND_TIMING
+				++t_nact;
+#endif
 				const int32_t c0 = cb + 4 * lane;
 				const bool inner = cb >= ilo && cb + kChunk - 1 <= ihi; // uniform: no window test needed anywhere
 				int32_t hx[4] = {phx[k].x, phx[k].y, phx[k].z, phx[k].w};
@@ -354,10 +367,20 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 		// order).  This penalty issued exactly 5*K loads, all before its stores; letting the youngest 5*K operations stay in
 		// flight therefore never leaves an older penalty's store pending, and keeps this penalty's own stores in flight when
 		// every H lag is >= 3.  Otherwise wait for everything.
+#ifdef MWF_BAND_TIMING
+		const unsigned long long t_c = __builtin_readcyclecounter();
+#endif
 		if (relaxed_stores) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(5 * K) : "memory");
 		else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 		__builtin_amdgcn_s_barrier();
 		asm volatile("" ::: "memory");
+#ifdef MWF_BAND_TIMING
+		{
+			const unsigned long long t_d = __builtin_readcyclecounter();
+			t_acc[0] += t_b - t_a, t_acc[1] += t_c - t_b, t_acc[2] += t_d - t_c;
+			t_steps += 1, t_active += (unsigned long long)t_nact;
+		}
+#endif
 
 		// ---- bookkeeping, identical on every thread
 		if (uni(sh.flags[npar][0])) wf_lo = lo;
@@ -395,6 +418,11 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 			break;
 		}
 	}
+#ifdef MWF_BAND_TIMING
+	if (lane == 0 && blockIdx.x == 0)
+		printf("wave %2d steps %llu active-slots %llu | header %llu  slots %llu  wait+barrier %llu cycles (per step %.0f / %.0f / %.0f)\n", wave, t_steps, t_active,
+		       t_acc[0], t_acc[1], t_acc[2], (double)t_acc[0] / t_steps, (double)t_acc[1] / t_steps, (double)t_acc[2] / t_steps);
+#endif
 	R.s = s, R.cells = cells;
 	return R;
 }
@@ -462,7 +490,10 @@ bool band_supported(const Penalty &p)
 
 #define MWF_BAND_DISPATCH(FN, ...)                                                    \
 	do {                                                                              \
-		if (g.block == 768) {                                                         \
+		if (g.block == 1024) {                                                        \
+			if (a_e1 == 2 && a_e2 == 1) return FN<1024, 2, 2, 1>(__VA_ARGS__);        \
+			if (a_e1 == 2 && a_e2 == 2) return FN<1024, 2, 2, 2>(__VA_ARGS__);        \
+		} else if (g.block == 768) {                                                  \
 			if (a_e1 == 2 && a_e2 == 1) return FN<768, 2, 2, 1>(__VA_ARGS__);         \
 			if (a_e1 == 2 && a_e2 == 2) return FN<768, 2, 2, 2>(__VA_ARGS__);         \
 		} else if (g.block == 256) {                                                  \

@@ -93,13 +93,31 @@ __device__ __forceinline__ int32_t lcp_wave(const PairMem &M, int32_t j, int32_t
 	return min(n, room);
 }
 
-// Device-wide barrier: all agent-scope stores of every wave are complete before its workgroup arrives.
-// FENCE adds the release/acquire pair that also publishes data written with ORDINARY stores (one lane per workgroup
-// fences, the __syncthreads() around it extend that to the workgroup) — only the shrink needs it.
+// Device-wide barrier that also reduces the three per-penalty flags.
+//
+// Arrivals are counted on two levels: workgroups with the same (blockIdx mod 8) — which the dispatcher is observed to
+// place on one XCD, though nothing here depends on it — count on their own word; the last of a group to arrive counts on
+// the top word, waits there for all groups and then releases its group through the group's 64-bit generation word.
+// The top word is 64 bits: arrivals in the low half, flag bits in the high half: bit 0 TOGGLES when the new low edge
+// is live, bit 1 when the new high edge is (exactly one wave owns an edge column, so each toggles at most once per
+// penalty and the change against the previous value is the flag); bits 2-5 become 1 | last_state<<1 once the end cell is
+// reached.  A workgroup that has something to report XORs it into the high half BEFORE it arrives (returning atomic, so
+// it is performed first); whoever releases a group copies the high half it saw next to the epoch, so every workgroup
+// leaves the barrier knowing the flags — no agent-scope flag loads afterwards.
+// `flags`: this workgroup's four LDS flag words of the penalty (or null).  `vm_keep`: how many of this wave's youngest
+// memory operations may still be in flight (0 = drain everything; see the call site).  FENCE: release/acquire pair for
+// data written with ordinary stores (only the shrink needs it).
 template <bool FENCE>
-__device__ __forceinline__ bool grid_sync(const BatchArgs &A, Shared &sh, unsigned &epoch, unsigned n_groups)
+__device__ __forceinline__ bool grid_sync(const BatchArgs &A, Shared &sh, unsigned &epoch, unsigned n_groups,
+                                          const int32_t *flags, unsigned &cum, int32_t vm_keep)
 {
-	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+	switch (vm_keep) { // the count must be an immediate
+	case 3:  asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); break;
+	case 4:  asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); break;
+	case 8:  asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); break;
+	case 9:  asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory"); break;
+	default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+	}
 	__syncthreads();
 	++epoch;
 	if (threadIdx.x == 0) {
@@ -107,33 +125,41 @@ __device__ __forceinline__ bool grid_sync(const BatchArgs &A, Shared &sh, unsign
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		}
-		// Two levels: workgroups with the same (blockIdx mod 8) — which the dispatcher is observed to place on one XCD, though
-		// nothing here depends on it — count on their own word; the last of a group to arrive counts on the top word, waits for
-		// all groups there and then releases its group through the group's generation word.  Pollers of a word are at most
-		// one group, and (usually) sit behind one L2.
-		unsigned *const sync = A.coop_sync;
+		unsigned long long *const top = (unsigned long long*)A.coop_sync;                 // [0]
+		unsigned *const grp_cnt = A.coop_sync + 16;                                        // [16 + 8*g]
+		unsigned long long *const grp_gen = (unsigned long long*)(A.coop_sync + 96);       // [96 + 8*g] (8-byte aligned)
 		const unsigned grp = blockIdx.x & 7u, n_grp = n_groups < 8u ? n_groups : 8u;
 		const unsigned gsize = (n_groups - grp + 7u) / 8u;
 		unsigned spins = 0;
 		int32_t ok = 1;
-		const unsigned old = __hip_atomic_fetch_add(&sync[8 * (1 + grp)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		unsigned long long seen = 0;
+		unsigned mine = 0;
+		if (flags) mine = (unsigned)(flags[0] != 0) | (unsigned)(flags[1] != 0) << 1 | (flags[2] != 0 ? (1u | (unsigned)flags[3] << 1) << 2 : 0u);
+		if (mine) (void)__hip_atomic_fetch_xor(top, (unsigned long long)mine << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const unsigned old = __hip_atomic_fetch_add(&grp_cnt[8 * grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (old + 1 == gsize * epoch) {
-			__hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_grp * epoch) {
+			(void)__hip_atomic_fetch_add(top, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			for (;;) {
+				seen = __hip_atomic_load(top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if ((unsigned)(seen & 0xffffffffu) >= n_grp * epoch) break;
 				__builtin_amdgcn_s_sleep(1);
 				if (++spins > kSpinLimit) { ok = 0; break; }
 			}
-			__hip_atomic_store(&sync[8 * (9 + grp)], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(&grp_gen[4 * grp], (seen & 0xffffffff00000000ull) | epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		} else {
-			while (__hip_atomic_load(&sync[8 * (9 + grp)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+			for (;;) {
+				seen = __hip_atomic_load(&grp_gen[4 * grp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if ((unsigned)(seen & 0xffffffffu) >= epoch) break;
 				__builtin_amdgcn_s_sleep(1);
 				if (++spins > kSpinLimit) { ok = 0; break; }
 			}
 		}
 		if (FENCE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 		sh.word[3] = ok;
+		sh.word[2] = (int32_t)(seen >> 32);
 	}
 	__syncthreads();
+	cum = (unsigned)uni(sh.word[2]);
 	return uni(sh.word[3]) != 0;
 }
 
@@ -147,13 +173,14 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 	const bool lead = blockIdx.x == 0 && tid == 0;
 	const int64_t W = A.W;
 	const int32_t nH = A.pen.nH, lagx = A.pen.x, lag1 = A.pen.oe1, lag2 = A.pen.oe2;
+	const bool relaxed_stores = min(lagx, min(lag1, lag2)) >= 3;
 	int32_t *const H = M.H;
 	int32_t *const eedge = A.coop_edge;                    // [D][TC][4]
 	int32_t *const hedge = A.coop_edge + (int64_t)D * TC * 4; // [nH][TC][2]: H of a chunk's first / last column
 	int32_t *const gflags = A.coop_flags;                  // [3][4]
 	PassResult R;
 	R.status = ST_OK, R.s = 0, R.info = 0, R.n_snap = 0, R.cells = 0;
-	unsigned epoch = 0; // the host zeroes the arrival counter before every pass
+	unsigned epoch = 0, cum = 0, cum_prev = 0; // the host zeroes the barrier words before every pass
 
 	int32_t e1h[E1][kK][4], f1h[E1][kK][4], e2h[E2][kK][4], f2h[E2][kK][4];
 #pragma unroll
@@ -178,7 +205,6 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 		if (tid == 0) {
 			const int32_t c0 = tl + 1;
 			st_ag(&H[c0], k0); // its owner is some other workgroup's wave: write through
-			for (int32_t j = 0; j < 12; ++j) st_ag(&gflags[j], 0);
 			st_ag(&gflags[12], k0);
 			// the origin's chunk edges for the first lagged reads
 			const int32_t r0 = (c0 >> 8) % TC;
@@ -186,7 +212,8 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 			if ((c0 & 255) == 255) st_ag(&hedge[(0 * TC + r0) * 2 + 1], k0);
 		}
 	}
-	if (!grid_sync<false>(A, sh, epoch, G)) { R.status = ST_INTERNAL; return R; }
+	if (tid == 0) for (int32_t j = 0; j < 12; ++j) (&sh.flags[0][0])[j] = 0;
+	if (!grid_sync<false>(A, sh, epoch, G, nullptr, cum, 0)) { R.status = ST_INTERNAL; return R; }
 	{
 		const int32_t k0 = uni(ld_ag(&gflags[12]));
 		if (k0 == tl - 1 && k0 == ql - 1) { R.cells = 0; return R; }
@@ -222,7 +249,13 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 		for (int k = 0; k < kK; ++k) prefetch(k, 1, hi1, gl);
 	}
 
+#ifdef MWF_BAND_TIMING
+	unsigned long long t_acc[4] = {0, 0, 0, 0}, t_steps = 0, t_active = 0;
+#endif
 	for (;;) {
+#ifdef MWF_BAND_TIMING
+		const unsigned long long t_a = __builtin_readcyclecounter();
+#endif
 		if (TB && sid < n_seg) { // checkpoint reset of the second pass (miniwfa.c:413-416)
 			if (uni(M.seg[2 * sid]) == s) {
 				const int32_t c = uni(M.seg[2 * sid + 1]);
@@ -262,15 +295,21 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 		int32_t d1 = dnew - E1; if (d1 < 0) d1 += D;
 		int32_t d2 = dnew - E2; if (d2 < 0) d2 += D;
 
-		if (tid == 0) sh.rng_lo[newH] = lo, sh.rng_hi[newH] = hi;
+		if (tid == 0) {
+			sh.rng_lo[newH] = lo, sh.rng_hi[newH] = hi;
+			const int32_t nn = npar + 1 == 3 ? 0 : npar + 1; // this workgroup's flag words of the NEXT penalty
+			sh.flags[nn][0] = sh.flags[nn][1] = sh.flags[nn][2] = sh.flags[nn][3] = 0;
+		}
 		if (lead) {
-			const int32_t nn = npar + 1 == 3 ? 0 : npar + 1;
-			st_ag(&gflags[nn * 4 + 0], 0), st_ag(&gflags[nn * 4 + 1], 0), st_ag(&gflags[nn * 4 + 2], 0), st_ag(&gflags[nn * 4 + 3], 0);
 			if (TB) M.row_off[s_new - 1] = tb_used, M.row_lo[s_new - 1] = origin;
 			if (A.dbg && s_new - 1 < A.dbg_cap) M.dbg[2 * (s_new - 1)] = lo, M.dbg[2 * (s_new - 1) + 1] = hi;
 		}
 
+#ifdef MWF_BAND_TIMING
+		const unsigned long long t_b = __builtin_readcyclecounter();
+#endif
 		const int32_t gbase = gl - gl % TC;
+		bool act0 = false, act1 = false;
 #pragma unroll
 		for (int k = 0; k < kK; ++k) {
 			const int32_t r = gw + NWt * k;
@@ -280,6 +319,7 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 			const bool active = cb <= hi && cb + kChunk - 1 >= lo;
 			int32_t ne1[4], nf1[4], ne2[4], nf2[4];
 			if (active) {
+				if (k == 0) act0 = true; else act1 = true;
 				const int32_t c0 = cb + 4 * lane;
 				const bool inner = cb >= ilo && cb + kChunk - 1 <= ihi;
 				int32_t hx[4] = {phx[k].x, phx[k].y, phx[k].z, phx[k].w};
@@ -345,6 +385,9 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 					hv[i] = v.h;
 					tbw |= v.tb << (8 * i);
 				}
+				// E/F of the outer columns are final: publish them now so that the write-through overlaps the probes below
+				if (lane == 63) st_ag(&eedge[((int64_t)dnew * TC + r) * 4 + 0], ne1[3]), st_ag(&eedge[((int64_t)dnew * TC + r) * 4 + 1], ne2[3]);
+				if (lane == 0) st_ag(&eedge[((int64_t)dnew * TC + r) * 4 + 2], nf1[0]), st_ag(&eedge[((int64_t)dnew * TC + r) * 4 + 3], nf2[0]);
 				// a run of >= 4 matches continues: the wave walks it together, one owning lane and column at a time
 				unsigned long long owners = __ballot(pend != 0);
 				while (owners) {
@@ -383,18 +426,14 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 						if (lane == 0) gword[i] = m;
 					}
 				}
-				// outer columns for the neighbouring waves (any workgroup): agent scope
-				if (lane == 63) {
-					st_ag(&eedge[((int64_t)dnew * TC + r) * 4 + 0], ne1[3]), st_ag(&eedge[((int64_t)dnew * TC + r) * 4 + 1], ne2[3]);
-					st_ag(&hedge[((int64_t)newH * TC + r) * 2 + 1], hv[3]);
+				// H of the outer columns: read again no sooner than min-lag penalties from now
+				if (lane == 63) st_ag(&hedge[((int64_t)newH * TC + r) * 2 + 1], hv[3]);
+				if (lane == 0) st_ag(&hedge[((int64_t)newH * TC + r) * 2 + 0], hv[0]);
+				if (__ballot(live & 1u)) sh.flags[npar][0] = 1;   // uniform branches; every lane stores the same word
+				if (__ballot(live & 2u)) sh.flags[npar][1] = 1;
+				if (__ballot(fin)) {
+					if (fin) sh.flags[npar][2] = 1, sh.flags[npar][3] = done_info;
 				}
-				if (lane == 0) {
-					st_ag(&eedge[((int64_t)dnew * TC + r) * 4 + 2], nf1[0]), st_ag(&eedge[((int64_t)dnew * TC + r) * 4 + 3], nf2[0]);
-					st_ag(&hedge[((int64_t)newH * TC + r) * 2 + 0], hv[0]);
-				}
-				if (__ballot(live & 1u)) { if (lane == 0) st_ag(&gflags[npar * 4 + 0], 1); }
-				if (__ballot(live & 2u)) { if (lane == 0) st_ag(&gflags[npar * 4 + 1], 1); }
-				if (fin) st_ag(&gflags[npar * 4 + 3], done_info), st_ag(&gflags[npar * 4 + 2], 1);
 			} else {
 				prefetch(k, nextH, phi, gl_next);
 #pragma unroll
@@ -410,17 +449,36 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 			}
 		}
 
-		if (!grid_sync<false>(A, sh, epoch, G)) { R.status = ST_INTERNAL; break; }
+		// Late stores of a chunk (H row, traceback dword, the two H edge words) are not read by anybody for at least
+		// min-lag - 1 penalties; when every lag is >= 3 they may stay in flight across this barrier.  They are the youngest
+		// operations of the wave, except that an idle second chunk still issues its 5 dummy prefetch loads after them.
+		int32_t vm_keep = 0;
+		if (relaxed_stores && !track_good) {
+			if (act1) vm_keep = 3 + (TB ? 1 : 0);
+			else if (act0) vm_keep = 8 + (TB ? 1 : 0);
+		}
+#ifdef MWF_BAND_TIMING
+		const unsigned long long t_c = __builtin_readcyclecounter();
+#endif
+		if (!grid_sync<false>(A, sh, epoch, G, &sh.flags[npar][0], cum, vm_keep)) { R.status = ST_INTERNAL; break; }
+#ifdef MWF_BAND_TIMING
+		{
+			const unsigned long long t_d = __builtin_readcyclecounter();
+			t_acc[0] += t_b - t_a, t_acc[1] += t_c - t_b, t_acc[2] += t_d - t_c;
+			t_steps += 1, t_active += (unsigned long long)(act0 ? 1 : 0) + (act1 ? 1 : 0);
+		}
+#endif
 
 		// ---- bookkeeping, identical on every thread of every workgroup
-		if (uni(ld_ag(&gflags[npar * 4 + 0]))) wf_lo = lo;
-		if (uni(ld_ag(&gflags[npar * 4 + 1]))) wf_hi = hi;
-		const int32_t done = uni(ld_ag(&gflags[npar * 4 + 2])), payload = uni(ld_ag(&gflags[npar * 4 + 3]));
+		if ((cum ^ cum_prev) & 1u) wf_lo = lo;
+		if ((cum ^ cum_prev) & 2u) wf_hi = hi;
+		const int32_t done = (int32_t)((cum >> 2) & 1u), payload = (int32_t)((cum >> 3) & 7u);
+		cum_prev = cum;
 		s = s_new, curH = newH, par = npar, dcur = dnew, gl = gl_next;
 		if (TB) tb_used += row_bytes;
 		if ((s & 0xff) == 0) { // shrink (miniwfa.c:144-171): the good bits were written with ordinary stores by every CU
 			if (lead) st_ag(&gflags[13], 0x7fffffff), st_ag(&gflags[14], -1);
-			if (!grid_sync<true>(A, sh, epoch, G)) { R.status = ST_INTERNAL; break; }
+			if (!grid_sync<true>(A, sh, epoch, G, nullptr, cum, 0)) { R.status = ST_INTERNAL; break; }
 			const int32_t gfirst = wf_lo >> 8, n_words = ((wf_hi >> 8) - gfirst + 1) * 4;
 			int32_t mylo = 0x7fffffff, myhi = -1;
 			for (int32_t q = (int32_t)blockIdx.x * kT + tid; q < n_words; q += G * kT) {
@@ -438,7 +496,7 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 				__hip_atomic_fetch_min(&gflags[13], mylo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				__hip_atomic_fetch_max(&gflags[14], myhi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
-			if (!grid_sync<false>(A, sh, epoch, G)) { R.status = ST_INTERNAL; break; }
+			if (!grid_sync<false>(A, sh, epoch, G, nullptr, cum, 0)) { R.status = ST_INTERNAL; break; }
 			const int32_t glo = uni(ld_ag(&gflags[13])), ghi = uni(ld_ag(&gflags[14]));
 			if (ghi < 0) { R.status = ST_INTERNAL; break; }
 			wf_lo = glo, wf_hi = ghi;
@@ -454,6 +512,11 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 			break;
 		}
 	}
+#ifdef MWF_BAND_TIMING
+	if (lane == 0 && (tid >> 6) < 2 && (blockIdx.x == 0 || blockIdx.x == 72 || blockIdx.x == 73 || blockIdx.x == 74 || blockIdx.x == 200))
+		printf("wg %3d wave %d steps %llu active-slots %llu | per step: header %.0f  slots %.0f  drain+grid-barrier %.0f cycles\n", (int)blockIdx.x, tid >> 6,
+		       t_steps, t_active, (double)t_acc[0] / t_steps, (double)t_acc[1] / t_steps, (double)t_acc[2] / t_steps);
+#endif
 	R.s = s, R.cells = cells;
 	return R;
 }

