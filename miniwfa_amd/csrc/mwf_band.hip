@@ -490,10 +490,7 @@ bool band_supported(const Penalty &p)
 
 #define MWF_BAND_DISPATCH(FN, ...)                                                    \
 	do {                                                                              \
-		if (g.block == 1024) {                                                        \
-			if (a_e1 == 2 && a_e2 == 1) return FN<1024, 2, 2, 1>(__VA_ARGS__);        \
-			if (a_e1 == 2 && a_e2 == 2) return FN<1024, 2, 2, 2>(__VA_ARGS__);        \
-		} else if (g.block == 768) {                                                  \
+		if (g.block == 768) {                                                         \
 			if (a_e1 == 2 && a_e2 == 1) return FN<768, 2, 2, 1>(__VA_ARGS__);         \
 			if (a_e1 == 2 && a_e2 == 2) return FN<768, 2, 2, 2>(__VA_ARGS__);         \
 		} else if (g.block == 256) {                                                  \
