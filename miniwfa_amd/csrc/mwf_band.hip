@@ -96,7 +96,7 @@ __device__ __forceinline__ uint32_t inm_bit(int32_t d, int32_t k, int32_t tl, in
 	return (uint32_t)((uint32_t)(k + 1) < (uint32_t)(tl + 1)) & (uint32_t)((uint32_t)(d + k + 1) < (uint32_t)(ql + 1));
 }
 
-template <int T, int K, int E1, int E2, bool TB, bool LSEQ>
+template <int T, int K, int E1, int E2, bool TB, bool LSEQ, bool PACK>
 __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh,
                                 int32_t (*edge)[(T / 64) * K][4], const uint8_t *lt, const uint8_t *lq,
                                 int32_t n_seg, bool trace_band)
@@ -112,17 +112,29 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 	PassResult R;
 	R.status = ST_OK, R.s = 0, R.info = 0, R.n_snap = 0, R.cells = 0;
 
-	// per-thread wavefront state: [age][slot][column-in-lane]; age 0 is the previous penalty
-	int32_t e1h[E1][K][4], f1h[E1][K][4], e2h[E2][K][4], f2h[E2][K][4];
+	// per-thread wavefront state: [age][slot][column-in-lane]; age 0 is the previous penalty.
+	// PACK: two columns per register as int16 (the host only selects it when every offset that can occur, phantom ones
+	// included, is below 32767 and the penalty count is too, so a dead value — stored as max(v, -32768) — can drift up by
+	// one per penalty without ever reaching -1).  Halves the state registers: what lets two workgroups share a CU.
+	constexpr int NS = PACK ? 2 : 4;
+	int32_t e1h[E1][K][NS], f1h[E1][K][NS], e2h[E2][K][NS], f2h[E2][K][NS];
+	constexpr int32_t kDeadState = PACK ? (int32_t)0x80008000u : kNegInf;
 #pragma unroll
 	for (int k = 0; k < K; ++k)
 #pragma unroll
-		for (int i = 0; i < 4; ++i) {
+		for (int i = 0; i < NS; ++i) {
 #pragma unroll
-			for (int a = 0; a < E1; ++a) e1h[a][k][i] = f1h[a][k][i] = kNegInf;
+			for (int a = 0; a < E1; ++a) e1h[a][k][i] = f1h[a][k][i] = kDeadState;
 #pragma unroll
-			for (int a = 0; a < E2; ++a) e2h[a][k][i] = f2h[a][k][i] = kNegInf;
+			for (int a = 0; a < E2; ++a) e2h[a][k][i] = f2h[a][k][i] = kDeadState;
 		}
+	auto col_of = [](const int32_t (&v)[NS], int i) -> int32_t { // column i (0..3) of a state vector
+		if (!PACK) return v[i];
+		return (i & 1) ? (v[i >> 1] >> 16) : (int32_t)(int16_t)(v[i >> 1] & 0xffff);
+	};
+	auto pack2 = [](int32_t a, int32_t b) -> int32_t { // two offsets -> one register; dead values clamp to -32768
+		return (int32_t)(((uint32_t)max(a, -32768) & 0xffffu) | ((uint32_t)max(b, -32768) << 16));
+	};
 	int4 phx[K], po1[K], po2[K];   // prefetched H rows of the next penalty: lags x, o1+e1, o2+e2
 	int32_t pe1[K], pe2[K];        // lane 0: column to the left of the chunk, lane 63: column to its right
 
@@ -167,8 +179,9 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 	{
 		const int32_t lo1 = wf_lo > 1 ? wf_lo - 1 : 1, hi1 = wf_hi < cmax ? wf_hi + 1 : cmax;
 		gl = lo1 >> 8;
+		if (!PACK)
 #pragma unroll
-		for (int k = 0; k < K; ++k) prefetch(k, 1, hi1, gl);
+			for (int k = 0; k < K; ++k) prefetch(k, 1, hi1, gl);
 	}
 
 #ifdef MWF_BAND_TIMING
@@ -230,13 +243,29 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 		int32_t t_nact = 0;
 #endif
 		const int32_t gbase = gl - gl % NWK;
+		if (PACK) prefetch(0, newH, hi, gl);
+		bool act_k[K];
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			int32_t g = gbase + wave + NW * k;
+			if (g < gl) g += NWK;
+			act_k[k] = g * kChunk <= hi && g * kChunk + kChunk - 1 >= lo;
+		}
+		// PACK (slot-pipelined loads): the rows of chunk k+1 are loaded while chunk k computes; only the first chunk's rows
+		// of the next penalty cross the barrier.  Otherwise every chunk's rows of the next penalty are prefetched.
+		auto refill = [&](int k) {
+			if (!PACK) prefetch(k, nextH, phi, gl_next);
+			else if (k + 1 < K) prefetch(k + 1, newH, hi, gl); // unconditional (an idle chunk loads columns 0..3): the registers
+			                                                   // must be dead until here for the allocator to share them
+			// (the packed variant keeps nothing in flight across the barrier: the co-resident workgroup hides chunk 0's load latency)
+		};
 #pragma unroll
 		for (int k = 0; k < K; ++k) {
 			const int32_t r = wave + NW * k;
 			int32_t g = gbase + r;
 			if (g < gl) g += NWK;
 			const int32_t cb = g * kChunk;
-			const bool active = cb <= hi && cb + kChunk - 1 >= lo; // this wave's chunk meets the window (uniform)
+			const bool active = act_k[k]; // this wave's chunk meets the window (uniform)
 			int32_t ne1[4], nf1[4], ne2[4], nf2[4];
 			if (active) {
 #ifdef MWF_BAND_TIMING
@@ -249,7 +278,7 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 				o1[1] = po1[k].x, o1[2] = po1[k].y, o1[3] = po1[k].z, o1[4] = po1[k].w;
 				o2[1] = po2[k].x, o2[2] = po2[k].y, o2[3] = po2[k].z, o2[4] = po2[k].w;
 				int32_t v1 = pe1[k], v2 = pe2[k];
-				prefetch(k, nextH, phi, gl_next); // the registers just read are free: refill them for penalty s_new+1 now
+				if (!PACK) refill(k); // the registers just read are free: start the next loads now
 				if (!inner) {
 #pragma unroll
 					for (int i = 0; i < 4; ++i) {
@@ -269,14 +298,14 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 				{
 					const int32_t rl = r == 0 ? NWK - 1 : r - 1, rr = r + 1 == NWK ? 0 : r + 1;
 					const int32_t le1 = edge[d1][rl][0], le2 = edge[d2][rl][1], rf1 = edge[d1][rr][2], rf2 = edge[d2][rr][3];
-					g1m[0] = from_left(e1h[E1 - 1][k][3], le1);
-					g2m[0] = from_left(e2h[E2 - 1][k][3], le2);
-					g1p[3] = from_right(f1h[E1 - 1][k][0], rf1);
-					g2p[3] = from_right(f2h[E2 - 1][k][0], rf2);
+					g1m[0] = from_left(col_of(e1h[E1 - 1][k], 3), le1);
+					g2m[0] = from_left(col_of(e2h[E2 - 1][k], 3), le2);
+					g1p[3] = from_right(col_of(f1h[E1 - 1][k], 0), rf1);
+					g2p[3] = from_right(col_of(f2h[E2 - 1][k], 0), rf2);
 #pragma unroll
-					for (int i = 1; i < 4; ++i) g1m[i] = e1h[E1 - 1][k][i - 1], g2m[i] = e2h[E2 - 1][k][i - 1];
+					for (int i = 1; i < 4; ++i) g1m[i] = col_of(e1h[E1 - 1][k], i - 1), g2m[i] = col_of(e2h[E2 - 1][k], i - 1);
 #pragma unroll
-					for (int i = 0; i < 3; ++i) g1p[i] = f1h[E1 - 1][k][i + 1], g2p[i] = f2h[E2 - 1][k][i + 1];
+					for (int i = 0; i < 3; ++i) g1p[i] = col_of(f1h[E1 - 1][k], i + 1), g2p[i] = col_of(f2h[E2 - 1][k], i + 1);
 				}
 				// ---- the recurrence, then the first 4-byte probe of the match extension, branch-free for all 4 columns
 				int32_t hv[4], room[4], nmat[4];
@@ -302,6 +331,7 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 					hv[i] = v.h;
 					tbw |= v.tb << (8 * i);
 				}
+				if (PACK) refill(k); // packed variant: after the register-hungry recurrence; the loads still overlap the probes and the tail
 				if (__ballot(pend != 0)) { // rare: a run of >= 4 matches continues; one shared loop for the four columns
 					while (pend) {
 						const int32_t ii = __builtin_ctz(pend);
@@ -346,7 +376,7 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 					if (fin) sh.flags[npar][2] = 1, sh.flags[npar][3] = done_info;
 				}
 			} else {
-				prefetch(k, nextH, phi, gl_next);
+				refill(k);
 #pragma unroll
 				for (int i = 0; i < 4; ++i) ne1[i] = nf1[i] = ne2[i] = nf2[i] = kNegInf;
 			}
@@ -354,12 +384,15 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 			if (lane == 63) edge[dnew][r][0] = ne1[3], edge[dnew][r][1] = ne2[3];
 			if (lane == 0) edge[dnew][r][2] = nf1[0], edge[dnew][r][3] = nf2[0];
 #pragma unroll
-			for (int i = 0; i < 4; ++i) {
+			for (int i = 0; i < NS; ++i) {
 #pragma unroll
 				for (int a = E1 - 1; a > 0; --a) e1h[a][k][i] = e1h[a - 1][k][i], f1h[a][k][i] = f1h[a - 1][k][i];
 #pragma unroll
 				for (int a = E2 - 1; a > 0; --a) e2h[a][k][i] = e2h[a - 1][k][i], f2h[a][k][i] = f2h[a - 1][k][i];
-				e1h[0][k][i] = ne1[i], f1h[0][k][i] = nf1[i], e2h[0][k][i] = ne2[i], f2h[0][k][i] = nf2[i];
+				if (PACK) {
+					e1h[0][k][i] = pack2(ne1[2 * i], ne1[2 * i + 1]), f1h[0][k][i] = pack2(nf1[2 * i], nf1[2 * i + 1]);
+					e2h[0][k][i] = pack2(ne2[2 * i], ne2[2 * i + 1]), f2h[0][k][i] = pack2(nf2[2 * i], nf2[2 * i + 1]);
+				} else e1h[0][k][i] = ne1[i], f1h[0][k][i] = nf1[i], e2h[0][k][i] = ne2[i], f2h[0][k][i] = nf2[i];
 			}
 		}
 
@@ -370,7 +403,7 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 #ifdef MWF_BAND_TIMING
 		const unsigned long long t_c = __builtin_readcyclecounter();
 #endif
-		if (relaxed_stores) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(5 * K) : "memory");
+		if (relaxed_stores) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PACK ? 2 : 5 * K) : "memory"); // PACK: at most the last chunk's H and traceback stores
 		else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 		__builtin_amdgcn_s_barrier();
 		asm volatile("" ::: "memory");
@@ -427,8 +460,9 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 	return R;
 }
 
-template <int T, int K, int E1, int E2, bool TB, bool LSEQ>
-__global__ __launch_bounds__(T) void wfa_band_kernel(const BatchArgs A)
+// PACK kernels are meant to run two workgroups per CU: 2 * T/64 waves = 2*T/256 waves per SIMD bounds their VGPRs
+template <int T, int K, int E1, int E2, bool TB, bool LSEQ, bool PACK>
+__global__ __launch_bounds__(T, PACK ? (2 * T / 256) : 1) void wfa_band_kernel(const BatchArgs A)
 {
 	constexpr int NWK = (T / 64) * K, D = (E1 > E2 ? E1 : E2) + 1;
 	__shared__ Shared sh;
@@ -451,31 +485,31 @@ __global__ __launch_bounds__(T) void wfa_band_kernel(const BatchArgs A)
 			__syncthreads();
 		}
 		const bool trace = A.dbg && pair == A.debug_pair;
-		const PassResult R = band_pass<T, K, E1, E2, TB, LSEQ>(A, M, sh, edge, lt, lq, 0, trace);
+		const PassResult R = band_pass<T, K, E1, E2, TB, LSEQ, PACK>(A, M, sh, edge, lt, lq, 0, trace);
 		finish_pair(A, M, (int32_t)blockIdx.x, pair, R, R.status, 0);
 	}
 }
 
-template <int T, int K, int E1, int E2>
+template <int T, int K, int E1, int E2, bool PACK>
 int launch_one(const BatchArgs &a, int grid, int lds, hipStream_t st)
 {
 	const bool tb = a.want_cigar != 0;
-	if (lds > 0 && tb) hipLaunchKernelGGL((wfa_band_kernel<T, K, E1, E2, true, true>), dim3(grid), dim3(T), lds, st, a);
-	else if (lds > 0) hipLaunchKernelGGL((wfa_band_kernel<T, K, E1, E2, false, true>), dim3(grid), dim3(T), lds, st, a);
-	else if (tb) hipLaunchKernelGGL((wfa_band_kernel<T, K, E1, E2, true, false>), dim3(grid), dim3(T), 0, st, a);
-	else hipLaunchKernelGGL((wfa_band_kernel<T, K, E1, E2, false, false>), dim3(grid), dim3(T), 0, st, a);
+	if (lds > 0 && tb) hipLaunchKernelGGL((wfa_band_kernel<T, K, E1, E2, true, true, PACK>), dim3(grid), dim3(T), lds, st, a);
+	else if (lds > 0) hipLaunchKernelGGL((wfa_band_kernel<T, K, E1, E2, false, true, PACK>), dim3(grid), dim3(T), lds, st, a);
+	else if (tb) hipLaunchKernelGGL((wfa_band_kernel<T, K, E1, E2, true, false, PACK>), dim3(grid), dim3(T), 0, st, a);
+	else hipLaunchKernelGGL((wfa_band_kernel<T, K, E1, E2, false, false, PACK>), dim3(grid), dim3(T), 0, st, a);
 	return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-template <int T, int K, int E1, int E2>
+template <int T, int K, int E1, int E2, bool PACK>
 int occ_one(int lds, bool tb)
 {
 	int n = 0;
 	hipError_t e;
-	if (lds > 0 && tb) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band_kernel<T, K, E1, E2, true, true>, T, lds);
-	else if (lds > 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band_kernel<T, K, E1, E2, false, true>, T, lds);
-	else if (tb) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band_kernel<T, K, E1, E2, true, false>, T, 0);
-	else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band_kernel<T, K, E1, E2, false, false>, T, 0);
+	if (lds > 0 && tb) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band_kernel<T, K, E1, E2, true, true, PACK>, T, lds);
+	else if (lds > 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band_kernel<T, K, E1, E2, false, true, PACK>, T, lds);
+	else if (tb) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band_kernel<T, K, E1, E2, true, false, PACK>, T, 0);
+	else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band_kernel<T, K, E1, E2, false, false, PACK>, T, 0);
 	return e == hipSuccess ? n : 0;
 }
 
@@ -490,12 +524,15 @@ bool band_supported(const Penalty &p)
 
 #define MWF_BAND_DISPATCH(FN, ...)                                                    \
 	do {                                                                              \
-		if (g.block == 768) {                                                         \
-			if (a_e1 == 2 && a_e2 == 1) return FN<768, 2, 2, 1>(__VA_ARGS__);         \
-			if (a_e1 == 2 && a_e2 == 2) return FN<768, 2, 2, 2>(__VA_ARGS__);         \
+		if (g.block == 512 && g.packed) {                                             \
+			if (a_e1 == 2 && a_e2 == 1) return FN<512, 3, 2, 1, true>(__VA_ARGS__);   \
+			if (a_e1 == 2 && a_e2 == 2) return FN<512, 3, 2, 2, true>(__VA_ARGS__);   \
+		} else if (g.block == 768) {                                                  \
+			if (a_e1 == 2 && a_e2 == 1) return FN<768, 2, 2, 1, false>(__VA_ARGS__);  \
+			if (a_e1 == 2 && a_e2 == 2) return FN<768, 2, 2, 2, false>(__VA_ARGS__);  \
 		} else if (g.block == 256) {                                                  \
-			if (a_e1 == 2 && a_e2 == 1) return FN<256, 2, 2, 1>(__VA_ARGS__);         \
-			if (a_e1 == 2 && a_e2 == 2) return FN<256, 2, 2, 2>(__VA_ARGS__);         \
+			if (a_e1 == 2 && a_e2 == 1) return FN<256, 2, 2, 1, false>(__VA_ARGS__);  \
+			if (a_e1 == 2 && a_e2 == 2) return FN<256, 2, 2, 2, false>(__VA_ARGS__);  \
 		}                                                                             \
 	} while (0)
 

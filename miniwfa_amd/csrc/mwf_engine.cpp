@@ -70,6 +70,7 @@ struct mwf_gpu_batch_s {
 	const int32_t *d_tl = nullptr, *d_ql = nullptr;
 	std::vector<int32_t> h_tl, h_ql;
 	int64_t max_seq_lds = 0;   // LDS bytes the band kernel needs to hold the longest pair's sequences
+	int64_t max_tl = 0;        // longest target (offsets are target indices: bounds what a 16-bit offset must hold)
 	int32_t *d_order = nullptr;
 	// outputs
 	int32_t *d_s = nullptr, *d_ncig = nullptr, *d_status = nullptr, *d_dbg4 = nullptr;
@@ -170,19 +171,27 @@ struct Plan {
 // Which kernel serves a set of pairs.  The band kernel keeps E/F in registers and therefore only holds windows up to
 // its span; it has no low-memory first pass.  kind: -1 automatic, 0 generic, 2 band.
 void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, int64_t max_len, int64_t max_bound,
-                   int64_t max_seq_lds, int want_kind, Plan &pl)
+                   int64_t max_seq_lds, int64_t max_tl, int want_kind, Plan &pl)
 {
 	pl.kind = 0;
 	const bool low_mem = (opt.flag & MWF_F_CIGAR) && opt.step > 0;
 	if (want_kind == 0 || low_mem || !band_supported(P)) return;
 	const int64_t max_window = std::min<int64_t>(max_len + 1, 2 * max_bound + 3);
 	BandGeom bg;
+	bg.packed = 0;
 	bg.block = max_window <= 8 * 256 - 256 - 64 ? 256 : 768;
+	// Wide windows: 512 threads x 3 chunks with the E/F registers packed as int16 pairs fits TWO workgroups per CU, which
+	// overlaps one pair's barrier phase with the other's compute.  Valid when no offset (a target index, plus at most one
+	// per penalty for offsets that ran past the matrix) and no penalty count can reach 32767.
+	// (score-only: with traceback the packed variant needs more than its 128 VGPRs, spills, and measures slower than 768 x 2)
+	const bool pack_ok = max_tl + max_bound < 32767 && !(opt.flag & MWF_F_CIGAR);
+	if (bg.block == 768 && pack_ok) bg.block = 512, bg.packed = 1;
 	// (measured alternatives on the 1024 x 10 kb batch: 1024 threads x 2 chunks spills and runs 50 ms, 512 x 3 runs 49 ms, 768 x 2 42 ms)
-	if (g->block == 256 || g->block == 768) bg.block = g->block;
-	bg.span = bg.block / 64 * 2 * 256;
+	if (g->block == 256 || g->block == 768) bg.block = g->block, bg.packed = 0;
+	if (g->block == 512 && pack_ok) bg.block = 512, bg.packed = 1;
+	bg.span = bg.block == 512 ? 8 * 3 * 256 : bg.block / 64 * 2 * 256;
 	if (want_kind != 2 && max_len + 1 > 4 * (int64_t)bg.span) return; // windows will mostly outgrow the span: go generic at once
-	const int64_t lds_cap = bg.block >= 768 ? 140 * 1024 : 36 * 1024;
+	const int64_t lds_cap = bg.block >= 768 ? 140 * 1024 : bg.block == 512 ? 70 * 1024 : 36 * 1024;
 	bg.lds_bytes = max_seq_lds <= lds_cap ? (int)((max_seq_lds + 15) / 16 * 16) : 0;
 	pl.kind = 2, pl.band = bg;
 }
@@ -196,12 +205,18 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	pl.cigar = (opt.flag & MWF_F_CIGAR) != 0;
 	pl.low_mem = pl.cigar && opt.step > 0;
 	pl.block = g->block > 0 && g->block != 768 ? g->block : 256;
-	choose_kernel(g, opt, P, max_len, max_bound, b->max_seq_lds, want_kind >= 0 ? want_kind : g->force_kind, pl);
+	choose_kernel(g, opt, P, max_len, max_bound, b->max_seq_lds, b->max_tl, want_kind >= 0 ? want_kind : g->force_kind, pl);
+	// `slots` is an upper bound from the caller (retries ask for fewer, larger slots); the chosen kernel's own residency
+	// bounds it as well
+	int per_cu;
 	if (pl.kind == 2) {
 		pl.block = pl.band.block;
-		int per_cu = g->slots_per_cu > 0 ? g->slots_per_cu : band_kernel_occupancy(P, pl.band, pl.cigar);
-		slots = std::max(1, std::min(slots, g->n_cu * std::max(1, per_cu)));
-	}
+		per_cu = g->slots_per_cu > 0 ? g->slots_per_cu : band_kernel_occupancy(P, pl.band, pl.cigar);
+	} else per_cu = g->slots_per_cu > 0 ? g->slots_per_cu : batch_kernel_occupancy(pl.block);
+	slots = std::max(1, std::min(slots, g->n_cu * std::max(1, per_cu)));
+	if (getenv("MWF_DEBUG"))
+		fprintf(stderr, "[libmwf_hip] kernel kind %d: block %d packed %d lds %d B, %d workgroup(s) per CU, %d slots\n", pl.kind, pl.block,
+		        pl.band.packed, pl.band.lds_bytes, per_cu, slots);
 	pl.grid = std::max(1, std::min<int>(slots, n_items));
 	// row stride: whole 256-column chunks plus room for the band kernel's neighbour loads past the last chunk
 	pl.W = (int32_t)((max_len + 3 + 255) / 256 * 256 + 512);
@@ -458,7 +473,7 @@ int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value)
 {
 	if (!g || !name) return -1;
 	if (!strcmp(name, "block")) {
-		if (value != 0 && value != 64 && value != 128 && value != 256 && value != 512 && value != 768 && value != 1024) return -1;
+		if (value != 0 && value != 64 && value != 128 && value != 256 && value != 384 && value != 512 && value != 768 && value != 1024) return -1;
 		g->block = (int)value;
 	} else if (!strcmp(name, "slots_per_cu")) g->slots_per_cu = (int)value;
 	else if (!strcmp(name, "coop_min_len")) g->coop_min_len = value;
@@ -494,6 +509,7 @@ static mwf_gpu_batch_t *batch_common(mwf_gpu_t *g, int32_t n, const int32_t *h_t
 	int64_t words = 0;
 	for (int32_t i = 0; i < n; ++i) {
 		words += (int64_t)h_tl[i] + h_ql[i] + 1;
+		b->max_tl = std::max<int64_t>(b->max_tl, h_tl[i]);
 		b->max_seq_lds = std::max<int64_t>(b->max_seq_lds, (((int64_t)h_tl[i] + 3) & ~3LL) + 8 + (((int64_t)h_ql[i] + 3) & ~3LL) + 16);
 	}
 	b->cig_pool_words = std::max<int64_t>(words, 1);
@@ -600,10 +616,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		max_bound1 = std::max(max_bound1, penalty_bound(*opt, b->h_tl[i], b->h_ql[i], false));
 	}
 	if (max_len + 4 >= ((int64_t)1 << 31)) { g->err = "tl+ql must be below 2^31-4"; return -2; }
-	const int block = g->block > 0 ? g->block : 256;
-	int per_cu = g->slots_per_cu > 0 ? g->slots_per_cu : batch_kernel_occupancy(block);
-	if (per_cu <= 0) per_cu = 1;
-	const int slots = std::max(1, g->n_cu * per_cu);
+	const int slots = 1 << 30; // as many as the chosen kernel can keep resident (run_batch_kernel bounds it)
 	if (b->debug_pair >= 0 && ensure(g, g->dbg, (size_t)8 * (max_bound + 2))) return -1;
 	HIP_TRY(g, hipMemsetAsync(b->d_cig_head, 0, 64, g->stream));
 	HIP_TRY(g, hipMemsetAsync(b->d_status, 0xff, (size_t)b->n * 4, g->stream));

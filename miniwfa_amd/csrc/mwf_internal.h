@@ -99,8 +99,9 @@ int batch_kernel_occupancy(int block);   // resident workgroups per CU for that 
 
 // launch wrappers implemented in mwf_band.hip (band kernel: E/F wavefronts live in registers)
 struct BandGeom {
-	int block;        // threads per workgroup (256 or 768)
-	int span;         // columns the workgroup can hold: (block/64) * 2 * 256
+	int block;        // threads per workgroup: 256 (x2 chunks), 768 (x2 chunks) or 512 (x3 chunks, packed state)
+	int packed;       // E/F register state held as int16 pairs (two workgroups fit a CU)
+	int span;         // columns the workgroup can hold: waves * chunks * 256
 	int lds_bytes;    // dynamic LDS for the sequence copy (0: read sequences from global memory)
 };
 // launch wrappers implemented in mwf_coop.hip (one pair across the whole device)

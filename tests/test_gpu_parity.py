@@ -147,7 +147,7 @@ def test_every_block_size_gives_identical_results(block, oracle):
     eng.close()
 
 
-@pytest.mark.parametrize("block", [256, 768])
+@pytest.mark.parametrize("block", [256, 512, 768])
 def test_band_kernel_against_oracle(block, oracle):
     """Register-resident band kernel forced on, both geometries: ragged sizes, both penalty sets it is instantiated
     for, score and CIGAR.  Pairs whose window outgrows the span (block 256 holds < 1800 columns) must come back
