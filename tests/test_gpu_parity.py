@@ -307,6 +307,37 @@ def test_whole_device_traceback_arena_grows(oracle):
     eng.close()
 
 
+def test_drop_in_api_is_reentrant_across_threads(oracle):
+    """The reference has no global mutable state (SURVEY §8b threading); here every host thread gets its own engine
+    (stream + device pool).  Four threads hammer mwf_wfa_exact / mwf_wfa_auto concurrently, each with its own kalloc arena."""
+    import threading
+    L = mw.lib()
+    pairs = [synth_pair(86500 + i, (200, 900, 2500)[i % 3], 0.07) for i in range(24)]
+    expect = [oracle.align(t, q, make_opt(flag=1)) for t, q in pairs]
+    errors = []
+
+    def worker(tid):
+        try:
+            km = L.km_init()
+            for rep in range(2):
+                for i in range(tid, len(pairs), 4):
+                    t, q = pairs[i]
+                    fn = mw.wfa_exact if (i + rep) % 2 == 0 else mw.wfa_auto
+                    got = fn(t, q, mw.opt_init(flag=mw.MWF_F_CIGAR), km=km)
+                    if got != expect[i]:
+                        errors.append((tid, i, got[:2], expect[i][:2]))
+            L.km_destroy(km)
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t_ in ts:
+        t_.start()
+    for t_ in ts:
+        t_.join()
+    assert not errors, errors[:3]
+
+
 def test_kalloc_arena_owns_the_cigar():
     L = mw.lib()
     km = L.km_init()
