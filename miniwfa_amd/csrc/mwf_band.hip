@@ -74,6 +74,29 @@ __device__ __forceinline__ uint32_t probe4(const PairMem &M, const uint8_t *lt, 
 	return a ^ b;
 }
 
+// Length of the exact-match run t[j..] == q[i..] (at most `room`, the first n0 bytes already known equal), walked by all
+// 64 lanes together: 256 bytes per trip.  Every argument is wave-uniform.
+template <bool LSEQ>
+__device__ __forceinline__ int32_t run_wave(const PairMem &M, const uint8_t *lt, const uint8_t *lq, int32_t j, int32_t i, int32_t room, int32_t n0)
+{
+	const int32_t lane = threadIdx.x & 63;
+	int32_t n = n0;
+	while (n < room) {
+		const int32_t off = n + 4 * lane;
+		int32_t m = 0;
+		if (off < room) {
+			const uint32_t x = probe4<LSEQ>(M, lt, lq, j + off, i + off);
+			m = min(x ? (int32_t)(__builtin_ctz(x) >> 3) : 4, room - off);
+		}
+		const unsigned long long stop = __ballot(m < 4); // lanes beyond `room` have m == 0 and stop the scan too
+		if (stop == 0) { n += 256; continue; }
+		const int32_t first = (int32_t)__builtin_ctzll(stop);
+		n += 4 * first + __builtin_amdgcn_readlane(m, first);
+		break;
+	}
+	return min(n, room);
+}
+
 // lanes l of interleaved word k (column = base + 4*l + k) whose column lies in [a,b]
 __device__ __forceinline__ unsigned long long lane_mask(int32_t base, int32_t k, int32_t a, int32_t b)
 {
@@ -185,7 +208,10 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 	}
 
 #ifdef MWF_BAND_TIMING
-	unsigned long long t_acc[4] = {0, 0, 0, 0}, t_steps = 0, t_active = 0;
+	unsigned long long t_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_steps = 0, t_active = 0, t_pend = 0, t_last = 0;
+#define MWF_TICK(i) do { const unsigned long long t_now = __builtin_readcyclecounter(); t_acc[i] += t_now - t_last; t_last = t_now; } while (0)
+#else
+#define MWF_TICK(i) do {} while (0)
 #endif
 	for (;;) {
 #ifdef MWF_BAND_TIMING
@@ -270,6 +296,11 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 			if (active) {
 #ifdef MWF_BAND_TIMING
 				++t_nact;
+				{
+					const unsigned long long t0 = __builtin_readcyclecounter();
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+					t_acc[3] += (t_last = __builtin_readcyclecounter()) - t0;
+				}
 #endif
 				const int32_t c0 = cb + 4 * lane;
 				const bool inner = cb >= ilo && cb + kChunk - 1 <= ihi; // uniform: no window test needed anywhere
@@ -307,6 +338,7 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 #pragma unroll
 					for (int i = 0; i < 3; ++i) g1p[i] = col_of(f1h[E1 - 1][k], i + 1), g2p[i] = col_of(f2h[E2 - 1][k], i + 1);
 				}
+				MWF_TICK(5);
 				// ---- the recurrence, then the first 4-byte probe of the match extension, branch-free for all 4 columns
 				int32_t hv[4], room[4], nmat[4];
 				uint32_t tbw = 0, pend = 0, live = 0, fin = 0, gbits = 0;
@@ -332,24 +364,47 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 					tbw |= v.tb << (8 * i);
 				}
 				if (PACK) refill(k); // packed variant: after the register-hungry recurrence; the loads still overlap the probes and the tail
-				if (__ballot(pend != 0)) { // rare: a run of >= 4 matches continues; one shared loop for the four columns
+				MWF_TICK(6);
+#ifdef MWF_BAND_TIMING
+				if (__ballot(pend != 0)) ++t_pend;
+#endif
+				// A run of >= 4 matches continues (one cell in 256 by chance, plus the cells on the alignment path, whose runs are
+				// 1/divergence long).  Each lane first walks its own runs 8 bytes per trip, four trips at most; what is still open
+				// after that (long runs: low divergence) the whole wave walks together, 256 bytes per trip.
+				if (__ballot(pend != 0)) {
+					uint32_t open = 0;
 					while (pend) {
 						const int32_t ii = __builtin_ctz(pend);
 						const int32_t hh = pick4(ii, hv[0], hv[1], hv[2], hv[3]);
 						const int32_t rm = pick4(ii, room[0], room[1], room[2], room[3]);
-						int32_t n = pick4(ii, nmat[0], nmat[1], nmat[2], nmat[3]);
+						int32_t n = 4; // pend is only set for a full first probe with room left
 						const int32_t j = hh + 1, q = c0 + ii - 1 - tl + j;
-						while (n < rm) {
-							const uint32_t x = probe4<LSEQ>(M, lt, lq, j + n, q + n);
-							if (x) { n += (int32_t)(__builtin_ctz(x) >> 3); break; }
-							n += 4;
+						for (int trip = 0; n < rm; ++trip) {
+							if (trip == 4) { open |= 1u << ii; break; }
+							const uint32_t xa = probe4<LSEQ>(M, lt, lq, j + n, q + n), xb = probe4<LSEQ>(M, lt, lq, j + n + 4, q + n + 4);
+							if (xa | xb) { n += xa ? (int32_t)(__builtin_ctz(xa) >> 3) : 4 + (int32_t)(__builtin_ctz(xb) >> 3); break; }
+							n += 8;
 						}
 						n = min(n, rm);
 #pragma unroll
 						for (int i = 0; i < 4; ++i) nmat[i] = ii == i ? n : nmat[i];
 						pend &= pend - 1;
 					}
+					for (unsigned long long owners = __ballot(open != 0); owners; owners &= owners - 1) {
+						const int32_t src = (int32_t)__builtin_ctzll(owners);
+						const int32_t c0s = cb + 4 * src;
+						for (uint32_t bits = (uint32_t)__builtin_amdgcn_readlane((int32_t)open, src); bits; bits &= bits - 1) {
+							const int32_t ii = (int32_t)__builtin_ctz(bits);
+							const int32_t hh = __builtin_amdgcn_readlane(pick4(ii, hv[0], hv[1], hv[2], hv[3]), src);
+							const int32_t rm = __builtin_amdgcn_readlane(pick4(ii, room[0], room[1], room[2], room[3]), src);
+							const int32_t j = hh + 1, q = c0s + ii - 1 - tl + j;
+							const int32_t n = run_wave<LSEQ>(M, lt, lq, j, q, rm, 36);
+#pragma unroll
+							for (int i = 0; i < 4; ++i) nmat[i] = (ii == i && lane == src) ? n : nmat[i];
+						}
+					}
 				}
+				MWF_TICK(4);
 				int32_t done_info = 0;
 #pragma unroll
 				for (int i = 0; i < 4; ++i) { // termination test of the extension sweep (miniwfa.c:405-409); only in-matrix cells have room or extend
@@ -375,6 +430,7 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 				if (__ballot(fin)) {
 					if (fin) sh.flags[npar][2] = 1, sh.flags[npar][3] = done_info;
 				}
+				MWF_TICK(7);
 			} else {
 				refill(k);
 #pragma unroll
@@ -453,16 +509,17 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 	}
 #ifdef MWF_BAND_TIMING
 	if (lane == 0 && blockIdx.x == 0)
-		printf("wave %2d steps %llu active-slots %llu | header %llu  slots %llu  wait+barrier %llu cycles (per step %.0f / %.0f / %.0f)\n", wave, t_steps, t_active,
-		       t_acc[0], t_acc[1], t_acc[2], (double)t_acc[0] / t_steps, (double)t_acc[1] / t_steps, (double)t_acc[2] / t_steps);
+		printf("wave %2d steps %llu active-slots %llu | header %llu  slots %llu  wait+barrier %llu cycles (per step %.0f / %.0f / %.0f) | per active slot: load wait %.0f, long-run loop %.0f (entered in %.0f %% of slots), setup %.0f, recurrence+probe %.0f, tail %.0f\n", wave, t_steps, t_active,
+		       t_acc[0], t_acc[1], t_acc[2], (double)t_acc[0] / t_steps, (double)t_acc[1] / t_steps, (double)t_acc[2] / t_steps,
+		       (double)t_acc[3] / t_active, (double)t_acc[4] / t_active, 100.0 * t_pend / t_active, (double)t_acc[5] / t_active, (double)t_acc[6] / t_active, (double)t_acc[7] / t_active);
 #endif
 	R.s = s, R.cells = cells;
 	return R;
 }
 
-// PACK kernels are meant to run two workgroups per CU: 2 * T/64 waves = 2*T/256 waves per SIMD bounds their VGPRs
+// the packed 512-thread kernel is meant to run two workgroups per CU: 16 waves = 4 per SIMD, i.e. at most 128 VGPRs
 template <int T, int K, int E1, int E2, bool TB, bool LSEQ, bool PACK>
-__global__ __launch_bounds__(T, PACK ? (2 * T / 256) : 1) void wfa_band_kernel(const BatchArgs A)
+__global__ __launch_bounds__(T, (PACK && T == 512) ? 4 : 1) void wfa_band_kernel(const BatchArgs A)
 {
 	constexpr int NWK = (T / 64) * K, D = (E1 > E2 ? E1 : E2) + 1;
 	__shared__ Shared sh;
@@ -527,6 +584,9 @@ bool band_supported(const Penalty &p)
 		if (g.block == 512 && g.packed) {                                             \
 			if (a_e1 == 2 && a_e2 == 1) return FN<512, 3, 2, 1, true>(__VA_ARGS__);   \
 			if (a_e1 == 2 && a_e2 == 2) return FN<512, 3, 2, 2, true>(__VA_ARGS__);   \
+		} else if (g.block == 768 && g.packed) {                                      \
+			if (a_e1 == 2 && a_e2 == 1) return FN<768, 2, 2, 1, true>(__VA_ARGS__);   \
+			if (a_e1 == 2 && a_e2 == 2) return FN<768, 2, 2, 2, true>(__VA_ARGS__);   \
 		} else if (g.block == 768) {                                                  \
 			if (a_e1 == 2 && a_e2 == 1) return FN<768, 2, 2, 1, false>(__VA_ARGS__);  \
 			if (a_e1 == 2 && a_e2 == 2) return FN<768, 2, 2, 2, false>(__VA_ARGS__);  \

@@ -52,6 +52,7 @@ struct mwf_gpu_s {
 	int64_t coop_min_len = 0;
 	int64_t tb_budget_mb = 0;   // 0: automatic
 	int force_kind = -1;
+	int band_pack = -1;        // int16-packed E/F registers in the band kernel: 0 never, otherwise whenever the value ranges allow
 	int64_t coop_tb_cap = (int64_t)96 << 30; // whole-device traceback arena: covers the 5 Mb pairs; doubles on overflow
 	// workspace (per-stream pool)
 	DevBuf ring, sring, good, tb, row_off, row_lo, cig_scratch, snap, snap_meta, seg, queue, dbg, coop_edge, coop_misc;
@@ -183,12 +184,15 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 	// Wide windows: 512 threads x 3 chunks with the E/F registers packed as int16 pairs fits TWO workgroups per CU, which
 	// overlaps one pair's barrier phase with the other's compute.  Valid when no offset (a target index, plus at most one
 	// per penalty for offsets that ran past the matrix) and no penalty count can reach 32767.
-	// (score-only: with traceback the packed variant needs more than its 128 VGPRs, spills, and measures slower than 768 x 2)
-	const bool pack_ok = max_tl + max_bound < 32767 && !(opt.flag & MWF_F_CIGAR);
-	if (bg.block == 768 && pack_ok) bg.block = 512, bg.packed = 1;
+	const bool range_ok = max_tl + max_bound < 32767 && g->band_pack != 0;
+	const bool cigar = (opt.flag & MWF_F_CIGAR) != 0;
+	// with traceback the 512-thread variant needs more than its 128 VGPRs and spills; there 768 x 2 packed (one workgroup per
+	// CU, 168 VGPRs, 48 B of scratch instead of 124 B unpacked) is the fastest: 52.9 ms against 60.3 ms unpacked
+	if (bg.block == 768 && range_ok && !cigar) bg.block = 512, bg.packed = 1;
+	if (bg.block == 768 && range_ok && cigar) bg.packed = 1;
 	// (measured alternatives on the 1024 x 10 kb batch: 1024 threads x 2 chunks spills and runs 50 ms, 512 x 3 runs 49 ms, 768 x 2 42 ms)
-	if (g->block == 256 || g->block == 768) bg.block = g->block, bg.packed = 0;
-	if (g->block == 512 && pack_ok) bg.block = 512, bg.packed = 1;
+	if (g->block == 256 || g->block == 768) bg.block = g->block, bg.packed = (g->block == 768 && range_ok && cigar);
+	if (g->block == 512 && range_ok) bg.block = 512, bg.packed = 1;
 	bg.span = bg.block == 512 ? 8 * 3 * 256 : bg.block / 64 * 2 * 256;
 	if (want_kind != 2 && max_len + 1 > 4 * (int64_t)bg.span) return; // windows will mostly outgrow the span: go generic at once
 	const int64_t lds_cap = bg.block >= 768 ? 140 * 1024 : bg.block == 512 ? 70 * 1024 : 36 * 1024;
@@ -479,6 +483,7 @@ int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value)
 	else if (!strcmp(name, "coop_min_len")) g->coop_min_len = value;
 	else if (!strcmp(name, "tb_budget_mb")) g->tb_budget_mb = value;
 	else if (!strcmp(name, "force_kind")) g->force_kind = (int)value;
+	else if (!strcmp(name, "band_pack")) g->band_pack = (int)value;
 	else if (!strcmp(name, "coop_tb_cap_mb")) g->coop_tb_cap = std::max<int64_t>(1, value) << 20;
 	else return -1;
 	return 0;

@@ -147,14 +147,15 @@ def test_every_block_size_gives_identical_results(block, oracle):
     eng.close()
 
 
-@pytest.mark.parametrize("block", [256, 512, 768])
-def test_band_kernel_against_oracle(block, oracle):
-    """Register-resident band kernel forced on, both geometries: ragged sizes, both penalty sets it is instantiated
-    for, score and CIGAR.  Pairs whose window outgrows the span (block 256 holds < 1800 columns) must come back
-    through the generic kernel with identical results."""
+@pytest.mark.parametrize("block,pack", [(256, -1), (512, -1), (768, -1), (768, 0)])
+def test_band_kernel_against_oracle(block, pack, oracle):
+    """Register-resident band kernel forced on, every geometry (pack=0: the variants without int16 packing): ragged
+    sizes, both penalty sets it is instantiated for, score and CIGAR.  Pairs whose window outgrows the span (block 256
+    holds < 1800 columns) must come back through the generic kernel with identical results."""
     eng = mw.Engine(0)
     eng.set("force_kind", 2)
     eng.set("block", block)
+    eng.set("band_pack", pack)
     pairs = [synth_pair(86000 + i, (3, 60, 500, 1800, 3000, 5000)[i % 6], (0.0, 0.02, 0.1, 0.3)[i % 4]) for i in range(48)]
     pairs += [(b"", b"ACGT"), (b"ACGT", b""), (b"GATTACA", b"GATTACA"), (b"A" * 3000, b"A" * 3000), (b"A" * 900, b"C" * 800)]
     for o in (make_opt(), make_opt(flag=1), make_opt(flag=1, o2=4, e2=2), make_opt(flag=0, x=6, o1=2, e1=2, o2=20, e2=1)):
