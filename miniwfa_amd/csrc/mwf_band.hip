@@ -128,7 +128,10 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 	const int32_t tl = M.tl, ql = M.ql, cmax = tl + ql + 1;
 	const int32_t tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
 	const int32_t W = A.W, nH = A.pen.nH, lagx = A.pen.x, lag1 = A.pen.oe1, lag2 = A.pen.oe2;
-	int32_t *const H = M.H; // every H access below is H[row * W + column] with a 32-bit index (band kernel rows are short)
+	int32_t *const H = M.H;
+	// every H access below is row * W + column with an unsigned 32-bit byte offset from the workgroup's (uniform) base: band
+	// kernel rows are short, and this is the SGPR-base + VGPR-offset addressing form (no 64-bit VALU address arithmetic)
+	auto at = [&](int32_t row, int32_t col) -> int32_t* { return (int32_t*)((char*)H + (size_t)((uint32_t)(row * W + col) << 2)); };
 	// H rows written at penalty s are loaded again, at the earliest, by the prefetch issued at the start of penalty
 	// s + lag - 1.  With every lag >= 3 the stores of a penalty may therefore stay in flight across its barrier.
 	const bool relaxed_stores = min(lagx, min(lag1, lag2)) >= 3;
@@ -156,7 +159,9 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 		return (i & 1) ? (v[i >> 1] >> 16) : (int32_t)(int16_t)(v[i >> 1] & 0xffff);
 	};
 	auto pack2 = [](int32_t a, int32_t b) -> int32_t { // two offsets -> one register; dead values clamp to -32768
-		return (int32_t)(((uint32_t)max(a, -32768) & 0xffffu) | ((uint32_t)max(b, -32768) << 16));
+		typedef short short2_t __attribute__((ext_vector_type(2)));
+		const short2_t v = __builtin_amdgcn_cvt_pk_i16(a, b); // saturating: live values are < 32767 by the host's choice of this variant
+		return __builtin_bit_cast(int32_t, v);
 	};
 	int4 phx[K], po1[K], po2[K];   // prefetched H rows of the next penalty: lags x, o1+e1, o2+e2
 	int32_t pe1[K], pe2[K];        // lane 0: column to the left of the chunk, lane 63: column to its right
@@ -192,11 +197,11 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 		int32_t g = g_lo - g_lo % NWK + wave + NW * k;
 		if (g < g_lo) g += NWK;
 		const int32_t c0 = g * kChunk <= phi ? g * kChunk + 4 * lane : 0;
-		phx[k] = *(const int4*)(H + (jx * W + c0));
-		po1[k] = *(const int4*)(H + (j1 * W + c0));
-		po2[k] = *(const int4*)(H + (j2 * W + c0));
+		phx[k] = *(const int4*)at(jx, c0);
+		po1[k] = *(const int4*)at(j1, c0);
+		po2[k] = *(const int4*)at(j2, c0);
 		const int32_t ce = lane == 0 ? max(c0 - 1, 0) : c0 + 4; // only lanes 0 and 63 use it; column 0 is a pad
-		pe1[k] = H[j1 * W + ce], pe2[k] = H[j2 * W + ce];
+		pe1[k] = *at(j1, ce), pe2[k] = *at(j2, ce);
 	};
 	int32_t gl; // lowest chunk of the mapping the prefetched registers were loaded under
 	{
@@ -352,9 +357,6 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 					const uint32_t inm = act & inm_bit(d, v.h, tl, ql);
 					if (track_good) // uniform
 						gbits |= (act & (inm | inm_bit(d, v.e1, tl, ql) | inm_bit(d, v.f1, tl, ql) | inm_bit(d, v.e2, tl, ql) | inm_bit(d, v.f2, tl, ql))) << i;
-					// edge rule (miniwfa.c:325-326): H is the max of the five, so "any live" == "H live"
-					const uint32_t lv = act & (uint32_t)(v.h >= -1);
-					live |= (lv & (uint32_t)(c == lo)) | ((lv & (uint32_t)(c == hi)) << 1);
 					const int32_t j = inm ? v.h + 1 : 0, q = inm ? d + v.h + 1 : 0;
 					room[i] = inm ? min(tl - j, ql - q) : 0;
 					const uint32_t x = probe4<LSEQ>(M, lt, lq, j, q);
@@ -363,6 +365,13 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 					hv[i] = v.h;
 					tbw |= v.tb << (8 * i);
 				}
+				if ((uint32_t)(lo - cb) < (uint32_t)kChunk || (uint32_t)(hi - cb) < (uint32_t)kChunk) // uniform: this chunk holds an edge column.
+					// Edge rule (miniwfa.c:325-326): H is the max of the five, so "any live" == "H live"
+#pragma unroll
+					for (int i = 0; i < 4; ++i) {
+						const uint32_t lv = (uint32_t)(hv[i] >= -1);
+						live |= (lv & (uint32_t)(c0 + i == lo)) | ((lv & (uint32_t)(c0 + i == hi)) << 1);
+					}
 				if (PACK) refill(k); // packed variant: after the register-hungry recurrence; the loads still overlap the probes and the tail
 				MWF_TICK(6);
 #ifdef MWF_BAND_TIMING
@@ -405,17 +414,21 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 					}
 				}
 				MWF_TICK(4);
+				// termination test of the extension sweep (miniwfa.c:405-409): the end cell (tl-1, ql-1) lies on diagonal ql-tl,
+				// i.e. column ql+1, and nowhere else
 				int32_t done_info = 0;
+				const int32_t cfin = ql + 1;
 #pragma unroll
-				for (int i = 0; i < 4; ++i) { // termination test of the extension sweep (miniwfa.c:405-409); only in-matrix cells have room or extend
-					const int32_t d = c0 + i - 1 - tl, kk = hv[i] + nmat[i];
-					const uint32_t act = inner ? 1u : (uint32_t)((c0 + i >= lo) & (c0 + i <= hi));
-					const uint32_t f = act & inm_bit(d, hv[i], tl, ql) & (uint32_t)(kk == tl - 1) & (uint32_t)(d + kk == ql - 1);
-					fin |= f;
-					done_info = f ? (nmat[i] == 0 ? (int32_t)((tbw >> (8 * i)) & 7u) : 0) : done_info;
-					hv[i] = kk;
+				for (int i = 0; i < 4; ++i) hv[i] += nmat[i];
+				if (cfin >= cb && cfin < cb + kChunk && cfin >= lo && cfin <= hi) { // uniform
+#pragma unroll
+					for (int i = 0; i < 4; ++i) {
+						const uint32_t f = (uint32_t)(c0 + i == cfin) & (uint32_t)(hv[i] == tl - 1) & inm_bit(ql - tl, hv[i] - nmat[i], tl, ql);
+						fin |= f;
+						done_info = f ? (nmat[i] == 0 ? (int32_t)((tbw >> (8 * i)) & 7u) : 0) : done_info;
+					}
 				}
-				*(int4*)(H + (newH * W + c0)) = make_int4(hv[0], hv[1], hv[2], hv[3]);
+				*(int4*)at(newH, c0) = make_int4(hv[0], hv[1], hv[2], hv[3]);
 				if (TB && c0 >= origin && c0 <= hi) *(uint32_t*)(M.tb + tb_used - origin + c0) = tbw;
 				if (track_good) {
 					unsigned long long *gword = M.good + (int64_t)newH * A.GW + g * 4;
