@@ -25,6 +25,7 @@
 // that becomes mapped has been outside every window for hundreds of penalties, so its registers already
 // hold NEG_INF).  A pair whose window outgrows that span is reported ST_BAND_OVERFLOW and re-run by the
 // host on the generic kernel.
+#include <type_traits>
 #include "mwf_device.h"
 
 namespace mwf {
@@ -45,7 +46,7 @@ __device__ __forceinline__ int32_t from_right(int32_t v, int32_t fill) { return 
 __device__ __forceinline__ uint32_t lds_ld4(const uint8_t *base, int32_t off)
 {
 	const uint32_t *p = (const uint32_t*)(base + (off & ~3));
-	return __builtin_amdgcn_alignbyte(p[1], p[0], (uint32_t)off & 3u);
+	return __builtin_amdgcn_alignbyte(p[1], p[0], (uint32_t)off); // v_alignbyte_b32 shifts by the low two bits of its third operand
 }
 
 template <bool LSEQ>
@@ -298,6 +299,22 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 			const int32_t cb = g * kChunk;
 			const bool active = act_k[k]; // this wave's chunk meets the window (uniform)
 			int32_t ne1[4], nf1[4], ne2[4], nf2[4];
+			// publish this chunk's outer columns for the neighbouring waves, then age the registers
+			auto retire = [&]() {
+				if (lane == 63) edge[dnew][r][0] = ne1[3], edge[dnew][r][1] = ne2[3];
+				if (lane == 0) edge[dnew][r][2] = nf1[0], edge[dnew][r][3] = nf2[0];
+#pragma unroll
+				for (int i = 0; i < NS; ++i) {
+#pragma unroll
+					for (int a = E1 - 1; a > 0; --a) e1h[a][k][i] = e1h[a - 1][k][i], f1h[a][k][i] = f1h[a - 1][k][i];
+#pragma unroll
+					for (int a = E2 - 1; a > 0; --a) e2h[a][k][i] = e2h[a - 1][k][i], f2h[a][k][i] = f2h[a - 1][k][i];
+					if (PACK) {
+						e1h[0][k][i] = pack2(ne1[2 * i], ne1[2 * i + 1]), f1h[0][k][i] = pack2(nf1[2 * i], nf1[2 * i + 1]);
+						e2h[0][k][i] = pack2(ne2[2 * i], ne2[2 * i + 1]), f2h[0][k][i] = pack2(nf2[2 * i], nf2[2 * i + 1]);
+					} else e1h[0][k][i] = ne1[i], f1h[0][k][i] = nf1[i], e2h[0][k][i] = ne2[i], f2h[0][k][i] = nf2[i];
+				}
+			};
 			if (active) {
 #ifdef MWF_BAND_TIMING
 				++t_nact;
@@ -345,26 +362,36 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 				}
 				MWF_TICK(5);
 				// ---- the recurrence, then the first 4-byte probe of the match extension, branch-free for all 4 columns
-				int32_t hv[4], room[4], nmat[4];
+				int32_t hv[4], nmat[4];
 				uint32_t tbw = 0, pend = 0, live = 0, fin = 0, gbits = 0;
+				// Two copies of the column code: chunks strictly inside every window (nearly all of them) carry no window tests.
+				// (Costs the two-workgroups-per-CU variant 60 B/lane of scratch and still measures 3 % faster: 28.5 against 29.3 ms.)
+				constexpr bool kTwoCopies = true;
+				auto columns = [&](auto inner_c) {
+					constexpr bool INNER = decltype(inner_c)::value;
 #pragma unroll
-				for (int i = 0; i < 4; ++i) {
-					const int32_t c = c0 + i, d = c - 1 - tl;
-					const uint32_t act = inner ? 1u : (uint32_t)((c >= lo) & (c <= hi));
-					const Cell v = wf_cell<TB>(hx[i], o1[i], g1m[i], o2[i], g2m[i], o1[i + 2], g1p[i], o2[i + 2], g2p[i]);
-					ne1[i] = act ? v.e1 : kNegInf, nf1[i] = act ? v.f1 : kNegInf;
-					ne2[i] = act ? v.e2 : kNegInf, nf2[i] = act ? v.f2 : kNegInf;
-					const uint32_t inm = act & inm_bit(d, v.h, tl, ql);
-					if (track_good) // uniform
-						gbits |= (act & (inm | inm_bit(d, v.e1, tl, ql) | inm_bit(d, v.f1, tl, ql) | inm_bit(d, v.e2, tl, ql) | inm_bit(d, v.f2, tl, ql))) << i;
-					const int32_t j = inm ? v.h + 1 : 0, q = inm ? d + v.h + 1 : 0;
-					room[i] = inm ? min(tl - j, ql - q) : 0;
-					const uint32_t x = probe4<LSEQ>(M, lt, lq, j, q);
-					nmat[i] = min(x ? (int32_t)(__builtin_ctz(x) >> 3) : 4, room[i]);
-					pend |= ((uint32_t)(x == 0) & (uint32_t)(room[i] > 4)) << i;
-					hv[i] = v.h;
-					tbw |= v.tb << (8 * i);
-				}
+					for (int i = 0; i < 4; ++i) {
+						const int32_t c = c0 + i, d = c - 1 - tl;
+						const uint32_t act = (INNER || inner) ? 1u : (uint32_t)((c >= lo) & (c <= hi));
+						const Cell v = wf_cell<TB>(hx[i], o1[i], g1m[i], o2[i], g2m[i], o1[i + 2], g1p[i], o2[i + 2], g2p[i]);
+						ne1[i] = act ? v.e1 : kNegInf, nf1[i] = act ? v.f1 : kNegInf;
+						ne2[i] = act ? v.e2 : kNegInf, nf2[i] = act ? v.f2 : kNegInf;
+						const uint32_t inm = act & inm_bit(d, v.h, tl, ql);
+						if (track_good) // uniform
+							gbits |= (act & (inm | inm_bit(d, v.e1, tl, ql) | inm_bit(d, v.f1, tl, ql) | inm_bit(d, v.e2, tl, ql) | inm_bit(d, v.f2, tl, ql))) << i;
+						const int32_t j = inm ? v.h + 1 : 0, q = inm ? d + v.h + 1 : 0;
+						const int32_t room = inm ? min(tl - j, ql - q) : 0;
+						const uint32_t x = probe4<LSEQ>(M, lt, lq, j, q);
+						// equal leading bytes: ffs() - 1 is v_ffbl_b32, which yields ~0 for x == 0
+						nmat[i] = min(min((int32_t)((uint32_t)(__builtin_ffs((int)x) - 1) >> 3), 4), room);
+						pend |= ((uint32_t)(x == 0) & (uint32_t)(room > 4)) << i;
+						hv[i] = v.h;
+						tbw |= v.tb << (8 * i);
+					}
+				};
+				if (kTwoCopies && inner) columns(std::true_type{});
+				else columns(std::false_type{});
+				retire(); // the new E/F are final and nothing below reads the old ages: frees their registers for the tail
 				if ((uint32_t)(lo - cb) < (uint32_t)kChunk || (uint32_t)(hi - cb) < (uint32_t)kChunk) // uniform: this chunk holds an edge column.
 					// Edge rule (miniwfa.c:325-326): H is the max of the five, so "any live" == "H live"
 #pragma unroll
@@ -385,9 +412,8 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 					while (pend) {
 						const int32_t ii = __builtin_ctz(pend);
 						const int32_t hh = pick4(ii, hv[0], hv[1], hv[2], hv[3]);
-						const int32_t rm = pick4(ii, room[0], room[1], room[2], room[3]);
-						int32_t n = 4; // pend is only set for a full first probe with room left
-						const int32_t j = hh + 1, q = c0 + ii - 1 - tl + j;
+						int32_t n = 4; // pend is only set for a full first probe of an in-matrix cell with room left
+						const int32_t j = hh + 1, q = c0 + ii - 1 - tl + j, rm = min(tl - j, ql - q);
 						for (int trip = 0; n < rm; ++trip) {
 							if (trip == 4) { open |= 1u << ii; break; }
 							const uint32_t xa = probe4<LSEQ>(M, lt, lq, j + n, q + n), xb = probe4<LSEQ>(M, lt, lq, j + n + 4, q + n + 4);
@@ -405,8 +431,7 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 						for (uint32_t bits = (uint32_t)__builtin_amdgcn_readlane((int32_t)open, src); bits; bits &= bits - 1) {
 							const int32_t ii = (int32_t)__builtin_ctz(bits);
 							const int32_t hh = __builtin_amdgcn_readlane(pick4(ii, hv[0], hv[1], hv[2], hv[3]), src);
-							const int32_t rm = __builtin_amdgcn_readlane(pick4(ii, room[0], room[1], room[2], room[3]), src);
-							const int32_t j = hh + 1, q = c0s + ii - 1 - tl + j;
+							const int32_t j = hh + 1, q = c0s + ii - 1 - tl + j, rm = min(tl - j, ql - q);
 							const int32_t n = run_wave<LSEQ>(M, lt, lq, j, q, rm, 36);
 #pragma unroll
 							for (int i = 0; i < 4; ++i) nmat[i] = (ii == i && lane == src) ? n : nmat[i];
@@ -448,31 +473,19 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 				refill(k);
 #pragma unroll
 				for (int i = 0; i < 4; ++i) ne1[i] = nf1[i] = ne2[i] = nf2[i] = kNegInf;
-			}
-			// publish this chunk's outer columns for the neighbouring waves, then age the registers
-			if (lane == 63) edge[dnew][r][0] = ne1[3], edge[dnew][r][1] = ne2[3];
-			if (lane == 0) edge[dnew][r][2] = nf1[0], edge[dnew][r][3] = nf2[0];
-#pragma unroll
-			for (int i = 0; i < NS; ++i) {
-#pragma unroll
-				for (int a = E1 - 1; a > 0; --a) e1h[a][k][i] = e1h[a - 1][k][i], f1h[a][k][i] = f1h[a - 1][k][i];
-#pragma unroll
-				for (int a = E2 - 1; a > 0; --a) e2h[a][k][i] = e2h[a - 1][k][i], f2h[a][k][i] = f2h[a - 1][k][i];
-				if (PACK) {
-					e1h[0][k][i] = pack2(ne1[2 * i], ne1[2 * i + 1]), f1h[0][k][i] = pack2(nf1[2 * i], nf1[2 * i + 1]);
-					e2h[0][k][i] = pack2(ne2[2 * i], ne2[2 * i + 1]), f2h[0][k][i] = pack2(nf2[2 * i], nf2[2 * i + 1]);
-				} else e1h[0][k][i] = ne1[i], f1h[0][k][i] = nf1[i], e2h[0][k][i] = ne2[i], f2h[0][k][i] = nf2[i];
+				retire();
 			}
 		}
 
 		// Everything issued before this penalty must be complete before another wave may load it (vmcnt retires in issue
-		// order).  This penalty issued exactly 5*K loads, all before its stores; letting the youngest 5*K operations stay in
-		// flight therefore never leaves an older penalty's store pending, and keeps this penalty's own stores in flight when
-		// every H lag is >= 3.  Otherwise wait for everything.
+		// order).  This penalty issued at least 5*K memory operations (its loads are unconditional); letting the youngest 5*K
+		// stay in flight therefore never leaves an older penalty's store pending, and keeps this penalty's own stores (and, in
+		// the variant that prefetches across the barrier, the next penalty's loads) in flight when every H lag is >= 3.
+		// Otherwise wait for everything.
 #ifdef MWF_BAND_TIMING
 		const unsigned long long t_c = __builtin_readcyclecounter();
 #endif
-		if (relaxed_stores) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PACK ? 2 : 5 * K) : "memory"); // PACK: at most the last chunk's H and traceback stores
+		if (relaxed_stores) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(5 * K) : "memory");
 		else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 		__builtin_amdgcn_s_barrier();
 		asm volatile("" ::: "memory");
