@@ -35,13 +35,28 @@ constexpr int kT = 512;          // threads per workgroup: 8 waves, up to 256 VG
 constexpr int kNW = kT / 64;
 constexpr int kK = 2;            // chunks per wave
 constexpr int kChunk = 256;
-constexpr unsigned kSpinLimit = 1u << 26;
+constexpr unsigned kSpinLimit = 1u << 23;
 
 __device__ __forceinline__ int32_t from_left(int32_t v, int32_t fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ int32_t from_right(int32_t v, int32_t fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false); }
 
 __device__ __forceinline__ int32_t ld_ag(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_ag(int32_t *p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Granule: one naturally aligned 8-byte {value, tag} word written by ONE agent-scope (write-through) store and read by
+// agent-scope loads: the reader knows the value is the one it wants because the tag is the penalty it was computed at.
+// No ordering between different granules is ever relied upon.
+typedef unsigned long long gran_t;
+__device__ __forceinline__ gran_t ld_gran(const gran_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_gran(gran_t *p, int32_t v, int32_t tag)
+{
+	__hip_atomic_store(p, (gran_t)(uint32_t)v | (gran_t)(uint32_t)tag << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int32_t gran_val(gran_t g) { return (int32_t)(uint32_t)g; }
+__device__ __forceinline__ int32_t gran_tag(gran_t g) { return (int32_t)(uint32_t)(g >> 32); }
+
+constexpr int kFlagRing = 64;    // penalties of edge/end flags kept; workgroups never drift further apart than 32 penalties
+constexpr int kDriftCheck = 16;  // every so many penalties a workgroup waits until all have finished the penalty 16 back
 
 __device__ __forceinline__ uint32_t probe4g(const PairMem &M, int32_t j, int32_t i)
 {
@@ -175,12 +190,18 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 	const int32_t nH = A.pen.nH, lagx = A.pen.x, lag1 = A.pen.oe1, lag2 = A.pen.oe2;
 	const bool relaxed_stores = min(lagx, min(lag1, lag2)) >= 3;
 	int32_t *const H = M.H;
-	int32_t *const eedge = A.coop_edge;                    // [D][TC][4]
-	int32_t *const hedge = A.coop_edge + (int64_t)D * TC * 4; // [nH][TC][2]: H of a chunk's first / last column
-	int32_t *const gflags = A.coop_flags;                  // [3][4]
+	// What crosses waves.  granule(row, r, side, which): per H slot (= penalty mod nH), chunk slot r and side (0: the chunk's
+	// last column, written by lane 63; 1: its first column, lane 0): which 0 = E1 | F1, 1 = E2 | F2, 2 = H after extension.
+	gran_t *const grans = (gran_t*)A.coop_edge;
+	auto granule = [&](int32_t row, int32_t r, int32_t side, int32_t which) -> gran_t* { return grans + ((((int64_t)row * TC + r) * 2 + side) * 4 + which); };
+	int32_t *const gflags = A.coop_flags;                  // [12..14]: origin offset, shrink reduction
+	// Per penalty (mod kFlagRing): "new low edge live", "new high edge live", "end cell reached | last state << 1", each as
+	// penalty << 4 | value, written by the one wave that owns the column in question.
+	int32_t *const fring = A.coop_flags + 1024;
+	unsigned long long *const arrived = (unsigned long long*)(A.coop_sync + 200); // workgroup-penalties finished (drift bound)
 	PassResult R;
 	R.status = ST_OK, R.s = 0, R.info = 0, R.n_snap = 0, R.cells = 0;
-	unsigned epoch = 0, cum = 0, cum_prev = 0; // the host zeroes the barrier words before every pass
+	unsigned epoch = 0, cum = 0; // the host zeroes the barrier words before every pass
 
 	int32_t e1h[E1][kK][4], f1h[E1][kK][4], e2h[E2][kK][4], f2h[E2][kK][4];
 #pragma unroll
@@ -193,12 +214,13 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 			for (int a = 0; a < E2; ++a) e2h[a][k][i] = f2h[a][k][i] = kNegInf;
 		}
 	int4 phx[kK], po1[kK], po2[kK];
-	int32_t pe1[kK], pe2[kK];
+	gran_t ph1[kK], ph2[kK];       // lanes 0 / 63: H granules of the neighbouring chunk's adjacent column for lags o1+e1, o2+e2
 
 	// ---- penalty 0: origin and its extension (the first wave of workgroup 0 walks it cooperatively)
 	if (tid == 0) {
 		for (int32_t j = 0; j < nH; ++j) sh.rng_lo[j] = 1, sh.rng_hi[j] = 0;
 		sh.rng_lo[0] = sh.rng_hi[0] = tl + 1;
+		sh.red[0] = 0; // set by a wave whose wait for a neighbour ran into the spin limit
 	}
 	if (blockIdx.x == 0 && tid < 64) {
 		const int32_t k0 = lcp_wave(M, 0, 0, min(tl, ql), 0) - 1;
@@ -208,8 +230,8 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 			st_ag(&gflags[12], k0);
 			// the origin's chunk edges for the first lagged reads
 			const int32_t r0 = (c0 >> 8) % TC;
-			if ((c0 & 255) == 0) st_ag(&hedge[(0 * TC + r0) * 2 + 0], k0);
-			if ((c0 & 255) == 255) st_ag(&hedge[(0 * TC + r0) * 2 + 1], k0);
+			if ((c0 & 255) == 0) st_gran(granule(0, r0, 1, 2), k0, 0);
+			if ((c0 & 255) == 255) st_gran(granule(0, r0, 0, 2), k0, 0);
 		}
 	}
 	if (tid == 0) for (int32_t j = 0; j < 12; ++j) (&sh.flags[0][0])[j] = 0;
@@ -237,9 +259,9 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 		po2[k] = *(const int4*)(H + (j2 * W + c0));
 		// neighbours' outer columns: lane 0 wants the LAST column of the chunk to the left, lane 63 the FIRST of the one to the right
 		const int32_t rn = lane == 0 ? (r == 0 ? TC - 1 : r - 1) : (r + 1 == TC ? 0 : r + 1);
-		const int32_t which = lane == 0 ? 1 : 0;
-		pe1[k] = ld_ag(&hedge[((int64_t)j1 * TC + rn) * 2 + which]);
-		pe2[k] = ld_ag(&hedge[((int64_t)j2 * TC + rn) * 2 + which]);
+		const int32_t side = lane == 0 ? 0 : 1;
+		ph1[k] = ld_gran(granule(j1, rn, side, 2));
+		ph2[k] = ld_gran(granule(j2, rn, side, 2));
 	};
 	int32_t gl;
 	{
@@ -292,13 +314,10 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 		const int32_t p2lo = uni(sh.rng_lo[jg2]), p2hi = uni(sh.rng_hi[jg2]);
 		const int32_t ilo = max(max(lo, xlo), max(alo, blo) + 1), ihi = min(min(hi, xhi), min(ahi, bhi) - 1);
 		const bool track_good = (((256 - (s_new & 255)) & 255) < nH);
-		int32_t d1 = dnew - E1; if (d1 < 0) d1 += D;
-		int32_t d2 = dnew - E2; if (d2 < 0) d2 += D;
+		const int32_t cfin = ql + 1; // the end cell (tl-1, ql-1) lies on diagonal ql-tl, i.e. in this column
 
 		if (tid == 0) {
 			sh.rng_lo[newH] = lo, sh.rng_hi[newH] = hi;
-			const int32_t nn = npar + 1 == 3 ? 0 : npar + 1; // this workgroup's flag words of the NEXT penalty
-			sh.flags[nn][0] = sh.flags[nn][1] = sh.flags[nn][2] = sh.flags[nn][3] = 0;
 		}
 		if (lead) {
 			if (TB) M.row_off[s_new - 1] = tb_used, M.row_lo[s_new - 1] = origin;
@@ -326,16 +345,33 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 				int32_t o1[6], o2[6];
 				o1[1] = po1[k].x, o1[2] = po1[k].y, o1[3] = po1[k].z, o1[4] = po1[k].w;
 				o2[1] = po2[k].x, o2[2] = po2[k].y, o2[3] = po2[k].z, o2[4] = po2[k].w;
-				int32_t v1 = pe1[k], v2 = pe2[k];
+				gran_t gh1 = ph1[k], gh2 = ph2[k];
 				prefetch(k, nextH, phi, gl_next);
-				// E/F of the neighbouring chunks' outer columns, written one (two) penalties ago
+				// What the neighbouring chunks computed for the column next to this chunk (lane 0: left neighbour's last column,
+				// lane 63: right neighbour's first): E1|F1 of penalty s_new-e1, E2|F2 of s_new-e2, H of s_new-lag1 and s_new-lag2.
+				// A neighbour column outside the window of that penalty was never computed: NEG_INF.  Otherwise wait for the
+				// granule carrying that penalty's tag — this wait is the only synchronisation between neighbouring waves.
 				const int32_t rl = r == 0 ? TC - 1 : r - 1, rr = r + 1 == TC ? 0 : r + 1;
-				int32_t le1 = ld_ag(&eedge[((int64_t)d1 * TC + rl) * 4 + 0]), le2 = ld_ag(&eedge[((int64_t)d2 * TC + rl) * 4 + 1]);
-				int32_t rf1 = ld_ag(&eedge[((int64_t)d1 * TC + rr) * 4 + 2]), rf2 = ld_ag(&eedge[((int64_t)d2 * TC + rr) * 4 + 3]);
-				{ // a neighbour that was outside the source window never published: read NEG_INF instead
-					const int32_t cl = cb - 1, cr = cb + kChunk;
-					le1 = ((cl >= p1lo) & (cl <= p1hi)) ? le1 : kNegInf, rf1 = ((cr >= p1lo) & (cr <= p1hi)) ? rf1 : kNegInf;
-					le2 = ((cl >= p2lo) & (cl <= p2hi)) ? le2 : kNegInf, rf2 = ((cr >= p2lo) & (cr <= p2hi)) ? rf2 : kNegInf;
+				int32_t xg1, xg2, v1, v2;
+				{
+					const int32_t nb = lane == 0 ? rl : rr, side = lane == 0 ? 0 : 1, cn = lane == 0 ? cb - 1 : cb + kChunk;
+					const bool edge_lane = lane == 0 || lane == 63;
+					const bool need_e1 = edge_lane & (cn >= p1lo) & (cn <= p1hi), need_e2 = edge_lane & (cn >= p2lo) & (cn <= p2hi);
+					const bool need_h1 = edge_lane & (cn >= alo) & (cn <= ahi), need_h2 = edge_lane & (cn >= blo) & (cn <= bhi);
+					// (Loading these at the end of the previous penalty instead, to overlap the wait for the flags, measured slower:
+					// memory operations return in issue order, so an early agent-scope load holds up whatever is issued behind it.)
+					gran_t ge1 = ld_gran(granule(jg1, nb, side, 0)), ge2 = ld_gran(granule(jg2, nb, side, 1));
+					for (unsigned spins = 0;; ++spins) {
+						const bool late = (need_e1 && gran_tag(ge1) != s_new - E1) || (need_e2 && gran_tag(ge2) != s_new - E2) ||
+						                  (need_h1 && gran_tag(gh1) != s_new - lag1) || (need_h2 && gran_tag(gh2) != s_new - lag2);
+						if (!__ballot(late)) break;
+						if (spins > kSpinLimit) { if (lane == 0) sh.red[0] = 1; break; }
+						__builtin_amdgcn_s_sleep(1);
+						ge1 = ld_gran(granule(jg1, nb, side, 0)), ge2 = ld_gran(granule(jg2, nb, side, 1));
+						gh1 = ld_gran(granule(j1, nb, side, 2)), gh2 = ld_gran(granule(j2, nb, side, 2));
+					}
+					xg1 = need_e1 ? gran_val(ge1) : kNegInf, xg2 = need_e2 ? gran_val(ge2) : kNegInf;
+					v1 = need_h1 ? gran_val(gh1) : kNegInf, v2 = need_h2 ? gran_val(gh2) : kNegInf;
 				}
 				if (!inner) {
 #pragma unroll
@@ -346,18 +382,13 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 						o2[i + 1] = ((c >= blo) & (c <= bhi)) ? o2[i + 1] : kNegInf;
 					}
 				}
-				{
-					const int32_t ce = lane == 0 ? c0 - 1 : c0 + 4;
-					v1 = ((ce >= alo) & (ce <= ahi)) ? v1 : kNegInf;
-					v2 = ((ce >= blo) & (ce <= bhi)) ? v2 : kNegInf;
-				}
 				o1[0] = from_left(o1[4], v1), o1[5] = from_right(o1[1], v1);
 				o2[0] = from_left(o2[4], v2), o2[5] = from_right(o2[1], v2);
 				int32_t g1m[4], g1p[4], g2m[4], g2p[4];
-				g1m[0] = from_left(e1h[E1 - 1][k][3], le1);
-				g2m[0] = from_left(e2h[E2 - 1][k][3], le2);
-				g1p[3] = from_right(f1h[E1 - 1][k][0], rf1);
-				g2p[3] = from_right(f2h[E2 - 1][k][0], rf2);
+				g1m[0] = from_left(e1h[E1 - 1][k][3], xg1);   // lane 0 keeps its own xg1: the left neighbour's E1
+				g2m[0] = from_left(e2h[E2 - 1][k][3], xg2);
+				g1p[3] = from_right(f1h[E1 - 1][k][0], xg1);  // lane 63 keeps its own xg1: the right neighbour's F1
+				g2p[3] = from_right(f2h[E2 - 1][k][0], xg2);
 #pragma unroll
 				for (int i = 1; i < 4; ++i) g1m[i] = e1h[E1 - 1][k][i - 1], g2m[i] = e2h[E2 - 1][k][i - 1];
 #pragma unroll
@@ -385,9 +416,17 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 					hv[i] = v.h;
 					tbw |= v.tb << (8 * i);
 				}
-				// E/F of the outer columns are final: publish them now so that the write-through overlaps the probes below
-				if (lane == 63) st_ag(&eedge[((int64_t)dnew * TC + r) * 4 + 0], ne1[3]), st_ag(&eedge[((int64_t)dnew * TC + r) * 4 + 1], ne2[3]);
-				if (lane == 0) st_ag(&eedge[((int64_t)dnew * TC + r) * 4 + 2], nf1[0]), st_ag(&eedge[((int64_t)dnew * TC + r) * 4 + 3], nf2[0]);
+				// E/F of the outer columns and the edge flags are final: publish them now, the write-through overlaps the probes
+				if (lane == 63) st_gran(granule(newH, r, 0, 0), ne1[3], s_new), st_gran(granule(newH, r, 0, 1), ne2[3], s_new);
+				if (lane == 0) st_gran(granule(newH, r, 1, 0), nf1[0], s_new), st_gran(granule(newH, r, 1, 1), nf2[0], s_new);
+				if ((uint32_t)(lo - cb) < (uint32_t)kChunk) { // this chunk holds the low edge column
+					const int32_t lv = __ballot(live & 1u) != 0;
+					if (lane == 0) st_ag(&fring[(s_new & (kFlagRing - 1)) * 4 + 0], s_new << 4 | lv);
+				}
+				if ((uint32_t)(hi - cb) < (uint32_t)kChunk) {
+					const int32_t lv = __ballot(live & 2u) != 0;
+					if (lane == 0) st_ag(&fring[(s_new & (kFlagRing - 1)) * 4 + 1], s_new << 4 | lv);
+				}
 				// a run of >= 4 matches continues: the wave walks it together, one owning lane and column at a time
 				unsigned long long owners = __ballot(pend != 0);
 				while (owners) {
@@ -427,18 +466,21 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 					}
 				}
 				// H of the outer columns: read again no sooner than min-lag penalties from now
-				if (lane == 63) st_ag(&hedge[((int64_t)newH * TC + r) * 2 + 1], hv[3]);
-				if (lane == 0) st_ag(&hedge[((int64_t)newH * TC + r) * 2 + 0], hv[0]);
-				if (__ballot(live & 1u)) sh.flags[npar][0] = 1;   // uniform branches; every lane stores the same word
-				if (__ballot(live & 2u)) sh.flags[npar][1] = 1;
-				if (__ballot(fin)) {
-					if (fin) sh.flags[npar][2] = 1, sh.flags[npar][3] = done_info;
+				if (lane == 63) st_gran(granule(newH, r, 0, 2), hv[3], s_new);
+				if (lane == 0) st_gran(granule(newH, r, 1, 2), hv[0], s_new);
+				if ((uint32_t)(cfin - cb) < (uint32_t)kChunk && cfin >= lo && cfin <= hi) { // this chunk holds the end diagonal
+					const unsigned long long fm = __ballot(fin);
+					int32_t val = 0;
+					if (fm) val = 1 | __builtin_amdgcn_readlane(done_info, (int32_t)__builtin_ctzll(fm)) << 1;
+					if (lane == 0) st_ag(&fring[(s_new & (kFlagRing - 1)) * 4 + 2], s_new << 4 | val);
 				}
+
 			} else {
 				prefetch(k, nextH, phi, gl_next);
 #pragma unroll
 				for (int i = 0; i < 4; ++i) ne1[i] = nf1[i] = ne2[i] = nf2[i] = kNegInf;
 			}
+
 #pragma unroll
 			for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -451,16 +493,50 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 
 		// Late stores of a chunk (H row, traceback dword, the two H edge words) are not read by anybody for at least
 		// min-lag - 1 penalties; when every lag is >= 3 they may stay in flight across this barrier.  They are the youngest
-		// operations of the wave, except that an idle second chunk still issues its 5 dummy prefetch loads after them.
+		// operations of the wave, except that an idle second chunk still issues its 5 dummy prefetch loads
+		// after them.  (A smaller count than the truth only waits for more.)
 		int32_t vm_keep = 0;
 		if (relaxed_stores && !track_good) {
 			if (act1) vm_keep = 3 + (TB ? 1 : 0);
 			else if (act0) vm_keep = 8 + (TB ? 1 : 0);
 		}
+
 #ifdef MWF_BAND_TIMING
 		const unsigned long long t_c = __builtin_readcyclecounter();
 #endif
-		if (!grid_sync<false>(A, sh, epoch, G, &sh.flags[npar][0], cum, vm_keep)) { R.status = ST_INTERNAL; break; }
+		// ---- end of the penalty.  No grid barrier: neighbours synchronise through the granules above; what every workgroup
+		// needs before it can go on is the fate of the two edge columns (the next window) and of the end cell, which their
+		// owners publish into the flag ring.  Thread 0 waits for them while the other waves wait at the workgroup barrier.
+		switch (vm_keep) { // own H rows are read back min-lag - 1 penalties from now: keep at most this penalty's late stores in flight
+		case 3:  asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+		case 4:  asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+		case 8:  asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+		case 9:  asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+		default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+		}
+		if (tid == 0) {
+			(void)__hip_atomic_fetch_add(arrived, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const int32_t *fr = &fring[(s_new & (kFlagRing - 1)) * 4];
+			const bool want_fin = cfin >= lo && cfin <= hi;
+			int32_t w0 = 0, w1 = 0, w2 = 0, ok = 1;
+			for (unsigned spins = 0;; ++spins) { // (a first look issued before the drain, to overlap it, measured no faster)
+				w0 = ld_ag(fr), w1 = ld_ag(fr + 1), w2 = want_fin ? ld_ag(fr + 2) : s_new << 4;
+				if ((w0 >> 4) == s_new && (w1 >> 4) == s_new && (w2 >> 4) == s_new) break;
+				if (spins > kSpinLimit) { ok = 0; break; }
+				__builtin_amdgcn_s_sleep(1);
+			}
+			// drift bound: the flag ring holds kFlagRing penalties, so nobody may run more than that ahead of the slowest workgroup
+			if (ok && s_new >= kDriftCheck && (s_new & (kDriftCheck - 1)) == 0) {
+				const unsigned long long want = (unsigned long long)G * (unsigned long long)(s_new - kDriftCheck);
+				for (unsigned spins = 0; __hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want; ++spins) {
+					if (spins > kSpinLimit) { ok = 0; break; }
+					__builtin_amdgcn_s_sleep(2);
+				}
+			}
+			sh.flags[npar][0] = (w0 & 1) | (w1 & 1) << 1 | (w2 & 15) << 2;
+			sh.flags[npar][1] = ok;
+		}
+		__syncthreads();
 #ifdef MWF_BAND_TIMING
 		{
 			const unsigned long long t_d = __builtin_readcyclecounter();
@@ -470,10 +546,11 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 #endif
 
 		// ---- bookkeeping, identical on every thread of every workgroup
-		if ((cum ^ cum_prev) & 1u) wf_lo = lo;
-		if ((cum ^ cum_prev) & 2u) wf_hi = hi;
-		const int32_t done = (int32_t)((cum >> 2) & 1u), payload = (int32_t)((cum >> 3) & 7u);
-		cum_prev = cum;
+		const int32_t fbits = uni(sh.flags[npar][0]);
+		if (uni(sh.flags[npar][1]) == 0 || uni(sh.red[0]) != 0) { R.status = ST_INTERNAL; break; }
+		if (fbits & 1) wf_lo = lo;
+		if (fbits & 2) wf_hi = hi;
+		const int32_t done = (fbits >> 2) & 1, payload = (fbits >> 3) & 7;
 		s = s_new, curH = newH, par = npar, dcur = dnew, gl = gl_next;
 		if (TB) tb_used += row_bytes;
 		if ((s & 0xff) == 0) { // shrink (miniwfa.c:144-171): the good bits were written with ordinary stores by every CU

@@ -326,8 +326,10 @@ int run_coop_pair(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, int32_
 	const int64_t TC = (int64_t)G * 8 * 2;
 	if (ensure(g, g->ring, (size_t)P.nH * W * 4 + 4096)) return -1;
 	if (ensure(g, g->good, (size_t)P.nH * GW * 8)) return -1;
-	if (ensure(g, g->coop_edge, (size_t)(3 * TC * 4 + (int64_t)P.nH * TC * 2) * 4)) return -1;
-	if (ensure(g, g->coop_misc, 4096)) return -1;
+	// granules crossing waves: [nH][TC][2 sides][4] x 8 bytes; misc: flags, barrier words, pass state, then the flag ring
+	const size_t gran_bytes = (size_t)P.nH * TC * 2 * 4 * 8;
+	if (ensure(g, g->coop_edge, gran_bytes)) return -1;
+	if (ensure(g, g->coop_misc, 8192)) return -1;
 	int64_t rows_slot = 0, tb_bytes = 0, cig_scratch = 0, seg_slot = 0;
 	if (cigar) {
 		rows_slot = std::max(bound, bound1) + 2;
@@ -382,13 +384,18 @@ int run_coop_pair(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, int32_
 	a.coop_state = (int32_t*)((char*)g->coop_misc.p + 2048);       // 16 ints
 
 	HIP_TRY(g, hipMemsetAsync(g->coop_misc.p, 0, 4096, g->stream));
+	// granule tags and the flag ring start out as "no penalty" (-1)
+	HIP_TRY(g, hipMemsetAsync((char*)g->coop_misc.p + 4096, 0xff, 4096, g->stream));
+	HIP_TRY(g, hipMemsetAsync(g->coop_edge.p, 0xff, gran_bytes, g->stream));
 	if (first) HIP_TRY(g, hipEventRecord(g->ev0, g->stream));
 	a.coop_pass = low_mem ? 1 : 0;
 	if (launch_coop_pass(a, G, g->stream)) { g->err = "kernel launch failed (whole-device pass)"; return -1; }
 	g->stats.n_launches += 1;
 	if (low_mem) {
 		if (launch_coop_walk(a, g->stream)) { g->err = "kernel launch failed (checkpoint walk)"; return -1; }
-		HIP_TRY(g, hipMemsetAsync((char*)g->coop_misc.p + 1024, 0, 1024, g->stream)); // barrier counter of the second pass
+		HIP_TRY(g, hipMemsetAsync((char*)g->coop_misc.p + 1024, 0, 1024, g->stream)); // barrier counters of the second pass
+		HIP_TRY(g, hipMemsetAsync((char*)g->coop_misc.p + 4096, 0xff, 4096, g->stream));
+		HIP_TRY(g, hipMemsetAsync(g->coop_edge.p, 0xff, gran_bytes, g->stream));
 		a.coop_pass = 2;
 		// the second pass is not traced: the band trace of a low-memory run is that of its second pass, traced below
 		if (launch_coop_pass(a, G, g->stream)) { g->err = "kernel launch failed (second pass)"; return -1; }

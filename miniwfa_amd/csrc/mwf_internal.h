@@ -87,9 +87,9 @@ struct BatchArgs {
 	// ---- whole-device (cooperative) kernel only: cross-workgroup state, all accessed at agent scope
 	int32_t coop_pair;         // the one pair this launch aligns
 	int32_t coop_pass;         // 0: plain pass; 1: pass whose traceback feeds the checkpoint walk; 2: second pass (uses seg)
-	int32_t *coop_edge;        // [3][waves*2][4] E1/E2 of a chunk's last column, F1/F2 of its first column
-	int32_t *coop_flags;       // [3][4] edge-live / end-cell flags per penalty (mod 3), + [16..] barrier counters etc.
-	unsigned int *coop_sync;   // [0]: arrivals, [1..8]: per-group arrivals, [9..16]: per-group generation, [32]: timeout
+	int32_t *coop_edge;        // granules [nH][waves*2][2][4] x 8 B: E/F/H of every chunk's outer columns, tagged with their penalty
+	int32_t *coop_flags;       // [12..14] origin offset and shrink reduction; [1024 + 4*(penalty mod 64) ..] edge-live / end-cell flag ring
+	unsigned int *coop_sync;   // [0..1]: arrivals of the full barrier, [16+8g]: per-group arrivals, [96+8g]: per-group generation, [200..201]: workgroup-penalties finished
 	int32_t *coop_state;       // results of a pass handed to the next launch: [0]=status [1]=s [2]=info [3]=n_seg [4..5]=cells
 };
 
