@@ -35,7 +35,7 @@ constexpr int kT = 512;          // threads per workgroup: 8 waves, up to 256 VG
 constexpr int kNW = kT / 64;
 constexpr int kK = 2;            // chunks per wave
 constexpr int kChunk = 256;
-constexpr unsigned kSpinLimit = 1u << 23;
+// (the bound on every wait between workgroups is A.coop_spin_limit polls: a lost workgroup yields an error, never a hang)
 
 __device__ __forceinline__ int32_t from_left(int32_t v, int32_t fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ int32_t from_right(int32_t v, int32_t fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false); }
@@ -158,7 +158,7 @@ __device__ __forceinline__ bool grid_sync(const BatchArgs &A, Shared &sh, unsign
 				seen = __hip_atomic_load(top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				if ((unsigned)(seen & 0xffffffffu) >= n_grp * epoch) break;
 				__builtin_amdgcn_s_sleep(1);
-				if (++spins > kSpinLimit) { ok = 0; break; }
+				if (++spins > A.coop_spin_limit) { ok = 0; break; }
 			}
 			__hip_atomic_store(&grp_gen[4 * grp], (seen & 0xffffffff00000000ull) | epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		} else {
@@ -166,7 +166,7 @@ __device__ __forceinline__ bool grid_sync(const BatchArgs &A, Shared &sh, unsign
 				seen = __hip_atomic_load(&grp_gen[4 * grp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				if ((unsigned)(seen & 0xffffffffu) >= epoch) break;
 				__builtin_amdgcn_s_sleep(1);
-				if (++spins > kSpinLimit) { ok = 0; break; }
+				if (++spins > A.coop_spin_limit) { ok = 0; break; }
 			}
 		}
 		if (FENCE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -365,7 +365,7 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 						const bool late = (need_e1 && gran_tag(ge1) != s_new - E1) || (need_e2 && gran_tag(ge2) != s_new - E2) ||
 						                  (need_h1 && gran_tag(gh1) != s_new - lag1) || (need_h2 && gran_tag(gh2) != s_new - lag2);
 						if (!__ballot(late)) break;
-						if (spins > kSpinLimit) { if (lane == 0) sh.red[0] = 1; break; }
+						if (spins > A.coop_spin_limit) { if (lane == 0) sh.red[0] = 1; break; }
 						__builtin_amdgcn_s_sleep(1);
 						ge1 = ld_gran(granule(jg1, nb, side, 0)), ge2 = ld_gran(granule(jg2, nb, side, 1));
 						gh1 = ld_gran(granule(j1, nb, side, 2)), gh2 = ld_gran(granule(j2, nb, side, 2));
@@ -522,14 +522,14 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 			for (unsigned spins = 0;; ++spins) { // (a first look issued before the drain, to overlap it, measured no faster)
 				w0 = ld_ag(fr), w1 = ld_ag(fr + 1), w2 = want_fin ? ld_ag(fr + 2) : s_new << 4;
 				if ((w0 >> 4) == s_new && (w1 >> 4) == s_new && (w2 >> 4) == s_new) break;
-				if (spins > kSpinLimit) { ok = 0; break; }
+				if (spins > A.coop_spin_limit) { ok = 0; break; }
 				__builtin_amdgcn_s_sleep(1);
 			}
 			// drift bound: the flag ring holds kFlagRing penalties, so nobody may run more than that ahead of the slowest workgroup
 			if (ok && s_new >= kDriftCheck && (s_new & (kDriftCheck - 1)) == 0) {
 				const unsigned long long want = (unsigned long long)G * (unsigned long long)(s_new - kDriftCheck);
 				for (unsigned spins = 0; __hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want; ++spins) {
-					if (spins > kSpinLimit) { ok = 0; break; }
+					if (spins > A.coop_spin_limit) { ok = 0; break; }
 					__builtin_amdgcn_s_sleep(2);
 				}
 			}

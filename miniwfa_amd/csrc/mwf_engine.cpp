@@ -53,6 +53,7 @@ struct mwf_gpu_s {
 	int64_t tb_budget_mb = 0;   // 0: automatic
 	int force_kind = -1;
 	int band_pack = -1;        // int16-packed E/F registers in the band kernel: 0 never, otherwise whenever the value ranges allow
+	int64_t coop_spin_limit = 1 << 23; // polls (about a microsecond each) before the whole-device kernel gives up on a workgroup
 	int64_t coop_tb_cap = (int64_t)96 << 30; // whole-device traceback arena: covers the 5 Mb pairs; doubles on overflow
 	// workspace (per-stream pool)
 	DevBuf ring, sring, good, tb, row_off, row_lo, cig_scratch, snap, snap_meta, seg, queue, dbg, coop_edge, coop_misc;
@@ -378,6 +379,7 @@ int run_coop_pair(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, int32_
 	a.dbg = b->debug_pair == pair ? (int32_t*)g->dbg.p : nullptr;
 	a.dbg_cap = b->debug_pair == pair ? (int32_t)(g->dbg.bytes / 8) : 0;
 	a.coop_pair = pair;
+	a.coop_spin_limit = (uint32_t)g->coop_spin_limit;
 	a.coop_edge = (int32_t*)g->coop_edge.p;
 	a.coop_flags = (int32_t*)g->coop_misc.p;                       // 64 ints
 	a.coop_sync = (unsigned int*)((char*)g->coop_misc.p + 1024);   // 64 uints
@@ -491,6 +493,7 @@ int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value)
 	else if (!strcmp(name, "tb_budget_mb")) g->tb_budget_mb = value;
 	else if (!strcmp(name, "force_kind")) g->force_kind = (int)value;
 	else if (!strcmp(name, "band_pack")) g->band_pack = (int)value;
+	else if (!strcmp(name, "coop_spin_limit")) g->coop_spin_limit = std::max<int64_t>(0, std::min<int64_t>(value, 0x7fffffff));
 	else if (!strcmp(name, "coop_tb_cap_mb")) g->coop_tb_cap = std::max<int64_t>(1, value) << 20;
 	else return -1;
 	return 0;
@@ -680,6 +683,12 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 		for (size_t i = 0; i < n; ++i) {
 			const int32_t st = b->h_status[i];
 			if (st == ST_BAND_OVERFLOW) band_overflow = true, redo.push_back((int32_t)i);
+			else if (st == ST_INTERNAL && g->stats.kernel_kind == 1 && round == 0) {
+				// a wait between workgroups of the whole-device kernel ran into its spin limit (they were not all resident, e.g.
+				// the device is shared): the one-workgroup kernel needs no such thing
+				fprintf(stderr, "[libmwf_hip] warning: whole-device kernel gave up waiting for a workgroup on pair %d; re-running it on one workgroup (slow)\n", (int)i);
+				band_overflow = true, redo.push_back((int32_t)i);
+			}
 			else if (st == ST_TB_OVERFLOW || st == ST_SNAP_OVERFLOW) redo.push_back((int32_t)i);
 			else if (st != ST_OK && st != ST_STOPPED) {
 				g->err = "pair " + std::to_string(i) + " failed on the device with status " + std::to_string(st);
@@ -689,7 +698,7 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 		if (redo.empty()) break;
 		if (band_overflow) {
 			redo_kind = 0; // the window outgrew the register-resident span: generic kernel, same slots
-			if (g->stats.kernel_kind == 1)
+			if (g->stats.kernel_kind == 1 && b->h_status[redo[0]] == ST_BAND_OVERFLOW)
 				fprintf(stderr, "[libmwf_hip] warning: wavefront of pair %d outgrew the whole-device kernel's span; re-running it on one workgroup (slow)\n", redo[0]);
 		}
 		else if (g->stats.kernel_kind == 1 && g->tb_budget_mb == 0 && g->coop_tb_cap < ((int64_t)1 << 40) && coop_can_grow(g)) {

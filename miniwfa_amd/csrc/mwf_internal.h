@@ -86,6 +86,7 @@ struct BatchArgs {
 	int32_t dbg_cap;
 	// ---- whole-device (cooperative) kernel only: cross-workgroup state, all accessed at agent scope
 	int32_t coop_pair;         // the one pair this launch aligns
+	uint32_t coop_spin_limit;  // polls after which a wait for another workgroup gives up (ST_INTERNAL)
 	int32_t coop_pass;         // 0: plain pass; 1: pass whose traceback feeds the checkpoint walk; 2: second pass (uses seg)
 	int32_t *coop_edge;        // granules [nH][waves*2][2][4] x 8 B: E/F/H of every chunk's outer columns, tagged with their penalty
 	int32_t *coop_flags;       // [12..14] origin offset and shrink reduction; [1024 + 4*(penalty mod 64) ..] edge-live / end-cell flag ring

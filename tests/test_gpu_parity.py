@@ -234,6 +234,28 @@ def test_whole_device_kernel_against_oracle(oracle):
     eng.close()
 
 
+def test_whole_device_kernel_gives_up_gracefully(oracle, capfd):
+    """The whole-device kernel synchronises workgroups by polling; every wait is bounded.  With the bound set to zero any
+    wait that is not satisfied at once gives up: the pair must come back, bit-exact, through the one-workgroup kernel."""
+    eng = mw.Engine(0)
+    eng.set("force_kind", 1)
+    eng.set("coop_spin_limit", 0)
+    pairs = [synth_pair(88100, 6000, 0.05), synth_pair(88101, 2500, 0.1)]
+    for o in (make_opt(), make_opt(flag=1), make_opt(flag=1, step=400)):
+        b = eng.upload(PackedBatch(pairs))
+        b.align(mw.opt_init(flag=o.flag, step=o.step))
+        s, it, nc = b.results()
+        for i, (t, q) in enumerate(pairs):
+            es, eit, ecig = oracle.align(t, q, o)
+            assert (int(s[i]), int(it[i])) == (es, eit), (i, o.flag, o.step)
+            if ecig is not None:
+                assert b.cigar(i, int(nc[i])).tolist() == ecig
+        b.free()
+    assert eng.stats().n_retries > 0
+    assert "gave up waiting" in capfd.readouterr().err
+    eng.close()
+
+
 def test_chain_and_auto_against_reference():
     """mwf_wfa_chain (reference miniwfa.c:850-896): host chaining + one GPU batch of gap fills must give the reference's
     penalty and CIGAR — on the stored chain-mode vectors and, when the compiled reference travelled with the snapshot,
