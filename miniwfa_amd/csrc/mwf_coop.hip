@@ -8,11 +8,14 @@
 //     slot (g / waves) mod 2 — for ever, so the H rows of a chunk are only ever touched by one CU and can
 //     use ordinary cached 16-byte loads/stores, and the E/F wavefronts stay in that wave's registers;
 //   * what crosses waves — the outer columns of each chunk (E1/E2 of the last, F1/F2 of the first, and the
-//     H of both for the three lags) — goes through two small tables in HBM that are written and read with
-//     agent-scope (sc1) accesses only, as do the three flags per penalty (new low/high edge live, end cell
-//     reached).  No fences are needed: nothing else is shared inside a pass;
-//   * one grid barrier per penalty: every wave drains its stores, each workgroup arrives on a device-scope
-//     counter and polls it (relaxed, s_sleep) — bounded, so a lost workgroup yields an error, not a hang;
+//     H of both for the three lags) — travels as granules: aligned 8-byte {value, penalty tag} words in a ring
+//     in HBM, written by one agent-scope (sc1, write-through) store and re-loaded by the one neighbour that
+//     wants them until the tag is the penalty it is waiting for.  That wait is the only synchronisation
+//     between neighbouring waves: no fences, no drains, no grid barrier per penalty;
+//   * the only thing everybody needs per penalty is the fate of the two edge columns (does the band grow?)
+//     and of the end cell: their owners publish three tagged words into a flag ring, thread 0 of every
+//     workgroup polls them.  Full grid barriers remain only around the shrink, every 256 penalties.  Every
+//     wait is bounded, so a lost workgroup yields an error (and a re-run on the one-workgroup kernel), not a hang;
 //   * long exact-match runs (these pairs are ~99 % identical) are walked by the whole wave: 64 lanes x
 //     4 bytes per trip for the lane that owns the diagonal, instead of one lane 4 bytes at a time;
 //   * low-memory mode (opt.step > 0, reference miniwfa.c:437-601): with 288 GB of HBM the full 1-byte-per-
