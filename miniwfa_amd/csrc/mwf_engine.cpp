@@ -74,6 +74,8 @@ struct mwf_gpu_batch_s {
 	int64_t max_seq_lds = 0;   // LDS bytes the band kernel needs to hold the longest pair's sequences
 	int64_t max_tl = 0;        // longest target (offsets are target indices: bounds what a 16-bit offset must hold)
 	int32_t *d_order = nullptr;
+	std::vector<int32_t> h_order;   // what d_order holds: pair ids, grouped by size class, longest first inside a class
+	std::vector<int8_t> h_class;    // size class of every pair in the last align (0 generic, 1 wide band, 2 narrow band)
 	// outputs
 	int32_t *d_s = nullptr, *d_ncig = nullptr, *d_status = nullptr, *d_dbg4 = nullptr;
 	int64_t *d_iter = nullptr, *d_cigoff = nullptr, *d_cells1 = nullptr;
@@ -203,14 +205,16 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 
 int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const int32_t *d_order, int32_t n_items,
                      int slots, int64_t max_len, int64_t max_bound, int64_t max_bound1, int64_t tb_total_budget, bool timed,
-                     int want_kind = -1)
+                     int want_kind = -1, int64_t max_tl = -1, int64_t max_seq_lds = -1, int timed_end = -1)
 {
+	if (max_tl < 0) max_tl = b->max_tl;
+	if (max_seq_lds < 0) max_seq_lds = b->max_seq_lds;
 	const Penalty P = make_penalty(opt);
 	Plan pl;
 	pl.cigar = (opt.flag & MWF_F_CIGAR) != 0;
 	pl.low_mem = pl.cigar && opt.step > 0;
 	pl.block = g->block > 0 && g->block != 768 ? g->block : 256;
-	choose_kernel(g, opt, P, max_len, max_bound, b->max_seq_lds, b->max_tl, want_kind >= 0 ? want_kind : g->force_kind, pl);
+	choose_kernel(g, opt, P, max_len, max_bound, max_seq_lds, max_tl, want_kind >= 0 ? want_kind : g->force_kind, pl);
 	// `slots` is an upper bound from the caller (retries ask for fewer, larger slots); the chosen kernel's own residency
 	// bounds it as well
 	int per_cu;
@@ -302,12 +306,12 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 		g->err = "kernel launch failed";
 		return -1;
 	}
-	if (timed) {
+	if (timed_end < 0 ? timed : timed_end != 0) { // the events bracket all launches of an align call, not the retries
 		HIP_TRY(g, hipEventRecord(g->ev1, g->stream));
 		g->ev_pending = true;
 	}
 	g->stats.n_launches += 1;
-	g->stats.grid = pl.grid, g->stats.block = pl.block, g->stats.kernel_kind = pl.kind;
+	g->stats.grid = std::max(g->stats.grid, pl.grid), g->stats.block = pl.block, g->stats.kernel_kind = pl.kind;
 	return 0;
 }
 
@@ -544,6 +548,7 @@ static mwf_gpu_batch_t *batch_common(mwf_gpu_t *g, int32_t n, const int32_t *h_t
 	std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
 		return (int64_t)h_tl[x] + h_ql[x] > (int64_t)h_tl[y] + h_ql[y];
 	});
+	b->h_order = order;
 	if (n > 0 && hipMemcpy(b->d_order, order.data(), (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess) {
 		g->err = "upload of the processing order failed";
 		mwf_gpu_batch_free(b);
@@ -647,7 +652,54 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		return 0;
 	}
 	const int64_t budget = cigar ? tb_budget_bytes(g) : 0;
-	if (run_batch_kernel(g, b, *opt, b->d_order, b->n, slots, max_len, max_bound, max_bound1, budget, true)) return -1;
+	// Size classes.  One long pair must not push a thousand short ones onto the slow kernel (mwf_wfa_chain's gap fills are
+	// exactly such a mix): pairs are grouped by what their window can grow to, and every group runs on the kernel that suits
+	// it — generic (largest workspace) first, so that later groups never have to grow a buffer.  Kernel and block size forced
+	// by the caller (tests, tuning) keep the whole batch in one group.
+	const bool low_mem = cigar && opt->step > 0;
+	const bool classes = g->force_kind < 0 && g->block == 0 && !low_mem && band_supported(P0);
+	struct Group { std::vector<int32_t> ids; int64_t max_len = 0, max_bound = 0, max_bound1 = 0, max_tl = 0, max_seq_lds = 0; } grp[3];
+	b->h_class.assign((size_t)b->n, 0);
+	for (int32_t i = 0; i < b->n; ++i) {
+		const int64_t len = (int64_t)b->h_tl[i] + b->h_ql[i], bound = penalty_bound(*opt, b->h_tl[i], b->h_ql[i], true);
+		int c = 0;
+		if (classes) {
+			const int64_t window = std::min<int64_t>(len + 1, 2 * bound + 3);
+			if (window <= 8 * 256 - 256 - 64) c = 2;          // fits the 256-thread band kernel's span whatever happens
+			else if (len + 1 <= 4 * (int64_t)(8 * 3 * 256)) c = 1; // windows that mostly stay inside the wide band kernel's span
+		}
+		b->h_class[i] = (int8_t)c;
+		Group &G = grp[c];
+		G.ids.push_back(i);
+		G.max_len = std::max(G.max_len, len), G.max_bound = std::max(G.max_bound, bound);
+		G.max_bound1 = std::max(G.max_bound1, penalty_bound(*opt, b->h_tl[i], b->h_ql[i], false));
+		G.max_tl = std::max<int64_t>(G.max_tl, b->h_tl[i]);
+		G.max_seq_lds = std::max<int64_t>(G.max_seq_lds, (((int64_t)b->h_tl[i] + 3) & ~3LL) + 8 + (((int64_t)b->h_ql[i] + 3) & ~3LL) + 16);
+	}
+	std::vector<int32_t> order;
+	order.reserve((size_t)b->n);
+	for (Group &G : grp) {
+		std::stable_sort(G.ids.begin(), G.ids.end(), [&](int32_t x, int32_t y) { // longest first: the persistent workgroups finish together
+			return (int64_t)b->h_tl[x] + b->h_ql[x] > (int64_t)b->h_tl[y] + b->h_ql[y];
+		});
+		order.insert(order.end(), G.ids.begin(), G.ids.end());
+	}
+	if (order != b->h_order) {
+		HIP_TRY(g, hipStreamSynchronize(g->stream)); // an earlier align of this batch may still be reading the old order
+		HIP_TRY(g, hipMemcpy(b->d_order, order.data(), order.size() * 4, hipMemcpyHostToDevice));
+		b->h_order = order;
+	}
+	int n_groups = 0, done_groups = 0;
+	for (const Group &G : grp) n_groups += !G.ids.empty();
+	size_t at = 0;
+	for (int c = 0; c < 3; ++c) {
+		const Group &G = grp[c];
+		if (G.ids.empty()) continue;
+		++done_groups;
+		if (run_batch_kernel(g, b, *opt, b->d_order + at, (int32_t)G.ids.size(), slots, G.max_len, G.max_bound, G.max_bound1, budget,
+		                     done_groups == 1, classes ? (c == 0 ? 0 : 2) : -1, G.max_tl, G.max_seq_lds, done_groups == n_groups)) return -1;
+		at += G.ids.size();
+	}
 	b->aligned = true;
 	return 0;
 }
@@ -696,6 +748,13 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 			}
 		}
 		if (redo.empty()) break;
+		if (round == 0 && g->stats.kernel_kind != 1 && !b->h_class.empty()) {
+			// the batch ran in size classes: stay on the band kernel only if every pair to redo came from one
+			bool any_class = false, all_band = true;
+			for (int8_t c : b->h_class) any_class |= c != 0;
+			for (int32_t i : redo) all_band &= b->h_class[i] != 0;
+			if (any_class) redo_kind = all_band ? 2 : 0;
+		}
 		if (band_overflow) {
 			redo_kind = 0; // the window outgrew the register-resident span: generic kernel, same slots
 			if (g->stats.kernel_kind == 1 && b->h_status[redo[0]] == ST_BAND_OVERFLOW)

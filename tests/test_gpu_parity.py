@@ -127,6 +127,33 @@ def test_ragged_batch_against_oracle(engine, oracle):
         b.free()
 
 
+def test_mixed_batch_runs_in_size_classes(oracle):
+    """One batch with three very different pair sizes (what mwf_wfa_chain's gap fills look like): every size class goes
+    to its own kernel in its own launch, results identical to the oracle, in the caller's order."""
+    eng = mw.Engine(0)
+    pairs = []
+    for i in range(120):
+        pairs.append(synth_pair(89000 + i, (40, 300, 700)[i % 3], (0.02, 0.1)[i % 2]))       # narrow band kernel
+        if i % 4 == 0:
+            pairs.append(synth_pair(89500 + i, 6000, 0.05))                                   # wide band kernel
+        if i % 60 == 0:
+            pairs.append(synth_pair(89900 + i, 14000, 0.03))                                  # generic kernel (tl+ql > 24 kb)
+    for o in (make_opt(), make_opt(flag=1)):
+        b = eng.upload(PackedBatch(pairs))
+        b.align(mw.opt_init(flag=o.flag))
+        assert eng.stats().n_launches == 3
+        s, it, nc = b.results()
+        for i, (t, q) in enumerate(pairs):
+            if len(t) < 1000 and i % 5:
+                continue
+            es, eit, ecig = oracle.align(t, q, o)
+            assert (int(s[i]), int(it[i])) == (es, eit), (i, len(t), o.flag)
+            if ecig is not None:
+                assert b.cigar(i, int(nc[i])).tolist() == ecig, i
+        b.free()
+    eng.close()
+
+
 @pytest.mark.parametrize("block", [64, 128, 256, 512, 1024])
 def test_every_block_size_gives_identical_results(block, oracle):
     """Generic kernel (ring in HBM), every workgroup size."""
