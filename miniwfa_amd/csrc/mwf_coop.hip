@@ -58,6 +58,7 @@ __device__ __forceinline__ void st_gran(gran_t *p, int32_t v, int32_t tag)
 __device__ __forceinline__ int32_t gran_val(gran_t g) { return (int32_t)(uint32_t)g; }
 __device__ __forceinline__ int32_t gran_tag(gran_t g) { return (int32_t)(uint32_t)(g >> 32); }
 
+constexpr int kFlagCopies = 32;  // every flag word is written to this many cache lines: 256 pollers on one line starve the line's writer
 constexpr int kFlagRing = 64;    // penalties of edge/end flags kept; workgroups never drift further apart than 32 penalties
 constexpr int kDriftCheck = 16;  // every so many penalties a workgroup waits until all have finished the penalty 16 back
 
@@ -201,6 +202,7 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 	// Per penalty (mod kFlagRing): "new low edge live", "new high edge live", "end cell reached | last state << 1", each as
 	// penalty << 4 | value, written by the one wave that owns the column in question.
 	int32_t *const fring = A.coop_flags + 1024;
+	auto flag_entry = [&](int32_t pen, int32_t copy) -> int32_t* { return fring + ((pen & (kFlagRing - 1)) * kFlagCopies + copy) * 32; }; // one 128-byte line each
 	unsigned long long *const arrived = (unsigned long long*)(A.coop_sync + 200); // workgroup-penalties finished (drift bound)
 	PassResult R;
 	R.status = ST_OK, R.s = 0, R.info = 0, R.n_snap = 0, R.cells = 0;
@@ -349,7 +351,6 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 				o1[1] = po1[k].x, o1[2] = po1[k].y, o1[3] = po1[k].z, o1[4] = po1[k].w;
 				o2[1] = po2[k].x, o2[2] = po2[k].y, o2[3] = po2[k].z, o2[4] = po2[k].w;
 				gran_t gh1 = ph1[k], gh2 = ph2[k];
-				prefetch(k, nextH, phi, gl_next);
 				// What the neighbouring chunks computed for the column next to this chunk (lane 0: left neighbour's last column,
 				// lane 63: right neighbour's first): E1|F1 of penalty s_new-e1, E2|F2 of s_new-e2, H of s_new-lag1 and s_new-lag2.
 				// A neighbour column outside the window of that penalty was never computed: NEG_INF.  Otherwise wait for the
@@ -363,6 +364,9 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 					const bool need_h1 = edge_lane & (cn >= alo) & (cn <= ahi), need_h2 = edge_lane & (cn >= blo) & (cn <= bhi);
 					// (Loading these at the end of the previous penalty instead, to overlap the wait for the flags, measured slower:
 					// memory operations return in issue order, so an early agent-scope load holds up whatever is issued behind it.)
+#ifdef MWF_BAND_TIMING
+					const unsigned long long t_g0 = __builtin_readcyclecounter();
+#endif
 					gran_t ge1 = ld_gran(granule(jg1, nb, side, 0)), ge2 = ld_gran(granule(jg2, nb, side, 1));
 					for (unsigned spins = 0;; ++spins) {
 						const bool late = (need_e1 && gran_tag(ge1) != s_new - E1) || (need_e2 && gran_tag(ge2) != s_new - E2) ||
@@ -373,6 +377,9 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 						ge1 = ld_gran(granule(jg1, nb, side, 0)), ge2 = ld_gran(granule(jg2, nb, side, 1));
 						gh1 = ld_gran(granule(j1, nb, side, 2)), gh2 = ld_gran(granule(j2, nb, side, 2));
 					}
+#ifdef MWF_BAND_TIMING
+					if (__ballot(gran_tag(ge1) == 0x7fffffff) == 0) t_acc[3] += __builtin_readcyclecounter() - t_g0; // (forces the wait here)
+#endif
 					xg1 = need_e1 ? gran_val(ge1) : kNegInf, xg2 = need_e2 ? gran_val(ge2) : kNegInf;
 					v1 = need_h1 ? gran_val(gh1) : kNegInf, v2 = need_h2 ? gran_val(gh2) : kNegInf;
 				}
@@ -424,12 +431,13 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 				if (lane == 0) st_gran(granule(newH, r, 1, 0), nf1[0], s_new), st_gran(granule(newH, r, 1, 1), nf2[0], s_new);
 				if ((uint32_t)(lo - cb) < (uint32_t)kChunk) { // this chunk holds the low edge column
 					const int32_t lv = __ballot(live & 1u) != 0;
-					if (lane == 0) st_ag(&fring[(s_new & (kFlagRing - 1)) * 4 + 0], s_new << 4 | lv);
+					if (lane < kFlagCopies) st_ag(flag_entry(s_new, lane) + 0, s_new << 4 | lv);
 				}
 				if ((uint32_t)(hi - cb) < (uint32_t)kChunk) {
 					const int32_t lv = __ballot(live & 2u) != 0;
-					if (lane == 0) st_ag(&fring[(s_new & (kFlagRing - 1)) * 4 + 1], s_new << 4 | lv);
+					if (lane < kFlagCopies) st_ag(flag_entry(s_new, lane) + 1, s_new << 4 | lv);
 				}
+				prefetch(k, nextH, phi, gl_next); // the next penalty's rows: only now, so that nothing queues in front of what was just published
 				// a run of >= 4 matches continues: the wave walks it together, one owning lane and column at a time
 				unsigned long long owners = __ballot(pend != 0);
 				while (owners) {
@@ -475,7 +483,7 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 					const unsigned long long fm = __ballot(fin);
 					int32_t val = 0;
 					if (fm) val = 1 | __builtin_amdgcn_readlane(done_info, (int32_t)__builtin_ctzll(fm)) << 1;
-					if (lane == 0) st_ag(&fring[(s_new & (kFlagRing - 1)) * 4 + 2], s_new << 4 | val);
+					if (lane < kFlagCopies) st_ag(flag_entry(s_new, lane) + 2, s_new << 4 | val);
 				}
 
 			} else {
@@ -510,6 +518,8 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 		// ---- end of the penalty.  No grid barrier: neighbours synchronise through the granules above; what every workgroup
 		// needs before it can go on is the fate of the two edge columns (the next window) and of the end cell, which their
 		// owners publish into the flag ring.  Thread 0 waits for them while the other waves wait at the workgroup barrier.
+		// (Measured and rejected: a wave without chunks that polls the ring from the start of the penalty so that the round
+		// trip overlaps the chunk work — the extra polling traffic delays the very stores it is waiting for: 1.43 -> 1.51 s.)
 		switch (vm_keep) { // own H rows are read back min-lag - 1 penalties from now: keep at most this penalty's late stores in flight
 		case 3:  asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
 		case 4:  asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
@@ -519,11 +529,17 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 		}
 		if (tid == 0) {
 			(void)__hip_atomic_fetch_add(arrived, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			const int32_t *fr = &fring[(s_new & (kFlagRing - 1)) * 4];
+			const int32_t *fr = flag_entry(s_new, (int32_t)blockIdx.x & (kFlagCopies - 1));
 			const bool want_fin = cfin >= lo && cfin <= hi;
 			int32_t w0 = 0, w1 = 0, w2 = 0, ok = 1;
-			for (unsigned spins = 0;; ++spins) { // (a first look issued before the drain, to overlap it, measured no faster)
-				w0 = ld_ag(fr), w1 = ld_ag(fr + 1), w2 = want_fin ? ld_ag(fr + 2) : s_new << 4;
+			// each look is ONE 16-byte agent-scope load of this workgroup's copy of the flag words
+			for (unsigned spins = 0;; ++spins) {
+#ifdef MWF_BAND_TIMING
+				t_acc[3] += 1;
+#endif
+				int4 w;
+				asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(fr) : "memory");
+				w0 = w.x, w1 = w.y, w2 = want_fin ? w.z : s_new << 4;
 				if ((w0 >> 4) == s_new && (w1 >> 4) == s_new && (w2 >> 4) == s_new) break;
 				if (spins > A.coop_spin_limit) { ok = 0; break; }
 				__builtin_amdgcn_s_sleep(1);
@@ -593,9 +609,9 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 		}
 	}
 #ifdef MWF_BAND_TIMING
-	if (lane == 0 && (tid >> 6) < 2 && (blockIdx.x == 0 || blockIdx.x == 72 || blockIdx.x == 73 || blockIdx.x == 74 || blockIdx.x == 200))
-		printf("wg %3d wave %d steps %llu active-slots %llu | per step: header %.0f  slots %.0f  drain+grid-barrier %.0f cycles\n", (int)blockIdx.x, tid >> 6,
-		       t_steps, t_active, (double)t_acc[0] / t_steps, (double)t_acc[1] / t_steps, (double)t_acc[2] / t_steps);
+	if (lane == 0 && ((tid >> 6) < 2 || (tid >> 6) == 7) && (blockIdx.x == 0 || blockIdx.x == 72 || blockIdx.x == 73 || blockIdx.x == 74 || blockIdx.x == 200))
+		printf("wg %3d wave %d steps %llu active-slots %llu | per step: header %.0f  slots %.0f  drain+flags+barrier %.0f cycles; granule wait per active slot %.0f (watcher: polls per step %.2f)\n", (int)blockIdx.x, tid >> 6,
+		       t_steps, t_active, (double)t_acc[0] / t_steps, (double)t_acc[1] / t_steps, (double)t_acc[2] / t_steps, (double)t_acc[3] / (t_active ? t_active : 1), (double)t_acc[3] / t_steps);
 #endif
 	R.s = s, R.cells = cells;
 	return R;
@@ -694,6 +710,8 @@ bool coop_supported(const Penalty &p)
 	const bool inst = (p.e1 == 2 && p.e2 == 1) || (p.e1 == 2 && p.e2 == 2);
 	return inst && p.x >= 2 && p.oe1 >= 2 && p.oe2 >= 2;
 }
+
+int64_t coop_chunk_slots(int grid) { return (int64_t)grid * kNW * kK; }
 
 int coop_max_grid(bool)
 {

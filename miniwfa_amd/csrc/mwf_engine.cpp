@@ -328,13 +328,14 @@ int run_coop_pair(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, int32_
 	const int64_t bound = penalty_bound(opt, b->h_tl[pair], b->h_ql[pair], true);
 	const int64_t bound1 = penalty_bound(opt, b->h_tl[pair], b->h_ql[pair], false);
 	const int32_t W = (int32_t)((len + 3 + 255) / 256 * 256 + 512), GW = W / 64 + 2;
-	const int64_t TC = (int64_t)G * 8 * 2;
+	const int64_t TC = coop_chunk_slots(G);
 	if (ensure(g, g->ring, (size_t)P.nH * W * 4 + 4096)) return -1;
 	if (ensure(g, g->good, (size_t)P.nH * GW * 8)) return -1;
 	// granules crossing waves: [nH][TC][2 sides][4] x 8 bytes; misc: flags, barrier words, pass state, then the flag ring
 	const size_t gran_bytes = (size_t)P.nH * TC * 2 * 4 * 8;
 	if (ensure(g, g->coop_edge, gran_bytes)) return -1;
-	if (ensure(g, g->coop_misc, 8192)) return -1;
+	const size_t flag_ring_bytes = (size_t)64 * 32 * 128; // mwf_coop.hip: kFlagRing x kFlagCopies lines of 128 bytes
+	if (ensure(g, g->coop_misc, 4096 + flag_ring_bytes)) return -1;
 	int64_t rows_slot = 0, tb_bytes = 0, cig_scratch = 0, seg_slot = 0;
 	if (cigar) {
 		rows_slot = std::max(bound, bound1) + 2;
@@ -391,7 +392,7 @@ int run_coop_pair(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, int32_
 
 	HIP_TRY(g, hipMemsetAsync(g->coop_misc.p, 0, 4096, g->stream));
 	// granule tags and the flag ring start out as "no penalty" (-1)
-	HIP_TRY(g, hipMemsetAsync((char*)g->coop_misc.p + 4096, 0xff, 4096, g->stream));
+	HIP_TRY(g, hipMemsetAsync((char*)g->coop_misc.p + 4096, 0xff, flag_ring_bytes, g->stream));
 	HIP_TRY(g, hipMemsetAsync(g->coop_edge.p, 0xff, gran_bytes, g->stream));
 	if (first) HIP_TRY(g, hipEventRecord(g->ev0, g->stream));
 	a.coop_pass = low_mem ? 1 : 0;
@@ -400,7 +401,7 @@ int run_coop_pair(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, int32_
 	if (low_mem) {
 		if (launch_coop_walk(a, g->stream)) { g->err = "kernel launch failed (checkpoint walk)"; return -1; }
 		HIP_TRY(g, hipMemsetAsync((char*)g->coop_misc.p + 1024, 0, 1024, g->stream)); // barrier counters of the second pass
-		HIP_TRY(g, hipMemsetAsync((char*)g->coop_misc.p + 4096, 0xff, 4096, g->stream));
+		HIP_TRY(g, hipMemsetAsync((char*)g->coop_misc.p + 4096, 0xff, flag_ring_bytes, g->stream));
 		HIP_TRY(g, hipMemsetAsync(g->coop_edge.p, 0xff, gran_bytes, g->stream));
 		a.coop_pass = 2;
 		// the second pass is not traced: the band trace of a low-memory run is that of its second pass, traced below

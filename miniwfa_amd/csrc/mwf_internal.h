@@ -107,7 +107,8 @@ struct BandGeom {
 };
 // launch wrappers implemented in mwf_coop.hip (one pair across the whole device)
 bool coop_supported(const Penalty &p);
-int  coop_max_grid(bool cigar);                      // co-resident workgroups the kernel may be launched with
+int  coop_max_grid(bool cigar);
+int64_t coop_chunk_slots(int grid);                  // 256-column chunks a launch of `grid` workgroups holds (window capacity + 1)                      // co-resident workgroups the kernel may be launched with
 int  launch_coop_pass(const BatchArgs &a, int grid, void *stream);       // forward pass (score / traceback bytes)
 int  launch_coop_walk(const BatchArgs &a, void *stream);                 // checkpoints from the traceback matrix
 int  launch_coop_finish(const BatchArgs &a, void *stream);               // traceback + per-pair outputs
