@@ -185,7 +185,6 @@ __device__ __forceinline__ bool grid_sync(const BatchArgs &A, Shared &sh, unsign
 template <int E1, int E2, bool TB>
 __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh, int32_t n_seg)
 {
-	constexpr int D = 3;
 	const int32_t G = (int32_t)gridDim.x, NWt = G * kNW, TC = NWt * kK;
 	const int32_t tl = M.tl, ql = M.ql, cmax = tl + ql + 1;
 	const int32_t tid = threadIdx.x, lane = tid & 63, gw = uni((int32_t)blockIdx.x * kNW + (tid >> 6));
@@ -247,7 +246,7 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 	}
 
 	int32_t s = 0, wf_lo = tl + 1, wf_hi = tl + 1;
-	int32_t curH = 0, par = 0, sid = 0, dcur = 0;
+	int32_t curH = 0, par = 0, sid = 0;
 	int64_t cells = 0, tb_used = 0;
 
 	auto prefetch = [&](int k, int32_t slotH, int32_t phi, int32_t g_lo) {
@@ -296,7 +295,6 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 		const int32_t s_new = s + 1;
 		const int32_t newH = curH + 1 == nH ? 0 : curH + 1;
 		const int32_t npar = par + 1 == 3 ? 0 : par + 1;
-		const int32_t dnew = dcur + 1 == D ? 0 : dcur + 1;
 		const int32_t origin = lo & ~3;
 		const int32_t row_bytes = (hi | 3) - origin + 1;
 		if (TB) {
@@ -570,7 +568,7 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 		if (fbits & 1) wf_lo = lo;
 		if (fbits & 2) wf_hi = hi;
 		const int32_t done = (fbits >> 2) & 1, payload = (fbits >> 3) & 7;
-		s = s_new, curH = newH, par = npar, dcur = dnew, gl = gl_next;
+		s = s_new, curH = newH, par = npar, gl = gl_next;
 		if (TB) tb_used += row_bytes;
 		if ((s & 0xff) == 0) { // shrink (miniwfa.c:144-171): the good bits were written with ordinary stores by every CU
 			if (lead) st_ag(&gflags[13], 0x7fffffff), st_ag(&gflags[14], -1);

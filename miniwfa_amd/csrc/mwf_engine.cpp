@@ -163,7 +163,7 @@ int64_t penalty_bound(const mwf_opt_t &o, int64_t tl, int64_t ql, bool honour_ma
 
 struct Plan {
 	int kind = 0;              // 0: generic kernel, 2: band kernel
-	BandGeom band{0, 0, 0};
+	BandGeom band{0, 0, 0, 0};
 	int block = 256, grid = 1;
 	int32_t W = 0, GW = 0;
 	int64_t ring_slot_ints = 0, rows_slot = 0, tb_slot_bytes = 0, cig_scratch_slot = 0;

@@ -261,6 +261,32 @@ def test_whole_device_kernel_against_oracle(oracle):
     eng.close()
 
 
+def test_whole_device_kernel_many_shapes(oracle):
+    """The whole-device kernel synchronises through tagged granules and a flag ring: a sweep over pair shapes (window
+    from a few to ~150 chunks, runs from 7 to 500 bases, long indels) for the rare orderings a fixed case cannot hit."""
+    eng = mw.Engine(0)
+    eng.set("force_kind", 1)
+    shapes = [(700, 0.15, 0, 0), (2500, 0.002, 0, 0), (5000, 0.08, 2, 300), (9000, 0.03, 0, 0), (12000, 0.12, 0, 0),
+              (16000, 0.005, 3, 1500), (22000, 0.06, 0, 0), (30000, 0.02, 1, 4000)]
+    pairs = [synth_pair(88200 + i, tl, p, nl, lm) for i, (tl, p, nl, lm) in enumerate(shapes)]
+    pairs += [(q, t) for t, q in pairs[:4]]  # and the other way round (insertions <-> deletions)
+    for o in (make_opt(), make_opt(flag=1), make_opt(flag=1, step=700)):
+        for lo in range(0, len(pairs), 4):
+            chunk = pairs[lo:lo + 4]
+            b = eng.upload(PackedBatch(chunk))
+            b.align(mw.opt_init(flag=o.flag, step=o.step))
+            assert eng.stats().kernel_kind == 1
+            s, it, nc = b.results()
+            for i, (t, q) in enumerate(chunk):
+                es, eit, ecig = oracle.align(t, q, o)
+                assert (int(s[i]), int(it[i])) == (es, eit), (lo + i, len(t), len(q), o.flag, o.step)
+                if ecig is not None:
+                    assert b.cigar(i, int(nc[i])).tolist() == ecig, (lo + i, o.step)
+            b.free()
+    assert eng.stats().n_retries == 0
+    eng.close()
+
+
 def test_whole_device_kernel_gives_up_gracefully(oracle, capfd):
     """The whole-device kernel synchronises workgroups by polling; every wait is bounded.  With the bound set to zero any
     wait that is not satisfied at once gives up: the pair must come back, bit-exact, through the one-workgroup kernel."""
