@@ -29,6 +29,7 @@
 //     checkpoints it yields drive the band resets of the second pass.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "mwf_internal.h"
 
 #include "mwf_device.h"
@@ -322,7 +323,338 @@ __device__ PassResult forward_pass(const BatchArgs &A, const PairMem &M, Shared 
 	return R;
 }
 
-template <int T>
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same pass with four columns per lane (the band kernel's inner code, mwf_band.hip) for every mode except the
+// low-memory first pass.  forward_pass above moves 9 dwords in and 5 out per lane per cell; here a lane owns four
+// consecutive columns of a 256-column chunk (chunk g belongs to wave g mod waves), so each array-slice is ONE 16-byte
+// load or store per lane, the d-1 / d+1 neighbours come from the adjacent lane through a DPP wave shift and only
+// lanes 0 and 63 load a neighbouring chunk's outer column.  Same 48 algorithmic bytes per cell, a quarter of the
+// memory instructions, four times the bytes in flight per wave.
+__device__ __forceinline__ int32_t from_left(int32_t v, int32_t fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int32_t from_right(int32_t v, int32_t fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false); }
+
+__device__ __forceinline__ uint32_t probe4g(const PairMem &M, int32_t j, int32_t i)
+{
+	uint32_t a, b;
+	__builtin_memcpy(&a, M.ts + j, 4);
+	__builtin_memcpy(&b, M.qs + i, 4);
+	return a ^ b;
+}
+
+__device__ __forceinline__ uint32_t inm_bit(int32_t d, int32_t k, int32_t tl, int32_t ql)
+{
+	return (uint32_t)((uint32_t)(k + 1) < (uint32_t)(tl + 1)) & (uint32_t)((uint32_t)(d + k + 1) < (uint32_t)(ql + 1));
+}
+
+__device__ __forceinline__ int32_t pick4(int32_t i, int32_t a0, int32_t a1, int32_t a2, int32_t a3)
+{
+	return i == 0 ? a0 : i == 1 ? a1 : i == 2 ? a2 : a3;
+}
+
+// lanes l of interleaved good word k (column = base + 4*l + k) whose column lies in [a,b]
+__device__ __forceinline__ unsigned long long lane_mask4(int32_t base, int32_t k, int32_t a, int32_t b)
+{
+	int32_t lmin = a - base - k, lmax = b - base - k;
+	if (lmax < 0) return 0ull;
+	lmin = lmin <= 0 ? 0 : (lmin + 3) >> 2;
+	lmax = min(lmax >> 2, 63);
+	if (lmin > lmax) return 0ull;
+	return (~0ull >> (63 - lmax)) & (~0ull << lmin);
+}
+
+// exact-match run t[j..] == q[i..] walked by the whole wave, 256 bytes per trip (arguments wave-uniform)
+__device__ __forceinline__ int32_t run_wave_g(const PairMem &M, int32_t j, int32_t i, int32_t room, int32_t n0)
+{
+	const int32_t lane = threadIdx.x & 63;
+	int32_t n = n0;
+	while (n < room) {
+		const int32_t off = n + 4 * lane;
+		int32_t m = 0;
+		if (off < room) {
+			const uint32_t x = probe4g(M, j + off, i + off);
+			m = min(x ? (int32_t)(__builtin_ctz(x) >> 3) : 4, room - off);
+		}
+		const unsigned long long stop = __ballot(m < 4);
+		if (stop == 0) { n += 256; continue; }
+		const int32_t first = (int32_t)__builtin_ctzll(stop);
+		n += 4 * first + __builtin_amdgcn_readlane(m, first);
+		break;
+	}
+	return min(n, room);
+}
+
+template <int T, bool TB>
+__device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &sh, int32_t n_seg, bool trace_band)
+{
+	constexpr int NW = T / 64;
+	constexpr int32_t kChunk = 256;
+	const Penalty &P = A.pen;
+	const int32_t tl = M.tl, ql = M.ql, cmax = tl + ql + 1;
+	const int32_t tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+	const int64_t W = A.W;
+	PassResult R;
+	R.status = ST_OK, R.s = 0, R.info = 0, R.n_snap = 0, R.cells = 0;
+
+	// ---- penalty 0 (reference wf_stripe_init, miniwfa.c:103-121) and its extension
+	if (tid == 0) {
+		for (int32_t j = 0; j < P.nH; ++j) sh.rng_lo[j] = 1, sh.rng_hi[j] = 0;
+		for (int32_t j = 0; j < 12; ++j) (&sh.flags[0][0])[j] = 0;
+		const int32_t c0 = tl + 1;
+		const int32_t k0 = extend_run(M.ts, M.qs, tl, ql, -1, 0);
+		M.H[c0] = k0;
+		M.E1[c0] = M.F1[c0] = M.E2[c0] = M.F2[c0] = kNegInf;
+		sh.rng_lo[0] = sh.rng_hi[0] = c0;
+		sh.word[1] = k0;
+	}
+	__syncthreads();
+	{
+		const int32_t k0 = uni(sh.word[1]);
+		if (k0 == tl - 1 && k0 == ql - 1) return R;
+	}
+
+	int32_t s = 0, wf_lo = tl + 1, wf_hi = tl + 1;
+	int32_t curH = 0, cur1 = 0, cur2 = 0, par = 0, sid = 0;
+	int64_t cells = 0, tb_used = 0;
+	const int32_t cfin = ql + 1; // the end cell (tl-1, ql-1) lies on diagonal ql-tl, i.e. in this column
+
+	for (;;) {
+		if (TB && sid < n_seg) { // checkpoint reset of the second pass (miniwfa.c:413-416)
+			if (uni(M.seg[2 * sid]) == s) {
+				const int32_t c = uni(M.seg[2 * sid + 1]);
+				if (c < wf_lo || c > wf_hi) { R.status = ST_INTERNAL; break; }
+				wf_lo = wf_hi = c;
+				++sid;
+			}
+		}
+		const int32_t lo = wf_lo > 1 ? wf_lo - 1 : 1;       // miniwfa.c:417-418
+		const int32_t hi = wf_hi < cmax ? wf_hi + 1 : cmax;
+		const int32_t s_new = s + 1;
+		const int32_t newH = curH + 1 == P.nH ? 0 : curH + 1;
+		const int32_t new1 = cur1 + 1 == P.n1 ? 0 : cur1 + 1;
+		const int32_t new2 = cur2 + 1 == P.n2 ? 0 : cur2 + 1;
+		const int32_t npar = par + 1 == 3 ? 0 : par + 1;
+		const int32_t origin = lo & ~3;                     // traceback rows start on a dword: one 4-byte store per lane
+		const int32_t row_bytes = (hi | 3) - origin + 1;
+		if (TB) {
+			if (s_new - 1 >= A.rows_slot) { R.status = ST_ROWS_OVERFLOW; break; }
+			if (tb_used + row_bytes > A.tb_slot_bytes) { R.status = ST_TB_OVERFLOW; break; }
+		}
+		// source slices (reference wf_next_prep, miniwfa.c:243-259) and their windows
+		int32_t jx = newH - P.x;    if (jx < 0) jx += P.nH;
+		int32_t j1 = newH - P.oe1;  if (j1 < 0) j1 += P.nH;
+		int32_t j2 = newH - P.oe2;  if (j2 < 0) j2 += P.nH;
+		int32_t jg1 = newH - P.e1;  if (jg1 < 0) jg1 += P.nH;
+		int32_t jg2 = newH - P.e2;  if (jg2 < 0) jg2 += P.nH;
+		const int32_t r1 = new1 + 1 == P.n1 ? 0 : new1 + 1; // row of penalty s_new - e1 in the E1/F1 ring
+		const int32_t r2 = new2 + 1 == P.n2 ? 0 : new2 + 1;
+		const int32_t xlo = uni(sh.rng_lo[jx]), xhi = uni(sh.rng_hi[jx]);
+		const int32_t alo = uni(sh.rng_lo[j1]), ahi = uni(sh.rng_hi[j1]);
+		const int32_t blo = uni(sh.rng_lo[j2]), bhi = uni(sh.rng_hi[j2]);
+		const int32_t p1lo = uni(sh.rng_lo[jg1]), p1hi = uni(sh.rng_hi[jg1]);
+		const int32_t p2lo = uni(sh.rng_lo[jg2]), p2hi = uni(sh.rng_hi[jg2]);
+		const int32_t ilo = max(max(lo, xlo), max(max(alo, blo), max(p1lo, p2lo)) + 1);
+		const int32_t ihi = min(min(hi, xhi), min(min(ahi, bhi), min(p1hi, p2hi)) - 1);
+		const int32_t *sHx = M.H + jx * W, *sHa = M.H + j1 * W, *sHb = M.H + j2 * W;
+		const int32_t *sE1 = M.E1 + r1 * W, *sF1 = M.F1 + r1 * W, *sE2 = M.E2 + r2 * W, *sF2 = M.F2 + r2 * W;
+		int32_t *dH = M.H + newH * W, *dE1 = M.E1 + new1 * W, *dF1 = M.F1 + new1 * W, *dE2 = M.E2 + new2 * W, *dF2 = M.F2 + new2 * W;
+		const bool track_good = (((256 - (s_new & 255)) & 255) < P.nH);
+
+		if (tid == 0) {
+			sh.rng_lo[newH] = lo, sh.rng_hi[newH] = hi;
+			const int32_t nn = npar + 1 == 3 ? 0 : npar + 1; // flags of the NEXT penalty (see forward_pass)
+			sh.flags[nn][0] = sh.flags[nn][1] = sh.flags[nn][2] = sh.flags[nn][3] = 0;
+			if (TB) M.row_off[s_new - 1] = tb_used, M.row_lo[s_new - 1] = origin;
+			if (trace_band && s_new - 1 < A.dbg_cap) M.dbg[2 * (s_new - 1)] = lo, M.dbg[2 * (s_new - 1) + 1] = hi;
+		}
+
+		const int32_t g_first = lo >> 8, g_last = hi >> 8;
+		int32_t g = g_first + (wave - g_first % NW + NW) % NW; // this wave's first chunk of the window
+		for (; g <= g_last; g += NW) {
+			const int32_t cb = g * kChunk, c0 = cb + 4 * lane;
+			const bool inner = cb >= ilo && cb + kChunk - 1 <= ihi; // uniform: no window test needed anywhere
+			const int4 hx4 = *(const int4*)(sHx + c0), a4 = *(const int4*)(sHa + c0), b4 = *(const int4*)(sHb + c0);
+			const int4 e14 = *(const int4*)(sE1 + c0), f14 = *(const int4*)(sF1 + c0);
+			const int4 e24 = *(const int4*)(sE2 + c0), f24 = *(const int4*)(sF2 + c0);
+			// the neighbouring chunks' outer columns: lane 0 the column to the left (H for the o-lags, E), lane 63 the one to the right (H, F)
+			const int32_t ce = lane == 0 ? max(c0 - 1, 0) : c0 + 4; // column 0 is a pad
+			int32_t va = sHa[ce], vb = sHb[ce];
+			int32_t vg1 = (lane == 0 ? sE1 : sF1)[ce], vg2 = (lane == 0 ? sE2 : sF2)[ce];
+			int32_t hx[4] = {hx4.x, hx4.y, hx4.z, hx4.w};
+			int32_t o1[6] = {0, a4.x, a4.y, a4.z, a4.w, 0}, o2[6] = {0, b4.x, b4.y, b4.z, b4.w, 0};
+			int32_t e1s[4] = {e14.x, e14.y, e14.z, e14.w}, f1s[4] = {f14.x, f14.y, f14.z, f14.w};
+			int32_t e2s[4] = {e24.x, e24.y, e24.z, e24.w}, f2s[4] = {f24.x, f24.y, f24.z, f24.w};
+			if (!inner) { // reads outside a source window yield NEG_INF (what the reference's pads supply, miniwfa.c:96-99)
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					const int32_t c = c0 + i;
+					hx[i] = ((c >= xlo) & (c <= xhi)) ? hx[i] : kNegInf;
+					o1[i + 1] = ((c >= alo) & (c <= ahi)) ? o1[i + 1] : kNegInf;
+					o2[i + 1] = ((c >= blo) & (c <= bhi)) ? o2[i + 1] : kNegInf;
+					const bool in1 = (c >= p1lo) & (c <= p1hi), in2 = (c >= p2lo) & (c <= p2hi);
+					e1s[i] = in1 ? e1s[i] : kNegInf, f1s[i] = in1 ? f1s[i] : kNegInf;
+					e2s[i] = in2 ? e2s[i] : kNegInf, f2s[i] = in2 ? f2s[i] : kNegInf;
+				}
+				const int32_t cn = lane == 0 ? c0 - 1 : c0 + 4;
+				va = ((cn >= alo) & (cn <= ahi)) ? va : kNegInf;
+				vb = ((cn >= blo) & (cn <= bhi)) ? vb : kNegInf;
+				vg1 = ((cn >= p1lo) & (cn <= p1hi)) ? vg1 : kNegInf;
+				vg2 = ((cn >= p2lo) & (cn <= p2hi)) ? vg2 : kNegInf;
+			}
+			o1[0] = from_left(o1[4], va), o1[5] = from_right(o1[1], va);
+			o2[0] = from_left(o2[4], vb), o2[5] = from_right(o2[1], vb);
+			int32_t g1m[4], g1p[4], g2m[4], g2p[4]; // E of column c-1, F of column c+1
+			g1m[0] = from_left(e1s[3], vg1), g2m[0] = from_left(e2s[3], vg2);
+			g1p[3] = from_right(f1s[0], vg1), g2p[3] = from_right(f2s[0], vg2);
+#pragma unroll
+			for (int i = 1; i < 4; ++i) g1m[i] = e1s[i - 1], g2m[i] = e2s[i - 1];
+#pragma unroll
+			for (int i = 0; i < 3; ++i) g1p[i] = f1s[i + 1], g2p[i] = f2s[i + 1];
+
+			// ---- the recurrence, then the first 4-byte probe of the match extension, branch-free for all 4 columns
+			int32_t hv[4], nmat[4], ne1[4], nf1[4], ne2[4], nf2[4];
+			uint32_t tbw = 0, pend = 0, live = 0, fin = 0, gbits = 0;
+			auto columns = [&](auto inner_c) {
+				constexpr bool INNER = decltype(inner_c)::value;
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					const int32_t c = c0 + i, d = c - 1 - tl;
+					const uint32_t act = INNER ? 1u : (uint32_t)((c >= lo) & (c <= hi));
+					const Cell v = wf_cell<TB>(hx[i], o1[i], g1m[i], o2[i], g2m[i], o1[i + 2], g1p[i], o2[i + 2], g2p[i]);
+					ne1[i] = act ? v.e1 : kNegInf, nf1[i] = act ? v.f1 : kNegInf;
+					ne2[i] = act ? v.e2 : kNegInf, nf2[i] = act ? v.f2 : kNegInf;
+					const uint32_t inm = act & inm_bit(d, v.h, tl, ql);
+					if (track_good) // uniform
+						gbits |= (act & (inm | inm_bit(d, v.e1, tl, ql) | inm_bit(d, v.f1, tl, ql) | inm_bit(d, v.e2, tl, ql) | inm_bit(d, v.f2, tl, ql))) << i;
+					const int32_t j = inm ? v.h + 1 : 0, q = inm ? d + v.h + 1 : 0;
+					const int32_t room = inm ? min(tl - j, ql - q) : 0;
+					const uint32_t x = probe4g(M, j, q);
+					nmat[i] = min(min((int32_t)((uint32_t)(__builtin_ffs((int)x) - 1) >> 3), 4), room);
+					pend |= ((uint32_t)(x == 0) & (uint32_t)(room > 4)) << i;
+					hv[i] = v.h;
+					tbw |= v.tb << (8 * i);
+				}
+			};
+			if (inner) columns(std::true_type{});
+			else columns(std::false_type{});
+			// E/F of this penalty: final, store now
+			*(int4*)(dE1 + c0) = make_int4(ne1[0], ne1[1], ne1[2], ne1[3]);
+			*(int4*)(dF1 + c0) = make_int4(nf1[0], nf1[1], nf1[2], nf1[3]);
+			*(int4*)(dE2 + c0) = make_int4(ne2[0], ne2[1], ne2[2], ne2[3]);
+			*(int4*)(dF2 + c0) = make_int4(nf2[0], nf2[1], nf2[2], nf2[3]);
+			if ((uint32_t)(lo - cb) < (uint32_t)kChunk || (uint32_t)(hi - cb) < (uint32_t)kChunk) // this chunk holds an edge column
+#pragma unroll
+				for (int i = 0; i < 4; ++i) { // edge rule (miniwfa.c:325-326): H is the max of the five, so "any live" == "H live"
+					const uint32_t lv = (uint32_t)(hv[i] >= -1);
+					live |= (lv & (uint32_t)(c0 + i == lo)) | ((lv & (uint32_t)(c0 + i == hi)) << 1);
+				}
+			// a run of >= 4 matches continues: its lane walks it 8 bytes per trip for four trips, then the whole wave does
+			if (__ballot(pend != 0)) {
+				uint32_t open = 0;
+				while (pend) {
+					const int32_t ii = __builtin_ctz(pend);
+					const int32_t hh = pick4(ii, hv[0], hv[1], hv[2], hv[3]);
+					int32_t n = 4;
+					const int32_t j = hh + 1, q = c0 + ii - 1 - tl + j, rm = min(tl - j, ql - q);
+					for (int trip = 0; n < rm; ++trip) {
+						if (trip == 4) { open |= 1u << ii; break; }
+						const uint64_t x = ld8(M.ts + j + n) ^ ld8(M.qs + q + n);
+						if (x) { n += (int32_t)(__builtin_ctzll(x) >> 3); break; }
+						n += 8;
+					}
+					n = min(n, rm);
+#pragma unroll
+					for (int i = 0; i < 4; ++i) nmat[i] = ii == i ? n : nmat[i];
+					pend &= pend - 1;
+				}
+				for (unsigned long long owners = __ballot(open != 0); owners; owners &= owners - 1) {
+					const int32_t src = (int32_t)__builtin_ctzll(owners);
+					const int32_t c0s = cb + 4 * src;
+					for (uint32_t bits = (uint32_t)__builtin_amdgcn_readlane((int32_t)open, src); bits; bits &= bits - 1) {
+						const int32_t ii = (int32_t)__builtin_ctz(bits);
+						const int32_t hh = __builtin_amdgcn_readlane(pick4(ii, hv[0], hv[1], hv[2], hv[3]), src);
+						const int32_t j = hh + 1, q = c0s + ii - 1 - tl + j, rm = min(tl - j, ql - q);
+						const int32_t n = run_wave_g(M, j, q, rm, 36);
+#pragma unroll
+						for (int i = 0; i < 4; ++i) nmat[i] = (ii == i && lane == src) ? n : nmat[i];
+					}
+				}
+			}
+			// termination test of the extension sweep (miniwfa.c:405-409): only column ql+1 can hold the end cell
+			int32_t done_info = 0;
+#pragma unroll
+			for (int i = 0; i < 4; ++i) hv[i] += nmat[i];
+			if (cfin >= cb && cfin < cb + kChunk && cfin >= lo && cfin <= hi) { // uniform
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					const uint32_t f = (uint32_t)(c0 + i == cfin) & (uint32_t)(hv[i] == tl - 1) & inm_bit(ql - tl, hv[i] - nmat[i], tl, ql);
+					fin |= f;
+					done_info = f ? (nmat[i] == 0 ? (int32_t)((tbw >> (8 * i)) & 7u) : 0) : done_info;
+				}
+			}
+			*(int4*)(dH + c0) = make_int4(hv[0], hv[1], hv[2], hv[3]);
+			if (TB && c0 >= origin && c0 <= hi) *(uint32_t*)(M.tb + tb_used - origin + c0) = tbw;
+			if (track_good) {
+				unsigned long long *gword = M.good + (int64_t)newH * A.GW + (int64_t)g * 4;
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					const unsigned long long m = __ballot((gbits >> i) & 1u);
+					if (lane == 0) gword[i] = m;
+				}
+			}
+			if (__ballot(live & 1u)) sh.flags[npar][0] = 1;   // uniform branches; every lane stores the same word
+			if (__ballot(live & 2u)) sh.flags[npar][1] = 1;
+			if (__ballot(fin)) {
+				if (fin) sh.flags[npar][2] = 1, sh.flags[npar][3] = done_info;
+			}
+		}
+		// rows written now are read by other waves from the next penalty on: drain, then one barrier
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+
+		// ---- bookkeeping, identical on every thread
+		if (uni(sh.flags[npar][0])) wf_lo = lo;
+		if (uni(sh.flags[npar][1])) wf_hi = hi;
+		const int32_t done = uni(sh.flags[npar][2]), payload = uni(sh.flags[npar][3]);
+		s = s_new, curH = newH, cur1 = new1, cur2 = new2, par = npar;
+		if (TB) tb_used += row_bytes;
+		if ((s & 0xff) == 0) { // shrink (reference wf_stripe_shrink, miniwfa.c:144-171) on the interleaved good bits
+			if (tid == 0) sh.red[0] = 0x7fffffff, sh.red[1] = -1;
+			__syncthreads();
+			const int32_t gfirst = wf_lo >> 8, n_words = ((wf_hi >> 8) - gfirst + 1) * 4;
+			for (int32_t q = tid; q < n_words; q += T) {
+				const int32_t gg = gfirst + (q >> 2), kq = q & 3, base = gg * kChunk;
+				unsigned long long m = 0;
+				for (int32_t j = 0; j < P.nH; ++j)
+					if (sh.rng_lo[j] <= sh.rng_hi[j] && sh.rng_lo[j] <= base + kChunk - 1 && sh.rng_hi[j] >= base) m |= M.good[(int64_t)j * A.GW + (int64_t)gg * 4 + kq];
+				m &= lane_mask4(base, kq, wf_lo, wf_hi);
+				if (m) {
+					atomicMin(&sh.red[0], base + 4 * (int32_t)__builtin_ctzll(m) + kq);
+					atomicMax(&sh.red[1], base + 4 * (63 - (int32_t)__builtin_clzll(m)) + kq);
+				}
+			}
+			__syncthreads();
+			const int32_t glo = uni(sh.red[0]), ghi = uni(sh.red[1]);
+			if (ghi < 0) { R.status = ST_INTERNAL; break; }
+			wf_lo = glo, wf_hi = ghi;
+		}
+		cells += hi - lo + 1;
+		if ((A.max_iter > 0 && cells > A.max_iter) || (A.max_s > 0 && s > A.max_s)) { // miniwfa.c:422-425
+			R.status = ST_STOPPED;
+			break;
+		}
+		if (done) {
+			R.info = payload;
+			break;
+		}
+	}
+	R.s = s, R.cells = cells;
+	return R;
+}
+
+// STREAM: the four-columns-per-lane pass for everything but the low-memory mode (two kernels rather than one, so that
+// neither pays for the other's registers)
+template <int T, bool STREAM>
 __device__ void align_pair(const BatchArgs &A, Shared &sh, int32_t slot, int32_t pair)
 {
 	PairMem M;
@@ -332,7 +664,7 @@ __device__ void align_pair(const BatchArgs &A, Shared &sh, int32_t slot, int32_t
 	int64_t cells1 = 0;
 	PassResult R;
 	R.status = ST_OK, R.s = 0, R.info = 0, R.n_snap = 0, R.cells = 0;
-	if (A.step > 0 && A.want_cigar) { // low-memory first pass (reference mwf_wfa_exact, miniwfa.c:610-611)
+	if (!STREAM && A.step > 0 && A.want_cigar) { // low-memory first pass (reference mwf_wfa_exact, miniwfa.c:610-611)
 		PassResult R1 = forward_pass<T, false, true>(A, M, sh, 0, false);
 		cells1 = R1.cells;
 		status = R1.status;
@@ -345,15 +677,15 @@ __device__ void align_pair(const BatchArgs &A, Shared &sh, int32_t slot, int32_t
 		__syncthreads();
 	}
 	if (status == ST_OK) {
-		if (A.want_cigar) R = forward_pass<T, true, false>(A, M, sh, n_seg, trace);
-		else R = forward_pass<T, false, false>(A, M, sh, 0, trace);
+		if (STREAM) R = A.want_cigar ? stream_pass<T, true>(A, M, sh, 0, trace) : stream_pass<T, false>(A, M, sh, 0, trace);
+		else R = A.want_cigar ? forward_pass<T, true, false>(A, M, sh, n_seg, trace) : forward_pass<T, false, false>(A, M, sh, 0, trace);
 		status = R.status;
 	}
 	finish_pair(A, M, slot, pair, R, status, cells1);
 }
 
 // Persistent workgroups: each pulls pairs from a shared counter until the batch is drained.
-template <int T>
+template <int T, bool STREAM>
 __global__ __launch_bounds__(T) void wfa_batch_kernel(const BatchArgs A)
 {
 	__shared__ Shared sh;
@@ -364,39 +696,50 @@ __global__ __launch_bounds__(T) void wfa_batch_kernel(const BatchArgs A)
 		__syncthreads();
 		if (item >= A.n_pairs) break;
 		const int32_t pair = A.order ? A.order[item] : item;
-		align_pair<T>(A, sh, (int32_t)blockIdx.x, pair);
+		align_pair<T, STREAM>(A, sh, (int32_t)blockIdx.x, pair);
 	}
 }
 
 } // namespace
 
-int launch_batch(const BatchArgs &a, int grid, int block, void *stream)
+// the low-memory mode (and scalar_generic, for comparison) runs the one-column-per-lane kernel
+static bool wants_stream(const BatchArgs &a) { return !a.scalar_generic && !(a.step > 0 && a.want_cigar); }
+
+template <bool STREAM>
+static int launch_batch_as(const BatchArgs &a, int grid, int block, hipStream_t st)
 {
-	hipStream_t st = (hipStream_t)stream;
 	switch (block) {
-	case 64:   hipLaunchKernelGGL(wfa_batch_kernel<64>,   dim3(grid), dim3(64),   0, st, a); break;
-	case 128:  hipLaunchKernelGGL(wfa_batch_kernel<128>,  dim3(grid), dim3(128),  0, st, a); break;
-	case 256:  hipLaunchKernelGGL(wfa_batch_kernel<256>,  dim3(grid), dim3(256),  0, st, a); break;
-	case 512:  hipLaunchKernelGGL(wfa_batch_kernel<512>,  dim3(grid), dim3(512),  0, st, a); break;
-	case 1024: hipLaunchKernelGGL(wfa_batch_kernel<1024>, dim3(grid), dim3(1024), 0, st, a); break;
+	case 64:   hipLaunchKernelGGL((wfa_batch_kernel<64, STREAM>),   dim3(grid), dim3(64),   0, st, a); break;
+	case 128:  hipLaunchKernelGGL((wfa_batch_kernel<128, STREAM>),  dim3(grid), dim3(128),  0, st, a); break;
+	case 256:  hipLaunchKernelGGL((wfa_batch_kernel<256, STREAM>),  dim3(grid), dim3(256),  0, st, a); break;
+	case 512:  hipLaunchKernelGGL((wfa_batch_kernel<512, STREAM>),  dim3(grid), dim3(512),  0, st, a); break;
+	case 1024: hipLaunchKernelGGL((wfa_batch_kernel<1024, STREAM>), dim3(grid), dim3(1024), 0, st, a); break;
 	default: return -1;
 	}
 	return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-int batch_kernel_occupancy(int block)
+int launch_batch(const BatchArgs &a, int grid, int block, void *stream)
+{
+	return wants_stream(a) ? launch_batch_as<true>(a, grid, block, (hipStream_t)stream) : launch_batch_as<false>(a, grid, block, (hipStream_t)stream);
+}
+
+template <bool STREAM>
+static int occupancy_as(int block)
 {
 	int n = 0;
 	hipError_t e = hipErrorInvalidValue;
 	switch (block) {
-	case 64:   e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<64>, 64, 0); break;
-	case 128:  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<128>, 128, 0); break;
-	case 256:  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<256>, 256, 0); break;
-	case 512:  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<512>, 512, 0); break;
-	case 1024: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<1024>, 1024, 0); break;
+	case 64:   e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<64, STREAM>, 64, 0); break;
+	case 128:  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<128, STREAM>, 128, 0); break;
+	case 256:  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<256, STREAM>, 256, 0); break;
+	case 512:  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<512, STREAM>, 512, 0); break;
+	case 1024: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<1024, STREAM>, 1024, 0); break;
 	default: break;
 	}
 	return e == hipSuccess ? n : 0;
 }
+
+int batch_kernel_occupancy(int block, bool stream_pass) { return stream_pass ? occupancy_as<true>(block) : occupancy_as<false>(block); }
 
 } // namespace mwf

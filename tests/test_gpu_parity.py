@@ -154,12 +154,14 @@ def test_mixed_batch_runs_in_size_classes(oracle):
     eng.close()
 
 
-@pytest.mark.parametrize("block", [64, 128, 256, 512, 1024])
-def test_every_block_size_gives_identical_results(block, oracle):
-    """Generic kernel (ring in HBM), every workgroup size."""
+@pytest.mark.parametrize("block,scalar", [(64, 0), (128, 0), (256, 0), (512, 0), (1024, 0), (256, 1)])
+def test_every_block_size_gives_identical_results(block, scalar, oracle):
+    """Generic kernel (ring in HBM), every workgroup size: the four-columns-per-lane pass, and (scalar=1) the
+    one-column-per-lane pass that otherwise only serves the low-memory mode."""
     eng = mw.Engine(0)
     eng.set("force_kind", 0)
     eng.set("block", block)
+    eng.set("scalar_generic", scalar)
     pairs = [synth_pair(82000 + i, 1500, 0.08) for i in range(12)]
     for o in (make_opt(), make_opt(flag=1), make_opt(flag=1, step=50)):
         b = eng.upload(PackedBatch(pairs))
