@@ -125,7 +125,7 @@ void mwf_gpu_get_stats(const mwf_gpu_t *g, mwf_gpu_stats_t *st);
  * wavefront slice the core pass opened for `pair`; returns the number of penalties written (<= cap). */
 int32_t mwf_gpu_debug_band(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt, int32_t pair, int32_t *lohi, int32_t cap);
 
-/* Tunables (call before align): name in {"block", "slots_per_cu", "coop_min_len", "tb_budget_mb", "force_kind", "coop_tb_cap_mb", "band_pack", "coop_spin_limit", "scalar_generic"}. */
+/* Tunables (call before align): name in {"block", "slots_per_cu", "coop_min_len", "tb_budget_mb", "force_kind", "coop_tb_cap_mb", "band_pack", "coop_spin_limit", "scalar_generic", "lds_e2"}. */
 int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value);
 
 #ifdef __cplusplus

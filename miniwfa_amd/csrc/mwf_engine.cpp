@@ -53,6 +53,7 @@ struct mwf_gpu_s {
 	int64_t tb_budget_mb = 0;   // 0: automatic
 	int force_kind = -1;
 	int band_pack = -1;        // int16-packed E/F registers in the band kernel: 0 never, otherwise whenever the value ranges allow
+	int lds_e2 = 1;            // generic kernel: keep E2/F2 in LDS where that applies (0: never)
 	int scalar_generic = 0;    // 1: the generic kernel's original one-column-per-lane pass everywhere (comparison / fallback)
 	int64_t coop_spin_limit = 1 << 23; // polls (about a microsecond each) before the whole-device kernel gives up on a workgroup
 	int64_t coop_tb_cap = (int64_t)96 << 30; // whole-device traceback arena: covers the 5 Mb pairs; doubles on overflow
@@ -219,11 +220,15 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	choose_kernel(g, opt, P, max_len, max_bound, max_seq_lds, max_tl, want_kind >= 0 ? want_kind : g->force_kind, pl);
 	// `slots` is an upper bound from the caller (retries ask for fewer, larger slots); the chosen kernel's own residency
 	// bounds it as well
-	int per_cu;
+	int per_cu, lds_e2_cols = 0;
 	if (pl.kind == 2) {
 		pl.block = pl.band.block;
 		per_cu = g->slots_per_cu > 0 ? g->slots_per_cu : band_kernel_occupancy(P, pl.band, pl.cigar);
-	} else per_cu = g->slots_per_cu > 0 ? g->slots_per_cu : batch_kernel_occupancy(pl.block, !g->scalar_generic && !pl.low_mem);
+	} else {
+		// wide windows (the 512-thread choice above), default gap extension: E2/F2 stay in LDS while the window fits 16 k columns
+		if (g->lds_e2 && pl.block == 512 && g->block == 0 && P.e2 == 1 && !g->scalar_generic && !pl.low_mem) lds_e2_cols = 16384;
+		per_cu = g->slots_per_cu > 0 ? g->slots_per_cu : batch_kernel_occupancy(pl.block, !g->scalar_generic && !pl.low_mem, lds_e2_cols);
+	}
 	slots = std::max(1, std::min(slots, g->n_cu * std::max(1, per_cu)));
 	if (getenv("MWF_DEBUG"))
 		fprintf(stderr, "[libmwf_hip] kernel kind %d: block %d packed %d lds %d B, %d workgroup(s) per CU, %d slots\n", pl.kind, pl.block,
@@ -278,6 +283,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	a.order = d_order, a.n_pairs = n_items;
 	a.queue = (int32_t*)g->queue.p;
 	a.scalar_generic = g->scalar_generic;
+	a.lds_e2_cols = lds_e2_cols;
 	a.pen = P;
 	a.want_cigar = pl.cigar ? 1 : 0;
 	a.step = pl.low_mem ? opt.step : 0;
@@ -501,6 +507,7 @@ int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value)
 	else if (!strcmp(name, "tb_budget_mb")) g->tb_budget_mb = value;
 	else if (!strcmp(name, "force_kind")) g->force_kind = (int)value;
 	else if (!strcmp(name, "band_pack")) g->band_pack = (int)value;
+	else if (!strcmp(name, "lds_e2")) g->lds_e2 = value != 0;
 	else if (!strcmp(name, "scalar_generic")) g->scalar_generic = value != 0;
 	else if (!strcmp(name, "coop_spin_limit")) g->coop_spin_limit = std::max<int64_t>(0, std::min<int64_t>(value, 0x7fffffff));
 	else if (!strcmp(name, "coop_tb_cap_mb")) g->coop_tb_cap = std::max<int64_t>(1, value) << 20;

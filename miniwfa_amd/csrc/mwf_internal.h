@@ -86,6 +86,7 @@ struct BatchArgs {
 	int32_t dbg_cap;
 	// ---- whole-device (cooperative) kernel only: cross-workgroup state, all accessed at agent scope
 	int32_t coop_pair;         // the one pair this launch aligns
+	int32_t lds_e2_cols;       // generic kernel, 512 threads, e2 == 1: columns of E2/F2 kept in LDS (power of two; 0 = all in HBM)
 	int32_t scalar_generic;    // generic kernel: 1 = one column per lane (forward_pass) also where the four-columns-per-lane pass applies
 	uint32_t coop_spin_limit;  // polls after which a wait for another workgroup gives up (ST_INTERNAL)
 	int32_t coop_pass;         // 0: plain pass; 1: pass whose traceback feeds the checkpoint walk; 2: second pass (uses seg)
@@ -97,7 +98,7 @@ struct BatchArgs {
 
 // launch wrappers implemented in mwf_kernels.hip (generic kernel: any penalties, any band, low-memory mode)
 int launch_batch(const BatchArgs &a, int grid, int block, void *stream);
-int  batch_kernel_occupancy(int block, bool stream_pass);   // resident workgroups per CU for that block size
+int  batch_kernel_occupancy(int block, bool stream_pass, int lds_e2_cols);   // resident workgroups per CU for that block size
 
 // launch wrappers implemented in mwf_band.hip (band kernel: E/F wavefronts live in registers)
 struct BandGeom {

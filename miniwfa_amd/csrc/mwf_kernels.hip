@@ -384,11 +384,22 @@ __device__ __forceinline__ int32_t run_wave_g(const PairMem &M, int32_t j, int32
 	return min(n, room);
 }
 
-template <int T, bool TB>
+// LDS2 (gap-extension penalty e2 == 1 only): E2/F2 are written at one penalty and read at the next and never again, so
+// while the window fits A.lds_e2_cols columns they live in LDS, updated in place (column c -> slot c mod cols; a chunk's
+// slots are only ever touched by the wave that owns the chunk), and never see HBM: 32 instead of 48 bytes per cell.
+// What a neighbouring wave needs of them — the chunk's first F2 and last E2 — goes through a small table with one copy
+// per penalty parity.  When the window outgrows the LDS span the pass carries on in the HBM rows (and comes back).
+extern __shared__ __attribute__((aligned(16))) int32_t lds_e2f2[];
+
+template <int T, bool TB, bool LDS2>
 __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &sh, int32_t n_seg, bool trace_band)
 {
 	constexpr int NW = T / 64;
 	constexpr int32_t kChunk = 256;
+	__shared__ int32_t e2_edge[2][64][2]; // [penalty parity][chunk mod 64]{first column's F2, last column's E2}
+	const int32_t cap = LDS2 ? A.lds_e2_cols : 0, cap_mask = cap - 1;
+	int32_t *const lE2 = lds_e2f2, *const lF2 = lds_e2f2 + cap;
+	bool prev_in_lds = false; // where the previous penalty left its E2/F2
 	const Penalty &P = A.pen;
 	const int32_t tl = M.tl, ql = M.ql, cmax = tl + ql + 1;
 	const int32_t tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
@@ -459,6 +470,9 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 		const int32_t *sE1 = M.E1 + r1 * W, *sF1 = M.F1 + r1 * W, *sE2 = M.E2 + r2 * W, *sF2 = M.F2 + r2 * W;
 		int32_t *dH = M.H + newH * W, *dE1 = M.E1 + new1 * W, *dF1 = M.F1 + new1 * W, *dE2 = M.E2 + new2 * W, *dF2 = M.F2 + new2 * W;
 		const bool track_good = (((256 - (s_new & 255)) & 255) < P.nH);
+		// every chunk the window touches is stored whole: those columns must map to distinct LDS slots (and at most 64 chunks)
+		const bool cur_in_lds = LDS2 && ((hi | 255) - (lo & ~255) + 1) <= cap;
+		const int32_t epar = s_new & 1;
 
 		if (tid == 0) {
 			sh.rng_lo[newH] = lo, sh.rng_hi[newH] = hi;
@@ -475,11 +489,15 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 			const bool inner = cb >= ilo && cb + kChunk - 1 <= ihi; // uniform: no window test needed anywhere
 			const int4 hx4 = *(const int4*)(sHx + c0), a4 = *(const int4*)(sHa + c0), b4 = *(const int4*)(sHb + c0);
 			const int4 e14 = *(const int4*)(sE1 + c0), f14 = *(const int4*)(sF1 + c0);
-			const int4 e24 = *(const int4*)(sE2 + c0), f24 = *(const int4*)(sF2 + c0);
+			int4 e24, f24;
+			if (LDS2 && prev_in_lds) e24 = *(const int4*)(lE2 + (c0 & cap_mask)), f24 = *(const int4*)(lF2 + (c0 & cap_mask));
+			else e24 = *(const int4*)(sE2 + c0), f24 = *(const int4*)(sF2 + c0);
 			// the neighbouring chunks' outer columns: lane 0 the column to the left (H for the o-lags, E), lane 63 the one to the right (H, F)
 			const int32_t ce = lane == 0 ? max(c0 - 1, 0) : c0 + 4; // column 0 is a pad
 			int32_t va = sHa[ce], vb = sHb[ce];
-			int32_t vg1 = (lane == 0 ? sE1 : sF1)[ce], vg2 = (lane == 0 ? sE2 : sF2)[ce];
+			int32_t vg1 = (lane == 0 ? sE1 : sF1)[ce], vg2;
+			if (LDS2 && prev_in_lds) vg2 = lane == 0 ? e2_edge[epar ^ 1][(g - 1) & 63][1] : e2_edge[epar ^ 1][(g + 1) & 63][0];
+			else vg2 = (lane == 0 ? sE2 : sF2)[ce];
 			int32_t hx[4] = {hx4.x, hx4.y, hx4.z, hx4.w};
 			int32_t o1[6] = {0, a4.x, a4.y, a4.z, a4.w, 0}, o2[6] = {0, b4.x, b4.y, b4.z, b4.w, 0};
 			int32_t e1s[4] = {e14.x, e14.y, e14.z, e14.w}, f1s[4] = {f14.x, f14.y, f14.z, f14.w};
@@ -540,8 +558,15 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 			// E/F of this penalty: final, store now
 			*(int4*)(dE1 + c0) = make_int4(ne1[0], ne1[1], ne1[2], ne1[3]);
 			*(int4*)(dF1 + c0) = make_int4(nf1[0], nf1[1], nf1[2], nf1[3]);
-			*(int4*)(dE2 + c0) = make_int4(ne2[0], ne2[1], ne2[2], ne2[3]);
-			*(int4*)(dF2 + c0) = make_int4(nf2[0], nf2[1], nf2[2], nf2[3]);
+			if (LDS2 && cur_in_lds) {
+				*(int4*)(lE2 + (c0 & cap_mask)) = make_int4(ne2[0], ne2[1], ne2[2], ne2[3]);
+				*(int4*)(lF2 + (c0 & cap_mask)) = make_int4(nf2[0], nf2[1], nf2[2], nf2[3]);
+				if (lane == 0) e2_edge[epar][g & 63][0] = nf2[0];
+				if (lane == 63) e2_edge[epar][g & 63][1] = ne2[3];
+			} else {
+				*(int4*)(dE2 + c0) = make_int4(ne2[0], ne2[1], ne2[2], ne2[3]);
+				*(int4*)(dF2 + c0) = make_int4(nf2[0], nf2[1], nf2[2], nf2[3]);
+			}
 			if ((uint32_t)(lo - cb) < (uint32_t)kChunk || (uint32_t)(hi - cb) < (uint32_t)kChunk) // this chunk holds an edge column
 #pragma unroll
 				for (int i = 0; i < 4; ++i) { // edge rule (miniwfa.c:325-326): H is the max of the five, so "any live" == "H live"
@@ -617,6 +642,7 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 		if (uni(sh.flags[npar][1])) wf_hi = hi;
 		const int32_t done = uni(sh.flags[npar][2]), payload = uni(sh.flags[npar][3]);
 		s = s_new, curH = newH, cur1 = new1, cur2 = new2, par = npar;
+		prev_in_lds = cur_in_lds;
 		if (TB) tb_used += row_bytes;
 		if ((s & 0xff) == 0) { // shrink (reference wf_stripe_shrink, miniwfa.c:144-171) on the interleaved good bits
 			if (tid == 0) sh.red[0] = 0x7fffffff, sh.red[1] = -1;
@@ -654,7 +680,7 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 
 // STREAM: the four-columns-per-lane pass for everything but the low-memory mode (two kernels rather than one, so that
 // neither pays for the other's registers)
-template <int T, bool STREAM>
+template <int T, bool STREAM, bool LDS2>
 __device__ void align_pair(const BatchArgs &A, Shared &sh, int32_t slot, int32_t pair)
 {
 	PairMem M;
@@ -677,7 +703,7 @@ __device__ void align_pair(const BatchArgs &A, Shared &sh, int32_t slot, int32_t
 		__syncthreads();
 	}
 	if (status == ST_OK) {
-		if (STREAM) R = A.want_cigar ? stream_pass<T, true>(A, M, sh, 0, trace) : stream_pass<T, false>(A, M, sh, 0, trace);
+		if (STREAM) R = A.want_cigar ? stream_pass<T, true, LDS2>(A, M, sh, 0, trace) : stream_pass<T, false, LDS2>(A, M, sh, 0, trace);
 		else R = A.want_cigar ? forward_pass<T, true, false>(A, M, sh, n_seg, trace) : forward_pass<T, false, false>(A, M, sh, 0, trace);
 		status = R.status;
 	}
@@ -685,7 +711,7 @@ __device__ void align_pair(const BatchArgs &A, Shared &sh, int32_t slot, int32_t
 }
 
 // Persistent workgroups: each pulls pairs from a shared counter until the batch is drained.
-template <int T, bool STREAM>
+template <int T, bool STREAM, bool LDS2 = false>
 __global__ __launch_bounds__(T) void wfa_batch_kernel(const BatchArgs A)
 {
 	__shared__ Shared sh;
@@ -696,7 +722,7 @@ __global__ __launch_bounds__(T) void wfa_batch_kernel(const BatchArgs A)
 		__syncthreads();
 		if (item >= A.n_pairs) break;
 		const int32_t pair = A.order ? A.order[item] : item;
-		align_pair<T, STREAM>(A, sh, (int32_t)blockIdx.x, pair);
+		align_pair<T, STREAM, LDS2>(A, sh, (int32_t)blockIdx.x, pair);
 	}
 }
 
@@ -719,8 +745,22 @@ static int launch_batch_as(const BatchArgs &a, int grid, int block, hipStream_t 
 	return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// E2/F2 in LDS: one 512-thread workgroup per CU with 2 x lds_e2_cols ints of dynamic LDS
+static bool wants_lds2(const BatchArgs &a, int block) { return wants_stream(a) && a.lds_e2_cols > 0 && block == 512 && a.pen.e2 == 1; }
+
 int launch_batch(const BatchArgs &a, int grid, int block, void *stream)
 {
+	if (wants_lds2(a, block)) {
+		const int lds = a.lds_e2_cols * 2 * 4;
+		static bool attr_set = false;
+		if (!attr_set) {
+			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wfa_batch_kernel<512, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+			(void)hipGetLastError();
+			attr_set = true;
+		}
+		hipLaunchKernelGGL((wfa_batch_kernel<512, true, true>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+		return hipGetLastError() == hipSuccess ? 0 : -2;
+	}
 	return wants_stream(a) ? launch_batch_as<true>(a, grid, block, (hipStream_t)stream) : launch_batch_as<false>(a, grid, block, (hipStream_t)stream);
 }
 
@@ -740,6 +780,14 @@ static int occupancy_as(int block)
 	return e == hipSuccess ? n : 0;
 }
 
-int batch_kernel_occupancy(int block, bool stream_pass) { return stream_pass ? occupancy_as<true>(block) : occupancy_as<false>(block); }
+int batch_kernel_occupancy(int block, bool stream_pass, int lds_e2_cols)
+{
+	if (stream_pass && lds_e2_cols > 0 && block == 512) {
+		int n = 0;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<512, true, true>, 512, (size_t)lds_e2_cols * 8) != hipSuccess) n = 0;
+		return n;
+	}
+	return stream_pass ? occupancy_as<true>(block) : occupancy_as<false>(block);
+}
 
 } // namespace mwf

@@ -127,6 +127,32 @@ def test_ragged_batch_against_oracle(engine, oracle):
         b.free()
 
 
+def test_generic_kernel_wide_windows(oracle):
+    """Generic kernel on windows wider than any register span, with E2/F2 in LDS: the window of the second pair passes
+    16384 columns, so the pass moves E2/F2 from LDS to the HBM rows on the way; and the same with LDS switched off."""
+    pairs = [synth_pair(89992, 9000, 0.1), synth_pair(89993, 20000, 0.12)]
+    expect = {flag: [oracle.align(t, q, make_opt(flag=flag)) for t, q in pairs] for flag in (0, 1)}
+    assert max(h - l + 1 for l, h in oracle.band_trace(*pairs[1], make_opt())) > 16384
+    for lds in (1, 0):
+        eng = mw.Engine(0)
+        eng.set("force_kind", 0)
+        eng.set("lds_e2", lds)
+        for flag in (0, 1):
+            b = eng.upload(PackedBatch(pairs))
+            b.align(mw.opt_init(flag=flag))
+            st = eng.stats()
+            assert (st.kernel_kind, st.block) == (0, 512)
+            s, it, nc = b.results()
+            for i in range(len(pairs)):
+                es, eit, ecig = expect[flag][i]
+                assert (int(s[i]), int(it[i])) == (es, eit), (lds, flag, i)
+                if ecig is not None:
+                    assert b.cigar(i, int(nc[i])).tolist() == ecig, (lds, flag, i)
+            b.free()
+        assert eng.stats().n_retries == 0
+        eng.close()
+
+
 def test_mixed_batch_runs_in_size_classes(oracle):
     """One batch with three very different pair sizes (what mwf_wfa_chain's gap fills look like): every size class goes
     to its own kernel in its own launch, results identical to the oracle, in the caller's order."""
