@@ -226,7 +226,10 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 		per_cu = g->slots_per_cu > 0 ? g->slots_per_cu : band_kernel_occupancy(P, pl.band, pl.cigar);
 	} else {
 		// wide windows (the 512-thread choice above), default gap extension: E2/F2 stay in LDS while the window fits 16 k columns
-		if (g->lds_e2 && pl.block == 512 && g->block == 0 && P.e2 == 1 && !g->scalar_generic && !pl.low_mem) lds_e2_cols = 16384;
+		if (g->lds_e2 && pl.block == 512 && g->block == 0 && P.e2 == 1 && !g->scalar_generic && !pl.low_mem) {
+			lds_e2_cols = 16384;
+			pl.block = 768; // one workgroup per CU either way (128 KB of LDS): twelve waves fit its 168-VGPR budget, 490 ms against 519 ms with eight
+		}
 		per_cu = g->slots_per_cu > 0 ? g->slots_per_cu : batch_kernel_occupancy(pl.block, !g->scalar_generic && !pl.low_mem, lds_e2_cols);
 	}
 	slots = std::max(1, std::min(slots, g->n_cu * std::max(1, per_cu)));

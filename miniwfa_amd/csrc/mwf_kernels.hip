@@ -484,18 +484,28 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 
 		const int32_t g_first = lo >> 8, g_last = hi >> 8;
 		int32_t g = g_first + (wave - g_first % NW + NW) % NW; // this wave's first chunk of the window
-		for (; g <= g_last; g += NW) {
+		// what a chunk reads from HBM; the next chunk's loads are issued before the current chunk's arithmetic
+		struct ChunkIn { int4 hx4, a4, b4, e14, f14; int32_t va, vb, vg1; };
+		auto issue = [&](int32_t gq, ChunkIn &x) {
+			const int32_t c0q = gq * kChunk + 4 * lane;
+			x.hx4 = *(const int4*)(sHx + c0q), x.a4 = *(const int4*)(sHa + c0q), x.b4 = *(const int4*)(sHb + c0q);
+			x.e14 = *(const int4*)(sE1 + c0q), x.f14 = *(const int4*)(sF1 + c0q);
+			// the neighbouring chunks' outer columns: lane 0 the column to the left (H for the o-lags, E), lane 63 the one to the right (H, F)
+			const int32_t ceq = lane == 0 ? max(c0q - 1, 0) : c0q + 4; // column 0 is a pad
+			x.va = sHa[ceq], x.vb = sHb[ceq], x.vg1 = (lane == 0 ? sE1 : sF1)[ceq];
+		};
+		ChunkIn in_cur, in_next;
+		if (g <= g_last) issue(g, in_cur);
+		for (; g <= g_last; g += NW, in_cur = in_next) {
+			if (g + NW <= g_last) issue(g + NW, in_next);
 			const int32_t cb = g * kChunk, c0 = cb + 4 * lane;
 			const bool inner = cb >= ilo && cb + kChunk - 1 <= ihi; // uniform: no window test needed anywhere
-			const int4 hx4 = *(const int4*)(sHx + c0), a4 = *(const int4*)(sHa + c0), b4 = *(const int4*)(sHb + c0);
-			const int4 e14 = *(const int4*)(sE1 + c0), f14 = *(const int4*)(sF1 + c0);
+			const int4 hx4 = in_cur.hx4, a4 = in_cur.a4, b4 = in_cur.b4, e14 = in_cur.e14, f14 = in_cur.f14;
 			int4 e24, f24;
 			if (LDS2 && prev_in_lds) e24 = *(const int4*)(lE2 + (c0 & cap_mask)), f24 = *(const int4*)(lF2 + (c0 & cap_mask));
 			else e24 = *(const int4*)(sE2 + c0), f24 = *(const int4*)(sF2 + c0);
-			// the neighbouring chunks' outer columns: lane 0 the column to the left (H for the o-lags, E), lane 63 the one to the right (H, F)
-			const int32_t ce = lane == 0 ? max(c0 - 1, 0) : c0 + 4; // column 0 is a pad
-			int32_t va = sHa[ce], vb = sHb[ce];
-			int32_t vg1 = (lane == 0 ? sE1 : sF1)[ce], vg2;
+			const int32_t ce = lane == 0 ? max(c0 - 1, 0) : c0 + 4;
+			int32_t va = in_cur.va, vb = in_cur.vb, vg1 = in_cur.vg1, vg2;
 			if (LDS2 && prev_in_lds) vg2 = lane == 0 ? e2_edge[epar ^ 1][(g - 1) & 63][1] : e2_edge[epar ^ 1][(g + 1) & 63][0];
 			else vg2 = (lane == 0 ? sE2 : sF2)[ce];
 			int32_t hx[4] = {hx4.x, hx4.y, hx4.z, hx4.w};
@@ -746,7 +756,7 @@ static int launch_batch_as(const BatchArgs &a, int grid, int block, hipStream_t 
 }
 
 // E2/F2 in LDS: one 512-thread workgroup per CU with 2 x lds_e2_cols ints of dynamic LDS
-static bool wants_lds2(const BatchArgs &a, int block) { return wants_stream(a) && a.lds_e2_cols > 0 && block == 512 && a.pen.e2 == 1; }
+static bool wants_lds2(const BatchArgs &a, int block) { return wants_stream(a) && a.lds_e2_cols > 0 && (block == 512 || block == 768) && a.pen.e2 == 1; }
 
 int launch_batch(const BatchArgs &a, int grid, int block, void *stream)
 {
@@ -758,7 +768,15 @@ int launch_batch(const BatchArgs &a, int grid, int block, void *stream)
 			(void)hipGetLastError();
 			attr_set = true;
 		}
-		hipLaunchKernelGGL((wfa_batch_kernel<512, true, true>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+		if (block == 768) {
+			static bool attr768 = false;
+			if (!attr768) {
+				(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wfa_batch_kernel<768, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+				(void)hipGetLastError();
+				attr768 = true;
+			}
+			hipLaunchKernelGGL((wfa_batch_kernel<768, true, true>), dim3(grid), dim3(768), lds, (hipStream_t)stream, a);
+		} else hipLaunchKernelGGL((wfa_batch_kernel<512, true, true>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
 		return hipGetLastError() == hipSuccess ? 0 : -2;
 	}
 	return wants_stream(a) ? launch_batch_as<true>(a, grid, block, (hipStream_t)stream) : launch_batch_as<false>(a, grid, block, (hipStream_t)stream);
@@ -782,10 +800,11 @@ static int occupancy_as(int block)
 
 int batch_kernel_occupancy(int block, bool stream_pass, int lds_e2_cols)
 {
-	if (stream_pass && lds_e2_cols > 0 && block == 512) {
+	if (stream_pass && lds_e2_cols > 0 && (block == 512 || block == 768)) {
 		int n = 0;
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<512, true, true>, 512, (size_t)lds_e2_cols * 8) != hipSuccess) n = 0;
-		return n;
+		hipError_t e = block == 768 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<768, true, true>, 768, (size_t)lds_e2_cols * 8)
+		                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<512, true, true>, 512, (size_t)lds_e2_cols * 8);
+		return e == hipSuccess ? n : 0;
 	}
 	return stream_pass ? occupancy_as<true>(block) : occupancy_as<false>(block);
 }

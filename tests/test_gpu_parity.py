@@ -141,7 +141,7 @@ def test_generic_kernel_wide_windows(oracle):
             b = eng.upload(PackedBatch(pairs))
             b.align(mw.opt_init(flag=flag))
             st = eng.stats()
-            assert (st.kernel_kind, st.block) == (0, 512)
+            assert (st.kernel_kind, st.block) == (0, 768 if lds else 512)
             s, it, nc = b.results()
             for i in range(len(pairs)):
                 es, eit, ecig = expect[flag][i]
