@@ -77,7 +77,7 @@ struct mwf_gpu_batch_s {
 	int64_t max_tl = 0;        // longest target (offsets are target indices: bounds what a 16-bit offset must hold)
 	int32_t *d_order = nullptr;
 	std::vector<int32_t> h_order;   // what d_order holds: pair ids, grouped by size class, longest first inside a class
-	std::vector<int8_t> h_class;    // size class of every pair in the last align (0 generic, 1 wide band, 2 narrow band)
+	std::vector<int8_t> h_class;    // size class of every pair in the last align (0 generic, then band kernels: 1 wide, 2 small, 3 tiny)
 	// outputs
 	int32_t *d_s = nullptr, *d_ncig = nullptr, *d_status = nullptr, *d_dbg4 = nullptr;
 	int64_t *d_iter = nullptr, *d_cigoff = nullptr, *d_cells1 = nullptr;
@@ -163,6 +163,9 @@ int64_t penalty_bound(const mwf_opt_t &o, int64_t tl, int64_t ql, bool honour_ma
 	return b;
 }
 
+// widest window the 128- and 256-thread packed band variants are chosen for: (waves x 3 chunks - 1) x 256 - 64 columns
+constexpr int64_t kBandTinyWindow = (2 * 3 - 1) * 256 - 64, kBandSmallWindow = (4 * 3 - 1) * 256 - 64;
+
 struct Plan {
 	int kind = 0;              // 0: generic kernel, 2: band kernel
 	BandGeom band{0, 0, 0, 0};
@@ -177,7 +180,7 @@ struct Plan {
 // Which kernel serves a set of pairs.  The band kernel keeps E/F in registers and therefore only holds windows up to
 // its span; it has no low-memory first pass.  kind: -1 automatic, 0 generic, 2 band.
 void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, int64_t max_len, int64_t max_bound,
-                   int64_t max_seq_lds, int64_t max_tl, int want_kind, Plan &pl)
+                   int64_t max_seq_lds, int64_t max_tl, int want_kind, Plan &pl, int geom_block = 0)
 {
 	pl.kind = 0;
 	const bool low_mem = (opt.flag & MWF_F_CIGAR) && opt.step > 0;
@@ -185,29 +188,39 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 	const int64_t max_window = std::min<int64_t>(max_len + 1, 2 * max_bound + 3);
 	BandGeom bg;
 	bg.packed = 0;
-	bg.block = max_window <= 8 * 256 - 256 - 64 ? 256 : 768;
-	// Wide windows: 512 threads x 3 chunks with the E/F registers packed as int16 pairs fits TWO workgroups per CU, which
-	// overlaps one pair's barrier phase with the other's compute.  Valid when no offset (a target index, plus at most one
-	// per penalty for offsets that ran past the matrix) and no penalty count can reach 32767.
+	// Packed variants (E/F registers as int16 pairs): valid when no offset (a target index, plus at most one per penalty for
+	// offsets that ran past the matrix) and no penalty count can reach 32767.  They halve the state registers, which is
+	// what lets several workgroups share a CU — one pair's barrier phase then overlaps another's compute:
+	//   window <= 1216: 128 threads x 3 chunks, eight pairs per CU (six with traceback)
+	//   window <= 2752: 256 threads x 3 chunks, four (three)
+	//   wider:          512 x 3, two per CU, score-only; with traceback 768 x 2 packed, one per CU (the 512-thread variant
+	//                   needs more than its 128 VGPRs then: 52.9 ms against 60.3 ms unpacked on the 1024 x 10 kb batch)
+	// Unpacked (long targets): 256 x 2 up to 1728 columns, 768 x 2 beyond.
+	// (measured alternatives on the 1024 x 10 kb batch: 1024 threads x 2 chunks spills and runs 50 ms, 512 x 3 unpacked 49 ms, 768 x 2 42 ms)
 	const bool range_ok = max_tl + max_bound < 32767 && g->band_pack != 0;
 	const bool cigar = (opt.flag & MWF_F_CIGAR) != 0;
-	// with traceback the 512-thread variant needs more than its 128 VGPRs and spills; there 768 x 2 packed (one workgroup per
-	// CU, 168 VGPRs, 48 B of scratch instead of 124 B unpacked) is the fastest: 52.9 ms against 60.3 ms unpacked
-	if (bg.block == 768 && range_ok && !cigar) bg.block = 512, bg.packed = 1;
-	if (bg.block == 768 && range_ok && cigar) bg.packed = 1;
-	// (measured alternatives on the 1024 x 10 kb batch: 1024 threads x 2 chunks spills and runs 50 ms, 512 x 3 runs 49 ms, 768 x 2 42 ms)
-	if (g->block == 256 || g->block == 768) bg.block = g->block, bg.packed = (g->block == 768 && range_ok && cigar);
+	if (range_ok) {
+		bg.packed = 1;
+		bg.block = max_window <= kBandTinyWindow ? 128 : max_window <= kBandSmallWindow ? 256 : cigar ? 768 : 512;
+	} else bg.block = max_window <= 8 * 256 - 256 - 64 ? 256 : 768;
+	// forced geometry (tests, tuning): 256 and 768 mean the unpacked variants unless packing is asked for as well
+	if (g->block == 128 && range_ok) bg.block = 128, bg.packed = 1;
+	if (g->block == 256) bg.block = 256, bg.packed = range_ok && g->band_pack == 1;
+	if (g->block == 768) bg.block = 768, bg.packed = range_ok && cigar;
 	if (g->block == 512 && range_ok) bg.block = 512, bg.packed = 1;
-	bg.span = bg.block == 512 ? 8 * 3 * 256 : bg.block / 64 * 2 * 256;
+	// geometry picked by the caller for a size class (pairs short enough that their window should stay inside a small span)
+	if (g->block == 0 && geom_block == 128 && range_ok) bg.block = 128, bg.packed = 1;
+	if (g->block == 0 && geom_block == 256) bg.block = 256, bg.packed = range_ok;
+	bg.span = bg.block / 64 * (bg.packed && bg.block != 768 ? 3 : 2) * 256;
 	if (want_kind != 2 && max_len + 1 > 4 * (int64_t)bg.span) return; // windows will mostly outgrow the span: go generic at once
-	const int64_t lds_cap = bg.block >= 768 ? 140 * 1024 : bg.block == 512 ? 70 * 1024 : 36 * 1024;
+	const int64_t lds_cap = bg.block >= 768 ? 140 * 1024 : bg.block == 512 ? 70 * 1024 : bg.block == 256 ? 36 * 1024 : 18 * 1024;
 	bg.lds_bytes = max_seq_lds <= lds_cap ? (int)((max_seq_lds + 15) / 16 * 16) : 0;
 	pl.kind = 2, pl.band = bg;
 }
 
 int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const int32_t *d_order, int32_t n_items,
                      int slots, int64_t max_len, int64_t max_bound, int64_t max_bound1, int64_t tb_total_budget, bool timed,
-                     int want_kind = -1, int64_t max_tl = -1, int64_t max_seq_lds = -1, int timed_end = -1)
+                     int want_kind = -1, int64_t max_tl = -1, int64_t max_seq_lds = -1, int timed_end = -1, int geom_block = 0)
 {
 	if (max_tl < 0) max_tl = b->max_tl;
 	if (max_seq_lds < 0) max_seq_lds = b->max_seq_lds;
@@ -217,7 +230,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	pl.low_mem = pl.cigar && opt.step > 0;
 	// generic kernel: four waves per pair, eight once the windows are wide (measured on 1250 x 50 kb: 708 ms against 782 ms)
 	pl.block = g->block > 0 && g->block != 768 ? g->block : (std::min<int64_t>(max_len + 1, 2 * max_bound + 3) >= 8192 ? 512 : 256);
-	choose_kernel(g, opt, P, max_len, max_bound, max_seq_lds, max_tl, want_kind >= 0 ? want_kind : g->force_kind, pl);
+	choose_kernel(g, opt, P, max_len, max_bound, max_seq_lds, max_tl, want_kind >= 0 ? want_kind : g->force_kind, pl, geom_block);
 	// `slots` is an upper bound from the caller (retries ask for fewer, larger slots); the chosen kernel's own residency
 	// bounds it as well
 	int per_cu, lds_e2_cols = 0;
@@ -673,15 +686,20 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	// by the caller (tests, tuning) keep the whole batch in one group.
 	const bool low_mem = cigar && opt->step > 0;
 	const bool classes = g->force_kind < 0 && g->block == 0 && !low_mem && band_supported(P0);
-	struct Group { std::vector<int32_t> ids; int64_t max_len = 0, max_bound = 0, max_bound1 = 0, max_tl = 0, max_seq_lds = 0; } grp[3];
+	struct Group { std::vector<int32_t> ids; int64_t max_len = 0, max_bound = 0, max_bound1 = 0, max_tl = 0, max_seq_lds = 0; } grp[4];
 	b->h_class.assign((size_t)b->n, 0);
 	for (int32_t i = 0; i < b->n; ++i) {
 		const int64_t len = (int64_t)b->h_tl[i] + b->h_ql[i], bound = penalty_bound(*opt, b->h_tl[i], b->h_ql[i], true);
 		int c = 0;
 		if (classes) {
 			const int64_t window = std::min<int64_t>(len + 1, 2 * bound + 3);
-			if (window <= 8 * 256 - 256 - 64) c = 2;          // fits the 256-thread band kernel's span whatever happens
-			else if (len + 1 <= 4 * (int64_t)(8 * 3 * 256)) c = 1; // windows that mostly stay inside the wide band kernel's span
+			const bool packable = (int64_t)b->h_tl[i] + bound < 32767 && g->band_pack != 0;
+			// A window cannot outgrow min(tl+ql+1, 2 x penalty bound + 3); in practice it stays far below tl+ql (a quarter of
+			// it at 5 % divergence), so a pair is also given to a small kernel when it is merely short — if its window does
+			// outgrow that span, finalize() moves it to the wide band kernel, and from there to the generic one.
+			if (packable && (window <= kBandTinyWindow || len + 1 <= 3 * (int64_t)(2 * 3 * 256))) c = 3;
+			else if (packable ? (window <= kBandSmallWindow || len + 1 <= 3 * (int64_t)(4 * 3 * 256)) : window <= 8 * 256 - 256 - 64) c = 2;
+			else if (len + 1 <= 4 * (int64_t)(8 * 3 * 256)) c = 1;
 		}
 		b->h_class[i] = (int8_t)c;
 		Group &G = grp[c];
@@ -707,12 +725,13 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	int n_groups = 0, done_groups = 0;
 	for (const Group &G : grp) n_groups += !G.ids.empty();
 	size_t at = 0;
-	for (int c = 0; c < 3; ++c) {
+	for (int c = 0; c < 4; ++c) {
 		const Group &G = grp[c];
 		if (G.ids.empty()) continue;
 		++done_groups;
 		if (run_batch_kernel(g, b, *opt, b->d_order + at, (int32_t)G.ids.size(), slots, G.max_len, G.max_bound, G.max_bound1, budget,
-		                     done_groups == 1, classes ? (c == 0 ? 0 : 2) : -1, G.max_tl, G.max_seq_lds, done_groups == n_groups)) return -1;
+		                     done_groups == 1, classes ? (c == 0 ? 0 : 2) : -1, G.max_tl, G.max_seq_lds, done_groups == n_groups,
+		                     c == 3 ? 128 : c == 2 ? 256 : 0)) return -1;
 		at += G.ids.size();
 	}
 	b->aligned = true;
@@ -772,6 +791,16 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 		}
 		if (band_overflow) {
 			redo_kind = 0; // the window outgrew the register-resident span: generic kernel, same slots
+			// ... unless the pair sat in one of the small size classes: then the wide band kernel first (the rest waits a round)
+			std::vector<int32_t> promote;
+			if (g->stats.kernel_kind != 1)
+				for (int32_t i : redo)
+					if (b->h_status[i] == ST_BAND_OVERFLOW && (size_t)i < b->h_class.size() && b->h_class[i] >= 2) promote.push_back(i);
+			if (!promote.empty()) {
+				for (int32_t i : promote) b->h_class[i] = 1;
+				redo.swap(promote);
+				redo_kind = 2;
+			}
 			if (g->stats.kernel_kind == 1 && b->h_status[redo[0]] == ST_BAND_OVERFLOW)
 				fprintf(stderr, "[libmwf_hip] warning: wavefront of pair %d outgrew the whole-device kernel's span; re-running it on one workgroup (slow)\n", redo[0]);
 		}

@@ -157,25 +157,28 @@ def test_mixed_batch_runs_in_size_classes(oracle):
     """One batch with three very different pair sizes (what mwf_wfa_chain's gap fills look like): every size class goes
     to its own kernel in its own launch, results identical to the oracle, in the caller's order."""
     eng = mw.Engine(0)
-    pairs = []
+    pairs, must = [], []
     for i in range(120):
-        pairs.append(synth_pair(89000 + i, (40, 300, 700)[i % 3], (0.02, 0.1)[i % 2]))       # narrow band kernel
+        pairs.append(synth_pair(89000 + i, (40, 300, 3500)[i % 3], (0.02, 0.1)[i % 2]))      # tiny / tiny / small band kernel
         if i % 4 == 0:
             pairs.append(synth_pair(89500 + i, 6000, 0.05))                                   # wide band kernel
         if i % 60 == 0:
             pairs.append(synth_pair(89900 + i, 14000, 0.03))                                  # generic kernel (tl+ql > 24 kb)
+            must.append(len(pairs))
+            pairs.append(synth_pair(89950 + i, 3500, 0.3))   # short, so "small" — but its window outgrows that span: moved up
     for o in (make_opt(), make_opt(flag=1)):
         b = eng.upload(PackedBatch(pairs))
         b.align(mw.opt_init(flag=o.flag))
-        assert eng.stats().n_launches == 3
+        assert eng.stats().n_launches == 4   # tiny, small, wide band classes + generic
         s, it, nc = b.results()
         for i, (t, q) in enumerate(pairs):
-            if len(t) < 1000 and i % 5:
+            if len(t) < 4000 and i % 5 and i not in must:
                 continue
             es, eit, ecig = oracle.align(t, q, o)
             assert (int(s[i]), int(it[i])) == (es, eit), (i, len(t), o.flag)
             if ecig is not None:
                 assert b.cigar(i, int(nc[i])).tolist() == ecig, i
+        assert eng.stats().n_retries >= 2       # the two divergent 3500 bp pairs went small -> wide (-> generic)
         b.free()
     eng.close()
 
@@ -202,9 +205,10 @@ def test_every_block_size_gives_identical_results(block, scalar, oracle):
     eng.close()
 
 
-@pytest.mark.parametrize("block,pack", [(256, -1), (512, -1), (768, -1), (768, 0)])
+@pytest.mark.parametrize("block,pack", [(128, -1), (256, -1), (256, 1), (512, -1), (768, -1), (768, 0)])
 def test_band_kernel_against_oracle(block, pack, oracle):
-    """Register-resident band kernel forced on, every geometry (pack=0: the variants without int16 packing): ragged
+    """Register-resident band kernel forced on, every geometry (pack=0: the variants without int16 packing, pack=1 with
+    block 256: the packed 256-thread variant): ragged
     sizes, both penalty sets it is instantiated for, score and CIGAR.  Pairs whose window outgrows the span (block 256
     holds < 1800 columns) must come back through the generic kernel with identical results."""
     eng = mw.Engine(0)
@@ -225,8 +229,8 @@ def test_band_kernel_against_oracle(block, pack, oracle):
             assert (s[i], it[i]) == (es, eit), (block, i, len(t), len(q), o.flag, o.o2, why)
             if ecig is not None:
                 assert b.cigar(i, int(nc[i])).tolist() == ecig, (block, i)
-        if block == 256:
-            assert eng.stats().n_retries > 0   # the 3000/5000 bp pairs at 30 % do not fit 2048 columns
+        if block <= 256:
+            assert eng.stats().n_retries > 0   # the 3000/5000 bp pairs at 30 % do not fit 2048 (3072, 1536) columns
         b.free()
     eng.close()
 
