@@ -544,7 +544,7 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 	return R;
 }
 
-// The packed kernels up to 512 threads are meant to share a CU — 2 x 512, 4 x 256 or 8 x 128 threads: 4 waves per SIMD, i.e.
+// The packed kernels up to 512 threads are meant to share a CU — 2 x 512, 4 x 256, 8 x 128 or 16 x 64 threads: 4 waves per SIMD, i.e.
 // at most 128 VGPRs; with traceback the two smaller ones get 168 (3 per SIMD), which they nearly fit.
 template <int T, int K, int E1, int E2, bool TB, bool LSEQ, bool PACK>
 __global__ __launch_bounds__(T, (PACK && T <= 512) ? ((TB && T < 512) ? 3 : 4) : 1) void wfa_band_kernel(const BatchArgs A)
@@ -618,6 +618,9 @@ bool band_supported(const Penalty &p)
 		} else if (g.block == 128 && g.packed) {                                      \
 			if (a_e1 == 2 && a_e2 == 1) return FN<128, 3, 2, 1, true>(__VA_ARGS__);   \
 			if (a_e1 == 2 && a_e2 == 2) return FN<128, 3, 2, 2, true>(__VA_ARGS__);   \
+		} else if (g.block == 64 && g.packed) {                                       \
+			if (a_e1 == 2 && a_e2 == 1) return FN<64, 3, 2, 1, true>(__VA_ARGS__);    \
+			if (a_e1 == 2 && a_e2 == 2) return FN<64, 3, 2, 2, true>(__VA_ARGS__);    \
 		} else if (g.block == 768 && g.packed) {                                      \
 			if (a_e1 == 2 && a_e2 == 1) return FN<768, 2, 2, 1, true>(__VA_ARGS__);   \
 			if (a_e1 == 2 && a_e2 == 2) return FN<768, 2, 2, 2, true>(__VA_ARGS__);   \

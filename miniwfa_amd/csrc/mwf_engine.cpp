@@ -77,7 +77,7 @@ struct mwf_gpu_batch_s {
 	int64_t max_tl = 0;        // longest target (offsets are target indices: bounds what a 16-bit offset must hold)
 	int32_t *d_order = nullptr;
 	std::vector<int32_t> h_order;   // what d_order holds: pair ids, grouped by size class, longest first inside a class
-	std::vector<int8_t> h_class;    // size class of every pair in the last align (0 generic, then band kernels: 1 wide, 2 small, 3 tiny)
+	std::vector<int8_t> h_class;    // size class of every pair in the last align (0 generic, then band kernels: 1 wide, 2 small, 3 tiny, 4 micro)
 	// outputs
 	int32_t *d_s = nullptr, *d_ncig = nullptr, *d_status = nullptr, *d_dbg4 = nullptr;
 	int64_t *d_iter = nullptr, *d_cigoff = nullptr, *d_cells1 = nullptr;
@@ -163,8 +163,8 @@ int64_t penalty_bound(const mwf_opt_t &o, int64_t tl, int64_t ql, bool honour_ma
 	return b;
 }
 
-// widest window the 128- and 256-thread packed band variants are chosen for: (waves x 3 chunks - 1) x 256 - 64 columns
-constexpr int64_t kBandTinyWindow = (2 * 3 - 1) * 256 - 64, kBandSmallWindow = (4 * 3 - 1) * 256 - 64;
+// widest window the 64-, 128- and 256-thread packed band variants are chosen for: (waves x 3 chunks - 1) x 256 - 64 columns
+constexpr int64_t kBandMicroWindow = (1 * 3 - 1) * 256 - 64, kBandTinyWindow = (2 * 3 - 1) * 256 - 64, kBandSmallWindow = (4 * 3 - 1) * 256 - 64;
 
 struct Plan {
 	int kind = 0;              // 0: generic kernel, 2: band kernel
@@ -191,6 +191,7 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 	// Packed variants (E/F registers as int16 pairs): valid when no offset (a target index, plus at most one per penalty for
 	// offsets that ran past the matrix) and no penalty count can reach 32767.  They halve the state registers, which is
 	// what lets several workgroups share a CU — one pair's barrier phase then overlaps another's compute:
+	//   window <=  448:  64 threads x 3 chunks, sixteen pairs per CU (twelve with traceback): short reads
 	//   window <= 1216: 128 threads x 3 chunks, eight pairs per CU (six with traceback)
 	//   window <= 2752: 256 threads x 3 chunks, four (three)
 	//   wider:          512 x 3, two per CU, score-only; with traceback 768 x 2 packed, one per CU (the 512-thread variant
@@ -201,19 +202,19 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 	const bool cigar = (opt.flag & MWF_F_CIGAR) != 0;
 	if (range_ok) {
 		bg.packed = 1;
-		bg.block = max_window <= kBandTinyWindow ? 128 : max_window <= kBandSmallWindow ? 256 : cigar ? 768 : 512;
+		bg.block = max_window <= kBandMicroWindow ? 64 : max_window <= kBandTinyWindow ? 128 : max_window <= kBandSmallWindow ? 256 : cigar ? 768 : 512;
 	} else bg.block = max_window <= 8 * 256 - 256 - 64 ? 256 : 768;
 	// forced geometry (tests, tuning): 256 and 768 mean the unpacked variants unless packing is asked for as well
-	if (g->block == 128 && range_ok) bg.block = 128, bg.packed = 1;
+	if ((g->block == 64 || g->block == 128) && range_ok) bg.block = g->block, bg.packed = 1;
 	if (g->block == 256) bg.block = 256, bg.packed = range_ok && g->band_pack == 1;
 	if (g->block == 768) bg.block = 768, bg.packed = range_ok && cigar;
 	if (g->block == 512 && range_ok) bg.block = 512, bg.packed = 1;
 	// geometry picked by the caller for a size class (pairs short enough that their window should stay inside a small span)
-	if (g->block == 0 && geom_block == 128 && range_ok) bg.block = 128, bg.packed = 1;
+	if (g->block == 0 && (geom_block == 64 || geom_block == 128) && range_ok) bg.block = geom_block, bg.packed = 1;
 	if (g->block == 0 && geom_block == 256) bg.block = 256, bg.packed = range_ok;
 	bg.span = bg.block / 64 * (bg.packed && bg.block != 768 ? 3 : 2) * 256;
 	if (want_kind != 2 && max_len + 1 > 4 * (int64_t)bg.span) return; // windows will mostly outgrow the span: go generic at once
-	const int64_t lds_cap = bg.block >= 768 ? 140 * 1024 : bg.block == 512 ? 70 * 1024 : bg.block == 256 ? 36 * 1024 : 18 * 1024;
+	const int64_t lds_cap = bg.block >= 768 ? 140 * 1024 : bg.block == 512 ? 70 * 1024 : bg.block == 256 ? 36 * 1024 : bg.block == 128 ? 18 * 1024 : 9 * 1024;
 	bg.lds_bytes = max_seq_lds <= lds_cap ? (int)((max_seq_lds + 15) / 16 * 16) : 0;
 	pl.kind = 2, pl.band = bg;
 }
@@ -686,7 +687,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	// by the caller (tests, tuning) keep the whole batch in one group.
 	const bool low_mem = cigar && opt->step > 0;
 	const bool classes = g->force_kind < 0 && g->block == 0 && !low_mem && band_supported(P0);
-	struct Group { std::vector<int32_t> ids; int64_t max_len = 0, max_bound = 0, max_bound1 = 0, max_tl = 0, max_seq_lds = 0; } grp[4];
+	struct Group { std::vector<int32_t> ids; int64_t max_len = 0, max_bound = 0, max_bound1 = 0, max_tl = 0, max_seq_lds = 0; } grp[5];
 	b->h_class.assign((size_t)b->n, 0);
 	for (int32_t i = 0; i < b->n; ++i) {
 		const int64_t len = (int64_t)b->h_tl[i] + b->h_ql[i], bound = penalty_bound(*opt, b->h_tl[i], b->h_ql[i], true);
@@ -697,7 +698,8 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 			// A window cannot outgrow min(tl+ql+1, 2 x penalty bound + 3); in practice it stays far below tl+ql (a quarter of
 			// it at 5 % divergence), so a pair is also given to a small kernel when it is merely short — if its window does
 			// outgrow that span, finalize() moves it to the wide band kernel, and from there to the generic one.
-			if (packable && (window <= kBandTinyWindow || len + 1 <= 3 * (int64_t)(2 * 3 * 256))) c = 3;
+			if (packable && (window <= kBandMicroWindow || len + 1 <= 2 * (int64_t)(1 * 3 * 256))) c = 4;
+			else if (packable && (window <= kBandTinyWindow || len + 1 <= 3 * (int64_t)(2 * 3 * 256))) c = 3;
 			else if (packable ? (window <= kBandSmallWindow || len + 1 <= 3 * (int64_t)(4 * 3 * 256)) : window <= 8 * 256 - 256 - 64) c = 2;
 			else if (len + 1 <= 4 * (int64_t)(8 * 3 * 256)) c = 1;
 		}
@@ -725,13 +727,13 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	int n_groups = 0, done_groups = 0;
 	for (const Group &G : grp) n_groups += !G.ids.empty();
 	size_t at = 0;
-	for (int c = 0; c < 4; ++c) {
+	for (int c = 0; c < 5; ++c) {
 		const Group &G = grp[c];
 		if (G.ids.empty()) continue;
 		++done_groups;
 		if (run_batch_kernel(g, b, *opt, b->d_order + at, (int32_t)G.ids.size(), slots, G.max_len, G.max_bound, G.max_bound1, budget,
 		                     done_groups == 1, classes ? (c == 0 ? 0 : 2) : -1, G.max_tl, G.max_seq_lds, done_groups == n_groups,
-		                     c == 3 ? 128 : c == 2 ? 256 : 0)) return -1;
+		                     c == 4 ? 64 : c == 3 ? 128 : c == 2 ? 256 : 0)) return -1;
 		at += G.ids.size();
 	}
 	b->aligned = true;

@@ -159,7 +159,7 @@ def test_mixed_batch_runs_in_size_classes(oracle):
     eng = mw.Engine(0)
     pairs, must = [], []
     for i in range(120):
-        pairs.append(synth_pair(89000 + i, (40, 300, 3500)[i % 3], (0.02, 0.1)[i % 2]))      # tiny / tiny / small band kernel
+        pairs.append(synth_pair(89000 + i, (40, 1500, 3500)[i % 3], (0.02, 0.1)[i % 2]))     # micro / tiny / small band kernel
         if i % 4 == 0:
             pairs.append(synth_pair(89500 + i, 6000, 0.05))                                   # wide band kernel
         if i % 60 == 0:
@@ -169,7 +169,7 @@ def test_mixed_batch_runs_in_size_classes(oracle):
     for o in (make_opt(), make_opt(flag=1)):
         b = eng.upload(PackedBatch(pairs))
         b.align(mw.opt_init(flag=o.flag))
-        assert eng.stats().n_launches == 4   # tiny, small, wide band classes + generic
+        assert eng.stats().n_launches == 5   # micro, tiny, small, wide band classes + generic
         s, it, nc = b.results()
         for i, (t, q) in enumerate(pairs):
             if len(t) < 4000 and i % 5 and i not in must:
@@ -205,7 +205,7 @@ def test_every_block_size_gives_identical_results(block, scalar, oracle):
     eng.close()
 
 
-@pytest.mark.parametrize("block,pack", [(128, -1), (256, -1), (256, 1), (512, -1), (768, -1), (768, 0)])
+@pytest.mark.parametrize("block,pack", [(64, -1), (128, -1), (256, -1), (256, 1), (512, -1), (768, -1), (768, 0)])
 def test_band_kernel_against_oracle(block, pack, oracle):
     """Register-resident band kernel forced on, every geometry (pack=0: the variants without int16 packing, pack=1 with
     block 256: the packed 256-thread variant): ragged
