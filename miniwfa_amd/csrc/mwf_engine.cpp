@@ -672,7 +672,12 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	// a few long pairs: each one gets the whole device in turn
 	const Penalty P0 = make_penalty(*opt);
 	const int64_t coop_len = g->coop_min_len > 0 ? g->coop_min_len : 65536;
-	const bool coop = g->force_kind == 1 || (g->force_kind < 0 && coop_supported(P0) && b->n <= 8 && max_len >= coop_len);
+	// One pair at a time on the whole device takes time ~ (tl+ql); the generic kernel runs up to 256 pairs side by side in
+	// time ~ (tl+ql)^2.  Measured at 3 % divergence (profiles/few_long_pairs.py): 100 kb pairs 88 ms each against 250 ms
+	// for any number of them, 150 kb pairs 128 ms against 550 ms — the whole-device kernel wins while the batch has fewer
+	// than about (tl+ql)/70000 pairs.
+	const int64_t coop_max_pairs = std::max<int64_t>(1, std::min<int64_t>(64, max_len / 70000));
+	const bool coop = g->force_kind == 1 || (g->force_kind < 0 && coop_supported(P0) && b->n <= coop_max_pairs && max_len >= coop_len);
 	if (coop) {
 		if (!coop_supported(P0)) { g->err = "whole-device kernel does not support these penalties"; return -2; }
 		for (int32_t i = 0; i < b->n; ++i)
