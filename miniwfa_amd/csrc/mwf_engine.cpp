@@ -348,9 +348,12 @@ int run_coop_pair(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, int32_
 {
 	const Penalty P = make_penalty(opt);
 	const bool cigar = (opt.flag & MWF_F_CIGAR) != 0, low_mem = cigar && opt.step > 0;
-	const int G = std::min(coop_max_grid(cigar), g->n_cu);
+	int G = std::min(coop_max_grid(cigar), g->n_cu);
 	if (G < 1) { g->err = "whole-device kernel cannot be made resident"; return -1; }
 	const int64_t len = (int64_t)b->h_tl[pair] + b->h_ql[pair];
+	// No more workgroups than chunk slots the widest possible window (tl+ql+1 columns) can use: the per-penalty latency does
+	// not depend on their number (C4-like 150 kb pair: 151 ms on 256 workgroups, 141 ms on 64), the flag traffic does.
+	while (G > 64 && (len >> 8) + 3 <= coop_chunk_slots(G / 2)) G /= 2;
 	const int64_t bound = penalty_bound(opt, b->h_tl[pair], b->h_ql[pair], true);
 	const int64_t bound1 = penalty_bound(opt, b->h_tl[pair], b->h_ql[pair], false);
 	const int32_t W = (int32_t)((len + 3 + 255) / 256 * 256 + 512), GW = W / 64 + 2;
