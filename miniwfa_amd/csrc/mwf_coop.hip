@@ -326,7 +326,9 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 		}
 		if (lead) {
 			if (TB) M.row_off[s_new - 1] = tb_used, M.row_lo[s_new - 1] = origin;
+#ifndef MWF_BAND_TIMING // (the timing build keeps hand-off timestamps in the trace buffer instead)
 			if (A.dbg && s_new - 1 < A.dbg_cap) M.dbg[2 * (s_new - 1)] = lo, M.dbg[2 * (s_new - 1) + 1] = hi;
+#endif
 		}
 
 #ifdef MWF_BAND_TIMING
@@ -432,6 +434,9 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 				if ((uint32_t)(lo - cb) < (uint32_t)kChunk) { // this chunk holds the low edge column
 					const int32_t lv = __ballot(live & 1u) != 0;
 					if (lane < kFlagCopies) st_ag(flag_entry(s_new, lane) + 0, s_new << 4 | lv);
+#ifdef MWF_BAND_TIMING
+					if (lane == 0 && A.dbg && s_new < A.dbg_cap / 4) ((unsigned long long*)A.dbg)[4 * s_new + 0] = __builtin_amdgcn_s_memrealtime(); // low edge published
+#endif
 				}
 				if ((uint32_t)(hi - cb) < (uint32_t)kChunk) {
 					const int32_t lv = __ballot(live & 2u) != 0;
@@ -518,8 +523,11 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 		// ---- end of the penalty.  No grid barrier: neighbours synchronise through the granules above; what every workgroup
 		// needs before it can go on is the fate of the two edge columns (the next window) and of the end cell, which their
 		// owners publish into the flag ring.  Thread 0 waits for them while the other waves wait at the workgroup barrier.
-		// (Measured and rejected: a wave without chunks that polls the ring from the start of the penalty so that the round
-		// trip overlaps the chunk work — the extra polling traffic delays the very stores it is waiting for: 1.43 -> 1.51 s.)
+		// Timestamps (profiles/handoff_probe.py, C4-like pair): the period is 5.2 us; an edge flag is seen 0.9 us after its
+		// store, the end-cell flag (known only after the alignment path's match extension) 1.5 us later — but reading that one
+		// a penalty late leaves the period at 5.2 us: it is every workgroup's own chunk work (3.7 us from flags seen to chunks
+		// done) plus one poll round trip after it.  Measured and rejected: a chunk-less wave that polls from the start of the
+		// penalty so that the round trip overlaps the chunk work (1.43 -> 1.50 s, with and without the late end-cell flag).
 		switch (vm_keep) { // own H rows are read back min-lag - 1 penalties from now: keep at most this penalty's late stores in flight
 		case 3:  asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
 		case 4:  asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
@@ -540,6 +548,14 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 				int4 w;
 				asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(fr) : "memory");
 				w0 = w.x, w1 = w.y, w2 = want_fin ? w.z : s_new << 4;
+#ifdef MWF_BAND_TIMING
+				if (blockIdx.x == 5 && A.dbg && s_new < A.dbg_cap / 4) { // profiles/handoff_probe.py
+					unsigned long long *tt = (unsigned long long*)A.dbg + 4 * s_new;
+					if (spins == 0) tt[1] = __builtin_amdgcn_s_memrealtime();                          // workgroup 5 starts looking
+					if ((w0 >> 4) == s_new && tt[2] == 0) tt[2] = __builtin_amdgcn_s_memrealtime();     // ... sees the low edge flag
+					if ((w0 >> 4) == s_new && (w1 >> 4) == s_new && (w2 >> 4) == s_new) tt[3] = __builtin_amdgcn_s_memrealtime(); // ... sees all
+				}
+#endif
 				if ((w0 >> 4) == s_new && (w1 >> 4) == s_new && (w2 >> 4) == s_new) break;
 				if (spins > A.coop_spin_limit) { ok = 0; break; }
 				__builtin_amdgcn_s_sleep(1);

@@ -390,7 +390,10 @@ int run_coop_pair(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, int32_
 		}
 		if (ensure(g, g->tb, (size_t)tb_bytes)) return -1;
 	}
-	if (b->debug_pair == pair && ensure(g, g->dbg, (size_t)8 * (bound + 2))) return -1;
+	if (b->debug_pair == pair) {
+		if (ensure(g, g->dbg, (size_t)8 * (bound + 2))) return -1;
+		HIP_TRY(g, hipMemsetAsync(g->dbg.p, 0, g->dbg.bytes, g->stream));
+	}
 
 	BatchArgs a;
 	memset(&a, 0, sizeof(a));
