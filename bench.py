@@ -34,6 +34,25 @@ ALGO_BYTES_PER_CELL = 48          # score-only; 49 with traceback, 97 in the low
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def host_cores() -> int:
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (on the GPU boxes the
+    container sees 256 logical CPUs but is throttled to 16; 256 threads then run slower than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, -(-q // per)))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 class _DevPtr:
     """Zero-copy torch view of a device buffer owned by the C library."""
 
@@ -204,21 +223,23 @@ def main():
     if world == 1 and args.cpu_sample > 0:
         from oracle.pyoracle import Oracle, Reference, make_opt
         n = min(args.cpu_sample, pk.n)
-        cores = os.cpu_count() or 1
+        cores = host_cores()
         o = make_opt(flag=1 if args.cigar else 0)
         orc = Oracle()
+        arena = None
         if Reference.available():
-            fn, kind = Reference().exact_addr(), "reference"
+            ref = Reference()
+            fn, kind, arena = ref.exact_addr(), "reference", ref.arena_addrs()   # one pair per thread, private arena
         else:
             fn, kind = None, "port"
         threads = min(cores, n)
-        cs, cit, sec = orc.batch(pk, o, threads, exact_fn=fn, n=n)   # pthread pool in C, one pair per thread at a time
+        cs, cit, sec = orc.batch(pk, o, threads, exact_fn=fn, n=n, arena=arena)   # pthread pool in C, one pair per thread at a time
         ok = bool((cs == s[:n]).all() and (cit == n_iter[:n]).all())
         sb = int(pk.tl[:n].sum() + pk.ql[:n].sum())
         out["cpu_baseline"] = {
             "value": sb / sec / 1e9, "unit": "Gbp/s", "cores": threads, "kind": kind,
-            "sample": f"first {n} of the {pk.n} pairs, pthread pool of {threads} threads (host has {cores} logical CPUs), "
-                      f"{'lh3/miniwfa compiled -O3 -msse4.2 (oracle/_ref)' if kind == 'reference' else 'oracle/mwf_oracle.c'}, {sec:.3f} s wall",
+            "sample": f"first {n} of the {pk.n} pairs, pthread pool of {threads} threads (= usable CPUs: affinity mask capped by the cgroup quota; os.cpu_count() = {os.cpu_count()}), "
+                      f"{'lh3/miniwfa compiled -O3 -msse4.2 (oracle/_ref), a private kalloc arena per thread' if kind == 'reference' else 'oracle/mwf_oracle.c'}, {sec:.3f} s wall",
             "gcells_per_s": float(cit.sum()) / sec / 1e9,
             "gpu_matches_cpu_on_sample": ok,
         }

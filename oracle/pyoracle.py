@@ -110,6 +110,8 @@ class Oracle(_Aligner):
         L.mwfo_batch.restype = C.c_double
         L.mwfo_batch_with.argtypes = [C.c_void_p] + L.mwfo_batch.argtypes
         L.mwfo_batch_with.restype = C.c_double
+        L.mwfo_batch_arena.argtypes = [C.c_void_p] * 4 + L.mwfo_batch.argtypes
+        L.mwfo_batch_arena.restype = C.c_double
         self._exact = L.mwfo_exact
         self._free = lambda p: L.mwfo_free(C.cast(p, C.c_void_p))
 
@@ -154,17 +156,19 @@ class Oracle(_Aligner):
         n = self.lib.mwfo_band_trace(C.byref(opt), len(t), t, len(q), q, buf, cap)
         return [(buf[2 * i], buf[2 * i + 1]) for i in range(min(n, cap))]
 
-    def batch(self, packed, opt: Opt, threads: int, exact_fn=None, n=None):
+    def batch(self, packed, opt: Opt, threads: int, exact_fn=None, n=None, arena=None):
         """Threaded (pthreads, one pair per thread at a time) batch over the first n pairs of a miniwfa_amd.synth.PackedBatch;
         returns (s[], n_iter[], wall seconds).  exact_fn: address of a function with mwf_wfa_exact's signature to time instead
-        of the restatement (e.g. Reference().exact_addr())."""
+        of the restatement (e.g. Reference().exact_addr()); arena: (km_init, km_destroy, kfree) addresses of the same library
+        — every worker thread then aligns inside a private kalloc arena (Reference().arena_addrs())."""
         import numpy as np
         n = packed.n if n is None else min(n, packed.n)
         s = np.zeros(n, dtype=np.int32)
         it = np.zeros(n, dtype=np.int64)
-        sec = self.lib.mwfo_batch_with(exact_fn, C.byref(opt), n, packed.seqs.ctypes.data, packed.t_off.ctypes.data,
-                                       packed.tl.ctypes.data, packed.q_off.ctypes.data, packed.ql.ctypes.data,
-                                       threads, s.ctypes.data, it.ctypes.data)
+        a = arena if (arena and exact_fn) else (None, None, None)
+        sec = self.lib.mwfo_batch_arena(exact_fn, a[0], a[1], a[2], C.byref(opt), n, packed.seqs.ctypes.data, packed.t_off.ctypes.data,
+                                        packed.tl.ctypes.data, packed.q_off.ctypes.data, packed.ql.ctypes.data,
+                                        threads, s.ctypes.data, it.ctypes.data)
         return s, it, sec
 
 
@@ -207,6 +211,10 @@ class Reference(_Aligner):
     def exact_addr(self) -> int:
         """Address of the reference's mwf_wfa_exact, for Oracle.batch(exact_fn=...)."""
         return C.cast(self.lib.mwf_wfa_exact, C.c_void_p).value
+
+    def arena_addrs(self):
+        """(km_init, km_destroy, kfree) of the reference's kalloc, for Oracle.batch(arena=...)."""
+        return tuple(C.cast(getattr(self.lib, n), C.c_void_p).value for n in ("km_init", "km_destroy", "kfree"))
 
     def _call(self, fn, t, q, opt):
         r = Rst()
