@@ -186,7 +186,9 @@ class Reference(_Aligner):
                 return False
         return os.path.exists(cls.path)
 
-    def __init__(self):
+    def __init__(self, arena: bool = False):
+        """arena=True: every call allocates inside one kalloc arena owned by this object (km_init) instead of km = NULL —
+        what a long-running caller of the library would do; saves the page faults of a fresh arena per call."""
         if not self.available():
             raise FileNotFoundError(self.path)
         L = C.CDLL(self.path)
@@ -200,8 +202,14 @@ class Reference(_Aligner):
         L.mwf_cigar2score.restype = C.c_int32
         self._libc = C.CDLL(None)
         self._libc.free.argtypes = [C.c_void_p]
-        self._exact = lambda o, tl, t, ql, q, r: L.mwf_wfa_exact(None, o, tl, t, ql, q, r)
-        self._free = lambda p: self._libc.free(C.cast(p, C.c_void_p))
+        L.km_init.restype = C.c_void_p
+        L.kfree.argtypes = [C.c_void_p, C.c_void_p]
+        self._km = C.c_void_p(L.km_init()) if arena else None
+        self._exact = lambda o, tl, t, ql, q, r: L.mwf_wfa_exact(self._km, o, tl, t, ql, q, r)
+        if arena:
+            self._free = lambda p: L.kfree(self._km, C.cast(p, C.c_void_p))
+        else:
+            self._free = lambda p: self._libc.free(C.cast(p, C.c_void_p))
 
     def opt_init(self) -> Opt:
         o = Opt()
@@ -218,7 +226,7 @@ class Reference(_Aligner):
 
     def _call(self, fn, t, q, opt):
         r = Rst()
-        fn(None, C.byref(opt), len(t), t, len(q), q, C.byref(r))
+        fn(self._km, C.byref(opt), len(t), t, len(q), q, C.byref(r))
         cig = None
         if r.cigar:
             cig = [r.cigar[i] for i in range(r.n_cigar)]

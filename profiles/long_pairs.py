@@ -37,8 +37,8 @@ def run(name, t, q, modes, cpu=False, cpu_kw=None):
             print(json.dumps({name: {"cpu": out["cpu_reference_score_only"]}}), flush=True)
     if cpu_kw is not None:  # the compiled reference (oracle/_ref, one thread) in the same mode as the LAST GPU mode; results compared
         from oracle.pyoracle import Reference, make_opt
-        R = Reference(); t0 = time.perf_counter(); rs = R.align(t, q, make_opt(**cpu_kw)); dt = time.perf_counter() - t0
-        rec = {"mode": cpu_kw, "s": rs[0], "n_iter": rs[1], "wall_s": round(dt, 3), "threads": 1,
+        R = Reference(arena=True); t0 = time.perf_counter(); rs = R.align(t, q, make_opt(**cpu_kw)); dt = time.perf_counter() - t0
+        rec = {"allocator": "one kalloc arena for the process (km_init), not km = NULL", "mode": cpu_kw, "s": rs[0], "n_iter": rs[1], "wall_s": round(dt, 3), "threads": 1,
                "same_s_n_iter_as_gpu": (rs[0], rs[1]) == (int(s[0]), int(it[0]))}
         if rs[2] is not None:
             rec["same_cigar_as_gpu"] = bool(len(rs[2]) == len(rec_cigar) and (np.asarray(rs[2], dtype=np.uint32) == rec_cigar).all())
