@@ -473,3 +473,24 @@ def test_full_size_batch_properties(engine, oracle):
         cig = b.cigar(i, int(nc[i])).tolist()
         assert mw.cigar2score(o, cig) == (int(s1[i]), len(pairs[i][0]), len(pairs[i][1])), i
     b.free()
+
+
+def test_config5_shaped_batch_properties(engine, oracle):
+    """BASELINE config 5's pair shape (50 kb, 3 %) on the generic kernel's wide path (768 threads, E2/F2 in LDS): one
+    pair against the oracle, and on every pair the size-independent properties — score-only and CIGAR runs agree, the
+    CIGAR re-scores to s and consumes both sequences."""
+    pairs = [synth_pair(60000 + i, 50000, 0.03) for i in range(12)]
+    b = engine.upload(PackedBatch(pairs))
+    b.align(mw.opt_init())
+    st = engine.stats()
+    assert (st.kernel_kind, st.block) == (0, 768)
+    s0, it0, _ = b.results()
+    b.align(mw.opt_init(flag=mw.MWF_F_CIGAR))
+    s1, it1, nc = b.results()
+    assert (s0 == s1).all() and (it0 == it1).all() and (s0 > 0).all()
+    assert (int(s0[0]), int(it0[0])) == oracle.align(pairs[0][0], pairs[0][1], make_opt())[:2]
+    o = mw.opt_init()
+    for i in range(len(pairs)):
+        cig = b.cigar(i, int(nc[i])).tolist()
+        assert mw.cigar2score(o, cig) == (int(s1[i]), len(pairs[i][0]), len(pairs[i][1])), i
+    b.free()
