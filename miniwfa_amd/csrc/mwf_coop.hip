@@ -128,8 +128,10 @@ __device__ __forceinline__ int32_t lcp_wave(const PairMem &M, int32_t j, int32_t
 // `flags`: this workgroup's four LDS flag words of the penalty (or null).  `vm_keep`: how many of this wave's youngest
 // memory operations may still be in flight (0 = drain everything; see the call site).  FENCE: release/acquire pair for
 // data written with ordinary stores (only the shrink needs it).
+// (`sync` and `lb`: the barrier words and the block index of this pair's group of workgroups — several pairs can run side
+// by side on disjoint groups, each with its own words)
 template <bool FENCE>
-__device__ __forceinline__ bool grid_sync(const BatchArgs &A, Shared &sh, unsigned &epoch, unsigned n_groups,
+__device__ __forceinline__ bool grid_sync(const BatchArgs &A, unsigned *sync, unsigned lb, Shared &sh, unsigned &epoch, unsigned n_groups,
                                           const int32_t *flags, unsigned &cum, int32_t vm_keep)
 {
 	switch (vm_keep) { // the count must be an immediate
@@ -146,10 +148,10 @@ __device__ __forceinline__ bool grid_sync(const BatchArgs &A, Shared &sh, unsign
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		}
-		unsigned long long *const top = (unsigned long long*)A.coop_sync;                 // [0]
-		unsigned *const grp_cnt = A.coop_sync + 16;                                        // [16 + 8*g]
-		unsigned long long *const grp_gen = (unsigned long long*)(A.coop_sync + 96);       // [96 + 8*g] (8-byte aligned)
-		const unsigned grp = blockIdx.x & 7u, n_grp = n_groups < 8u ? n_groups : 8u;
+		unsigned long long *const top = (unsigned long long*)sync;                        // [0]
+		unsigned *const grp_cnt = sync + 16;                                               // [16 + 8*g]
+		unsigned long long *const grp_gen = (unsigned long long*)(sync + 96);              // [96 + 8*g] (8-byte aligned)
+		const unsigned grp = lb & 7u, n_grp = n_groups < 8u ? n_groups : 8u;
 		const unsigned gsize = (n_groups - grp + 7u) / 8u;
 		unsigned spins = 0;
 		int32_t ok = 1;
@@ -184,27 +186,31 @@ __device__ __forceinline__ bool grid_sync(const BatchArgs &A, Shared &sh, unsign
 	return uni(sh.word[3]) != 0;
 }
 
+// grp / lb / G: this pair's group of workgroups, this workgroup's index in it, the group's size (the whole grid when one pair
+// has the device to itself)
 template <int E1, int E2, bool TB>
-__device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh, int32_t n_seg)
+__device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh, int32_t n_seg, int32_t grp, int32_t lb, int32_t G)
 {
-	const int32_t G = (int32_t)gridDim.x, NWt = G * kNW, TC = NWt * kK;
+	const int32_t NWt = G * kNW, TC = NWt * kK;
 	const int32_t tl = M.tl, ql = M.ql, cmax = tl + ql + 1;
-	const int32_t tid = threadIdx.x, lane = tid & 63, gw = uni((int32_t)blockIdx.x * kNW + (tid >> 6));
-	const bool lead = blockIdx.x == 0 && tid == 0;
+	const int32_t tid = threadIdx.x, lane = tid & 63, gw = uni(lb * kNW + (tid >> 6));
+	const bool lead = lb == 0 && tid == 0;
+	char *const misc = (char*)A.coop_flags + (int64_t)grp * A.coop_misc_stride; // this group's flags | barrier words | pass state | flag ring
+	unsigned *const sync = (unsigned*)(misc + 1024);
 	const int64_t W = A.W;
 	const int32_t nH = A.pen.nH, lagx = A.pen.x, lag1 = A.pen.oe1, lag2 = A.pen.oe2;
 	const bool relaxed_stores = min(lagx, min(lag1, lag2)) >= 3;
 	int32_t *const H = M.H;
 	// What crosses waves.  granule(row, r, side, which): per H slot (= penalty mod nH), chunk slot r and side (0: the chunk's
 	// last column, written by lane 63; 1: its first column, lane 0): which 0 = E1 | F1, 1 = E2 | F2, 2 = H after extension.
-	gran_t *const grans = (gran_t*)A.coop_edge;
+	gran_t *const grans = (gran_t*)(A.coop_edge + (int64_t)grp * A.coop_edge_stride);
 	auto granule = [&](int32_t row, int32_t r, int32_t side, int32_t which) -> gran_t* { return grans + ((((int64_t)row * TC + r) * 2 + side) * 4 + which); };
-	int32_t *const gflags = A.coop_flags;                  // [12..14]: origin offset, shrink reduction
+	int32_t *const gflags = (int32_t*)misc;                // [12..14]: origin offset, shrink reduction
 	// Per penalty (mod kFlagRing): "new low edge live", "new high edge live", "end cell reached | last state << 1", each as
 	// penalty << 4 | value, written by the one wave that owns the column in question.
-	int32_t *const fring = A.coop_flags + 1024;
+	int32_t *const fring = (int32_t*)misc + 1024;
 	auto flag_entry = [&](int32_t pen, int32_t copy) -> int32_t* { return fring + ((pen & (kFlagRing - 1)) * kFlagCopies + copy) * 32; }; // one 128-byte line each
-	unsigned long long *const arrived = (unsigned long long*)(A.coop_sync + 200); // workgroup-penalties finished (drift bound)
+	unsigned long long *const arrived = (unsigned long long*)(sync + 200); // workgroup-penalties finished (drift bound)
 	PassResult R;
 	R.status = ST_OK, R.s = 0, R.info = 0, R.n_snap = 0, R.cells = 0;
 	unsigned epoch = 0, cum = 0; // the host zeroes the barrier words before every pass
@@ -228,7 +234,7 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 		sh.rng_lo[0] = sh.rng_hi[0] = tl + 1;
 		sh.red[0] = 0; // set by a wave whose wait for a neighbour ran into the spin limit
 	}
-	if (blockIdx.x == 0 && tid < 64) {
+	if (lb == 0 && tid < 64) {
 		const int32_t k0 = lcp_wave(M, 0, 0, min(tl, ql), 0) - 1;
 		if (tid == 0) {
 			const int32_t c0 = tl + 1;
@@ -241,7 +247,7 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 		}
 	}
 	if (tid == 0) for (int32_t j = 0; j < 12; ++j) (&sh.flags[0][0])[j] = 0;
-	if (!grid_sync<false>(A, sh, epoch, G, nullptr, cum, 0)) { R.status = ST_INTERNAL; return R; }
+	if (!grid_sync<false>(A, sync, (unsigned)lb, sh, epoch, G, nullptr, cum, 0)) { R.status = ST_INTERNAL; return R; }
 	{
 		const int32_t k0 = uni(ld_ag(&gflags[12]));
 		if (k0 == tl - 1 && k0 == ql - 1) { R.cells = 0; return R; }
@@ -537,7 +543,7 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 		}
 		if (tid == 0) {
 			(void)__hip_atomic_fetch_add(arrived, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			const int32_t *fr = flag_entry(s_new, (int32_t)blockIdx.x & (kFlagCopies - 1));
+			const int32_t *fr = flag_entry(s_new, lb & (kFlagCopies - 1));
 			const bool want_fin = cfin >= lo && cfin <= hi;
 			int32_t w0 = 0, w1 = 0, w2 = 0, ok = 1;
 			// each look is ONE 16-byte agent-scope load of this workgroup's copy of the flag words
@@ -549,7 +555,7 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 				asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(fr) : "memory");
 				w0 = w.x, w1 = w.y, w2 = want_fin ? w.z : s_new << 4;
 #ifdef MWF_BAND_TIMING
-				if (blockIdx.x == 5 && A.dbg && s_new < A.dbg_cap / 4) { // profiles/handoff_probe.py
+				if (lb == 5 && A.dbg && s_new < A.dbg_cap / 4) { // profiles/handoff_probe.py
 					unsigned long long *tt = (unsigned long long*)A.dbg + 4 * s_new;
 					if (spins == 0) tt[1] = __builtin_amdgcn_s_memrealtime();                          // workgroup 5 starts looking
 					if ((w0 >> 4) == s_new && tt[2] == 0) tt[2] = __builtin_amdgcn_s_memrealtime();     // ... sees the low edge flag
@@ -590,10 +596,10 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 		if (TB) tb_used += row_bytes;
 		if ((s & 0xff) == 0) { // shrink (miniwfa.c:144-171): the good bits were written with ordinary stores by every CU
 			if (lead) st_ag(&gflags[13], 0x7fffffff), st_ag(&gflags[14], -1);
-			if (!grid_sync<true>(A, sh, epoch, G, nullptr, cum, 0)) { R.status = ST_INTERNAL; break; }
+			if (!grid_sync<true>(A, sync, (unsigned)lb, sh, epoch, G, nullptr, cum, 0)) { R.status = ST_INTERNAL; break; }
 			const int32_t gfirst = wf_lo >> 8, n_words = ((wf_hi >> 8) - gfirst + 1) * 4;
 			int32_t mylo = 0x7fffffff, myhi = -1;
-			for (int32_t q = (int32_t)blockIdx.x * kT + tid; q < n_words; q += G * kT) {
+			for (int32_t q = lb * kT + tid; q < n_words; q += G * kT) {
 				const int32_t gg = gfirst + (q >> 2), kq = q & 3, base = gg * kChunk;
 				unsigned long long m = 0;
 				for (int32_t j = 0; j < nH; ++j)
@@ -608,7 +614,7 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 				__hip_atomic_fetch_min(&gflags[13], mylo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				__hip_atomic_fetch_max(&gflags[14], myhi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
-			if (!grid_sync<false>(A, sh, epoch, G, nullptr, cum, 0)) { R.status = ST_INTERNAL; break; }
+			if (!grid_sync<false>(A, sync, (unsigned)lb, sh, epoch, G, nullptr, cum, 0)) { R.status = ST_INTERNAL; break; }
 			const int32_t glo = uni(ld_ag(&gflags[13])), ghi = uni(ld_ag(&gflags[14]));
 			if (ghi < 0) { R.status = ST_INTERNAL; break; }
 			wf_lo = glo, wf_hi = ghi;
@@ -633,23 +639,29 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 	return R;
 }
 
+// which pair a group of workgroups works on, and where its pass state lives
+__device__ __forceinline__ int32_t group_pair(const BatchArgs &A, int32_t grp) { return A.coop_pair_ids ? A.coop_pair_ids[grp] : A.coop_pair; }
+__device__ __forceinline__ int32_t *group_state(const BatchArgs &A, int32_t grp) { return (int32_t*)((char*)A.coop_flags + (int64_t)grp * A.coop_misc_stride + 2048); }
+
 template <int E1, int E2>
 __global__ __launch_bounds__(kT) void wfa_coop_kernel(const BatchArgs A)
 {
 	__shared__ Shared sh;
-	const int32_t pair = A.coop_pair;
+	const int32_t G = A.coop_group_size, grp = (int32_t)blockIdx.x / G, lb = (int32_t)blockIdx.x % G;
+	const int32_t pair = group_pair(A, grp);
+	int32_t *const state = group_state(A, grp);
 	PairMem M;
-	pair_mem(A, 0, pair, M);
+	pair_mem(A, grp, pair, M);
 	int32_t n_seg = 0;
 	if (A.coop_pass == 2) { // second pass of the low-memory mode: checkpoints left by the walk
-		if (A.coop_state[0] != ST_OK) return; // first pass failed: nothing to do, the finish kernel reports it
-		n_seg = A.coop_state[3];
+		if (state[0] != ST_OK) return; // first pass failed: nothing to do, the finish kernel reports it
+		n_seg = state[3];
 	}
 	PassResult R;
-	if (A.want_cigar) R = coop_pass<E1, E2, true>(A, M, sh, n_seg);
-	else R = coop_pass<E1, E2, false>(A, M, sh, 0);
-	if (blockIdx.x == 0 && threadIdx.x == 0) {
-		int32_t *st = A.coop_state + (A.coop_pass == 2 ? 8 : 0);
+	if (A.want_cigar) R = coop_pass<E1, E2, true>(A, M, sh, n_seg, grp, lb, G);
+	else R = coop_pass<E1, E2, false>(A, M, sh, 0, grp, lb, G);
+	if (lb == 0 && threadIdx.x == 0) {
+		int32_t *st = state + (A.coop_pass == 2 ? 8 : 0);
 		st[0] = R.status, st[1] = R.s, st[2] = R.info;
 		st[4] = (int32_t)(R.cells & 0xffffffff), st[5] = (int32_t)(R.cells >> 32);
 	}
@@ -665,13 +677,14 @@ __global__ __launch_bounds__(kT) void wfa_coop_kernel(const BatchArgs A)
 // diagonal over.  Walking those bits here reproduces the same chain, hence the same checkpoints.
 __global__ void coop_walk_kernel(const BatchArgs A)
 {
-	if (threadIdx.x != 0 || blockIdx.x != 0) return;
-	int32_t *st = A.coop_state;
+	if (threadIdx.x != 0) return;
+	const int32_t grp = (int32_t)blockIdx.x; // one block per pair
+	int32_t *st = group_state(A, grp);
 	st[3] = 0;
 	if (st[0] != ST_OK) return;
 	const Penalty &P = A.pen;
 	PairMem M;
-	pair_mem(A, 0, A.coop_pair, M);
+	pair_mem(A, grp, group_pair(A, grp), M);
 	const int32_t s_final = st[1], step = A.step;
 	const int32_t n_seg = s_final / step;
 	if (n_seg > A.seg_slot) { st[0] = ST_SNAP_OVERFLOW; return; }
@@ -700,16 +713,17 @@ __global__ void coop_walk_kernel(const BatchArgs A)
 
 __global__ __launch_bounds__(64) void coop_finish_kernel(const BatchArgs A)
 {
-	const int32_t pair = A.coop_pair;
+	const int32_t grp = (int32_t)blockIdx.x; // one block per pair
+	const int32_t pair = group_pair(A, grp);
 	PairMem M;
-	pair_mem(A, 0, pair, M);
-	const int32_t *st1 = A.coop_state, *st = A.step > 0 && A.want_cigar ? A.coop_state + 8 : A.coop_state;
+	pair_mem(A, grp, pair, M);
+	const int32_t *st1 = group_state(A, grp), *st = A.step > 0 && A.want_cigar ? st1 + 8 : st1;
 	PassResult R;
 	int32_t status = st1[0] != ST_OK ? st1[0] : st[0];
 	R.status = status, R.s = st[1], R.info = st[2], R.n_snap = 0;
 	R.cells = (int64_t)(uint32_t)st[4] | (int64_t)st[5] << 32;
 	const int64_t cells1 = A.step > 0 && A.want_cigar ? ((int64_t)(uint32_t)st1[4] | (int64_t)st1[5] << 32) : 0;
-	finish_pair(A, M, 0, pair, R, status, cells1);
+	finish_pair(A, M, grp, pair, R, status, cells1);
 }
 
 template <int E1, int E2>
@@ -747,13 +761,13 @@ int launch_coop_pass(const BatchArgs &a, int grid, void *stream)
 
 int launch_coop_walk(const BatchArgs &a, void *stream)
 {
-	hipLaunchKernelGGL(coop_walk_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
+	hipLaunchKernelGGL(coop_walk_kernel, dim3(a.coop_groups > 0 ? a.coop_groups : 1), dim3(64), 0, (hipStream_t)stream, a);
 	return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 int launch_coop_finish(const BatchArgs &a, void *stream)
 {
-	hipLaunchKernelGGL(coop_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
+	hipLaunchKernelGGL(coop_finish_kernel, dim3(a.coop_groups > 0 ? a.coop_groups : 1), dim3(64), 0, (hipStream_t)stream, a);
 	return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -77,6 +77,7 @@ struct mwf_gpu_batch_s {
 	int64_t max_tl = 0;        // longest target (offsets are target indices: bounds what a 16-bit offset must hold)
 	int32_t *d_order = nullptr;
 	std::vector<int32_t> h_order;   // what d_order holds: pair ids, grouped by size class, longest first inside a class
+	bool coop_grouped = false;      // the last align ran several pairs side by side on the whole-device kernel
 	std::vector<int8_t> h_class;    // size class of every pair in the last align (0 generic, then band kernels: 1 wide, 2 small, 3 tiny, 4 micro)
 	// outputs
 	int32_t *d_s = nullptr, *d_ncig = nullptr, *d_status = nullptr, *d_dbg4 = nullptr;
@@ -344,27 +345,47 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 
 // One pair across the whole device (mwf_coop.hip).  Everything is enqueued on the stream: first pass, and in low-memory
 // mode the checkpoint walk over its traceback matrix and the second pass, then traceback + outputs.
-int run_coop_pair(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, int32_t pair, bool first, bool last)
+// Workgroups per pair when `n` pairs of at most `len` columns share the device: as many as the widest possible window can
+// use when the pair is alone (it can then never outgrow them); when several pairs run side by side, as many as a window of
+// a third of tl+ql needs (windows stay near a quarter at 3-5 % divergence) — a pair that does outgrow its group is re-run
+// alone by finalize().  The per-penalty latency does not depend on the group size (C4-like 150 kb pair: 151 ms on 256
+// workgroups, 141 ms on 64), so pairs side by side multiply the throughput.
+int coop_group_size(int n_cu, int64_t len, bool alone)
+{
+	int G = n_cu;
+	const int64_t chunks = alone ? (len >> 8) + 3 : (len >> 8) / 3 + 8;
+	while (G > (alone ? 64 : 16) && chunks <= coop_chunk_slots(G / 2)) G /= 2;
+	return G;
+}
+
+// Up to n_cu / group size pairs side by side on the whole-device kernel, each on its own group of workgroups (mwf_coop.hip).
+// Everything is enqueued on the stream: first pass, and in low-memory mode the checkpoint walk over its traceback matrix
+// and the second pass, then traceback + outputs.
+int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const std::vector<int32_t> &pairs, int Gs, bool first, bool last)
 {
 	const Penalty P = make_penalty(opt);
 	const bool cigar = (opt.flag & MWF_F_CIGAR) != 0, low_mem = cigar && opt.step > 0;
-	int G = std::min(coop_max_grid(cigar), g->n_cu);
-	if (G < 1) { g->err = "whole-device kernel cannot be made resident"; return -1; }
-	const int64_t len = (int64_t)b->h_tl[pair] + b->h_ql[pair];
-	// No more workgroups than chunk slots the widest possible window (tl+ql+1 columns) can use: the per-penalty latency does
-	// not depend on their number (C4-like 150 kb pair: 151 ms on 256 workgroups, 141 ms on 64), the flag traffic does.
-	while (G > 64 && (len >> 8) + 3 <= coop_chunk_slots(G / 2)) G /= 2;
-	const int64_t bound = penalty_bound(opt, b->h_tl[pair], b->h_ql[pair], true);
-	const int64_t bound1 = penalty_bound(opt, b->h_tl[pair], b->h_ql[pair], false);
+	const int n_groups = (int)pairs.size();
+	if (n_groups < 1 || Gs < 1 || (int64_t)Gs * n_groups > std::min(coop_max_grid(cigar), g->n_cu)) { g->err = "whole-device kernel cannot be made resident"; return -1; }
+	int64_t len = 0, bound = 0, bound1 = 0;
+	bool traced = false;
+	for (int32_t pair : pairs) {
+		len = std::max<int64_t>(len, (int64_t)b->h_tl[pair] + b->h_ql[pair]);
+		bound = std::max(bound, penalty_bound(opt, b->h_tl[pair], b->h_ql[pair], true));
+		bound1 = std::max(bound1, penalty_bound(opt, b->h_tl[pair], b->h_ql[pair], false));
+		traced |= b->debug_pair == pair;
+	}
 	const int32_t W = (int32_t)((len + 3 + 255) / 256 * 256 + 512), GW = W / 64 + 2;
-	const int64_t TC = coop_chunk_slots(G);
-	if (ensure(g, g->ring, (size_t)P.nH * W * 4 + 4096)) return -1;
-	if (ensure(g, g->good, (size_t)P.nH * GW * 8)) return -1;
+	const int64_t TC = coop_chunk_slots(Gs);
+	const size_t NG = (size_t)n_groups;
+	if (ensure(g, g->ring, NG * (size_t)P.nH * W * 4 + 4096)) return -1;
+	if (ensure(g, g->good, NG * (size_t)P.nH * GW * 8)) return -1;
 	// granules crossing waves: [nH][TC][2 sides][4] x 8 bytes; misc: flags, barrier words, pass state, then the flag ring
 	const size_t gran_bytes = (size_t)P.nH * TC * 2 * 4 * 8;
-	if (ensure(g, g->coop_edge, gran_bytes)) return -1;
 	const size_t flag_ring_bytes = (size_t)64 * 32 * 128; // mwf_coop.hip: kFlagRing x kFlagCopies lines of 128 bytes
-	if (ensure(g, g->coop_misc, 4096 + flag_ring_bytes)) return -1;
+	const size_t misc_bytes = 4096 + flag_ring_bytes;
+	if (ensure(g, g->coop_edge, NG * gran_bytes)) return -1;
+	if (ensure(g, g->coop_misc, NG * misc_bytes + 4096)) return -1; // (+ the pair ids behind the last group)
 	int64_t rows_slot = 0, tb_bytes = 0, cig_scratch = 0, seg_slot = 0;
 	if (cigar) {
 		rows_slot = std::max(bound, bound1) + 2;
@@ -372,7 +393,7 @@ int run_coop_pair(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, int32_
 		// Arena: the worst case (every row as wide as the matrix) is out of reach for long pairs, so start from a cap that
 		// holds the real ones (s^2 bytes: 51 GB for the MHC pair) and let finalize() double it after an overflow.  An
 		// arena that is already large enough is reused as is, so repeated calls never re-allocate.
-		const int64_t worst = (rows_slot + 1) * (len + 8);
+		const int64_t worst = NG * (rows_slot + 1) * (len + 8);
 		int64_t want = std::min(worst, g->tb_budget_mb > 0 ? (g->tb_budget_mb << 20) : g->coop_tb_cap);
 		if ((int64_t)g->tb.bytes >= want) want = (int64_t)g->tb.bytes;
 		else {
@@ -380,17 +401,17 @@ int run_coop_pair(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, int32_
 			if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = (size_t)8 << 30;
 			want = std::min<int64_t>(want, (int64_t)(fr / 10 * 9) + (int64_t)g->tb.bytes);
 		}
-		tb_bytes = std::max<int64_t>(4096, want) / 4 * 4;
-		if (ensure(g, g->row_off, (size_t)rows_slot * 8)) return -1;
-		if (ensure(g, g->row_lo, (size_t)rows_slot * 4)) return -1;
-		if (ensure(g, g->cig_scratch, (size_t)cig_scratch * 4)) return -1;
+		tb_bytes = std::max<int64_t>(4096, want / (int64_t)NG) / 4 * 4; // per pair
+		if (ensure(g, g->row_off, NG * (size_t)rows_slot * 8)) return -1;
+		if (ensure(g, g->row_lo, NG * (size_t)rows_slot * 4)) return -1;
+		if (ensure(g, g->cig_scratch, NG * (size_t)cig_scratch * 4)) return -1;
 		if (low_mem) {
 			seg_slot = bound1 / opt.step + 2;
-			if (ensure(g, g->seg, (size_t)seg_slot * 8)) return -1;
+			if (ensure(g, g->seg, NG * (size_t)seg_slot * 8)) return -1;
 		}
-		if (ensure(g, g->tb, (size_t)tb_bytes)) return -1;
+		if (ensure(g, g->tb, NG * (size_t)tb_bytes)) return -1;
 	}
-	if (b->debug_pair == pair) {
+	if (traced) {
 		if (ensure(g, g->dbg, (size_t)8 * (bound + 2))) return -1;
 		HIP_TRY(g, hipMemsetAsync(g->dbg.p, 0, g->dbg.bytes, g->stream));
 	}
@@ -413,31 +434,40 @@ int run_coop_pair(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, int32_
 	a.seg = low_mem ? (int32_t*)g->seg.p : nullptr, a.seg_slot = seg_slot;
 	a.out_s = b->d_s, a.out_iter = b->d_iter, a.out_ncig = b->d_ncig, a.out_cigoff = b->d_cigoff;
 	a.out_status = b->d_status, a.out_cells1 = b->d_cells1, a.out_dbg = b->d_dbg4;
-	a.dbg = b->debug_pair == pair ? (int32_t*)g->dbg.p : nullptr;
-	a.dbg_cap = b->debug_pair == pair ? (int32_t)(g->dbg.bytes / 8) : 0;
-	a.coop_pair = pair;
+	a.dbg = traced && n_groups == 1 ? (int32_t*)g->dbg.p : nullptr; // the band trace is a single-pair diagnostic
+	a.dbg_cap = a.dbg ? (int32_t)(g->dbg.bytes / 8) : 0;
+	a.coop_pair = pairs[0];
 	a.coop_spin_limit = (uint32_t)g->coop_spin_limit;
-	a.coop_edge = (int32_t*)g->coop_edge.p;
-	a.coop_flags = (int32_t*)g->coop_misc.p;                       // 64 ints
-	a.coop_sync = (unsigned int*)((char*)g->coop_misc.p + 1024);   // 64 uints
-	a.coop_state = (int32_t*)((char*)g->coop_misc.p + 2048);       // 16 ints
+	a.coop_groups = n_groups, a.coop_group_size = Gs;
+	a.coop_edge = (int32_t*)g->coop_edge.p, a.coop_edge_stride = (int64_t)(gran_bytes / 4);
+	a.coop_flags = (int32_t*)g->coop_misc.p, a.coop_misc_stride = (int64_t)misc_bytes; // per group: flags | +1024 barrier words | +2048 pass state | +4096 flag ring
+	a.coop_sync = (unsigned int*)((char*)g->coop_misc.p + 1024);
+	a.coop_state = (int32_t*)((char*)g->coop_misc.p + 2048);
+	int32_t *d_ids = (int32_t*)((char*)g->coop_misc.p + NG * misc_bytes);
+	HIP_TRY(g, hipMemcpyAsync(d_ids, pairs.data(), NG * 4, hipMemcpyHostToDevice, g->stream));
+	a.coop_pair_ids = d_ids;
 
-	HIP_TRY(g, hipMemsetAsync(g->coop_misc.p, 0, 4096, g->stream));
-	// granule tags and the flag ring start out as "no penalty" (-1)
-	HIP_TRY(g, hipMemsetAsync((char*)g->coop_misc.p + 4096, 0xff, flag_ring_bytes, g->stream));
-	HIP_TRY(g, hipMemsetAsync(g->coop_edge.p, 0xff, gran_bytes, g->stream));
+	auto reset_sync = [&](bool all) -> int { // granule tags and the flag ring start out as "no penalty" (-1), counters at zero
+		for (size_t q = 0; q < NG; ++q) {
+			char *m = (char*)g->coop_misc.p + q * misc_bytes;
+			if (all) { HIP_TRY(g, hipMemsetAsync(m, 0, 4096, g->stream)); }
+			else HIP_TRY(g, hipMemsetAsync(m + 1024, 0, 1024, g->stream));
+			HIP_TRY(g, hipMemsetAsync(m + 4096, 0xff, flag_ring_bytes, g->stream));
+		}
+		HIP_TRY(g, hipMemsetAsync(g->coop_edge.p, 0xff, NG * gran_bytes, g->stream));
+		return 0;
+	};
+	if (reset_sync(true)) return -1;
 	if (first) HIP_TRY(g, hipEventRecord(g->ev0, g->stream));
 	a.coop_pass = low_mem ? 1 : 0;
-	if (launch_coop_pass(a, G, g->stream)) { g->err = "kernel launch failed (whole-device pass)"; return -1; }
+	if (launch_coop_pass(a, Gs * n_groups, g->stream)) { g->err = "kernel launch failed (whole-device pass)"; return -1; }
 	g->stats.n_launches += 1;
 	if (low_mem) {
 		if (launch_coop_walk(a, g->stream)) { g->err = "kernel launch failed (checkpoint walk)"; return -1; }
-		HIP_TRY(g, hipMemsetAsync((char*)g->coop_misc.p + 1024, 0, 1024, g->stream)); // barrier counters of the second pass
-		HIP_TRY(g, hipMemsetAsync((char*)g->coop_misc.p + 4096, 0xff, flag_ring_bytes, g->stream));
-		HIP_TRY(g, hipMemsetAsync(g->coop_edge.p, 0xff, gran_bytes, g->stream));
+		if (reset_sync(false)) return -1; // barrier counters, flag ring and granules of the second pass
 		a.coop_pass = 2;
 		// the second pass is not traced: the band trace of a low-memory run is that of its second pass, traced below
-		if (launch_coop_pass(a, G, g->stream)) { g->err = "kernel launch failed (second pass)"; return -1; }
+		if (launch_coop_pass(a, Gs * n_groups, g->stream)) { g->err = "kernel launch failed (second pass)"; return -1; }
 		g->stats.n_launches += 2;
 	}
 	if (launch_coop_finish(a, g->stream)) { g->err = "kernel launch failed (traceback)"; return -1; }
@@ -446,8 +476,16 @@ int run_coop_pair(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, int32_
 		HIP_TRY(g, hipEventRecord(g->ev1, g->stream));
 		g->ev_pending = true;
 	}
-	g->stats.grid = G, g->stats.block = 512, g->stats.kernel_kind = 1;
+	g->stats.grid = Gs * n_groups, g->stats.block = 512, g->stats.kernel_kind = 1;
 	return 0;
+}
+
+// one pair with the device to itself
+int run_coop_pair(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, int32_t pair, bool first, bool last)
+{
+	const bool cigar = (opt.flag & MWF_F_CIGAR) != 0;
+	const int G = coop_group_size(std::min(coop_max_grid(cigar), g->n_cu), (int64_t)b->h_tl[pair] + b->h_ql[pair], true);
+	return run_coop_group(g, b, opt, std::vector<int32_t>{pair}, G, first, last);
 }
 
 // can the whole-device traceback arena still grow? (free memory beyond what it already holds)
@@ -678,16 +716,34 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	// a few long pairs: each one gets the whole device in turn
 	const Penalty P0 = make_penalty(*opt);
 	const int64_t coop_len = g->coop_min_len > 0 ? g->coop_min_len : 65536;
-	// One pair at a time on the whole device takes time ~ (tl+ql); the generic kernel runs up to 256 pairs side by side in
-	// time ~ (tl+ql)^2.  Measured at 3 % divergence (profiles/few_long_pairs.py): 100 kb pairs 88 ms each against 250 ms
-	// for any number of them, 150 kb pairs 128 ms against 550 ms — the whole-device kernel wins while the batch has fewer
-	// than about (tl+ql)/70000 pairs.
-	const int64_t coop_max_pairs = std::max<int64_t>(1, std::min<int64_t>(64, max_len / 70000));
+	// The whole-device kernel takes time ~ (tl+ql) per pair — and several pairs fit side by side, each on its own group of
+	// workgroups; the generic kernel runs up to 256 pairs side by side in time ~ (tl+ql)^2.  Measured at 3 % divergence
+	// (profiles/few_long_pairs.py): 100 kb pairs 88 ms each against 250 ms for any number of them, 150 kb pairs 128 ms
+	// against 550 ms — the whole-device kernel wins while the batch has fewer than about (tl+ql)/70000 pairs per group.
+	const int n_cu_coop = std::min(coop_max_grid(cigar), g->n_cu);
+	const int coop_side_by_side = n_cu_coop > 0 ? std::max(1, n_cu_coop / coop_group_size(n_cu_coop, max_len, false)) : 1;
+	const int64_t coop_max_pairs = std::max<int64_t>(1, std::min<int64_t>(256, max_len / 70000 * coop_side_by_side));
 	const bool coop = g->force_kind == 1 || (g->force_kind < 0 && coop_supported(P0) && b->n <= coop_max_pairs && max_len >= coop_len);
+	b->coop_grouped = false;
 	if (coop) {
 		if (!coop_supported(P0)) { g->err = "whole-device kernel does not support these penalties"; return -2; }
-		for (int32_t i = 0; i < b->n; ++i)
-			if (run_coop_pair(g, b, *opt, i, i == 0, i == b->n - 1)) return -1;
+		if (n_cu_coop < 1) { g->err = "whole-device kernel cannot be made resident"; return -1; }
+		std::vector<int32_t> idx(b->h_order.begin(), b->h_order.end()); // longest first
+		std::stable_sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) { return (int64_t)b->h_tl[x] + b->h_ql[x] > (int64_t)b->h_tl[y] + b->h_ql[y]; });
+		for (size_t at = 0; at < idx.size();) {
+			const int64_t len0 = (int64_t)b->h_tl[idx[at]] + b->h_ql[idx[at]];
+			const int Gs = coop_group_size(n_cu_coop, len0, false);
+			const size_t n_side = std::min<size_t>(idx.size() - at, (size_t)std::max(1, n_cu_coop / Gs));
+			const bool last = at + n_side == idx.size();
+			if (n_side <= 1 || b->debug_pair >= 0) { // alone (also: band traces are single-pair diagnostics)
+				if (run_coop_pair(g, b, *opt, idx[at], at == 0, at + 1 == idx.size())) return -1;
+				at += 1;
+				continue;
+			}
+			b->coop_grouped = true;
+			if (run_coop_group(g, b, *opt, std::vector<int32_t>(idx.begin() + at, idx.begin() + at + n_side), Gs, at == 0, last)) return -1;
+			at += n_side;
+		}
 		b->aligned = true;
 		return 0;
 	}
@@ -775,18 +831,19 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 	};
 	if (fetch()) return -1;
 	int slots = g->stats.grid, redo_kind = g->stats.kernel_kind == 2 ? 2 : 0;
-	bool coop_fell_back = false;
+	bool coop_fell_back = false, coop_gave_up = false, coop_gave_up_now = false;
 	for (int round = 0; round < 14; ++round) {
 		std::vector<int32_t> redo;
 		bool band_overflow = false;
 		for (size_t i = 0; i < n; ++i) {
 			const int32_t st = b->h_status[i];
 			if (st == ST_BAND_OVERFLOW) band_overflow = true, redo.push_back((int32_t)i);
-			else if (st == ST_INTERNAL && g->stats.kernel_kind == 1 && round == 0) {
+			else if (st == ST_INTERNAL && g->stats.kernel_kind == 1 && round <= 1 && !coop_gave_up) {
 				// a wait between workgroups of the whole-device kernel ran into its spin limit (they were not all resident, e.g.
 				// the device is shared): the one-workgroup kernel needs no such thing
 				fprintf(stderr, "[libmwf_hip] warning: whole-device kernel gave up waiting for a workgroup on pair %d; re-running it on one workgroup (slow)\n", (int)i);
 				band_overflow = true, redo.push_back((int32_t)i);
+				coop_gave_up_now = true;
 			}
 			else if (st == ST_TB_OVERFLOW || st == ST_SNAP_OVERFLOW) redo.push_back((int32_t)i);
 			else if (st != ST_OK && st != ST_STOPPED) {
@@ -795,6 +852,16 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 			}
 		}
 		if (redo.empty()) break;
+		if (g->stats.kernel_kind == 1 && b->coop_grouped && !coop_gave_up_now) {
+			// pairs that ran side by side had a share of the workgroups and of the traceback arena: whatever did not fit gets
+			// the device to itself (and from there the usual remedies)
+			b->coop_grouped = false;
+			for (int32_t i : redo)
+				if (run_coop_pair(g, b, b->opt, i, false, false)) return -1;
+			g->stats.n_retries += (int32_t)redo.size();
+			if (fetch()) return -1;
+			continue;
+		}
 		if (round == 0 && g->stats.kernel_kind != 1 && !b->h_class.empty()) {
 			// the batch ran in size classes: stay on the band kernel only if every pair to redo came from one
 			bool any_class = false, all_band = true;
@@ -802,6 +869,7 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 			for (int32_t i : redo) all_band &= b->h_class[i] != 0;
 			if (any_class) redo_kind = all_band ? 2 : 0;
 		}
+		if (coop_gave_up_now) coop_gave_up = true, coop_gave_up_now = false, b->coop_grouped = false;
 		if (band_overflow) {
 			redo_kind = 0; // the window outgrew the register-resident span: generic kernel, same slots
 			// ... unless the pair sat in one of the small size classes: then the wide band kernel first (the rest waits a round)

@@ -88,6 +88,10 @@ struct BatchArgs {
 	int32_t coop_pair;         // the one pair this launch aligns
 	int32_t lds_e2_cols;       // generic kernel, 512 threads, e2 == 1: columns of E2/F2 kept in LDS (power of two; 0 = all in HBM)
 	int32_t scalar_generic;    // generic kernel: 1 = one column per lane (forward_pass) also where the four-columns-per-lane pass applies
+	int32_t coop_groups, coop_group_size; // pairs side by side on the whole-device kernel and workgroups per pair (grid = product)
+	int64_t coop_edge_stride;  // ints between two groups' granule arrays
+	int64_t coop_misc_stride;  // bytes between two groups' flags / barrier words / pass state / flag ring
+	const int32_t *coop_pair_ids; // [coop_groups] pair of every group (null: coop_pair)
 	uint32_t coop_spin_limit;  // polls after which a wait for another workgroup gives up (ST_INTERNAL)
 	int32_t coop_pass;         // 0: plain pass; 1: pass whose traceback feeds the checkpoint walk; 2: second pass (uses seg)
 	int32_t *coop_edge;        // granules [nH][waves*2][2][4] x 8 B: E/F/H of every chunk's outer columns, tagged with their penalty

@@ -319,6 +319,28 @@ def test_whole_device_kernel_many_shapes(oracle):
     eng.close()
 
 
+def test_long_pairs_run_side_by_side(oracle):
+    """A handful of long pairs (chosen automatically): each gets its own group of workgroups of the whole-device kernel and
+    they run side by side; a pair whose window outgrows its group's share (the divergent one) is re-run with the device
+    to itself.  Results against the oracle, score and CIGAR."""
+    eng = mw.Engine(0)
+    pairs = [synth_pair(88300 + i, 35000 + 3000 * i, 0.03) for i in range(5)] + [synth_pair(88310, 34000, 0.22)]
+    for o in (make_opt(), make_opt(flag=1)):
+        b = eng.upload(PackedBatch(pairs))
+        b.align(mw.opt_init(flag=o.flag))
+        st = eng.stats()
+        assert st.kernel_kind == 1 and st.grid > 16 * 4          # several groups in one launch
+        s, it, nc = b.results()
+        for i, (t, q) in enumerate(pairs):
+            es, eit, ecig = oracle.align(t, q, o)
+            assert (int(s[i]), int(it[i])) == (es, eit), (i, o.flag)
+            if ecig is not None:
+                assert b.cigar(i, int(nc[i])).tolist() == ecig, i
+        assert eng.stats().n_retries >= 1 and eng.stats().kernel_kind == 1   # the divergent pair went again, alone
+        b.free()
+    eng.close()
+
+
 def test_whole_device_kernel_gives_up_gracefully(oracle, capfd):
     """The whole-device kernel synchronises workgroups by polling; every wait is bounded.  With the bound set to zero any
     wait that is not satisfied at once gives up: the pair must come back, bit-exact, through the one-workgroup kernel."""
@@ -475,10 +497,12 @@ def test_full_size_batch_properties(engine, oracle):
     b.free()
 
 
-def test_config5_shaped_batch_properties(engine, oracle):
+def test_config5_shaped_batch_properties(oracle):
     """BASELINE config 5's pair shape (50 kb, 3 %) on the generic kernel's wide path (768 threads, E2/F2 in LDS): one
     pair against the oracle, and on every pair the size-independent properties — score-only and CIGAR runs agree, the
     CIGAR re-scores to s and consumes both sequences."""
+    engine = mw.Engine(0)
+    engine.set("force_kind", 0)   # (a dozen such pairs alone would go side by side on the whole-device kernel)
     pairs = [synth_pair(60000 + i, 50000, 0.03) for i in range(12)]
     b = engine.upload(PackedBatch(pairs))
     b.align(mw.opt_init())
@@ -494,3 +518,4 @@ def test_config5_shaped_batch_properties(engine, oracle):
         cig = b.cigar(i, int(nc[i])).tolist()
         assert mw.cigar2score(o, cig) == (int(s1[i]), len(pairs[i][0]), len(pairs[i][1])), i
     b.free()
+    engine.close()
