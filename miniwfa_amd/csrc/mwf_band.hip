@@ -284,6 +284,13 @@ __device__ PassResult band_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 			if (g < gl) g += NWK;
 			act_k[k] = g * kChunk <= hi && g * kChunk + kChunk - 1 >= lo;
 		}
+		{ // the waves with the most chunks to do set the pace of the penalty: let them issue first
+			int n_act = 0;
+#pragma unroll
+			for (int k = 0; k < K; ++k) n_act += act_k[k] ? 1 : 0;
+			if (n_act >= 2) __builtin_amdgcn_s_setprio(3);
+			else __builtin_amdgcn_s_setprio(0);
+		}
 		// PACK (slot-pipelined loads): the rows of chunk k+1 are loaded while chunk k computes; only the first chunk's rows
 		// of the next penalty cross the barrier.  Otherwise every chunk's rows of the next penalty are prefetched.
 		auto refill = [&](int k) {
