@@ -1,21 +1,27 @@
 #!/usr/bin/env python3
 """bench.py — aligned Gbp/s of the exact WFA hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W                 # BASELINE configs[2]: 1024 x 10 kb per GPU, weak scaling
+    python bench.py --config 5 --gpus N --steps K --warmup W      # BASELINE configs[4]: 10 000 x 50 kb in total, strong scaling
     (N > 1: launched by  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (BASELINE.json configs[2], the batch the metric is quoted on): per GPU, 1024 synthetic pairs,
-10 kb target, query = target mutated at 5 % (60/20/20 sub/ins/del, geometric indels), score-only
-mwf_wfa_exact semantics, default penalties.  One "step" = one pass of the hot path over that batch, with
-the packed sequences already resident in HBM (torch tensors wrapped zero-copy by the C ABI).  Pairs are
-independent, so ranks shard them with no data-path collective (weak scaling); the only collective is the
-final RCCL all_gather of the fixed 12-byte (s, n_iter) records, inside the timed region.
+Default workload (the batch BASELINE.json's metric is quoted on): per GPU, 1024 synthetic pairs, 10 kb target, query =
+target mutated at 5 % (60/20/20 sub/ins/del, geometric indels), score-only mwf_wfa_exact semantics, default
+penalties.  One "step" = one pass of the hot path over that batch: the alignment kernels on sequences already
+resident in HBM (torch tensors wrapped zero-copy by the C ABI), every pair's (s, n_iter) record back on the host
+(mwf_gpu_batch_results: one device-to-host copy, and any pair that needs a re-run gets it inside the step), and — at
+N > 1 — the one RCCL collective that gathers the records of all ranks.  `value` = bases aligned by all ranks / wall.
+The host-buffers-in to host-results-out rate of the same batch (PCIe both ways, warmed, pooled allocations) is
+printed beside it as `end_to_end_gbps`; it is never `value`.
 
 Printed JSON (one line, rank 0): the driver contract fields plus
-  roofline     — 48 algorithmic bytes per (penalty,diagonal) cell (7 int32 loads + 5 stores, reference
-                 miniwfa.c:269-276) x cells per launch / HIP-event kernel time, against 8 TB/s
+  roofline     — SURVEY.md §8(d)'s algorithmic bytes per (penalty, diagonal) cell (48 score-only: 7 int32 loads + 5
+                 stores of reference miniwfa.c:269-276) x cells per launch / HIP-event kernel time, against 8 TB/s; and,
+                 because the band kernel keeps four of the five wavefront arrays on chip, `binding`: the larger of the
+                 HBM fraction on the bytes the kernel itself must move and the VALU-issue fraction (what actually limits)
   cpu_baseline — the compiled reference (oracle/_ref, kind "reference") or our C restatement (kind "port")
                  on the host cores, bounded sample of the same batch (rank 0, N=1 only)
+  call_latency_us, long_pairs, peak_device_bytes, n_retries — extras (rank 0, N=1 only)
 """
 from __future__ import annotations
 
@@ -32,6 +38,9 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_CELL = 48          # score-only; 49 with traceback, 97 in the low-memory first pass
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# VALU issue peak: 256 CUs x 4 SIMD-32 per CU x 2.4 GHz, a wave64 VALU instruction occupies its SIMD for 2 cycles
+# (MI355X_MICROARCH.md: "issues each VALU instruction over 2 cycles (32 lanes/cycle x 2)", v_fma_f32 row: 2 cyc)
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2
 
 
 def host_cores() -> int:
@@ -60,25 +69,127 @@ class _DevPtr:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
+KERNEL_NAMES = {0: "wfa_batch_kernel (generic: one workgroup per pair, ring in HBM)", 1: "wfa_coop_kernel (one pair across the device)",
+                2: "wfa_band_kernel (one workgroup per pair, E/F in registers, H rows prefetched)"}
+
+
+def call_latency(mw, synth_pair, reps=40):
+    """Per-call time of the drop-in mwf_wfa_exact (host strings in, mwf_rst_t out) next to the compiled reference's."""
+    out = {}
+    try:
+        from oracle.pyoracle import Reference, make_opt
+        ref = Reference(arena=True) if Reference.available() else None
+    except Exception:
+        ref = None
+    for tl in (200, 2000, 10000):
+        t, q = synth_pair(123, tl, 0.05)
+        for label, flag in (("score", 0), ("cigar", 1)):
+            o = mw.opt_init(flag=flag)
+            for _ in range(3):
+                mw.wfa_exact(t, q, o)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                mw.wfa_exact(t, q, o)
+            rec = {"gpu_us": (time.perf_counter() - t0) / reps * 1e6}
+            if ref is not None:
+                ro = make_opt(flag=flag)
+                ref.align(t, q, ro)
+                n = max(3, reps // 4)
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    ref.align(t, q, ro)
+                rec["cpu_reference_us"] = (time.perf_counter() - t0) / n * 1e6
+            out[f"{tl}bp_{label}"] = rec
+    return out
+
+
+def long_pairs(mw, synth_pair, PackedBatch, cpu: bool):
+    """BASELINE configs[1] and configs[3] (stand-ins): one pair on the whole device, each mode on a fresh
+    engine so that `peak_device_bytes` is that mode's own need; the compiled reference timed beside it where that takes
+    seconds (the 5 Mb pair's reference time — minutes — comes from the committed golden fixture)."""
+    lp = {}
+    gold = {}
+    try:
+        for line in open(os.path.join(ROOT, "tests", "golden", "long_pairs.jsonl")):
+            v = json.loads(line)
+            gold[v["id"]] = v
+    except Exception:
+        pass
+    ref = None
+    if cpu:
+        try:
+            from oracle.pyoracle import Reference, make_opt
+            ref = Reference(arena=True) if Reference.available() else None
+        except Exception:
+            ref = None
+    specs = (("c4_like_150kb", 2001, 150000, 0.035, 0, 0,
+              (("score", {}, "c4-score"), ("cigar_highmem", {"flag": 1}, "c4-cigar"), ("cigar_lowmem_p5000", {"flag": 1, "step": 5000}, "c4-lowmem"))),
+             ("mhc_like_5Mb", 2002, 5000000, 0.008, 3, 15000,
+              (("cigar_lowmem_p5000", {"flag": 1, "step": 5000}, "mhc-lowmem"), ("score", {}, "mhc-score"))))
+    for name, seed, tl_, p_, nl, lm, modes in specs:
+        t_, q_ = synth_pair(seed, tl_, p_, nl, lm)
+        for label, kw, gid in modes:
+            eng = mw.Engine(0)
+            bb = eng.upload(PackedBatch([(t_, q_)]))
+            o_ = mw.opt_init(**kw)
+            bb.align(o_)
+            bb.results()               # first call also sizes the workspace
+            t0 = time.perf_counter()
+            bb.align(o_)
+            s_, it_, nc_ = bb.results()
+            wall = time.perf_counter() - t0
+            st_ = eng.stats()
+            rec = {"s": int(s_[0]), "n_iter": int(it_[0]), "kernel_s": st_.kernel_ms * 1e-3, "wall_s": wall, "cells_pass1": int(st_.cells_pass1),
+                   "gbp_s": (len(t_) + len(q_)) / wall / 1e9, "peak_device_bytes": int(st_.dev_bytes_peak), "n_retries": int(st_.n_retries)}
+            if kw.get("flag"):
+                cg = bb.cigar(0, int(nc_[0])).tolist()
+                rec["cigar_rescored_ok"] = mw.cigar2score(mw.opt_init(), cg) == (int(s_[0]), len(t_), len(q_))
+            g = gold.get(gid)
+            if g:
+                rec["matches_reference_golden"] = (int(s_[0]), int(it_[0])) == (g["expect"]["s"], g["expect"]["n_iter"])
+                rec["cpu_reference_s_build_container"] = g.get("reference_wall_s")
+            if ref is not None and tl_ <= 200000:
+                ro = make_opt(**kw)
+                t0 = time.perf_counter()
+                rs = ref.align(t_, q_, ro)
+                rec["cpu_reference_s"] = time.perf_counter() - t0
+                rec["cpu_reference_matches"] = (rs[0], rs[1]) == (int(s_[0]), int(it_[0]))
+            lp.setdefault(name, {"tl": len(t_), "ql": len(q_)})[label] = rec
+            bb.free()
+            eng.close()
+    return lp
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=1024, help="pairs per GPU")
-    ap.add_argument("--len", type=int, default=10000, dest="tl")
-    ap.add_argument("--div", type=float, default=0.05)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", type=int, default=3, choices=(3, 5), help="3: 1024 x 10 kb per GPU (weak); 5: 10 000 x 50 kb in total (strong)")
+    ap.add_argument("--pairs", type=int, default=None, help="pairs per GPU (config 3) / in total (config 5)")
+    ap.add_argument("--len", type=int, default=None, dest="tl")
+    ap.add_argument("--div", type=float, default=None)
     ap.add_argument("--cigar", action="store_true", help="score+CIGAR (high-memory) instead of score-only")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--slots-per-cu", type=int, default=0)
-    ap.add_argument("--cpu-sample", type=int, default=1024, help="pairs in the cpu_baseline sample (0: skip)")
+    ap.add_argument("--cpu-sample", type=int, default=None, help="pairs in the cpu_baseline sample (0: skip)")
     ap.add_argument("--long-pairs", type=int, default=1, help="also time the single-pair configs (C4-like 150 kb, MHC-like 5 Mb) on rank 0 at N=1")
-    ap.add_argument("--seed", type=int, default=50000)
+    ap.add_argument("--extras", type=int, default=1, help="0: skip end_to_end / call latency / long pairs (profiling runs)")
+    ap.add_argument("--seed", type=int, default=None)
     args = ap.parse_args()
+    strong = args.config == 5
+    if strong:
+        defaults = dict(pairs=10000, tl=50000, div=0.03, seed=60000, steps=2, warmup=1, cpu_sample=32)
+    else:
+        defaults = dict(pairs=1024, tl=10000, div=0.05, seed=50000, steps=10, warmup=2, cpu_sample=1024)
+    for k, v in defaults.items():
+        if getattr(args, k) is None:
+            setattr(args, k, v)
 
     import torch
     import miniwfa_amd as mw
     from miniwfa_amd.synth import synth_pair, PackedBatch
+    from miniwfa_amd.shard import gather_records, deal_pairs
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -96,7 +207,15 @@ def main():
         dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
 
     # ---- synthetic batch of this rank, resident in HBM before anything is timed
-    pairs = [synth_pair(args.seed + rank * args.pairs + i, args.tl, args.div) for i in range(args.pairs)]
+    if strong:   # fixed total work: the pairs are dealt by work (uniform lengths here: an even deal), every rank generates its own
+        n_total = args.pairs
+        deal = deal_pairs([2 * args.tl] * n_total, world)
+        my_ids = deal[rank].tolist()
+    else:        # fixed work per GPU: contiguous seeds per rank
+        n_total = args.pairs * world
+        deal = [np.arange(r * args.pairs, (r + 1) * args.pairs) for r in range(world)]
+        my_ids = deal[rank].tolist()
+    pairs = [synth_pair(args.seed + i, args.tl, args.div) for i in my_ids]
     pk = PackedBatch(pairs)
     d_seqs = torch.from_numpy(pk.seqs.copy()).to(dev)
     d_toff, d_qoff = torch.from_numpy(pk.t_off).to(dev), torch.from_numpy(pk.q_off).to(dev)
@@ -112,19 +231,19 @@ def main():
     opt = mw.opt_init(flag=mw.MWF_F_CIGAR if args.cigar else 0)
     d_s = torch.as_tensor(_DevPtr(batch.dev_scores_ptr(), pk.n, "<i4"), device=dev)
     d_it = torch.as_tensor(_DevPtr(batch.dev_iters_ptr(), pk.n, "<i8"), device=dev)
-    from miniwfa_amd.shard import gather_records
 
-    kernel_ms = []
+    kernel_ms, retries = [], 0
 
     def step(record: bool):
+        nonlocal retries
         batch.align(opt)                       # kernels enqueued on torch's current stream
-        if args.cigar:
-            batch.results()                    # CIGAR mode may have to retry pairs: needs the host in the loop
-        if world > 1:                          # the result gather of the multi-GPU job (RCCL all_gather over xGMI)
-            gather_records(dist, d_s, d_it, world * pk.n, device=dev)
+        res = batch.results()                  # (s, n_iter) records on the host; re-runs of pairs that did not fit happen here
+        retries += eng.stats().n_retries
+        if world > 1:                          # the result gather of the multi-GPU job: one RCCL all_gather over xGMI
+            gather_records(dist, d_s, d_it, n_total, device=dev, deal=deal)
         if record:
-            torch.cuda.synchronize(dev)
             kernel_ms.append(eng.stats().kernel_ms)
+        return res
 
     def fence():
         if world > 1:
@@ -134,26 +253,27 @@ def main():
     for _ in range(args.warmup):
         step(False)
     fence()
+    retries = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(False)
     fence()
     elapsed = time.perf_counter() - t0
-    # kernel-only timing (HIP events on the launch stream), outside the wall-clock region so the per-step
-    # event sync does not perturb it
+    timed_retries = retries
+    # kernel-only timing (HIP events recorded by the library on the launch stream), outside the wall-clock region
     for _ in range(max(3, min(args.steps, 10))):
-        step(True)
-    s, n_iter, _ = batch.results()
+        s, n_iter, _ = step(True)
     cells = int(n_iter.sum())
     assert (s >= 0).all(), "some pairs did not finish"
+    st = eng.stats()
 
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        tot = torch.tensor([pk.bases, cells], dtype=torch.int64, device=dev)
+        tot = torch.tensor([pk.bases, cells, timed_retries], dtype=torch.int64, device=dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        total_bases, total_cells = int(tot[0].item()), int(tot[1].item())
+        total_bases, total_cells, timed_retries = int(tot[0].item()), int(tot[1].item()), int(tot[2].item())
     else:
         total_bases, total_cells = pk.bases, cells
 
@@ -165,59 +285,84 @@ def main():
     k_ms = float(np.mean(kernel_ms))
     bytes_per_cell = 49 if args.cigar else ALGO_BYTES_PER_CELL
     achieved = bytes_per_cell * cells / (k_ms * 1e-3) / 1e9
+    mode = "score+CIGAR high-mem" if args.cigar else "score-only"
+    if strong:
+        workload = (f"{n_total} pairs in total x {args.tl} bp, {args.div:g} divergence, {mode} mwf_wfa_exact, default penalties, dealt over "
+                    f"{world} GPU(s) (BASELINE configs[4])")
+    else:
+        workload = (f"{args.pairs} pairs/GPU x {args.tl} bp, {args.div:g} divergence, {mode} mwf_wfa_exact, default penalties (BASELINE configs[2])")
     out = {
         "metric": "aligned Gbp/s (q+t)",
         "value": total_bases * args.steps / elapsed / 1e9,
         "unit": "Gbp/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "int32", "data": "synthetic",
         "config": {
-            "workload": f"{args.pairs} pairs/GPU x {args.tl} bp, {args.div:g} divergence, "
-                        f"{'score+CIGAR high-mem' if args.cigar else 'score-only'} mwf_wfa_exact, default penalties (BASELINE configs[2])",
-            "pairs_per_gpu": args.pairs, "target_len": args.tl, "divergence": args.div,
-            "bases_per_gpu": pk.bases, "cells_per_gpu": cells, "mean_s": float(s.mean()),
-            "kernel": {0: "wfa_batch_kernel (generic: one workgroup per pair, ring in HBM)", 1: "wfa_coop_kernel (one pair across the device)",
-                       2: "wfa_band_kernel (one workgroup per pair, E/F in registers, H rows prefetched)"}.get(eng.stats().kernel_kind, "?"),
-            "grid": eng.stats().grid, "block": eng.stats().block,
-            "parallelism": f"pairs sharded over {world} GPU(s), RCCL all_gather of (s,n_iter)",
+            "workload": workload,
+            "pairs_this_gpu": pk.n, "pairs_total": n_total, "target_len": args.tl, "divergence": args.div,
+            "bases_this_gpu": pk.bases, "cells_this_gpu": cells, "mean_s": float(s.mean()),
+            "step": "alignment kernels on HBM-resident sequences + (s, n_iter) records to the host" + (" + RCCL all_gather of the records" if world > 1 else ""),
+            "kernel": KERNEL_NAMES.get(st.kernel_kind, "?"), "grid": st.grid, "block": st.block,
+            "parallelism": f"pairs dealt over {world} GPU(s), no data-path collective, one RCCL all_gather of (s,n_iter)",
         },
         "gcells_per_s": total_cells * args.steps / elapsed / 1e9,
+        "kernel_gbps": pk.bases / (k_ms * 1e-3) / 1e9,
+        "n_retries": timed_retries,
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": None, "bytes_per_cell": bytes_per_cell, "cells_per_launch": cells, "kernel_ms": k_ms,
         },
     }
-    if eng.stats().kernel_kind == 2:
-        # The band kernel keeps E1/F1/E2/F2 in registers: of the 48 algorithmic bytes per cell only H crosses HBM (three
-        # 4-byte loads + one 4-byte store, +1 traceback byte).  `achieved`/`frac` above follow SURVEY 8(d)'s definition and
-        # can therefore exceed the HBM peak; the figures below are the kernel's own floor and what the PMC counters saw.
-        kb = 17 if args.cigar else 16
-        out["roofline"]["kernel_bytes_per_cell"] = kb
-        out["roofline"]["achieved_kernel_bytes"] = kb * cells / (k_ms * 1e-3) / 1e9
-        out["roofline"]["frac_kernel_bytes"] = out["roofline"]["achieved_kernel_bytes"] / HBM_PEAK_GBS
-        out["roofline"]["note"] = ("frac uses SURVEY 8(d)'s 48 B/cell (the reference's 7 loads + 5 stores); this kernel moves only H "
-                                   "(kernel_bytes_per_cell) and is bound by instruction issue + one barrier per penalty, not by HBM: DESIGN.md 4.2")
-    traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(traffic_file):
-        try:
-            tr = json.load(open(traffic_file))
-            key = f"{args.pairs}x{args.tl}@{args.div:g}{'c' if args.cigar else 's'}"
-            if key in tr:
-                out["roofline"]["traffic"] = tr[key]["hbm_bytes_per_launch"]
-                out["roofline"]["traffic_gbs"] = tr[key]["hbm_bytes_per_launch"] / (k_ms * 1e-3) / 1e9
-                out["roofline"]["traffic_source"] = tr[key].get("source")
-        except Exception:
-            pass
+    # What the kernel itself must move per cell (the floor of ITS traffic): the band kernel keeps E1/F1/E2/F2 in registers,
+    # so only H crosses HBM (three loads + one store per cell; 2-byte offsets in the packed variants), +1 traceback byte;
+    # the generic kernel with E2/F2 in LDS moves 32 of the 48.
+    tr = {}
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except Exception:
+        pass
+    key = f"{pk.n}x{args.tl}@{args.div:g}{'c' if args.cigar else 's'}"
+    prof = tr.get(key, {})
+    rf = out["roofline"]
+    if st.kernel_kind == 2:
+        kb = prof.get("kernel_bytes_per_cell", 16) + (1 if args.cigar else 0)
+    elif st.kernel_kind == 0:
+        kb = 32 + (1 if args.cigar else 0)
+    else:
+        kb = 16 + (1 if args.cigar else 0)
+    rf["kernel_bytes_per_cell"] = kb
+    hbm_frac = kb * cells / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    cands = [{"bound": "hbm (bytes this kernel must move)", "achieved": kb * cells / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac}]
+    if "hbm_bytes_per_launch" in prof:
+        rf["traffic"] = prof["hbm_bytes_per_launch"]
+        rf["traffic_gbs"] = prof["hbm_bytes_per_launch"] / (k_ms * 1e-3) / 1e9
+        rf["traffic_source"] = prof.get("source")
+    if "valu_insts_per_launch" in prof:
+        vi = prof["valu_insts_per_launch"]
+        cands.append({"bound": "valu issue", "achieved": vi / (k_ms * 1e-3) / 1e9, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
+                      "frac": vi / (k_ms * 1e-3) / 1e9 / VALU_PEAK_GINST, "valu_lane_ops_per_cell": vi * 64 / prof.get("cells_per_launch", cells),
+                      "source": prof.get("valu_source")})
+    rf["binding"] = max(cands, key=lambda c: c["frac"])
+    rf["candidates"] = cands
+    rf["note"] = ("frac follows SURVEY 8(d): the reference's 48 B per cell; a kernel that keeps wavefront arrays on chip can exceed 1 by that "
+                  "definition. `binding` is the largest fraction among the rooflines of what this kernel really does; what is left is "
+                  "per-penalty synchronisation latency (DESIGN.md section 4).")
 
-    # ---- PCIe-inclusive rate (host buffers in, host results out) — reported beside, never as `value`
-    t1 = time.perf_counter()
-    b2 = eng.upload(pk)
-    b2.align(opt)
-    b2.results()
-    out["pcie_inclusive_gbps"] = pk.bases / (time.perf_counter() - t1) / 1e9
-    b2.free()
+    if world == 1 and args.extras:
+        out["peak_device_bytes"] = int(st.dev_bytes_peak)
+        # ---- host buffers in -> host results out (PCIe both ways), warmed, pooled allocations — reported beside, never as `value`
+        try:
+            for _ in range(2):
+                b2 = eng.upload(pk); b2.align(opt); b2.results(); b2.free()
+            reps = max(3, min(args.steps, 10))
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                b2 = eng.upload(pk); b2.align(opt); b2.results(); b2.free()
+            out["end_to_end_gbps"] = pk.bases * reps / (time.perf_counter() - t1) / 1e9
+        except Exception as e:
+            out["end_to_end_gbps"] = repr(e)
 
     # ---- CPU baseline: same pairs (a bounded sample), host cores of this box
     if world == 1 and args.cpu_sample > 0:
@@ -243,33 +388,18 @@ def main():
             "gcells_per_s": float(cit.sum()) / sec / 1e9,
             "gpu_matches_cpu_on_sample": ok,
         }
-    # ---- the single-pair configs of BASELINE.json (configs[1] and configs[3]); stand-ins, see SURVEY.md §8d
-    if world == 1 and args.long_pairs:
-        lp = {}
+    batch.free()
+    eng.close()
+    if world == 1 and args.extras:
         try:
-            batch.free()
-            for name, seed, tl_, p_, nl, lm, modes in (
-                    ("c4_like_150kb", 2001, 150000, 0.035, 0, 0, (("score", {}), ("cigar_highmem", {"flag": 1}))),
-                    ("mhc_like_5Mb", 2002, 5000000, 0.008, 3, 15000, (("cigar_lowmem_p5000", {"flag": 1, "step": 5000}),))):
-                t_, q_ = synth_pair(seed, tl_, p_, nl, lm)
-                bb = eng.upload(PackedBatch([(t_, q_)]))
-                for label, kw in modes:
-                    o_ = mw.opt_init(**kw)
-                    bb.align(o_)
-                    bb.results()               # first call also sizes the workspace (55 GB traceback arena for the 5 Mb pair)
-                    bb.align(o_)
-                    s_, it_, nc_ = bb.results()
-                    st_ = eng.stats()
-                    rec = {"s": int(s_[0]), "n_iter": int(it_[0]), "kernel_s": st_.kernel_ms * 1e-3, "cells_pass1": int(st_.cells_pass1),
-                           "gbp_s": (len(t_) + len(q_)) / (st_.kernel_ms * 1e-3) / 1e9}
-                    if kw.get("flag"):
-                        cg = bb.cigar(0, int(nc_[0])).tolist()
-                        rec["cigar_rescored_ok"] = mw.cigar2score(mw.opt_init(), cg) == (int(s_[0]), len(t_), len(q_))
-                    lp.setdefault(name, {"tl": len(t_), "ql": len(q_)})[label] = rec
-                bb.free()
+            out["call_latency_us"] = call_latency(mw, synth_pair)
         except Exception as e:  # never lose the headline line over the extras
-            lp["error"] = repr(e)
-        out["long_pairs"] = lp
+            out["call_latency_us"] = {"error": repr(e)}
+        if args.long_pairs and not strong:
+            try:
+                out["long_pairs"] = long_pairs(mw, synth_pair, PackedBatch, cpu=args.cpu_sample > 0)
+            except Exception as e:
+                out["long_pairs"] = {"error": repr(e)}
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

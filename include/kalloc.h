@@ -44,8 +44,65 @@ void  km_stat_print(const void *km);
 }
 #endif
 
+/* typed convenience forms, reference kalloc.h:29-31 */
 #define Kmalloc(km, type, cnt)       ((type*)kmalloc((km), (cnt) * sizeof(type)))
 #define Kcalloc(km, type, cnt)       ((type*)kcalloc((km), (cnt), sizeof(type)))
 #define Krealloc(km, type, ptr, cnt) ((type*)krealloc((km), (ptr), (cnt) * sizeof(type)))
+
+/* assign-in-place forms, reference kalloc.h:33-35: `ptr` receives `len` elements of its own pointee type */
+#define KMALLOC(km, ptr, len)  ((ptr) = (__typeof__(ptr))kmalloc((km), (len) * sizeof(*(ptr))))
+#define KCALLOC(km, ptr, len)  ((ptr) = (__typeof__(ptr))kcalloc((km), (len), sizeof(*(ptr))))
+#define KREALLOC(km, ptr, len) ((ptr) = (__typeof__(ptr))krealloc((km), (ptr), (len) * sizeof(*(ptr))))
+
+/* grow array `a` of capacity `m` (an lvalue): 16 elements at first, then by half — reference kalloc.h:37-40 */
+#define KEXPAND(km, a, m) \
+	do { \
+		(m) = (m) >= 4 ? (m) + ((m) >> 1) : 16; \
+		KREALLOC((km), (a), (m)); \
+	} while (0)
+
+#ifndef klib_unused
+#if defined(__GNUC__) || defined(__clang__)
+#define klib_unused __attribute__((__unused__))
+#else
+#define klib_unused
+#endif
+#endif
+
+/* Object pool over an arena, reference kalloc.h:50-80.  KALLOC_POOL_INIT(name, T) defines kmp_<name>_t and
+ * kmp_init_<name>(km), kmp_destroy_<name>(mp), kmp_alloc_<name>(mp) (zero-filled when fresh, recycled as is),
+ * kmp_free_<name>(mp, p) (parks p for re-use); `cnt` counts objects currently handed out. */
+#define KALLOC_POOL_INIT2(SCOPE, name, kmptype_t) \
+	typedef struct { \
+		size_t cnt, n, max; \
+		kmptype_t **buf; \
+		void *km; \
+	} kmp_##name##_t; \
+	SCOPE kmp_##name##_t *kmp_init_##name(void *km) \
+	{ \
+		kmp_##name##_t *pool = (kmp_##name##_t*)kcalloc(km, 1, sizeof(kmp_##name##_t)); \
+		pool->km = km; \
+		return pool; \
+	} \
+	SCOPE void kmp_destroy_##name(kmp_##name##_t *pool) \
+	{ \
+		size_t i_; \
+		for (i_ = 0; i_ < pool->n; ++i_) kfree(pool->km, pool->buf[i_]); \
+		kfree(pool->km, pool->buf); \
+		kfree(pool->km, pool); \
+	} \
+	SCOPE kmptype_t *kmp_alloc_##name(kmp_##name##_t *pool) \
+	{ \
+		++pool->cnt; \
+		return pool->n ? pool->buf[--pool->n] : (kmptype_t*)kcalloc(pool->km, 1, sizeof(kmptype_t)); \
+	} \
+	SCOPE void kmp_free_##name(kmp_##name##_t *pool, kmptype_t *obj) \
+	{ \
+		--pool->cnt; \
+		if (pool->n == pool->max) KEXPAND(pool->km, pool->buf, pool->max); \
+		pool->buf[pool->n++] = obj; \
+	}
+
+#define KALLOC_POOL_INIT(name, kmptype_t) KALLOC_POOL_INIT2(static inline klib_unused, name, kmptype_t)
 
 #endif

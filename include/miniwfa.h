@@ -54,7 +54,11 @@ typedef struct {
 void mwf_opt_init(mwf_opt_t *opt);
 
 /* reference miniwfa.h:83 / miniwfa.c:603-615: optimal global alignment of ts[0,tl) vs qs[0,ql).
- * Sequences are length-delimited arbitrary bytes compared verbatim.  *r is fully overwritten. */
+ * Sequences are length-delimited arbitrary bytes compared verbatim.  *r is fully overwritten.
+ * Limits of this implementation (the reference has neither; both end in a message and abort(), like the reference's
+ * own assert/panic paths): max(x, o1+e1, o2+e2) < 256 (ring slots kept in LDS tables), and tl+ql < 2^31-4 (columns
+ * are 32-bit).  x, e1, e2 >= 1 and o1, o2 >= 0, as the reference requires implicitly (miniwfa.c:390-392).
+ * Device: MWF_DEVICE=<ordinal> (default 0).  Any number of host threads may call concurrently. */
 void mwf_wfa_exact(void *km, const mwf_opt_t *opt, int32_t tl, const char *ts, int32_t ql, const char *qs, mwf_rst_t *r);
 
 /* reference miniwfa.h:85 / miniwfa.c:898-908: exact with step=0 and max_iter=1e8; if that stops, mwf_wfa_chain. */
@@ -72,9 +76,19 @@ void mwf_assert_cigar(const mwf_opt_t *opt, int32_t n_cigar, const uint32_t *cig
  * PART 2 — batch and device-resident API (new; SURVEY.md §8b "New")
  * ---------------------------------------------------------------------------------------- */
 
-/* n independent pairs from host buffers; r[i] is filled exactly as mwf_wfa_exact would fill it. */
+/* n independent pairs from host buffers; r[i] is filled exactly as mwf_wfa_exact would fill it.  Replaces the serial
+ * loop over pairs of reference main.c:67-72.  Runs on the device MWF_DEVICE names, or — when the environment sets
+ * MWF_DEVICES to "all" or a count — dealt over that many devices as mwf_wfa_batch_multi does. */
 void mwf_wfa_batch(void *km, const mwf_opt_t *opt, int32_t n, const int32_t *tl, const char *const *ts,
                    const int32_t *ql, const char *const *qs, mwf_rst_t *r);
+
+/* The same over several devices of one node: pairs are dealt longest first to the device with the least
+ * work so far, every device runs its share on a host thread with its own engine, nothing crosses devices while they
+ * work, and the results are merged back in the caller's order.  devices: n_dev HIP ordinals (an ordinal may repeat),
+ * or NULL for ordinals 0..n_dev-1 (n_dev <= 0: every visible device).  CIGARs are allocated from `km` on the calling
+ * thread only. */
+void mwf_wfa_batch_multi(void *km, const mwf_opt_t *opt, int32_t n, const int32_t *tl, const char *const *ts,
+                         const int32_t *ql, const char *const *qs, mwf_rst_t *r, int32_t n_dev, const int32_t *devices);
 
 typedef struct mwf_gpu_s mwf_gpu_t;             /* engine: one device, one stream, one memory pool */
 typedef struct mwf_gpu_batch_s mwf_gpu_batch_t; /* a set of pairs resident in that device's HBM */
@@ -97,17 +111,24 @@ mwf_gpu_batch_t *mwf_gpu_batch_wrap(mwf_gpu_t *g, int32_t n, const void *d_seqs,
 void mwf_gpu_batch_free(mwf_gpu_batch_t *b);
 
 /* Align every pair of the batch with `opt`.  Kernels are enqueued on the engine's stream; the call
- * returns after they are enqueued (it only synchronises when a pair has to be retried with a larger
- * traceback arena).  Returns 0, or a negative error (see mwf_gpu_last_error). */
+ * returns after they are enqueued — except on the whole-device kernel (a few long pairs), whose launches are serialised
+ * per device and waited for.  Pairs that need a re-run get it in mwf_gpu_batch_results().  Returns 0, or a negative
+ * error (see mwf_gpu_last_error). */
 int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt);
 
 /* Wait for the batch and copy the fixed-size results to host arrays of length n (any may be NULL). */
 int mwf_gpu_batch_results(mwf_gpu_t *g, mwf_gpu_batch_t *b, int32_t *s, int64_t *n_iter, int32_t *n_cigar);
-/* Device pointers to the same fixed-size results (int32 s[n], int64 n_iter[n]) for zero-copy consumers. */
+/* Device pointers to the same fixed-size results (int32 s[n], int64 n_iter[n], int32 status[n]) for zero-copy consumers.
+ * They are FINAL only after mwf_gpu_batch_results() returned: a pair whose window or traceback outgrew the workspace of
+ * the kernel it ran on is re-run by that call.  Until then such a pair reads s == -2 (never a valid answer; -1 means
+ * "stopped by max_s / max_iter", as in the reference) and status != 0 (0: done, 1: stopped). */
 const int32_t *mwf_gpu_batch_dev_scores(const mwf_gpu_batch_t *b);
 const int64_t *mwf_gpu_batch_dev_iters(const mwf_gpu_batch_t *b);
+const int32_t *mwf_gpu_batch_dev_status(const mwf_gpu_batch_t *b);
 /* CIGAR of pair i into dst (capacity cap words); returns n_cigar or a negative error. */
 int32_t mwf_gpu_batch_cigar(mwf_gpu_t *g, mwf_gpu_batch_t *b, int32_t i, uint32_t *dst, int32_t cap);
+/* Optional: bring every CIGAR of the batch to the host in one copy; mwf_gpu_batch_cigar then serves from that copy. */
+int mwf_gpu_batch_fetch_cigars(mwf_gpu_t *g, mwf_gpu_batch_t *b);
 
 /* Timing and counters of the most recent mwf_gpu_batch_align on this engine. */
 typedef struct {
@@ -117,7 +138,9 @@ typedef struct {
 	int32_t n_launches;    /* kernel launches issued */
 	int32_t n_retries;     /* pairs re-run with a larger traceback arena */
 	int32_t grid, block;   /* geometry of the dominant launch */
-	int32_t kernel_kind;   /* 0: one workgroup per pair; 1: one pair across the whole device */
+	int32_t kernel_kind;   /* 0: one workgroup per pair (generic); 1: one pair across the whole device; 2: one workgroup per pair (band) */
+	int64_t dev_bytes;     /* device memory the engine holds now: workspace pools + recycled batch allocations (live batches hold their own) */
+	int64_t dev_bytes_peak;/* ... and the most it held since creation or the last mwf_gpu_set(g, "trim", 0) */
 } mwf_gpu_stats_t;
 void mwf_gpu_get_stats(const mwf_gpu_t *g, mwf_gpu_stats_t *st);
 
@@ -125,7 +148,8 @@ void mwf_gpu_get_stats(const mwf_gpu_t *g, mwf_gpu_stats_t *st);
  * wavefront slice the core pass opened for `pair`; returns the number of penalties written (<= cap). */
 int32_t mwf_gpu_debug_band(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt, int32_t pair, int32_t *lohi, int32_t cap);
 
-/* Tunables (call before align): name in {"block", "slots_per_cu", "coop_min_len", "tb_budget_mb", "force_kind", "coop_tb_cap_mb", "band_pack", "coop_spin_limit", "scalar_generic", "lds_e2"}. */
+/* Tunables (call before align): name in {"block", "slots_per_cu", "coop_min_len", "tb_budget_mb", "force_kind", "coop_tb_cap_mb", "band_pack",
+ * "coop_spin_limit", "scalar_generic", "lds_e2", "lowmem_budget_mb"}; "trim" frees the engine's workspace pools (they grow back on demand). */
 int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value);
 
 #ifdef __cplusplus

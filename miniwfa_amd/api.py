@@ -39,7 +39,8 @@ class MwfRst(C.Structure):
 
 class GpuStats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("cells", C.c_int64), ("cells_pass1", C.c_int64), ("n_launches", C.c_int32),
-                ("n_retries", C.c_int32), ("grid", C.c_int32), ("block", C.c_int32), ("kernel_kind", C.c_int32)]
+                ("n_retries", C.c_int32), ("grid", C.c_int32), ("block", C.c_int32), ("kernel_kind", C.c_int32),
+                ("dev_bytes", C.c_int64), ("dev_bytes_peak", C.c_int64)]
 
 
 class KmStat(C.Structure):
@@ -50,7 +51,7 @@ class KmStat(C.Structure):
 # every symbol include/miniwfa.h and include/kalloc.h declare
 ABI_SYMBOLS = (
     "mwf_opt_init", "mwf_wfa_exact", "mwf_wfa_auto", "mwf_wfa_chain", "mwf_cigar2score", "mwf_assert_cigar",
-    "mwf_wfa_batch", "mwf_gpu_device_count", "mwf_gpu_create", "mwf_gpu_destroy", "mwf_gpu_last_error",
+    "mwf_wfa_batch", "mwf_wfa_batch_multi", "mwf_gpu_batch_dev_status", "mwf_gpu_batch_fetch_cigars", "mwf_gpu_device_count", "mwf_gpu_create", "mwf_gpu_destroy", "mwf_gpu_last_error",
     "mwf_gpu_batch_upload", "mwf_gpu_batch_wrap", "mwf_gpu_batch_free", "mwf_gpu_batch_align", "mwf_gpu_batch_results",
     "mwf_gpu_batch_dev_scores", "mwf_gpu_batch_dev_iters", "mwf_gpu_batch_cigar", "mwf_gpu_get_stats", "mwf_gpu_set",
     "mwf_gpu_debug_band",
@@ -84,6 +85,12 @@ def lib() -> C.CDLL:
     L.mwf_assert_cigar.restype = None
     L.mwf_wfa_batch.argtypes = [C.c_void_p, P(MwfOpt), C.c_int32, P(C.c_int32), P(C.c_char_p), P(C.c_int32), P(C.c_char_p), P(MwfRst)]
     L.mwf_wfa_batch.restype = None
+    L.mwf_wfa_batch_multi.argtypes = L.mwf_wfa_batch.argtypes + [C.c_int32, P(C.c_int32)]
+    L.mwf_wfa_batch_multi.restype = None
+    L.mwf_gpu_batch_dev_status.argtypes = [C.c_void_p]
+    L.mwf_gpu_batch_dev_status.restype = C.c_void_p
+    L.mwf_gpu_batch_fetch_cigars.argtypes = [C.c_void_p, C.c_void_p]
+    L.mwf_gpu_batch_fetch_cigars.restype = C.c_int
     L.mwf_gpu_device_count.restype = C.c_int
     L.mwf_gpu_create.argtypes = [C.c_int, C.c_void_p]
     L.mwf_gpu_create.restype = C.c_void_p
@@ -177,6 +184,21 @@ def wfa_batch(pairs: Sequence[tuple[bytes, bytes]], opt: MwfOpt, km=None):
     qs = (C.c_char_p * n)(*[q for _, q in pairs])
     r = (MwfRst * n)()
     lib().mwf_wfa_batch(km, C.byref(opt), n, tl, ts, ql, qs, r)
+    return [_take(r[i], km) for i in range(n)]
+
+
+def wfa_batch_multi(pairs: Sequence[tuple[bytes, bytes]], opt: MwfOpt, devices: Sequence[int] | None = None, n_dev: int = 0, km=None):
+    """mwf_wfa_batch_multi: the batch dealt over several devices (an ordinal may repeat) -> list of (s, n_iter, cigar)."""
+    n = len(pairs)
+    if n == 0:
+        return []
+    tl = (C.c_int32 * n)(*[len(t) for t, _ in pairs])
+    ql = (C.c_int32 * n)(*[len(q) for _, q in pairs])
+    ts = (C.c_char_p * n)(*[t for t, _ in pairs])
+    qs = (C.c_char_p * n)(*[q for _, q in pairs])
+    r = (MwfRst * n)()
+    dv = (C.c_int32 * len(devices))(*devices) if devices else None
+    lib().mwf_wfa_batch_multi(km, C.byref(opt), n, tl, ts, ql, qs, r, len(devices) if devices else n_dev, dv)
     return [_take(r[i], km) for i in range(n)]
 
 
@@ -291,6 +313,15 @@ class Batch:
 
     def dev_iters_ptr(self) -> int:
         return lib().mwf_gpu_batch_dev_iters(self.h)
+
+    def dev_status_ptr(self) -> int:
+        return lib().mwf_gpu_batch_dev_status(self.h)
+
+    def fetch_cigars(self):
+        """Bring every CIGAR of the batch to the host in one copy (cigar() then serves from it)."""
+        rc = lib().mwf_gpu_batch_fetch_cigars(self.eng.h, self.h)
+        if rc != 0:
+            raise RuntimeError(f"CIGAR download failed ({rc}): " + self.eng.error())
 
     def debug_band(self, opt: MwfOpt, pair: int, cap: int = 1 << 20):
         """[(lo, hi)] in DIAGONAL coordinates of every slice the core pass opened for `pair` (diagnostics)."""

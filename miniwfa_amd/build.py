@@ -29,19 +29,40 @@ def stale() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """One object per source (only stale ones are recompiled, in parallel), then one link."""
     if not force and not stale():
         return LIB
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-           "-I", os.path.join(ROOT, "include"), "-I", CSRC, *srcs, "-o", LIB + ".tmp", "-lpthread"]
-    if verbose:
-        print(" ".join(cmd))
-    r = subprocess.run(cmd, capture_output=True, text=True)
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    hdr_time = max(os.path.getmtime(h) for h in HEADERS + [os.path.abspath(__file__)])
+    jobs, objs = [], []
+    for name in SOURCES:
+        src = os.path.join(CSRC, name)
+        if not os.path.exists(src):
+            continue
+        obj = os.path.join(objdir, name + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            jobs.append([hipcc(), *flags, "-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd))
+        return cmd, subprocess.run(cmd, capture_output=True, text=True)
+
+    with ThreadPoolExecutor(max(1, min(4, len(jobs)))) as ex:
+        for cmd, r in ex.map(run, jobs):
+            if r.returncode != 0:
+                sys.stderr.write(r.stdout + r.stderr)
+                raise RuntimeError("hipcc failed: " + " ".join(cmd))
+            if verbose and r.stderr.strip():
+                sys.stderr.write(r.stderr)
+    cmd, r = run([hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", LIB + ".tmp", "-lpthread"])
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
-        raise RuntimeError("hipcc failed building libmwf_hip.so")
-    if verbose and r.stderr.strip():
-        sys.stderr.write(r.stderr)
+        raise RuntimeError("hipcc failed linking libmwf_hip.so")
     os.replace(LIB + ".tmp", LIB)
     return LIB
 

@@ -149,6 +149,7 @@ __device__ __forceinline__ bool grid_sync(const BatchArgs &A, unsigned *sync, un
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		}
 		unsigned long long *const top = (unsigned long long*)sync;                        // [0]
+		int32_t *const abort_flag = (int32_t*)sync - 256 + 15;                            // this group's flags[15] (the barrier words sit 1024 bytes behind the flags)
 		unsigned *const grp_cnt = sync + 16;                                               // [16 + 8*g]
 		unsigned long long *const grp_gen = (unsigned long long*)(sync + 96);              // [96 + 8*g] (8-byte aligned)
 		const unsigned grp = lb & 7u, n_grp = n_groups < 8u ? n_groups : 8u;
@@ -166,7 +167,7 @@ __device__ __forceinline__ bool grid_sync(const BatchArgs &A, unsigned *sync, un
 				seen = __hip_atomic_load(top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				if ((unsigned)(seen & 0xffffffffu) >= n_grp * epoch) break;
 				__builtin_amdgcn_s_sleep(1);
-				if (++spins > A.coop_spin_limit) { ok = 0; break; }
+				if (++spins > A.coop_spin_limit || ((spins & 255u) == 0 && ld_ag(abort_flag))) { ok = 0; break; }
 			}
 			__hip_atomic_store(&grp_gen[4 * grp], (seen & 0xffffffff00000000ull) | epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		} else {
@@ -174,10 +175,11 @@ __device__ __forceinline__ bool grid_sync(const BatchArgs &A, unsigned *sync, un
 				seen = __hip_atomic_load(&grp_gen[4 * grp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				if ((unsigned)(seen & 0xffffffffu) >= epoch) break;
 				__builtin_amdgcn_s_sleep(1);
-				if (++spins > A.coop_spin_limit) { ok = 0; break; }
+				if (++spins > A.coop_spin_limit || ((spins & 255u) == 0 && ld_ag(abort_flag))) { ok = 0; break; }
 			}
 		}
 		if (FENCE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+		if (!ok) st_ag(abort_flag, 1); // whoever gives up first releases everybody else at once
 		sh.word[3] = ok;
 		sh.word[2] = (int32_t)(seen >> 32);
 	}
@@ -205,7 +207,7 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 	// last column, written by lane 63; 1: its first column, lane 0): which 0 = E1 | F1, 1 = E2 | F2, 2 = H after extension.
 	gran_t *const grans = (gran_t*)(A.coop_edge + (int64_t)grp * A.coop_edge_stride);
 	auto granule = [&](int32_t row, int32_t r, int32_t side, int32_t which) -> gran_t* { return grans + ((((int64_t)row * TC + r) * 2 + side) * 4 + which); };
-	int32_t *const gflags = (int32_t*)misc;                // [12..14]: origin offset, shrink reduction
+	int32_t *const gflags = (int32_t*)misc;                // [12..14]: origin offset, shrink reduction; [15]: set by the first workgroup that gives up a wait
 	// Per penalty (mod kFlagRing): "new low edge live", "new high edge live", "end cell reached | last state << 1", each as
 	// penalty << 4 | value, written by the one wave that owns the column in question.
 	int32_t *const fring = (int32_t*)misc + 1024;
@@ -380,7 +382,10 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 						const bool late = (need_e1 && gran_tag(ge1) != s_new - E1) || (need_e2 && gran_tag(ge2) != s_new - E2) ||
 						                  (need_h1 && gran_tag(gh1) != s_new - lag1) || (need_h2 && gran_tag(gh2) != s_new - lag2);
 						if (!__ballot(late)) break;
-						if (spins > A.coop_spin_limit) { if (lane == 0) sh.red[0] = 1; break; }
+						if (spins > A.coop_spin_limit || ((spins & 255u) == 255u && uni(ld_ag(&gflags[15])))) {
+							if (lane == 0) sh.red[0] = 1, st_ag(&gflags[15], 1);
+							break;
+						}
 						__builtin_amdgcn_s_sleep(1);
 						ge1 = ld_gran(granule(jg1, nb, side, 0)), ge2 = ld_gran(granule(jg2, nb, side, 1));
 						gh1 = ld_gran(granule(j1, nb, side, 2)), gh2 = ld_gran(granule(j2, nb, side, 2));
@@ -563,17 +568,18 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 				}
 #endif
 				if ((w0 >> 4) == s_new && (w1 >> 4) == s_new && (w2 >> 4) == s_new) break;
-				if (spins > A.coop_spin_limit) { ok = 0; break; }
+				if (spins > A.coop_spin_limit || ((spins & 255u) == 255u && ld_ag(&gflags[15]))) { ok = 0; break; }
 				__builtin_amdgcn_s_sleep(1);
 			}
 			// drift bound: the flag ring holds kFlagRing penalties, so nobody may run more than that ahead of the slowest workgroup
 			if (ok && s_new >= kDriftCheck && (s_new & (kDriftCheck - 1)) == 0) {
 				const unsigned long long want = (unsigned long long)G * (unsigned long long)(s_new - kDriftCheck);
 				for (unsigned spins = 0; __hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want; ++spins) {
-					if (spins > A.coop_spin_limit) { ok = 0; break; }
+					if (spins > A.coop_spin_limit || ((spins & 255u) == 255u && ld_ag(&gflags[15]))) { ok = 0; break; }
 					__builtin_amdgcn_s_sleep(2);
 				}
 			}
+			if (!ok) st_ag(&gflags[15], 1); // release everybody else at once
 			sh.flags[npar][0] = (w0 & 1) | (w1 & 1) << 1 | (w2 & 15) << 2;
 			sh.flags[npar][1] = ok;
 		}

@@ -245,7 +245,8 @@ __device__ __forceinline__ void finish_pair(const BatchArgs &A, const PairMem &M
 		}
 	}
 	if (threadIdx.x == 0) {
-		A.out_s[pair] = (status == ST_OK) ? R.s : -1;
+		// -1 is the reference's "stopped" answer (miniwfa.c:427); a pair the host still has to re-run holds -2
+		A.out_s[pair] = status == ST_OK ? R.s : status == ST_STOPPED ? -1 : -2;
 		A.out_iter[pair] = R.cells;
 		A.out_ncig[pair] = n_cigar;
 		A.out_cigoff[pair] = cig_off;

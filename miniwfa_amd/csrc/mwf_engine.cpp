@@ -1,12 +1,18 @@
-// mwf_engine.cpp — host side of libmwf_hip.so: the device engine (stream, memory pool, launch
+// mwf_engine.cpp — host side of libmwf_hip.so: the device engine (stream, memory pools, launch
 // geometry, retry policy) and every entry point of include/miniwfa.h.
 //
 // Boundary: the reference's device-free API mwf_wfa_exact/auto/chain
 // (miniwfa.c:603-615, :850-908) is kept; a call ships its pair(s) to HBM, runs the kernels of
-// mwf_kernels.hip and copies back (s, n_iter, n_cigar, CIGAR).  r->cigar is allocated from the
-// caller's kalloc arena exactly as the reference does (miniwfa.c:434).  kalloc arenas for
-// scratch are replaced by one device workspace per engine that only ever grows (a per-stream
-// hipMalloc pool): ring, traceback arena, row table, CIGAR scratch, snapshots.
+// mwf_kernels.hip / mwf_band.hip / mwf_coop.hip and copies back (s, n_iter, n_cigar, CIGAR).  r->cigar is
+// allocated from the caller's kalloc arena exactly as the reference does (miniwfa.c:434).  kalloc arenas for
+// scratch are replaced by device pools that only ever grow:
+//   * one workspace per engine (ring, traceback arena, row table, CIGAR scratch, snapshots);
+//   * ONE device allocation per batch (inputs, processing order, every result array), recycled through the
+//     engine when the batch is freed, so a program that calls mwf_wfa_exact in a loop never reaches hipMalloc;
+//   * one pinned staging buffer per engine: a call's inputs go up in one host-to-device copy, its fixed-size
+//     results (and, when asked for, all its CIGARs) come back in one device-to-host copy each.
+// Engines themselves are pooled per device and handed to whichever host thread calls next; mwf_wfa_batch_multi
+// deals the pairs of one call over several devices (reference main.c:67-72 is the serial loop it replaces).
 //
 // There is no CPU alignment path in this file or anywhere in the library.
 #include <hip/hip_runtime.h>
@@ -14,8 +20,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 #include "miniwfa.h"
 #include "kalloc.h"
@@ -37,6 +46,12 @@ struct DevBuf {
 	size_t bytes = 0;
 };
 
+constexpr size_t kPinHalfMax = (size_t)16 << 20; // pinned staging: two halves of at most this many bytes
+constexpr int kQueueSlots = 64;                  // work counters zeroed at the start of an align call, one per launch
+constexpr int kMaxDevices = 64;
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
 } // namespace
 
 struct mwf_gpu_s {
@@ -57,17 +72,28 @@ struct mwf_gpu_s {
 	int scalar_generic = 0;    // 1: the generic kernel's original one-column-per-lane pass everywhere (comparison / fallback)
 	int64_t coop_spin_limit = 1 << 23; // polls (about a microsecond each) before the whole-device kernel gives up on a workgroup
 	int64_t coop_tb_cap = (int64_t)96 << 30; // whole-device traceback arena: covers the 5 Mb pairs; doubles on overflow
+	int64_t lowmem_budget_mb = 0; // whole-device low-memory mode: first-pass traceback above this many MB -> true two-pass (0: automatic)
 	// workspace (per-stream pool)
 	DevBuf ring, sring, good, tb, row_off, row_lo, cig_scratch, snap, snap_meta, seg, queue, dbg, coop_edge, coop_misc;
+	DevBuf spare_block, spare_cig; // allocations of freed batches, waiting for the next batch
+	int queue_next = 0;            // next unused work counter of the current align call
+	// pinned staging
+	void *pin = nullptr;
+	size_t pin_half = 0;
+	hipEvent_t pin_ev[2] = {nullptr, nullptr};
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	bool ev_pending = false;
 	mwf_gpu_stats_t stats{};
+	int64_t dev_bytes = 0, dev_bytes_peak = 0; // device memory this engine holds right now / held at most since the last "trim"
+	std::map<uint64_t, int> occ_cache;         // kernel variant -> resident workgroups per CU
+	int coop_grid = -1;
 };
 
 struct mwf_gpu_batch_s {
 	mwf_gpu_t *g = nullptr;
 	int32_t n = 0;
 	bool owns_inputs = false;
+	DevBuf block;              // the batch's one device allocation: [order | inputs (when owned) | results]
 	const uint8_t *d_seqs = nullptr;
 	int64_t seq_bytes = 0;
 	const int64_t *d_t_off = nullptr, *d_q_off = nullptr;
@@ -77,19 +103,26 @@ struct mwf_gpu_batch_s {
 	int64_t max_tl = 0;        // longest target (offsets are target indices: bounds what a 16-bit offset must hold)
 	int32_t *d_order = nullptr;
 	std::vector<int32_t> h_order;   // what d_order holds: pair ids, grouped by size class, longest first inside a class
-	bool coop_grouped = false;      // the last align ran several pairs side by side on the whole-device kernel
-	std::vector<int8_t> h_class;    // size class of every pair in the last align (0 generic, then band kernels: 1 wide, 2 small, 3 tiny, 4 micro)
-	// outputs
-	int32_t *d_s = nullptr, *d_ncig = nullptr, *d_status = nullptr, *d_dbg4 = nullptr;
+	std::vector<int8_t> h_class;    // size class of every pair (0 generic, then band kernels: 1 wide, 2 small, 3 tiny, 4 micro)
+	std::vector<int8_t> h_kind;     // kernel that ran the pair last (0 generic, 1 whole-device, 2 band)
+	std::vector<int8_t> h_flags;    // bit 0: runs as high-memory although opt.step > 0 (its penalty bound is below step);
+	                                // bit 1: shared the whole-device kernel with other pairs; bit 2: walk variant of the low-memory mode
+	// results: one region of the block, fetched by one copy
+	unsigned long long *d_cig_head = nullptr;
+	int32_t *d_status = nullptr, *d_s = nullptr, *d_ncig = nullptr, *d_dbg4 = nullptr;
 	int64_t *d_iter = nullptr, *d_cigoff = nullptr, *d_cells1 = nullptr;
+	size_t out_off = 0, out_bytes = 0;
+	DevBuf cig;                     // CIGAR pool (allocated by the first CIGAR-mode align)
 	uint32_t *d_cig_pool = nullptr;
 	int64_t cig_pool_words = 0;
-	unsigned long long *d_cig_head = nullptr;
 	// state of the last align
-	bool aligned = false, finalized = false;
+	bool aligned = false, finalized = false, busy = false;
 	mwf_opt_t opt{};
 	std::vector<int32_t> h_s, h_ncig, h_status;
 	std::vector<int64_t> h_iter, h_cigoff, h_cells1;
+	int64_t cig_used = 0;           // words of the pool in use (known after finalize)
+	std::vector<uint32_t> h_cig;    // host copy of the used part of the pool (fetch_cigars)
+	bool h_cig_valid = false;
 	// debug band trace (tests)
 	int32_t debug_pair = -1;
 };
@@ -105,12 +138,19 @@ namespace {
 		}                                                                             \
 	} while (0)
 
+void account(mwf_gpu_t *g, int64_t delta)
+{
+	g->dev_bytes += delta;
+	g->dev_bytes_peak = std::max(g->dev_bytes_peak, g->dev_bytes);
+}
+
 int ensure(mwf_gpu_t *g, DevBuf &b, size_t bytes)
 {
 	if (bytes <= b.bytes) return 0;
 	if (b.p) {
 		HIP_TRY(g, hipStreamSynchronize(g->stream));
 		HIP_TRY(g, hipFree(b.p));
+		account(g, -(int64_t)b.bytes);
 		b.p = nullptr, b.bytes = 0;
 	}
 	size_t want = bytes < ((size_t)1 << 30) ? bytes + bytes / 8 + 256 : bytes; // small buffers get slack so they rarely regrow
@@ -126,14 +166,105 @@ int ensure(mwf_gpu_t *g, DevBuf &b, size_t bytes)
 		return -1;
 	}
 	b.bytes = want;
+	account(g, (int64_t)want);
 	return 0;
 }
 
-void release(DevBuf &b)
+void release(mwf_gpu_t *g, DevBuf &b)
 {
-	if (b.p) (void)hipFree(b.p);
+	if (b.p) {
+		(void)hipFree(b.p);
+		account(g, -(int64_t)b.bytes);
+	}
 	b.p = nullptr, b.bytes = 0;
 }
+
+// A batch allocation: the engine's spare one when it is large enough, else a fresh hipMalloc.
+int take_block(mwf_gpu_t *g, DevBuf &spare, DevBuf &out, size_t bytes)
+{
+	if (spare.p && spare.bytes >= bytes) {
+		out = spare;
+		spare = DevBuf{};
+		return 0;
+	}
+	release(g, spare);
+	out = DevBuf{};
+	return ensure(g, out, std::max<size_t>(bytes, 4096));
+}
+
+// ... and back: the engine keeps the larger of the two
+void give_block(mwf_gpu_t *g, DevBuf &spare, DevBuf &b)
+{
+	if (!b.p) return;
+	if (!spare.p || spare.bytes < b.bytes) std::swap(spare, b);
+	release(g, b);
+}
+
+// ---- pinned staging ------------------------------------------------------------------------------------------------
+
+int pin_reserve(mwf_gpu_t *g, size_t half)
+{
+	half = std::min(std::max<size_t>(align_up(half, 4096), (size_t)64 << 10), kPinHalfMax);
+	if (g->pin && g->pin_half >= half) return 0;
+	HIP_TRY(g, hipStreamSynchronize(g->stream));
+	if (g->pin) (void)hipHostFree(g->pin);
+	g->pin = nullptr, g->pin_half = 0;
+	HIP_TRY(g, hipHostMalloc(&g->pin, 2 * half, hipHostMallocDefault));
+	g->pin_half = half;
+	for (hipEvent_t &e : g->pin_ev)
+		if (!e) HIP_TRY(g, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+	return 0;
+}
+
+struct Seg { const void *src; size_t len; }; // src == nullptr: `len` zero bytes
+
+// The concatenation of `segs` to device memory at `dst`: packed into the pinned halves by the host while the previous
+// half is on its way.  One copy for a call whose inputs fit a half.  Returns after the last copy completed.
+int upload_segments(mwf_gpu_t *g, char *dst, const std::vector<Seg> &segs)
+{
+	size_t total = 0;
+	for (const Seg &s : segs) total += s.len;
+	if (total == 0) return 0;
+	if (pin_reserve(g, total)) return -1;
+	const size_t half = g->pin_half;
+	size_t si = 0, so = 0, done = 0;
+	bool used[2] = {false, false};
+	for (int h = 0; done < total; h ^= 1) {
+		char *buf = (char*)g->pin + (size_t)h * half;
+		if (used[h]) HIP_TRY(g, hipEventSynchronize(g->pin_ev[h]));
+		size_t fill = 0;
+		while (fill < half && si < segs.size()) {
+			const size_t take = std::min(half - fill, segs[si].len - so);
+			if (segs[si].src) memcpy(buf + fill, (const char*)segs[si].src + so, take);
+			else memset(buf + fill, 0, take);
+			fill += take, so += take;
+			if (so == segs[si].len) ++si, so = 0;
+		}
+		HIP_TRY(g, hipMemcpyAsync(dst + done, buf, fill, hipMemcpyHostToDevice, g->stream));
+		HIP_TRY(g, hipEventRecord(g->pin_ev[h], g->stream));
+		used[h] = true;
+		done += fill;
+	}
+	HIP_TRY(g, hipStreamSynchronize(g->stream));
+	return 0;
+}
+
+// `bytes` from device memory into host memory at `dst`, through the pinned buffer when they fit one half
+int download(mwf_gpu_t *g, void *dst, const void *src, size_t bytes)
+{
+	if (bytes == 0) return 0;
+	if (bytes <= kPinHalfMax && pin_reserve(g, bytes) == 0) {
+		HIP_TRY(g, hipMemcpyAsync(g->pin, src, bytes, hipMemcpyDeviceToHost, g->stream));
+		HIP_TRY(g, hipStreamSynchronize(g->stream));
+		memcpy(dst, g->pin, bytes);
+		return 0;
+	}
+	HIP_TRY(g, hipStreamSynchronize(g->stream));
+	HIP_TRY(g, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+// ---- penalties, kernel choice -----------------------------------------------------------------------------------------
 
 Penalty make_penalty(const mwf_opt_t &o)
 {
@@ -177,7 +308,6 @@ struct Plan {
 	bool low_mem = false, cigar = false;
 };
 
-// Run the one-workgroup-per-pair kernel over `n_items` pairs given by d_order (device) on `slots` workgroups.
 // Which kernel serves a set of pairs.  The band kernel keeps E/F in registers and therefore only holds windows up to
 // its span; it has no low-memory first pass.  kind: -1 automatic, 0 generic, 2 band.
 void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, int64_t max_len, int64_t max_bound,
@@ -220,12 +350,38 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 	pl.kind = 2, pl.band = bg;
 }
 
-int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const int32_t *d_order, int32_t n_items,
-                     int slots, int64_t max_len, int64_t max_bound, int64_t max_bound1, int64_t tb_total_budget, bool timed,
-                     int want_kind = -1, int64_t max_tl = -1, int64_t max_seq_lds = -1, int timed_end = -1, int geom_block = 0)
+// resident workgroups per CU of a kernel variant (one runtime query per variant and engine)
+int cached_occupancy(mwf_gpu_t *g, const Penalty &P, const Plan &pl, int lds_e2_cols, bool stream_pass)
 {
-	if (max_tl < 0) max_tl = b->max_tl;
-	if (max_seq_lds < 0) max_seq_lds = b->max_seq_lds;
+	uint64_t key;
+	if (pl.kind == 2)
+		key = 1ull | (uint64_t)pl.band.block << 4 | (uint64_t)pl.band.packed << 16 | (uint64_t)(pl.band.lds_bytes > 0) << 17 | (uint64_t)pl.cigar << 18 |
+		      (uint64_t)P.e1 << 20 | (uint64_t)P.e2 << 28 | (uint64_t)pl.band.lds_bytes << 36;
+	else key = 2ull | (uint64_t)pl.block << 4 | (uint64_t)stream_pass << 16 | (uint64_t)lds_e2_cols << 20;
+	auto it = g->occ_cache.find(key);
+	if (it != g->occ_cache.end()) return it->second;
+	const int per = pl.kind == 2 ? band_kernel_occupancy(P, pl.band, pl.cigar) : batch_kernel_occupancy(pl.block, stream_pass, lds_e2_cols);
+	g->occ_cache[key] = per;
+	return per;
+}
+
+int64_t tb_budget_bytes(mwf_gpu_t *g)
+{
+	if (g->tb_budget_mb > 0) return g->tb_budget_mb << 20;
+	size_t fr = 0, tot = 0;
+	if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = (size_t)8 << 30, tot = fr;
+	// leave a fifth of what is free right now alone, and never claim more than a quarter of the device for one engine
+	// (the drop-in API is re-entrant: other host threads have engines of their own); the arena is kept between calls
+	int64_t b = (int64_t)(fr / 5 * 4) + (int64_t)g->tb.bytes;
+	return std::min<int64_t>(b, std::min<int64_t>((int64_t)64 << 30, (int64_t)(tot / 4)));
+}
+
+// Run the one-workgroup-per-pair kernel over `n_items` pairs given by d_order (device) on at most `slots` workgroups.
+// tb_total_budget < 0: the traceback budget is looked up here, and only when the arena has to grow.
+int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const int32_t *d_order, int32_t n_items,
+                     int slots, int64_t max_len, int64_t max_bound, int64_t max_bound1, bool timed,
+                     int want_kind, int64_t max_tl, int64_t max_seq_lds, int timed_end, int geom_block, int *ran_kind)
+{
 	const Penalty P = make_penalty(opt);
 	Plan pl;
 	pl.cigar = (opt.flag & MWF_F_CIGAR) != 0;
@@ -238,19 +394,19 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	int per_cu, lds_e2_cols = 0;
 	if (pl.kind == 2) {
 		pl.block = pl.band.block;
-		per_cu = g->slots_per_cu > 0 ? g->slots_per_cu : band_kernel_occupancy(P, pl.band, pl.cigar);
+		per_cu = g->slots_per_cu > 0 ? g->slots_per_cu : cached_occupancy(g, P, pl, 0, false);
 	} else {
 		// wide windows (the 512-thread choice above), default gap extension: E2/F2 stay in LDS while the window fits 16 k columns
 		if (g->lds_e2 && pl.block == 512 && g->block == 0 && P.e2 == 1 && !g->scalar_generic && !pl.low_mem) {
 			lds_e2_cols = 16384;
 			pl.block = 768; // one workgroup per CU either way (128 KB of LDS): twelve waves fit its 168-VGPR budget, 490 ms against 519 ms with eight
 		}
-		per_cu = g->slots_per_cu > 0 ? g->slots_per_cu : batch_kernel_occupancy(pl.block, !g->scalar_generic && !pl.low_mem, lds_e2_cols);
+		per_cu = g->slots_per_cu > 0 ? g->slots_per_cu : cached_occupancy(g, P, pl, lds_e2_cols, !g->scalar_generic && !pl.low_mem);
 	}
 	slots = std::max(1, std::min(slots, g->n_cu * std::max(1, per_cu)));
 	if (getenv("MWF_DEBUG"))
-		fprintf(stderr, "[libmwf_hip] kernel kind %d: block %d packed %d lds %d B, %d workgroup(s) per CU, %d slots\n", pl.kind, pl.block,
-		        pl.band.packed, pl.band.lds_bytes, per_cu, slots);
+		fprintf(stderr, "[libmwf_hip] kernel kind %d: block %d packed %d lds %d B, %d workgroup(s) per CU, %d slots, %d pairs\n", pl.kind, pl.block,
+		        pl.band.packed, pl.band.lds_bytes, per_cu, slots, n_items);
 	pl.grid = std::max(1, std::min<int>(slots, n_items));
 	// row stride: whole 256-column chunks plus room for the band kernel's neighbour loads past the last chunk
 	pl.W = (int32_t)((max_len + 3 + 255) / 256 * 256 + 512);
@@ -260,19 +416,21 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 
 	if (ensure(g, g->ring, S * pl.ring_slot_ints * 4)) return -1;
 	if (ensure(g, g->good, S * (size_t)P.nH * pl.GW * 8)) return -1;
-	if (ensure(g, g->queue, 64)) return -1;
 	if (pl.cigar) {
 		pl.rows_slot = max_bound + 2;
 		pl.cig_scratch_slot = max_len + 2;
-		int64_t per = tb_total_budget / (int64_t)S;
-		const int64_t worst = (max_bound + 1) * (max_len + 1); // every penalty as wide as the whole matrix
+		int64_t worst = (max_bound + 1) * (max_len + 1); // every penalty as wide as the whole matrix
 		if (pl.low_mem && opt.step > 2 * P.nH) {
 			// the second pass collapses the band to one diagonal at every checkpoint (miniwfa.c:413-416) and consecutive
 			// checkpoints are at most step+nH penalties apart, so a row is never wider than about 2*(step+nH)
-			const int64_t seg_worst = (max_bound + 1) * std::min<int64_t>(max_len + 1, 2 * (int64_t)(opt.step + 2 * P.nH) + 8);
-			per = std::min(per, seg_worst);
+			worst = std::min(worst, (max_bound + 1) * std::min<int64_t>(max_len + 1, 2 * (int64_t)(opt.step + 2 * P.nH) + 8));
 		}
-		pl.tb_slot_bytes = std::max<int64_t>(4096, std::min(per, worst + 8 * (max_bound + 2))) / 4 * 4; // rows are padded to dwords
+		worst += 8 * (max_bound + 2);
+		// the device is only asked how much is free when the arena at hand cannot hold the worst case
+		int64_t per = worst;
+		if ((int64_t)g->tb.bytes < (int64_t)S * worst || g->tb_budget_mb > 0) per = std::min(per, std::max<int64_t>(tb_budget_bytes(g), (int64_t)g->tb.bytes) / (int64_t)S);
+		if (g->tb_budget_mb > 0) per = std::min(per, (g->tb_budget_mb << 20) / (int64_t)S);
+		pl.tb_slot_bytes = std::max<int64_t>(4096, per) / 4 * 4; // rows are padded to dwords
 		if (ensure(g, g->tb, S * (size_t)pl.tb_slot_bytes)) return -1;
 		if (ensure(g, g->row_off, S * (size_t)pl.rows_slot * 8)) return -1;
 		if (ensure(g, g->row_lo, S * (size_t)pl.rows_slot * 4)) return -1;
@@ -287,7 +445,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 		int64_t worst = 0;
 		for (int64_t j = 1; j <= n_snap_max; ++j)
 			worst += NS * std::min<int64_t>(max_len + 1, 2 * j * opt.step + 3);
-		const int64_t budget = (int64_t)(tb_total_budget / 4 / (int64_t)S);
+		const int64_t budget = (int64_t)(std::max<int64_t>(tb_budget_bytes(g), (int64_t)g->snap.bytes) / 4 / (int64_t)S);
 		pl.snap_slot_ints = std::max<int64_t>(1024, std::min(worst, budget));
 		if (ensure(g, g->sring, S * pl.ring_slot_ints * 4)) return -1;
 		if (ensure(g, g->snap, S * (size_t)pl.snap_slot_ints * 4)) return -1;
@@ -299,7 +457,12 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	memset(&a, 0, sizeof(a));
 	a.seqs = b->d_seqs, a.t_off = b->d_t_off, a.q_off = b->d_q_off, a.tl = b->d_tl, a.ql = b->d_ql;
 	a.order = d_order, a.n_pairs = n_items;
-	a.queue = (int32_t*)g->queue.p;
+	// a fresh work counter: the first kQueueSlots launches of an align call use the ones its reset kernel zeroed
+	if (g->queue_next < kQueueSlots) a.queue = (int32_t*)g->queue.p + g->queue_next++;
+	else {
+		a.queue = (int32_t*)g->queue.p;
+		HIP_TRY(g, hipMemsetAsync(g->queue.p, 0, 4, g->stream)); // (stream order: the launch that used it last is complete by then)
+	}
 	a.scalar_generic = g->scalar_generic;
 	a.lds_e2_cols = lds_e2_cols;
 	a.pen = P;
@@ -325,7 +488,6 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	a.dbg = b->debug_pair >= 0 ? (int32_t*)g->dbg.p : nullptr;
 	a.dbg_cap = b->debug_pair >= 0 ? (int32_t)(g->dbg.bytes / 8) : 0;
 
-	HIP_TRY(g, hipMemsetAsync(g->queue.p, 0, 64, g->stream));
 	// HIP events bracket the kernel only: every workspace allocation above is already done
 	if (timed) HIP_TRY(g, hipEventRecord(g->ev0, g->stream));
 	const int lrc = pl.kind == 2 ? launch_band(a, pl.grid, pl.band, g->stream) : launch_batch(a, pl.grid, pl.block, g->stream);
@@ -339,12 +501,23 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	}
 	g->stats.n_launches += 1;
 	g->stats.grid = std::max(g->stats.grid, pl.grid), g->stats.block = pl.block, g->stats.kernel_kind = pl.kind;
+	if (ran_kind) *ran_kind = pl.kind;
 	return 0;
 }
 
+// ---- whole-device kernel ------------------------------------------------------------------------------------------------
 
-// One pair across the whole device (mwf_coop.hip).  Everything is enqueued on the stream: first pass, and in low-memory
-// mode the checkpoint walk over its traceback matrix and the second pass, then traceback + outputs.
+// Its workgroups wait for one another, so all of them must be resident: launches on one device are serialised process-wide
+// (two host threads' engines would otherwise starve each other until the spin limit), and the call returns after the kernels
+// completed.  Other processes' kernels can still hold CUs; that is what the bounded waits and the fallback are for.
+std::mutex g_coop_mutex[kMaxDevices];
+
+int coop_grid_limit(mwf_gpu_t *g)
+{
+	if (g->coop_grid < 0) g->coop_grid = std::min(coop_max_grid(true), g->n_cu);
+	return g->coop_grid;
+}
+
 // Workgroups per pair when `n` pairs of at most `len` columns share the device: as many as the widest possible window can
 // use when the pair is alone (it can then never outgrow them); when several pairs run side by side, as many as a window of
 // a third of tl+ql needs (windows stay near a quarter at 3-5 % divergence) — a pair that does outgrow its group is re-run
@@ -366,7 +539,7 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 	const Penalty P = make_penalty(opt);
 	const bool cigar = (opt.flag & MWF_F_CIGAR) != 0, low_mem = cigar && opt.step > 0;
 	const int n_groups = (int)pairs.size();
-	if (n_groups < 1 || Gs < 1 || (int64_t)Gs * n_groups > std::min(coop_max_grid(cigar), g->n_cu)) { g->err = "whole-device kernel cannot be made resident"; return -1; }
+	if (n_groups < 1 || Gs < 1 || (int64_t)Gs * n_groups > coop_grid_limit(g)) { g->err = "whole-device kernel cannot be made resident"; return -1; }
 	int64_t len = 0, bound = 0, bound1 = 0;
 	bool traced = false;
 	for (int32_t pair : pairs) {
@@ -457,6 +630,7 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 		HIP_TRY(g, hipMemsetAsync(g->coop_edge.p, 0xff, NG * gran_bytes, g->stream));
 		return 0;
 	};
+	std::lock_guard<std::mutex> lock(g_coop_mutex[g->device % kMaxDevices]);
 	if (reset_sync(true)) return -1;
 	if (first) HIP_TRY(g, hipEventRecord(g->ev0, g->stream));
 	a.coop_pass = low_mem ? 1 : 0;
@@ -477,14 +651,15 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 		g->ev_pending = true;
 	}
 	g->stats.grid = Gs * n_groups, g->stats.block = 512, g->stats.kernel_kind = 1;
+	for (int32_t pair : pairs) b->h_kind[pair] = 1, b->h_flags[pair] = (int8_t)((b->h_flags[pair] & ~2) | (n_groups > 1 ? 2 : 0));
+	HIP_TRY(g, hipStreamSynchronize(g->stream)); // the device stays ours until the kernels are through
 	return 0;
 }
 
 // one pair with the device to itself
 int run_coop_pair(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, int32_t pair, bool first, bool last)
 {
-	const bool cigar = (opt.flag & MWF_F_CIGAR) != 0;
-	const int G = coop_group_size(std::min(coop_max_grid(cigar), g->n_cu), (int64_t)b->h_tl[pair] + b->h_ql[pair], true);
+	const int G = coop_group_size(coop_grid_limit(g), (int64_t)b->h_tl[pair] + b->h_ql[pair], true);
 	return run_coop_group(g, b, opt, std::vector<int32_t>{pair}, G, first, last);
 }
 
@@ -493,20 +668,130 @@ bool coop_can_grow(mwf_gpu_t *g)
 {
 	size_t fr = 0, tot = 0;
 	if (hipMemGetInfo(&fr, &tot) != hipSuccess) return false;
-	return (int64_t)(fr / 10 * 9) + (int64_t)g->tb.bytes > (int64_t)g->tb.bytes + ((int64_t)1 << 30) && (int64_t)g->tb.bytes >= g->coop_tb_cap / 4 * 3;
-}
-
-int64_t tb_budget_bytes(mwf_gpu_t *g)
-{
-	if (g->tb_budget_mb > 0) return g->tb_budget_mb << 20;
-	size_t fr = 0, tot = 0;
-	if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = (size_t)8 << 30;
-	// leave a fifth of what is free right now alone; the arena is kept between calls
-	int64_t b = (int64_t)(fr / 5 * 4) + (int64_t)g->tb.bytes;
-	return std::min<int64_t>(b, (int64_t)64 << 30);
+	return (int64_t)(fr / 10 * 9) > ((int64_t)1 << 30) && (int64_t)g->tb.bytes >= g->coop_tb_cap / 4 * 3;
 }
 
 int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b);
+
+// ---- batches ------------------------------------------------------------------------------------------------------------
+
+// Carve the batch's one allocation.  [order | t_off q_off tl ql seqs (owned inputs) | results]; the input part is laid
+// out exactly as upload_segments() streams it.
+struct BlockLayout {
+	size_t order = 0, t_off = 0, q_off = 0, tl = 0, ql = 0, seqs = 0, in_end = 0;
+	size_t head = 0, status = 0, s = 0, ncig = 0, iter = 0, cigoff = 0, cells1 = 0, out_end = 0, dbg4 = 0, total = 0;
+};
+
+BlockLayout layout_block(size_t n, size_t seq_bytes, bool owned)
+{
+	const size_t N = std::max<size_t>(n, 1);
+	BlockLayout L;
+	size_t at = 0;
+	L.order = at, at += align_up(N * 4, 16);
+	if (owned) {
+		L.t_off = at, at += N * 8;
+		L.q_off = at, at += N * 8;
+		L.tl = at, at += align_up(N * 4, 16);
+		L.ql = at, at += align_up(N * 4, 16);
+		L.seqs = at, at += seq_bytes + 64; // word-sized probes may read past the last base
+	}
+	L.in_end = at;
+	at = align_up(at, 256);
+	L.head = at, at += 64;
+	L.status = at, at += align_up(N * 4, 8);
+	L.s = at, at += align_up(N * 4, 8);
+	L.ncig = at, at += align_up(N * 4, 8);
+	L.iter = at, at += N * 8;
+	L.cigoff = at, at += N * 8;
+	L.cells1 = at, at += N * 8;
+	L.out_end = at;
+	L.dbg4 = at, at += N * 16;
+	L.total = at;
+	return L;
+}
+
+mwf_gpu_batch_t *batch_common(mwf_gpu_t *g, int32_t n, const int32_t *h_tl, const int32_t *h_ql, size_t seq_bytes, bool owned, BlockLayout &L)
+{
+	mwf_gpu_batch_t *b = new mwf_gpu_batch_t();
+	b->g = g, b->n = n, b->owns_inputs = owned;
+	b->h_tl.assign(h_tl, h_tl + n);
+	b->h_ql.assign(h_ql, h_ql + n);
+	int64_t words = 0;
+	for (int32_t i = 0; i < n; ++i) {
+		words += (int64_t)h_tl[i] + h_ql[i] + 1;
+		b->max_tl = std::max<int64_t>(b->max_tl, h_tl[i]);
+		b->max_seq_lds = std::max<int64_t>(b->max_seq_lds, (((int64_t)h_tl[i] + 3) & ~3LL) + 8 + (((int64_t)h_ql[i] + 3) & ~3LL) + 16);
+	}
+	b->cig_pool_words = std::max<int64_t>(words, 1);
+	L = layout_block((size_t)n, seq_bytes, owned);
+	if (take_block(g, g->spare_block, b->block, L.total)) {
+		delete b;
+		return nullptr;
+	}
+	char *base = (char*)b->block.p;
+	b->d_order = (int32_t*)(base + L.order);
+	b->d_cig_head = (unsigned long long*)(base + L.head);
+	b->d_status = (int32_t*)(base + L.status), b->d_s = (int32_t*)(base + L.s), b->d_ncig = (int32_t*)(base + L.ncig);
+	b->d_iter = (int64_t*)(base + L.iter), b->d_cigoff = (int64_t*)(base + L.cigoff), b->d_cells1 = (int64_t*)(base + L.cells1);
+	b->d_dbg4 = (int32_t*)(base + L.dbg4);
+	b->out_off = L.head, b->out_bytes = L.out_end - L.head;
+	// longest pairs first, so the persistent workgroups finish together
+	b->h_order.resize((size_t)n);
+	std::iota(b->h_order.begin(), b->h_order.end(), 0);
+	std::stable_sort(b->h_order.begin(), b->h_order.end(), [&](int32_t x, int32_t y) {
+		return (int64_t)h_tl[x] + h_ql[x] > (int64_t)h_tl[y] + h_ql[y];
+	});
+	b->h_class.assign((size_t)n, 0), b->h_kind.assign((size_t)n, 0), b->h_flags.assign((size_t)n, 0);
+	return b;
+}
+
+// A batch from host memory: pair i is (ts[i], tl[i]) / (qs[i], ql[i]) when `ts` is given, else it lies in `packed` at
+// t_off[i] / q_off[i].  Everything goes up in one stream of copies through the pinned buffer.
+mwf_gpu_batch_t *batch_from_host(mwf_gpu_t *g, int32_t n, const int32_t *tl, const char *const *ts, const int32_t *ql, const char *const *qs,
+                                 const char *packed, int64_t packed_bytes, const int64_t *p_t_off, const int64_t *p_q_off)
+{
+	(void)hipSetDevice(g->device);
+	std::vector<int64_t> t_off, q_off;
+	int64_t seq_bytes = packed_bytes;
+	if (ts) {
+		t_off.resize((size_t)n), q_off.resize((size_t)n);
+		seq_bytes = 0;
+		for (int32_t i = 0; i < n; ++i) {
+			t_off[i] = seq_bytes, seq_bytes += tl[i];
+			q_off[i] = seq_bytes, seq_bytes += ql[i];
+		}
+		p_t_off = t_off.data(), p_q_off = q_off.data();
+	}
+	BlockLayout L;
+	mwf_gpu_batch_t *b = batch_common(g, n, tl, ql, (size_t)seq_bytes, true, L);
+	if (!b) return nullptr;
+	b->seq_bytes = seq_bytes;
+	char *base = (char*)b->block.p;
+	b->d_t_off = (const int64_t*)(base + L.t_off), b->d_q_off = (const int64_t*)(base + L.q_off);
+	b->d_tl = (const int32_t*)(base + L.tl), b->d_ql = (const int32_t*)(base + L.ql);
+	b->d_seqs = (const uint8_t*)(base + L.seqs);
+	const size_t N = (size_t)n;
+	std::vector<Seg> segs;
+	segs.reserve(ts ? 2 * N + 12 : 12);
+	auto pad_to = [&](size_t have, size_t want) { if (want > have) segs.push_back(Seg{nullptr, want - have}); };
+	segs.push_back(Seg{b->h_order.data(), N * 4}), pad_to(L.order + N * 4, L.t_off);
+	segs.push_back(Seg{p_t_off, N * 8});
+	segs.push_back(Seg{p_q_off, N * 8});
+	segs.push_back(Seg{tl, N * 4}), pad_to(L.tl + N * 4, L.ql);
+	segs.push_back(Seg{ql, N * 4}), pad_to(L.ql + N * 4, L.seqs);
+	if (ts) {
+		for (int32_t i = 0; i < n; ++i) {
+			if (tl[i]) segs.push_back(Seg{ts[i], (size_t)tl[i]});
+			if (ql[i]) segs.push_back(Seg{qs[i], (size_t)ql[i]});
+		}
+	} else if (packed_bytes > 0) segs.push_back(Seg{packed, (size_t)packed_bytes});
+	segs.push_back(Seg{nullptr, 64});
+	if (upload_segments(g, base, segs)) {
+		mwf_gpu_batch_free(b);
+		return nullptr;
+	}
+	return b;
+}
 
 } // namespace
 
@@ -539,18 +824,31 @@ mwf_gpu_t *mwf_gpu_create(int device, void *stream)
 	}
 	(void)hipEventCreate(&g->ev0);
 	(void)hipEventCreate(&g->ev1);
+	if (ensure(g, g->queue, kQueueSlots * 4) || hipMemsetAsync(g->queue.p, 0, kQueueSlots * 4, g->stream) != hipSuccess) {
+		mwf_gpu_destroy(g);
+		return nullptr;
+	}
 	return g;
+}
+
+static void trim(mwf_gpu_t *g)
+{
+	(void)hipStreamSynchronize(g->stream);
+	for (DevBuf *b : {&g->ring, &g->sring, &g->good, &g->tb, &g->row_off, &g->row_lo, &g->cig_scratch, &g->snap, &g->snap_meta, &g->seg, &g->dbg,
+	                  &g->coop_edge, &g->coop_misc, &g->spare_block, &g->spare_cig})
+		release(g, *b);
+	g->dev_bytes_peak = g->dev_bytes;
 }
 
 void mwf_gpu_destroy(mwf_gpu_t *g)
 {
 	if (!g) return;
 	(void)hipSetDevice(g->device);
-	(void)hipStreamSynchronize(g->stream);
-	for (DevBuf *b : {&g->ring, &g->sring, &g->good, &g->tb, &g->row_off, &g->row_lo, &g->cig_scratch, &g->snap, &g->snap_meta, &g->seg, &g->queue, &g->dbg, &g->coop_edge, &g->coop_misc})
-		release(*b);
-	if (g->ev0) (void)hipEventDestroy(g->ev0);
-	if (g->ev1) (void)hipEventDestroy(g->ev1);
+	trim(g);
+	release(g, g->queue);
+	if (g->pin) (void)hipHostFree(g->pin);
+	for (hipEvent_t e : {g->ev0, g->ev1, g->pin_ev[0], g->pin_ev[1]})
+		if (e) (void)hipEventDestroy(e);
 	if (g->own_stream) (void)hipStreamDestroy(g->stream);
 	delete g;
 }
@@ -572,6 +870,8 @@ int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value)
 	else if (!strcmp(name, "scalar_generic")) g->scalar_generic = value != 0;
 	else if (!strcmp(name, "coop_spin_limit")) g->coop_spin_limit = std::max<int64_t>(0, std::min<int64_t>(value, 0x7fffffff));
 	else if (!strcmp(name, "coop_tb_cap_mb")) g->coop_tb_cap = std::max<int64_t>(1, value) << 20;
+	else if (!strcmp(name, "lowmem_budget_mb")) g->lowmem_budget_mb = std::max<int64_t>(0, value);
+	else if (!strcmp(name, "trim")) { (void)hipSetDevice(g->device); trim(g); }
 	else return -1;
 	return 0;
 }
@@ -586,79 +886,17 @@ void mwf_gpu_get_stats(const mwf_gpu_t *g, mwf_gpu_stats_t *st)
 		if (hipEventSynchronize(m->ev1) == hipSuccess && hipEventElapsedTime(&ms, m->ev0, m->ev1) == hipSuccess) m->stats.kernel_ms = ms;
 		m->ev_pending = false;
 	}
+	m->stats.dev_bytes = m->dev_bytes, m->stats.dev_bytes_peak = m->dev_bytes_peak;
 	*st = m->stats;
 }
 
 /* ------------------------------------------------------------------ batches */
 
-static mwf_gpu_batch_t *batch_common(mwf_gpu_t *g, int32_t n, const int32_t *h_tl, const int32_t *h_ql)
-{
-	mwf_gpu_batch_t *b = new mwf_gpu_batch_t();
-	b->g = g, b->n = n;
-	b->h_tl.assign(h_tl, h_tl + n);
-	b->h_ql.assign(h_ql, h_ql + n);
-	const size_t N = (size_t)std::max(n, 1);
-	int64_t words = 0;
-	for (int32_t i = 0; i < n; ++i) {
-		words += (int64_t)h_tl[i] + h_ql[i] + 1;
-		b->max_tl = std::max<int64_t>(b->max_tl, h_tl[i]);
-		b->max_seq_lds = std::max<int64_t>(b->max_seq_lds, (((int64_t)h_tl[i] + 3) & ~3LL) + 8 + (((int64_t)h_ql[i] + 3) & ~3LL) + 16);
-	}
-	b->cig_pool_words = std::max<int64_t>(words, 1);
-	bool ok = hipMalloc(&b->d_s, N * 4) == hipSuccess && hipMalloc(&b->d_ncig, N * 4) == hipSuccess &&
-	          hipMalloc(&b->d_status, N * 4) == hipSuccess && hipMalloc(&b->d_dbg4, N * 16) == hipSuccess &&
-	          hipMalloc(&b->d_iter, N * 8) == hipSuccess && hipMalloc(&b->d_cigoff, N * 8) == hipSuccess &&
-	          hipMalloc(&b->d_cells1, N * 8) == hipSuccess && hipMalloc(&b->d_order, N * 4) == hipSuccess &&
-	          hipMalloc(&b->d_cig_head, 64) == hipSuccess;
-	if (!ok) {
-		g->err = "hipMalloc of result arrays failed";
-		mwf_gpu_batch_free(b);
-		return nullptr;
-	}
-	// longest pairs first, so the persistent workgroups finish together
-	std::vector<int32_t> order(n);
-	std::iota(order.begin(), order.end(), 0);
-	std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
-		return (int64_t)h_tl[x] + h_ql[x] > (int64_t)h_tl[y] + h_ql[y];
-	});
-	b->h_order = order;
-	if (n > 0 && hipMemcpy(b->d_order, order.data(), (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess) {
-		g->err = "upload of the processing order failed";
-		mwf_gpu_batch_free(b);
-		return nullptr;
-	}
-	return b;
-}
-
 mwf_gpu_batch_t *mwf_gpu_batch_upload(mwf_gpu_t *g, int32_t n, const char *seqs, int64_t seq_bytes,
                                       const int64_t *t_off, const int32_t *tl, const int64_t *q_off, const int32_t *ql)
 {
-	if (!g || n < 0) return nullptr;
-	(void)hipSetDevice(g->device);
-	mwf_gpu_batch_t *b = batch_common(g, n, tl, ql);
-	if (!b) return nullptr;
-	b->owns_inputs = true;
-	b->seq_bytes = seq_bytes;
-	const size_t N = (size_t)std::max(n, 1);
-	void *ds = nullptr, *dto = nullptr, *dqo = nullptr, *dtl = nullptr, *dql = nullptr;
-	bool ok = hipMalloc(&ds, (size_t)seq_bytes + 64) == hipSuccess && hipMalloc(&dto, N * 8) == hipSuccess &&
-	          hipMalloc(&dqo, N * 8) == hipSuccess && hipMalloc(&dtl, N * 4) == hipSuccess && hipMalloc(&dql, N * 4) == hipSuccess;
-	b->d_seqs = (const uint8_t*)ds, b->d_t_off = (const int64_t*)dto, b->d_q_off = (const int64_t*)dqo;
-	b->d_tl = (const int32_t*)dtl, b->d_ql = (const int32_t*)dql;
-	if (ok) ok = hipMemsetAsync(ds, 0, (size_t)seq_bytes + 64, g->stream) == hipSuccess;
-	if (ok && seq_bytes > 0) ok = hipMemcpyAsync(ds, seqs, (size_t)seq_bytes, hipMemcpyHostToDevice, g->stream) == hipSuccess;
-	if (ok && n > 0)
-		ok = hipMemcpyAsync(dto, t_off, (size_t)n * 8, hipMemcpyHostToDevice, g->stream) == hipSuccess &&
-		     hipMemcpyAsync(dqo, q_off, (size_t)n * 8, hipMemcpyHostToDevice, g->stream) == hipSuccess &&
-		     hipMemcpyAsync(dtl, tl, (size_t)n * 4, hipMemcpyHostToDevice, g->stream) == hipSuccess &&
-		     hipMemcpyAsync(dql, ql, (size_t)n * 4, hipMemcpyHostToDevice, g->stream) == hipSuccess;
-	if (ok) ok = hipStreamSynchronize(g->stream) == hipSuccess; // the host buffers are borrowed only for this call
-	if (!ok) {
-		g->err = "upload of the batch failed";
-		mwf_gpu_batch_free(b);
-		return nullptr;
-	}
-	return b;
+	if (!g || n < 0 || seq_bytes < 0) return nullptr;
+	return batch_from_host(g, n, tl, nullptr, ql, nullptr, seqs, seq_bytes, t_off, q_off);
 }
 
 mwf_gpu_batch_t *mwf_gpu_batch_wrap(mwf_gpu_t *g, int32_t n, const void *d_seqs, int64_t seq_bytes,
@@ -667,25 +905,26 @@ mwf_gpu_batch_t *mwf_gpu_batch_wrap(mwf_gpu_t *g, int32_t n, const void *d_seqs,
 {
 	if (!g || n < 0) return nullptr;
 	(void)hipSetDevice(g->device);
-	mwf_gpu_batch_t *b = batch_common(g, n, h_tl, h_ql);
+	BlockLayout L;
+	mwf_gpu_batch_t *b = batch_common(g, n, h_tl, h_ql, 0, false, L);
 	if (!b) return nullptr;
-	b->owns_inputs = false;
 	b->d_seqs = (const uint8_t*)d_seqs, b->seq_bytes = seq_bytes;
 	b->d_t_off = d_t_off, b->d_q_off = d_q_off, b->d_tl = d_tl, b->d_ql = d_ql;
+	if (upload_segments(g, (char*)b->block.p, std::vector<Seg>{Seg{b->h_order.data(), (size_t)n * 4}})) {
+		mwf_gpu_batch_free(b);
+		return nullptr;
+	}
 	return b;
 }
 
 void mwf_gpu_batch_free(mwf_gpu_batch_t *b)
 {
 	if (!b) return;
-	(void)hipSetDevice(b->g->device);
-	(void)hipStreamSynchronize(b->g->stream);
-	if (b->owns_inputs)
-		for (const void *p : {(const void*)b->d_seqs, (const void*)b->d_t_off, (const void*)b->d_q_off, (const void*)b->d_tl, (const void*)b->d_ql})
-			if (p) (void)hipFree(const_cast<void*>(p));
-	for (void *p : {(void*)b->d_s, (void*)b->d_ncig, (void*)b->d_status, (void*)b->d_dbg4, (void*)b->d_iter, (void*)b->d_cigoff,
-	                (void*)b->d_cells1, (void*)b->d_order, (void*)b->d_cig_pool, (void*)b->d_cig_head})
-		if (p) (void)hipFree(p);
+	mwf_gpu_t *g = b->g;
+	(void)hipSetDevice(g->device);
+	if (b->busy) (void)hipStreamSynchronize(g->stream); // kernels of an align nobody waited for may still use the block
+	give_block(g, g->spare_block, b->block);
+	give_block(g, g->spare_cig, b->cig);
 	delete b;
 }
 
@@ -695,24 +934,26 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	if (const char *why = validate(*opt)) { g->err = why; return -2; }
 	(void)hipSetDevice(g->device);
 	b->opt = *opt;
-	b->aligned = false, b->finalized = false;
+	b->aligned = false, b->finalized = false, b->h_cig_valid = false;
 	g->stats = mwf_gpu_stats_t{};
 	if (b->n == 0) { b->aligned = b->finalized = true; return 0; }
 	const bool cigar = (opt->flag & MWF_F_CIGAR) != 0;
 	if (cigar && !b->d_cig_pool) {
-		if (hipMalloc(&b->d_cig_pool, (size_t)b->cig_pool_words * 4) != hipSuccess) { g->err = "hipMalloc of the CIGAR pool failed"; return -1; }
+		if (take_block(g, g->spare_cig, b->cig, (size_t)b->cig_pool_words * 4)) return -1;
+		b->d_cig_pool = (uint32_t*)b->cig.p;
 	}
-	int64_t max_len = 0, max_bound = 0, max_bound1 = 0;
+	int64_t max_len = 0, max_bound = 0;
 	for (int32_t i = 0; i < b->n; ++i) {
 		max_len = std::max<int64_t>(max_len, (int64_t)b->h_tl[i] + b->h_ql[i]);
 		max_bound = std::max(max_bound, penalty_bound(*opt, b->h_tl[i], b->h_ql[i], true));
-		max_bound1 = std::max(max_bound1, penalty_bound(*opt, b->h_tl[i], b->h_ql[i], false));
 	}
 	if (max_len + 4 >= ((int64_t)1 << 31)) { g->err = "tl+ql must be below 2^31-4"; return -2; }
 	const int slots = 1 << 30; // as many as the chosen kernel can keep resident (run_batch_kernel bounds it)
 	if (b->debug_pair >= 0 && ensure(g, g->dbg, (size_t)8 * (max_bound + 2))) return -1;
-	HIP_TRY(g, hipMemsetAsync(b->d_cig_head, 0, 64, g->stream));
-	HIP_TRY(g, hipMemsetAsync(b->d_status, 0xff, (size_t)b->n * 4, g->stream));
+	b->busy = true;
+	g->queue_next = 0;
+	if (launch_reset(b->d_status, b->d_s, b->n, b->d_cig_head, (int32_t*)g->queue.p, kQueueSlots, g->stream)) { g->err = "kernel launch failed (reset)"; return -1; }
+	std::fill(b->h_flags.begin(), b->h_flags.end(), 0);
 	// a few long pairs: each one gets the whole device in turn
 	const Penalty P0 = make_penalty(*opt);
 	const int64_t coop_len = g->coop_min_len > 0 ? g->coop_min_len : 65536;
@@ -720,16 +961,19 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	// workgroups; the generic kernel runs up to 256 pairs side by side in time ~ (tl+ql)^2.  Measured at 3 % divergence
 	// (profiles/few_long_pairs.py): 100 kb pairs 88 ms each against 250 ms for any number of them, 150 kb pairs 128 ms
 	// against 550 ms — the whole-device kernel wins while the batch has fewer than about (tl+ql)/70000 pairs per group.
-	const int n_cu_coop = std::min(coop_max_grid(cigar), g->n_cu);
-	const int coop_side_by_side = n_cu_coop > 0 ? std::max(1, n_cu_coop / coop_group_size(n_cu_coop, max_len, false)) : 1;
-	const int64_t coop_max_pairs = std::max<int64_t>(1, std::min<int64_t>(256, max_len / 70000 * coop_side_by_side));
-	const bool coop = g->force_kind == 1 || (g->force_kind < 0 && coop_supported(P0) && b->n <= coop_max_pairs && max_len >= coop_len);
-	b->coop_grouped = false;
+	bool coop = g->force_kind == 1;
+	int n_cu_coop = 0;
+	if (coop || (g->force_kind < 0 && max_len >= coop_len && coop_supported(P0))) {
+		n_cu_coop = coop_grid_limit(g);
+		const int coop_side_by_side = n_cu_coop > 0 ? std::max(1, n_cu_coop / coop_group_size(n_cu_coop, max_len, false)) : 1;
+		const int64_t coop_max_pairs = std::max<int64_t>(1, std::min<int64_t>(256, max_len / 70000 * coop_side_by_side));
+		coop = coop || b->n <= coop_max_pairs;
+	}
 	if (coop) {
 		if (!coop_supported(P0)) { g->err = "whole-device kernel does not support these penalties"; return -2; }
 		if (n_cu_coop < 1) { g->err = "whole-device kernel cannot be made resident"; return -1; }
-		std::vector<int32_t> idx(b->h_order.begin(), b->h_order.end()); // longest first
-		std::stable_sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) { return (int64_t)b->h_tl[x] + b->h_ql[x] > (int64_t)b->h_tl[y] + b->h_ql[y]; });
+		std::vector<int32_t> idx(b->h_order.begin(), b->h_order.end());
+		std::stable_sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) { return (int64_t)b->h_tl[x] + b->h_ql[x] > (int64_t)b->h_tl[y] + b->h_ql[y]; }); // longest first
 		for (size_t at = 0; at < idx.size();) {
 			const int64_t len0 = (int64_t)b->h_tl[idx[at]] + b->h_ql[idx[at]];
 			const int Gs = coop_group_size(n_cu_coop, len0, false);
@@ -740,26 +984,29 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 				at += 1;
 				continue;
 			}
-			b->coop_grouped = true;
 			if (run_coop_group(g, b, *opt, std::vector<int32_t>(idx.begin() + at, idx.begin() + at + n_side), Gs, at == 0, last)) return -1;
 			at += n_side;
 		}
 		b->aligned = true;
 		return 0;
 	}
-	const int64_t budget = cigar ? tb_budget_bytes(g) : 0;
 	// Size classes.  One long pair must not push a thousand short ones onto the slow kernel (mwf_wfa_chain's gap fills are
 	// exactly such a mix): pairs are grouped by what their window can grow to, and every group runs on the kernel that suits
 	// it — generic (largest workspace) first, so that later groups never have to grow a buffer.  Kernel and block size forced
 	// by the caller (tests, tuning) keep the whole batch in one group.
+	// Low-memory mode (opt.step > 0): a pair whose penalty cannot reach `step` never takes a snapshot (the first one is due at
+	// penalty step-1, miniwfa.c:585), so its low-memory result IS its high-memory result, n_iter included — such pairs (the
+	// gap fills of mwf_wfa_auto's chain fallback, which inherit step = 5000) run in the classes as high-memory pairs; only
+	// genuinely long pairs go through the two-pass kernel (group 5).
 	const bool low_mem = cigar && opt->step > 0;
-	const bool classes = g->force_kind < 0 && g->block == 0 && !low_mem && band_supported(P0);
-	struct Group { std::vector<int32_t> ids; int64_t max_len = 0, max_bound = 0, max_bound1 = 0, max_tl = 0, max_seq_lds = 0; } grp[5];
-	b->h_class.assign((size_t)b->n, 0);
+	const bool classes = g->force_kind < 0 && g->block == 0 && band_supported(P0);
+	struct Group { std::vector<int32_t> ids; int64_t max_len = 0, max_bound = 0, max_bound1 = 0, max_tl = 0, max_seq_lds = 0; } grp[6];
 	for (int32_t i = 0; i < b->n; ++i) {
 		const int64_t len = (int64_t)b->h_tl[i] + b->h_ql[i], bound = penalty_bound(*opt, b->h_tl[i], b->h_ql[i], true);
-		int c = 0;
-		if (classes) {
+		const int64_t bound1 = penalty_bound(*opt, b->h_tl[i], b->h_ql[i], false);
+		const bool step0 = low_mem && bound1 < opt->step;
+		int c = low_mem && !step0 ? 5 : 0;
+		if (classes && c == 0) {
 			const int64_t window = std::min<int64_t>(len + 1, 2 * bound + 3);
 			const bool packable = (int64_t)b->h_tl[i] + bound < 32767 && g->band_pack != 0;
 			// A window cannot outgrow min(tl+ql+1, 2 x penalty bound + 3); in practice it stays far below tl+ql (a quarter of
@@ -770,37 +1017,43 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 			else if (packable ? (window <= kBandSmallWindow || len + 1 <= 3 * (int64_t)(4 * 3 * 256)) : window <= 8 * 256 - 256 - 64) c = 2;
 			else if (len + 1 <= 4 * (int64_t)(8 * 3 * 256)) c = 1;
 		}
-		b->h_class[i] = (int8_t)c;
+		b->h_class[i] = (int8_t)(c == 5 ? 0 : c);
+		b->h_flags[i] = (int8_t)(step0 ? 1 : 0);
 		Group &G = grp[c];
 		G.ids.push_back(i);
 		G.max_len = std::max(G.max_len, len), G.max_bound = std::max(G.max_bound, bound);
-		G.max_bound1 = std::max(G.max_bound1, penalty_bound(*opt, b->h_tl[i], b->h_ql[i], false));
+		G.max_bound1 = std::max(G.max_bound1, bound1);
 		G.max_tl = std::max<int64_t>(G.max_tl, b->h_tl[i]);
 		G.max_seq_lds = std::max<int64_t>(G.max_seq_lds, (((int64_t)b->h_tl[i] + 3) & ~3LL) + 8 + (((int64_t)b->h_ql[i] + 3) & ~3LL) + 16);
 	}
+	static const int run_order[6] = {5, 0, 1, 2, 3, 4}; // largest workspace first
 	std::vector<int32_t> order;
 	order.reserve((size_t)b->n);
-	for (Group &G : grp) {
+	for (int c : run_order) {
+		Group &G = grp[c];
 		std::stable_sort(G.ids.begin(), G.ids.end(), [&](int32_t x, int32_t y) { // longest first: the persistent workgroups finish together
 			return (int64_t)b->h_tl[x] + b->h_ql[x] > (int64_t)b->h_tl[y] + b->h_ql[y];
 		});
 		order.insert(order.end(), G.ids.begin(), G.ids.end());
 	}
 	if (order != b->h_order) {
-		HIP_TRY(g, hipStreamSynchronize(g->stream)); // an earlier align of this batch may still be reading the old order
-		HIP_TRY(g, hipMemcpy(b->d_order, order.data(), order.size() * 4, hipMemcpyHostToDevice));
 		b->h_order = order;
+		if (upload_segments(g, (char*)b->d_order, std::vector<Seg>{Seg{b->h_order.data(), order.size() * 4}})) return -1; // (waits for earlier work on the stream first)
 	}
 	int n_groups = 0, done_groups = 0;
 	for (const Group &G : grp) n_groups += !G.ids.empty();
+	mwf_opt_t opt_hi = *opt;
+	opt_hi.step = 0;
 	size_t at = 0;
-	for (int c = 0; c < 5; ++c) {
+	for (int c : run_order) {
 		const Group &G = grp[c];
 		if (G.ids.empty()) continue;
 		++done_groups;
-		if (run_batch_kernel(g, b, *opt, b->d_order + at, (int32_t)G.ids.size(), slots, G.max_len, G.max_bound, G.max_bound1, budget,
-		                     done_groups == 1, classes ? (c == 0 ? 0 : 2) : -1, G.max_tl, G.max_seq_lds, done_groups == n_groups,
-		                     c == 4 ? 64 : c == 3 ? 128 : c == 2 ? 256 : 0)) return -1;
+		int ran = 0;
+		if (run_batch_kernel(g, b, c == 5 ? *opt : opt_hi, b->d_order + at, (int32_t)G.ids.size(), slots, G.max_len, G.max_bound, G.max_bound1,
+		                     done_groups == 1, classes ? (c == 0 || c == 5 ? 0 : 2) : -1, G.max_tl, G.max_seq_lds, done_groups == n_groups,
+		                     c == 4 ? 64 : c == 3 ? 128 : c == 2 ? 256 : 0, &ran)) return -1;
+		for (int32_t i : G.ids) b->h_kind[i] = (int8_t)ran;
 		at += G.ids.size();
 	}
 	b->aligned = true;
@@ -811,119 +1064,136 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 
 namespace {
 
-// Wait for the batch, re-run pairs whose traceback arena overflowed with fewer, larger slots.
+// Wait for the batch; re-run what did not fit where it ran:
+//   window outgrew a band kernel's span   -> the wide band kernel, from there the generic kernel
+//   traceback / snapshot arena too small  -> the same kernel on fewer workgroups (= larger slots)
+//   whole-device kernel: a pair that shared the device gets it alone; the arena grows while memory lasts; a wait that
+//   gave up (workgroups not resident) or a window beyond the device's span falls back to the generic kernel.
 int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 {
 	if (b->finalized) return 0;
 	if (!b->aligned) { g->err = "batch was not aligned"; return -1; }
 	const size_t n = (size_t)b->n;
 	b->h_s.resize(n), b->h_ncig.resize(n), b->h_status.resize(n), b->h_iter.resize(n), b->h_cigoff.resize(n), b->h_cells1.resize(n);
+	std::vector<char> host(b->out_bytes);
+	const BlockLayout L = layout_block(n, 0, false); // (only differences between result offsets are used)
 	auto fetch = [&]() -> int {
-		HIP_TRY(g, hipStreamSynchronize(g->stream));
-		if (n == 0) return 0;
-		HIP_TRY(g, hipMemcpy(b->h_status.data(), b->d_status, n * 4, hipMemcpyDeviceToHost));
-		HIP_TRY(g, hipMemcpy(b->h_s.data(), b->d_s, n * 4, hipMemcpyDeviceToHost));
-		HIP_TRY(g, hipMemcpy(b->h_iter.data(), b->d_iter, n * 8, hipMemcpyDeviceToHost));
-		HIP_TRY(g, hipMemcpy(b->h_ncig.data(), b->d_ncig, n * 4, hipMemcpyDeviceToHost));
-		HIP_TRY(g, hipMemcpy(b->h_cigoff.data(), b->d_cigoff, n * 8, hipMemcpyDeviceToHost));
-		HIP_TRY(g, hipMemcpy(b->h_cells1.data(), b->d_cells1, n * 8, hipMemcpyDeviceToHost));
+		if (n == 0) { HIP_TRY(g, hipStreamSynchronize(g->stream)); return 0; }
+		if (download(g, host.data(), (const char*)b->block.p + b->out_off, b->out_bytes)) return -1;
+		const char *o = host.data() - L.head;
+		memcpy(&b->cig_used, o + L.head, 8);
+		memcpy(b->h_status.data(), o + L.status, n * 4), memcpy(b->h_s.data(), o + L.s, n * 4), memcpy(b->h_ncig.data(), o + L.ncig, n * 4);
+		memcpy(b->h_iter.data(), o + L.iter, n * 8), memcpy(b->h_cigoff.data(), o + L.cigoff, n * 8), memcpy(b->h_cells1.data(), o + L.cells1, n * 8);
 		return 0;
 	};
 	if (fetch()) return -1;
-	int slots = g->stats.grid, redo_kind = g->stats.kernel_kind == 2 ? 2 : 0;
-	bool coop_fell_back = false, coop_gave_up = false, coop_gave_up_now = false;
-	for (int round = 0; round < 14; ++round) {
-		std::vector<int32_t> redo;
-		bool band_overflow = false;
+	b->busy = false;
+	mwf_opt_t opt_hi = b->opt;
+	opt_hi.step = 0;
+	int tb_slots = std::max(1, g->stats.grid);
+	bool coop_warned = false;
+	const char *fail = nullptr;
+	for (int round = 0; round < 16 && !fail; ++round) {
+		// where every unfinished pair goes next: route = kind (0 generic, 1 whole-device alone, 2 band) and, for the band kernel, the class
+		std::vector<int32_t> to_generic[2], to_band_wide[2], same_fewer[3][2], coop_alone;
+		bool grow_coop = false;
 		for (size_t i = 0; i < n; ++i) {
 			const int32_t st = b->h_status[i];
-			if (st == ST_BAND_OVERFLOW) band_overflow = true, redo.push_back((int32_t)i);
-			else if (st == ST_INTERNAL && g->stats.kernel_kind == 1 && round <= 1 && !coop_gave_up) {
+			if (st == ST_OK || st == ST_STOPPED) continue;
+			const int kind = b->h_kind[i], step0 = b->h_flags[i] & 1;
+			if (st == ST_BAND_OVERFLOW && kind == 2) {
+				if (b->h_class[i] >= 2) b->h_class[i] = 1, to_band_wide[step0].push_back((int32_t)i);
+				else b->h_class[i] = 0, to_generic[step0].push_back((int32_t)i);
+			} else if (kind == 1 && st == ST_INTERNAL && !(b->h_flags[i] & 8)) {
 				// a wait between workgroups of the whole-device kernel ran into its spin limit (they were not all resident, e.g.
 				// the device is shared): the one-workgroup kernel needs no such thing
 				fprintf(stderr, "[libmwf_hip] warning: whole-device kernel gave up waiting for a workgroup on pair %d; re-running it on one workgroup (slow)\n", (int)i);
-				band_overflow = true, redo.push_back((int32_t)i);
-				coop_gave_up_now = true;
-			}
-			else if (st == ST_TB_OVERFLOW || st == ST_SNAP_OVERFLOW) redo.push_back((int32_t)i);
-			else if (st != ST_OK && st != ST_STOPPED) {
+				b->h_flags[i] |= 8;
+				to_generic[step0].push_back((int32_t)i);
+			} else if (kind == 1 && (st == ST_BAND_OVERFLOW || st == ST_TB_OVERFLOW || st == ST_SNAP_OVERFLOW)) {
+				if (b->h_flags[i] & 2) coop_alone.push_back((int32_t)i); // had a share of the workgroups and of the arena: now alone
+				else if (st == ST_BAND_OVERFLOW) {
+					if (!coop_warned) fprintf(stderr, "[libmwf_hip] warning: wavefront of pair %d outgrew the whole-device kernel's span; re-running it on one workgroup (slow)\n", (int)i);
+					coop_warned = true;
+					to_generic[step0].push_back((int32_t)i);
+				} else if (g->tb_budget_mb == 0 && g->coop_tb_cap < ((int64_t)1 << 40) && coop_can_grow(g)) grow_coop = true, coop_alone.push_back((int32_t)i);
+				else if (b->opt.step > 0 && !step0) to_generic[0].push_back((int32_t)i); // the first-pass traceback does not fit: true two-pass mode
+				else fail = "traceback";
+			} else if (st == ST_TB_OVERFLOW || st == ST_SNAP_OVERFLOW) {
+				if (tb_slots == 1) fail = st == ST_TB_OVERFLOW ? "traceback" : "low-memory snapshots"; // already had the whole budget
+				same_fewer[kind == 2 ? 2 : 0][step0].push_back((int32_t)i);
+			} else {
 				g->err = "pair " + std::to_string(i) + " failed on the device with status " + std::to_string(st);
 				return -3;
 			}
-		}
-		if (redo.empty()) break;
-		if (g->stats.kernel_kind == 1 && b->coop_grouped && !coop_gave_up_now) {
-			// pairs that ran side by side had a share of the workgroups and of the traceback arena: whatever did not fit gets
-			// the device to itself (and from there the usual remedies)
-			b->coop_grouped = false;
-			for (int32_t i : redo)
-				if (run_coop_pair(g, b, b->opt, i, false, false)) return -1;
-			g->stats.n_retries += (int32_t)redo.size();
-			if (fetch()) return -1;
-			continue;
-		}
-		if (round == 0 && g->stats.kernel_kind != 1 && !b->h_class.empty()) {
-			// the batch ran in size classes: stay on the band kernel only if every pair to redo came from one
-			bool any_class = false, all_band = true;
-			for (int8_t c : b->h_class) any_class |= c != 0;
-			for (int32_t i : redo) all_band &= b->h_class[i] != 0;
-			if (any_class) redo_kind = all_band ? 2 : 0;
-		}
-		if (coop_gave_up_now) coop_gave_up = true, coop_gave_up_now = false, b->coop_grouped = false;
-		if (band_overflow) {
-			redo_kind = 0; // the window outgrew the register-resident span: generic kernel, same slots
-			// ... unless the pair sat in one of the small size classes: then the wide band kernel first (the rest waits a round)
-			std::vector<int32_t> promote;
-			if (g->stats.kernel_kind != 1)
-				for (int32_t i : redo)
-					if (b->h_status[i] == ST_BAND_OVERFLOW && (size_t)i < b->h_class.size() && b->h_class[i] >= 2) promote.push_back(i);
-			if (!promote.empty()) {
-				for (int32_t i : promote) b->h_class[i] = 1;
-				redo.swap(promote);
-				redo_kind = 2;
+			if (fail) {
+				g->err = std::string(fail) + " of pair " + std::to_string(i) + " (tl=" + std::to_string(b->h_tl[i]) + ", ql=" + std::to_string(b->h_ql[i]) +
+				         ") do not fit in device memory" + (b->opt.step > 0 ? "" : "; set opt.step > 0 (low-memory mode)");
+				return -4;
 			}
-			if (g->stats.kernel_kind == 1 && b->h_status[redo[0]] == ST_BAND_OVERFLOW)
-				fprintf(stderr, "[libmwf_hip] warning: wavefront of pair %d outgrew the whole-device kernel's span; re-running it on one workgroup (slow)\n", redo[0]);
 		}
-		else if (g->stats.kernel_kind == 1 && g->tb_budget_mb == 0 && g->coop_tb_cap < ((int64_t)1 << 40) && coop_can_grow(g)) {
-			g->coop_tb_cap *= 2;
-			for (int32_t i : redo)
-				if (run_coop_pair(g, b, b->opt, i, false, false)) return -1;
-			g->stats.n_retries += (int32_t)redo.size();
-			if (fetch()) return -1;
-			continue;
-		} else if (g->stats.kernel_kind == 1 && b->opt.step > 0 && !coop_fell_back) {
-			coop_fell_back = true;
-			// whole-device low-memory run whose first-pass traceback does not fit: the generic kernel's true two-pass mode
-			redo_kind = 0, slots = (int)redo.size(), band_overflow = true;
-		} else if (slots == 1) {
-			g->err = std::string(b->h_status[redo[0]] == ST_TB_OVERFLOW ? "traceback" : "low-memory snapshots") + " of pair " + std::to_string(redo[0]) +
-			         " (tl=" + std::to_string(b->h_tl[redo[0]]) + ", ql=" + std::to_string(b->h_ql[redo[0]]) + ") do not fit in device memory" +
-			         (b->opt.step > 0 ? "" : "; set opt.step > 0 (low-memory mode)");
-			return -4;
+		size_t n_redo = coop_alone.size();
+		for (int z = 0; z < 2; ++z) n_redo += to_generic[z].size() + to_band_wide[z].size() + same_fewer[0][z].size() + same_fewer[2][z].size();
+		if (n_redo == 0) break;
+		g->stats.n_retries += (int32_t)n_redo;
+		if (grow_coop) g->coop_tb_cap *= 2;
+		for (int32_t i : coop_alone)
+			if (run_coop_pair(g, b, b->opt, i, false, false)) return -1;
+		const bool shrink = !same_fewer[0][0].empty() || !same_fewer[0][1].empty() || !same_fewer[2][0].empty() || !same_fewer[2][1].empty();
+		if (shrink) tb_slots = std::max(1, tb_slots / 8);
+		auto rerun = [&](std::vector<int32_t> &ids, int step0, int want_kind, int slots) -> int {
+			if (ids.empty()) return 0;
+			std::stable_sort(ids.begin(), ids.end(), [&](int32_t x, int32_t y) { return (int64_t)b->h_tl[x] + b->h_ql[x] > (int64_t)b->h_tl[y] + b->h_ql[y]; });
+			const mwf_opt_t &o = step0 ? opt_hi : b->opt;
+			int64_t max_len = 0, max_bound = 0, max_bound1 = 0, max_tl = 0, max_seq_lds = 0;
+			for (int32_t i : ids) {
+				max_len = std::max<int64_t>(max_len, (int64_t)b->h_tl[i] + b->h_ql[i]);
+				max_bound = std::max(max_bound, penalty_bound(o, b->h_tl[i], b->h_ql[i], true));
+				max_bound1 = std::max(max_bound1, penalty_bound(o, b->h_tl[i], b->h_ql[i], false));
+				max_tl = std::max<int64_t>(max_tl, b->h_tl[i]);
+				max_seq_lds = std::max<int64_t>(max_seq_lds, (((int64_t)b->h_tl[i] + 3) & ~3LL) + 8 + (((int64_t)b->h_ql[i] + 3) & ~3LL) + 16);
+			}
+			DevBuf tmp; // the ids of this re-run (retries are rare: a scratch allocation of their own)
+			if (ensure(g, tmp, ids.size() * 4)) return -1;
+			int rc = upload_segments(g, (char*)tmp.p, std::vector<Seg>{Seg{ids.data(), ids.size() * 4}});
+			int ran = 0;
+			if (rc == 0) rc = run_batch_kernel(g, b, o, (const int32_t*)tmp.p, (int32_t)ids.size(), slots, max_len, max_bound, max_bound1, false,
+			                                   want_kind, max_tl, max_seq_lds, 0, 0, &ran);
+			if (rc == 0) rc = hipStreamSynchronize(g->stream) == hipSuccess ? 0 : -1;
+			release(g, tmp);
+			if (rc) return -1;
+			for (int32_t i : ids) b->h_kind[i] = (int8_t)ran;
+			return 0;
+		};
+		const int wide = 1 << 30;
+		for (int z = 0; z < 2; ++z) {
+			if (rerun(to_generic[z], z, 0, std::max(1, g->stats.grid))) return -1;
+			if (rerun(to_band_wide[z], z, 2, wide)) return -1;
+			if (rerun(same_fewer[0][z], z, 0, std::max(1, std::min<int>(tb_slots, (int)same_fewer[0][z].size())))) return -1;
+			if (rerun(same_fewer[2][z], z, 2, std::max(1, std::min<int>(tb_slots, (int)same_fewer[2][z].size())))) return -1;
 		}
-		if (!band_overflow) slots = std::max(1, std::min<int>(slots / 8, (int)redo.size()));
-		std::stable_sort(redo.begin(), redo.end(), [&](int32_t x, int32_t y) {
-			return (int64_t)b->h_tl[x] + b->h_ql[x] > (int64_t)b->h_tl[y] + b->h_ql[y];
-		});
-		int64_t max_len = 0, max_bound = 0, max_bound1 = 0;
-		for (int32_t i : redo) {
-			max_len = std::max<int64_t>(max_len, (int64_t)b->h_tl[i] + b->h_ql[i]);
-			max_bound = std::max(max_bound, penalty_bound(b->opt, b->h_tl[i], b->h_ql[i], true));
-			max_bound1 = std::max(max_bound1, penalty_bound(b->opt, b->h_tl[i], b->h_ql[i], false));
-		}
-		int32_t *d_redo = nullptr;
-		HIP_TRY(g, hipMalloc(&d_redo, redo.size() * 4));
-		HIP_TRY(g, hipMemcpy(d_redo, redo.data(), redo.size() * 4, hipMemcpyHostToDevice));
-		g->stats.n_retries += (int32_t)redo.size();
-		const int rc = run_batch_kernel(g, b, b->opt, d_redo, (int32_t)redo.size(), slots, max_len, max_bound, max_bound1, tb_budget_bytes(g), false, redo_kind);
-		if (rc == 0 && fetch()) { (void)hipFree(d_redo); return -1; }
-		(void)hipFree(d_redo);
-		if (rc) return -1;
+		if (fetch()) return -1;
 	}
+	// nothing may be handed out as a result that is not one
+	for (size_t i = 0; i < n; ++i)
+		if (b->h_status[i] != ST_OK && b->h_status[i] != ST_STOPPED) {
+			g->err = "pair " + std::to_string(i) + " is still unfinished after every retry (status " + std::to_string(b->h_status[i]) + ")";
+			return -3;
+		}
 	g->stats.cells = 0, g->stats.cells_pass1 = 0;
 	for (size_t i = 0; i < n; ++i) g->stats.cells += b->h_iter[i], g->stats.cells_pass1 += b->h_cells1[i];
 	b->finalized = true;
+	return 0;
+}
+
+// every CIGAR of the batch in one copy (the used part of the pool)
+int fetch_cigars(mwf_gpu_t *g, mwf_gpu_batch_t *b)
+{
+	if (b->h_cig_valid) return 0;
+	if (int rc = finalize(g, b)) return rc;
+	b->h_cig.resize((size_t)std::max<int64_t>(b->cig_used, 0));
+	if (b->cig_used > 0 && download(g, b->h_cig.data(), b->d_cig_pool, (size_t)b->cig_used * 4)) return -1;
+	b->h_cig_valid = true;
 	return 0;
 }
 
@@ -945,6 +1215,7 @@ int mwf_gpu_batch_results(mwf_gpu_t *g, mwf_gpu_batch_t *b, int32_t *s, int64_t 
 
 const int32_t *mwf_gpu_batch_dev_scores(const mwf_gpu_batch_t *b) { return b ? b->d_s : nullptr; }
 const int64_t *mwf_gpu_batch_dev_iters(const mwf_gpu_batch_t *b) { return b ? b->d_iter : nullptr; }
+const int32_t *mwf_gpu_batch_dev_status(const mwf_gpu_batch_t *b) { return b ? b->d_status : nullptr; }
 
 int32_t mwf_gpu_batch_cigar(mwf_gpu_t *g, mwf_gpu_batch_t *b, int32_t i, uint32_t *dst, int32_t cap)
 {
@@ -953,8 +1224,17 @@ int32_t mwf_gpu_batch_cigar(mwf_gpu_t *g, mwf_gpu_batch_t *b, int32_t i, uint32_
 	if (int rc = finalize(g, b)) return rc;
 	const int32_t nc = b->h_ncig[i];
 	if (nc > cap) return -5;
-	if (nc > 0) HIP_TRY(g, hipMemcpy(dst, b->d_cig_pool + b->h_cigoff[i], (size_t)nc * 4, hipMemcpyDeviceToHost));
+	if (nc <= 0) return nc;
+	if (b->h_cig_valid) memcpy(dst, b->h_cig.data() + b->h_cigoff[i], (size_t)nc * 4);
+	else HIP_TRY(g, hipMemcpy(dst, b->d_cig_pool + b->h_cigoff[i], (size_t)nc * 4, hipMemcpyDeviceToHost));
 	return nc;
+}
+
+int mwf_gpu_batch_fetch_cigars(mwf_gpu_t *g, mwf_gpu_batch_t *b)
+{
+	if (!g || !b) return -1;
+	(void)hipSetDevice(g->device);
+	return fetch_cigars(g, b);
 }
 
 /* test hook: trace the band of one pair (columns lo,hi per penalty); returns penalties traced */
@@ -982,67 +1262,170 @@ void mwf_opt_init(mwf_opt_t *opt) // reference miniwfa.c:11-18
 	opt->kmer = 13, opt->max_occ = 2, opt->min_len = 30;
 }
 
-static mwf_gpu_t *thread_engine()
+} // extern "C"
+
+namespace {
+
+// Engines (stream + device pools) are pooled per device: a call takes an idle one — or creates one — and puts it back, so
+// any number of host threads may call the drop-in API concurrently (the reference is re-entrant), each
+// holding its own engine while it is inside a call, and an engine's warm pools serve whichever thread calls next.
+// (Deliberately never destroyed: tearing streams down from static destructors can run after the HIP runtime's own teardown.)
+struct EnginePool {
+	std::mutex mu;
+	std::vector<mwf_gpu_t*> idle[kMaxDevices];
+};
+EnginePool &engine_pool() { static EnginePool *p = new EnginePool(); return *p; }
+
+mwf_gpu_t *acquire_engine(int dev)
 {
-	// One engine (stream + pool) per host thread keeps the reference's re-entrancy: no shared
-	// mutable state between threads beyond the HIP runtime itself.
-	// (deliberately never destroyed: tearing a stream down from a thread_local destructor can run after
-	// the HIP runtime's own static teardown)
-	struct Holder { mwf_gpu_t *g = nullptr; };
-	static thread_local Holder h;
-	if (!h.g) {
-		int dev = 0;
-		if (const char *e = getenv("MWF_DEVICE")) dev = atoi(e);
-		h.g = mwf_gpu_create(dev, nullptr);
-		if (!h.g) fatal("cannot open a HIP device; this library has no CPU path", nullptr);
+	EnginePool &P = engine_pool();
+	{
+		std::lock_guard<std::mutex> lock(P.mu);
+		std::vector<mwf_gpu_t*> &v = P.idle[dev % kMaxDevices];
+		if (!v.empty()) {
+			mwf_gpu_t *g = v.back();
+			v.pop_back();
+			return g;
+		}
 	}
-	return h.g;
+	mwf_gpu_t *g = mwf_gpu_create(dev, nullptr);
+	if (!g) fatal("cannot open a HIP device; this library has no CPU path", nullptr);
+	return g;
+}
+
+void release_engine(mwf_gpu_t *g)
+{
+	EnginePool &P = engine_pool();
+	std::lock_guard<std::mutex> lock(P.mu);
+	P.idle[g->device % kMaxDevices].push_back(g);
+}
+
+int default_device()
+{
+	const char *e = getenv("MWF_DEVICE");
+	return e ? atoi(e) : 0;
+}
+
+// What one device produced for its share of a call, in host memory; the caller's thread turns it into mwf_rst_t's (kalloc
+// arenas are not thread-safe, so nothing is allocated from `km` on a worker thread).
+struct HostResult {
+	std::vector<int32_t> s, ncig, dbg4;
+	std::vector<int64_t> iter, cigoff;
+	std::vector<uint32_t> cig;
+	std::string err;
+};
+
+// Align pairs ids[0..m) of the caller's arrays on device `dev`.
+void run_share(int dev, const mwf_opt_t *opt, const std::vector<int32_t> &ids, const int32_t *tl, const char *const *ts,
+               const int32_t *ql, const char *const *qs, HostResult &R)
+{
+	const int32_t m = (int32_t)ids.size();
+	if (m == 0) return;
+	mwf_gpu_t *g = acquire_engine(dev);
+	std::vector<int32_t> ltl((size_t)m), lql((size_t)m);
+	std::vector<const char*> lts((size_t)m), lqs((size_t)m);
+	for (int32_t j = 0; j < m; ++j) ltl[j] = tl[ids[j]], lql[j] = ql[ids[j]], lts[j] = ts[ids[j]], lqs[j] = qs[ids[j]];
+	mwf_gpu_batch_t *b = batch_from_host(g, m, ltl.data(), lts.data(), lql.data(), lqs.data(), nullptr, 0, nullptr, nullptr);
+	const bool cigar = (opt->flag & MWF_F_CIGAR) != 0;
+	if (!b) R.err = std::string("batch upload failed: ") + mwf_gpu_last_error(g);
+	else {
+		R.s.resize((size_t)m), R.ncig.resize((size_t)m), R.iter.resize((size_t)m);
+		if (mwf_gpu_batch_align(g, b, opt) || mwf_gpu_batch_results(g, b, R.s.data(), R.iter.data(), R.ncig.data()) || (cigar && fetch_cigars(g, b)))
+			R.err = std::string("alignment failed: ") + mwf_gpu_last_error(g);
+		else {
+			if (cigar) R.cig.swap(b->h_cig), R.cigoff = b->h_cigoff;
+			if ((opt->flag & MWF_F_DEBUG) && cigar) {
+				R.dbg4.resize((size_t)m * 4);
+				if (hipMemcpy(R.dbg4.data(), b->d_dbg4, (size_t)m * 16, hipMemcpyDeviceToHost) != hipSuccess) R.dbg4.clear();
+			}
+		}
+		mwf_gpu_batch_free(b);
+	}
+	release_engine(g);
+}
+
+void fill_results(void *km, const mwf_opt_t *opt, const std::vector<int32_t> &ids, const HostResult &R, mwf_rst_t *r)
+{
+	for (size_t j = 0; j < ids.size(); ++j) {
+		mwf_rst_t &o = r[ids[j]];
+		memset(&o, 0, sizeof(mwf_rst_t)); // reference miniwfa.c:387
+		o.s = R.s[j], o.n_iter = R.iter[j];
+		if ((opt->flag & MWF_F_CIGAR) && R.s[j] >= 0 && R.ncig[j] > 0) {
+			// reference krelocate()s the CIGAR into the caller's arena (miniwfa.c:434); a zero-length one stays NULL
+			o.n_cigar = R.ncig[j];
+			o.cigar = (uint32_t*)kmalloc(km, (size_t)R.ncig[j] * 4);
+			memcpy(o.cigar, R.cig.data() + R.cigoff[j], (size_t)R.ncig[j] * 4);
+		}
+		if ((opt->flag & MWF_F_DEBUG) && !R.dbg4.empty() && R.s[j] >= 0) // reference miniwfa.c:367 prints the traceback end state
+			fprintf(stderr, "s0=%d, s=%d, i=%d, k=%d\n", R.s[j] - 1, R.dbg4[4 * j], R.dbg4[4 * j + 1], R.dbg4[4 * j + 2]);
+	}
+}
+
+} // namespace
+
+extern "C" {
+
+void mwf_wfa_batch_multi(void *km, const mwf_opt_t *opt, int32_t n, const int32_t *tl, const char *const *ts,
+                         const int32_t *ql, const char *const *qs, mwf_rst_t *r, int32_t n_dev, const int32_t *devices)
+{
+	if (n <= 0) return;
+	std::vector<int32_t> devs;
+	if (devices && n_dev > 0) devs.assign(devices, devices + n_dev);
+	else {
+		const int have = mwf_gpu_device_count();
+		if (have < 1) fatal("cannot open a HIP device; this library has no CPU path", nullptr);
+		const int want = n_dev > 0 ? std::min<int>(n_dev, have) : have;
+		for (int d = 0; d < want; ++d) devs.push_back(d);
+	}
+	const int D = (int)std::min<size_t>(devs.size(), (size_t)n);
+	std::vector<std::vector<int32_t>> share((size_t)D);
+	if (D == 1) {
+		share[0].resize((size_t)n);
+		std::iota(share[0].begin(), share[0].end(), 0);
+	} else {
+		// Longest first, each to the device with the least work so far.  Work of a pair ~ cells ~ s^2 ~ (tl+ql)^2 at equal
+		// divergence; nothing crosses devices while they work.
+		std::vector<int32_t> idx((size_t)n);
+		std::iota(idx.begin(), idx.end(), 0);
+		std::stable_sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) { return (int64_t)tl[x] + ql[x] > (int64_t)tl[y] + ql[y]; });
+		std::vector<double> load((size_t)D, 0.0);
+		for (int32_t i : idx) {
+			const int d = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+			const double len = (double)tl[i] + ql[i] + 1;
+			load[d] += len * len;
+			share[d].push_back(i);
+		}
+	}
+	std::vector<HostResult> res((size_t)D);
+	if (D == 1) run_share(devs[0], opt, share[0], tl, ts, ql, qs, res[0]);
+	else {
+		std::vector<std::thread> th;
+		for (int d = 1; d < D; ++d) th.emplace_back(run_share, devs[d], opt, std::cref(share[d]), tl, ts, ql, qs, std::ref(res[d]));
+		run_share(devs[0], opt, share[0], tl, ts, ql, qs, res[0]);
+		for (std::thread &t : th) t.join();
+	}
+	for (int d = 0; d < D; ++d)
+		if (!res[d].err.empty()) fatal(res[d].err.c_str(), nullptr);
+	for (int d = 0; d < D; ++d) fill_results(km, opt, share[d], res[d], r); // merged back in the caller's order
 }
 
 void mwf_wfa_batch(void *km, const mwf_opt_t *opt, int32_t n, const int32_t *tl, const char *const *ts,
                    const int32_t *ql, const char *const *qs, mwf_rst_t *r)
 {
-	mwf_gpu_t *g = thread_engine();
-	if (n <= 0) return;
-	std::vector<int64_t> t_off(n), q_off(n);
-	int64_t total = 0;
-	for (int32_t i = 0; i < n; ++i) {
-		t_off[i] = total, total += tl[i];
-		q_off[i] = total, total += ql[i];
+	// MWF_DEVICES = "all" or a count: deal the batch over that many devices; otherwise the one device MWF_DEVICE names
+	const char *e = getenv("MWF_DEVICES");
+	if (e && n > 1) {
+		const int32_t k = !strcmp(e, "all") ? 0 : atoi(e);
+		if (k != 1) { mwf_wfa_batch_multi(km, opt, n, tl, ts, ql, qs, r, k, nullptr); return; }
 	}
-	std::vector<char> packed((size_t)total + 16, 0);
-	for (int32_t i = 0; i < n; ++i) {
-		if (tl[i]) memcpy(&packed[t_off[i]], ts[i], tl[i]);
-		if (ql[i]) memcpy(&packed[q_off[i]], qs[i], ql[i]);
-	}
-	mwf_gpu_batch_t *b = mwf_gpu_batch_upload(g, n, packed.data(), total, t_off.data(), tl, q_off.data(), ql);
-	if (!b) fatal("batch upload failed", mwf_gpu_last_error(g));
-	if (mwf_gpu_batch_align(g, b, opt)) fatal("alignment failed", mwf_gpu_last_error(g));
-	std::vector<int32_t> s(n), nc(n);
-	std::vector<int64_t> it(n);
-	if (mwf_gpu_batch_results(g, b, s.data(), it.data(), nc.data())) fatal("alignment failed", mwf_gpu_last_error(g));
-	for (int32_t i = 0; i < n; ++i) {
-		memset(&r[i], 0, sizeof(mwf_rst_t)); // reference miniwfa.c:387
-		r[i].s = s[i], r[i].n_iter = it[i];
-		if ((opt->flag & MWF_F_CIGAR) && s[i] >= 0) {
-			r[i].n_cigar = nc[i];
-			// reference krelocate()s the CIGAR into the caller's arena (miniwfa.c:434); a zero-length one stays NULL
-			r[i].cigar = nc[i] > 0 ? (uint32_t*)kmalloc(km, (size_t)nc[i] * 4) : nullptr;
-			if (nc[i] > 0 && mwf_gpu_batch_cigar(g, b, i, r[i].cigar, nc[i]) != nc[i]) fatal("CIGAR download failed", mwf_gpu_last_error(g));
-		}
-	}
-	if (opt->flag & MWF_F_DEBUG) { // reference miniwfa.c:367 prints the traceback end state
-		std::vector<int32_t> d4((size_t)n * 4);
-		if ((opt->flag & MWF_F_CIGAR) && hipMemcpy(d4.data(), b->d_dbg4, (size_t)n * 16, hipMemcpyDeviceToHost) == hipSuccess)
-			for (int32_t i = 0; i < n; ++i)
-				if (s[i] >= 0) fprintf(stderr, "s0=%d, s=%d, i=%d, k=%d\n", s[i] - 1, d4[4 * i], d4[4 * i + 1], d4[4 * i + 2]);
-	}
-	mwf_gpu_batch_free(b);
+	const int32_t dev = default_device();
+	mwf_wfa_batch_multi(km, opt, n, tl, ts, ql, qs, r, 1, &dev);
 }
 
 void mwf_wfa_exact(void *km, const mwf_opt_t *opt, int32_t tl, const char *ts, int32_t ql, const char *qs, mwf_rst_t *r)
 {
-	mwf_wfa_batch(km, opt, 1, &tl, &ts, &ql, &qs, r);
+	const int32_t dev = default_device();
+	mwf_wfa_batch_multi(km, opt, 1, &tl, &ts, &ql, &qs, r, 1, &dev);
 }
 
 // mwf_wfa_chain lives in mwf_chain.cpp

@@ -101,6 +101,7 @@ struct BatchArgs {
 };
 
 // launch wrappers implemented in mwf_kernels.hip (generic kernel: any penalties, any band, low-memory mode)
+int launch_reset(int32_t *status, int32_t *s, int32_t n, unsigned long long *cig_head, int32_t *queue, int32_t n_queue, void *stream);
 int launch_batch(const BatchArgs &a, int grid, int block, void *stream);
 int  batch_kernel_occupancy(int block, bool stream_pass, int lds_e2_cols);   // resident workgroups per CU for that block size
 

@@ -100,3 +100,55 @@ def test_align_without_gpu_fails_loudly():
         pytest.skip("a GPU is present")
     with pytest.raises(RuntimeError):
         mw.Engine(0)
+
+
+def test_kalloc_macros_compile_and_work(tmp_path):
+    """A C program written against the reference's kalloc.h convenience macros (kalloc.h:33-80: KMALLOC, KCALLOC,
+    KREALLOC, KEXPAND, KALLOC_POOL_INIT) compiles against include/kalloc.h and runs on the library's allocator."""
+    import subprocess
+    from miniwfa_amd import build as b
+    b.build()
+    src = tmp_path / "km.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "kalloc.h"
+typedef struct { int a, b; } item_t;
+KALLOC_POOL_INIT(item, item_t)
+int main(void)
+{
+	void *km = km_init();
+	int *v = 0, i;
+	size_t m = 0, n = 0;
+	long sum = 0;
+	double *w;
+	char *z;
+	kmp_item_t *mp;
+	item_t *x, *y;
+	for (i = 0; i < 1000; ++i) {
+		if (n == m) KEXPAND(km, v, m);
+		v[n++] = i;
+	}
+	for (i = 0; i < 1000; ++i) sum += v[i];
+	KMALLOC(km, w, 10); w[9] = 1.5;
+	KCALLOC(km, z, 64);
+	for (i = 0; i < 64; ++i) if (z[i]) return 2;
+	KREALLOC(km, w, 100); if (w[9] != 1.5) return 3;
+	mp = kmp_init_item(km);
+	x = kmp_alloc_item(mp); if (x->a || x->b || mp->cnt != 1) return 4;
+	x->a = 7; kmp_free_item(mp, x); if (mp->cnt != 0 || mp->n != 1) return 5;
+	y = kmp_alloc_item(mp); if (y != x || y->a != 7) return 6;
+	kmp_free_item(mp, y);
+	kmp_destroy_item(mp);
+	kfree(km, v); kfree(km, w); kfree(km, z);
+	km_destroy(km);
+	printf("%ld %zu\n", sum, m);
+	return 0;
+}
+''')
+    exe = tmp_path / "km"
+    csrc = os.path.dirname(b.LIB)
+    subprocess.run(["gcc", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                    "-L", csrc, "-lmwf_hip", "-Wl,-rpath," + csrc], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert out[0] == str(sum(range(1000))) and int(out[1]) >= 1000

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from miniwfa_amd.shard import shard_bounds, gather_records, gather_cigars
+from miniwfa_amd.shard import shard_bounds, deal_pairs, gather_records, gather_cigars
 from miniwfa_amd.synth import synth_pair
 
 
@@ -22,6 +22,66 @@ def test_shard_bounds_cover_everything_once():
             assert all(a[1] == b[0] for a, b in zip(got, got[1:]))
             sizes = [e - b for b, e in got]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_deal_is_balanced_and_complete():
+    rng = np.random.default_rng(7)
+    for world in (1, 2, 3, 8):
+        lengths = np.concatenate([rng.integers(100, 400, 500), rng.integers(20000, 100000, 9), [5000000]])
+        deal = deal_pairs(lengths, world)
+        assert sorted(np.concatenate(deal).tolist()) == list(range(len(lengths)))
+        work = [float(((lengths[d].astype(np.float64) + 1) ** 2).sum()) for d in deal]
+        # the one huge pair dominates; the other ranks share the rest evenly (LPT: within one pair of the mean)
+        rest = sorted(work)[:-1] if world > 1 else []
+        if len(rest) > 1:
+            assert max(rest) - min(rest) <= (100000.0 + 1) ** 2
+        assert deal_pairs(lengths, world)[0].tolist() == deal[0].tolist()   # deterministic
+
+
+def _ragged_pair(i):
+    # a ragged batch: mostly short pairs, every ninth one long
+    return synth_pair(92000 + i, 3000 if i % 9 == 4 else 150 + 17 * (i % 5), 0.06)
+
+
+def _worker_ragged(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.pyoracle import Oracle, make_opt
+        orc = Oracle()
+        pairs = [_ragged_pair(i) for i in range(n)]
+        deal = deal_pairs([len(t) + len(qq) for t, qq in pairs], world)
+        res = [orc.align(*pairs[i], make_opt(flag=1)) for i in deal[rank]]
+        s_loc = torch.tensor([r[0] for r in res], dtype=torch.int32)
+        it_loc = torch.tensor([r[1] for r in res], dtype=torch.int64)
+        s, it = gather_records(dist, s_loc, it_loc, n, deal=deal)
+        cigs = gather_cigars(dist, [np.array(r[2], dtype=np.uint32) for r in res], n, deal=deal)
+        q.put((rank, s.tolist(), it.tolist(), [c.tolist() for c in cigs], [len(d) for d in deal]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_ragged_deal():
+    from oracle.pyoracle import Oracle, make_opt
+    n = 20
+    orc = Oracle()
+    expect = [orc.align(*_ragged_pair(i), make_opt(flag=1)) for i in range(n)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ragged, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, s, it, cigs, sizes in got:
+        assert s == [e[0] for e in expect], rank
+        assert it == [e[1] for e in expect], rank
+        assert cigs == [e[2] for e in expect], rank
+        assert sum(sizes) == n and min(sizes) >= 1
 
 
 def _free_port():
