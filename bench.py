@@ -70,7 +70,8 @@ class _DevPtr:
 
 
 KERNEL_NAMES = {0: "wfa_batch_kernel (generic: one workgroup per pair, ring in HBM)", 1: "wfa_coop_kernel (one pair across the device)",
-                2: "wfa_band_kernel (one workgroup per pair, E/F in registers, H rows prefetched)"}
+                2: "wfa_band_kernel (one workgroup per pair, E/F in registers, 32-bit H rows in HBM)",
+                3: "wfa_band2_kernel (one workgroup per pair, E/F in registers, 16-bit H rows in HBM, sequences in LDS)"}
 
 
 def call_latency(mw, synth_pair, reps=40):
@@ -172,6 +173,7 @@ def main():
     ap.add_argument("--cigar", action="store_true", help="score+CIGAR (high-memory) instead of score-only")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--slots-per-cu", type=int, default=0)
+    ap.add_argument("--band-pack", type=int, default=-1, help="band kernel: 1 forces the int16-packed variants where the forced block has both")
     ap.add_argument("--cpu-sample", type=int, default=None, help="pairs in the cpu_baseline sample (0: skip)")
     ap.add_argument("--long-pairs", type=int, default=1, help="also time the single-pair configs (C4-like 150 kb, MHC-like 5 Mb) on rank 0 at N=1")
     ap.add_argument("--extras", type=int, default=1, help="0: skip end_to_end / call latency / long pairs (profiling runs)")
@@ -226,6 +228,8 @@ def main():
         eng.set("block", args.block)
     if args.slots_per_cu:
         eng.set("slots_per_cu", args.slots_per_cu)
+    if args.band_pack >= 0:
+        eng.set("band_pack", args.band_pack)
     batch = eng.wrap(pk.n, d_seqs.data_ptr(), pk.total, d_toff.data_ptr(), d_tl.data_ptr(), d_qoff.data_ptr(), d_ql.data_ptr(),
                      pk.tl, pk.ql, keep=(d_seqs, d_toff, d_qoff, d_tl, d_ql))
     opt = mw.opt_init(flag=mw.MWF_F_CIGAR if args.cigar else 0)
@@ -304,7 +308,7 @@ def main():
             "pairs_this_gpu": pk.n, "pairs_total": n_total, "target_len": args.tl, "divergence": args.div,
             "bases_this_gpu": pk.bases, "cells_this_gpu": cells, "mean_s": float(s.mean()),
             "step": "alignment kernels on HBM-resident sequences + (s, n_iter) records to the host" + (" + RCCL all_gather of the records" if world > 1 else ""),
-            "kernel": KERNEL_NAMES.get(st.kernel_kind, "?"), "grid": st.grid, "block": st.block,
+            "kernel": KERNEL_NAMES.get(3 if (st.kernel_kind == 2 and st.packed) else st.kernel_kind, "?"), "grid": st.grid, "block": st.block,
             "parallelism": f"pairs dealt over {world} GPU(s), no data-path collective, one RCCL all_gather of (s,n_iter)",
         },
         "gcells_per_s": total_cells * args.steps / elapsed / 1e9,
@@ -315,8 +319,8 @@ def main():
             "traffic": None, "bytes_per_cell": bytes_per_cell, "cells_per_launch": cells, "kernel_ms": k_ms,
         },
     }
-    # What the kernel itself must move per cell (the floor of ITS traffic): the band kernel keeps E1/F1/E2/F2 in registers,
-    # so only H crosses HBM (three loads + one store per cell; 2-byte offsets in the packed variants), +1 traceback byte;
+    # What the kernel itself must move per cell (the floor of ITS traffic): the band kernels keep E1/F1/E2/F2 in registers,
+    # so only H crosses HBM (three loads + one store per cell: 16 bytes, 8 with the packed kernel's 16-bit rows), +1 traceback byte;
     # the generic kernel with E2/F2 in LDS moves 32 of the 48.
     tr = {}
     try:
@@ -327,7 +331,7 @@ def main():
     prof = tr.get(key, {})
     rf = out["roofline"]
     if st.kernel_kind == 2:
-        kb = prof.get("kernel_bytes_per_cell", 16) + (1 if args.cigar else 0)
+        kb = (8 if st.packed else 16) + (1 if args.cigar else 0)
     elif st.kernel_kind == 0:
         kb = 32 + (1 if args.cigar else 0)
     else:

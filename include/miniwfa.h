@@ -141,6 +141,8 @@ typedef struct {
 	int32_t kernel_kind;   /* 0: one workgroup per pair (generic); 1: one pair across the whole device; 2: one workgroup per pair (band) */
 	int64_t dev_bytes;     /* device memory the engine holds now: workspace pools + recycled batch allocations (live batches hold their own) */
 	int64_t dev_bytes_peak;/* ... and the most it held since creation or the last mwf_gpu_set(g, "trim", 0) */
+	int32_t packed;        /* band kernel: 1 = the 16-bit variant (mwf_band2.hip: 8 bytes of H traffic per cell instead of 16) */
+	int32_t reserved_;
 } mwf_gpu_stats_t;
 void mwf_gpu_get_stats(const mwf_gpu_t *g, mwf_gpu_stats_t *st);
 

@@ -614,24 +614,10 @@ bool band_supported(const Penalty &p)
 	return inst && p.x >= 2 && p.oe1 >= 2 && p.oe2 >= 2;
 }
 
+// (the int16-packed geometries live in mwf_band2.hip; here: long targets, whose offsets need 32 bits)
 #define MWF_BAND_DISPATCH(FN, ...)                                                    \
 	do {                                                                              \
-		if (g.block == 512 && g.packed) {                                             \
-			if (a_e1 == 2 && a_e2 == 1) return FN<512, 3, 2, 1, true>(__VA_ARGS__);   \
-			if (a_e1 == 2 && a_e2 == 2) return FN<512, 3, 2, 2, true>(__VA_ARGS__);   \
-		} else if (g.block == 256 && g.packed) {                                      \
-			if (a_e1 == 2 && a_e2 == 1) return FN<256, 3, 2, 1, true>(__VA_ARGS__);   \
-			if (a_e1 == 2 && a_e2 == 2) return FN<256, 3, 2, 2, true>(__VA_ARGS__);   \
-		} else if (g.block == 128 && g.packed) {                                      \
-			if (a_e1 == 2 && a_e2 == 1) return FN<128, 3, 2, 1, true>(__VA_ARGS__);   \
-			if (a_e1 == 2 && a_e2 == 2) return FN<128, 3, 2, 2, true>(__VA_ARGS__);   \
-		} else if (g.block == 64 && g.packed) {                                       \
-			if (a_e1 == 2 && a_e2 == 1) return FN<64, 3, 2, 1, true>(__VA_ARGS__);    \
-			if (a_e1 == 2 && a_e2 == 2) return FN<64, 3, 2, 2, true>(__VA_ARGS__);    \
-		} else if (g.block == 768 && g.packed) {                                      \
-			if (a_e1 == 2 && a_e2 == 1) return FN<768, 2, 2, 1, true>(__VA_ARGS__);   \
-			if (a_e1 == 2 && a_e2 == 2) return FN<768, 2, 2, 2, true>(__VA_ARGS__);   \
-		} else if (g.block == 768) {                                                  \
+		if (g.block == 768) {                                                         \
 			if (a_e1 == 2 && a_e2 == 1) return FN<768, 2, 2, 1, false>(__VA_ARGS__);  \
 			if (a_e1 == 2 && a_e2 == 2) return FN<768, 2, 2, 2, false>(__VA_ARGS__);  \
 		} else if (g.block == 256) {                                                  \

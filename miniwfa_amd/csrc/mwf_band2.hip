@@ -1,0 +1,602 @@
+// mwf_band2.hip — the packed band kernel: the fast path for batches of pairs whose offsets fit 16 bits (targets below
+// ~32 kb: BASELINE configs[2], read-length batches, chain-mode gap fills).
+//
+// Same decomposition as mwf_band.hip (one workgroup per pair, a wave owns 256-column chunks, four columns per lane, E/F
+// wavefronts in registers, one barrier per penalty; reference loops miniwfa.c:261-308 and :212-226, driver :397-426),
+// rebuilt around what the profile of that kernel showed: a wave issues at most one instruction every ~5 cycles, the
+// workgroup moves at the pace of its busiest wave, and that wave executed ~1500 instructions per penalty — two thirds of
+// them bookkeeping.  Here
+//   * everything is 16 bits where it rests: the H rows in HBM (8 instead of 16 bytes per cell of traffic, one 8-byte load
+//     per lane and row), the E/F state, the edge table; arithmetic is 32-bit on sign-extended halves (SDWA operands, free);
+//   * a chunk that lies nH+1 columns inside the window can read no column outside any source window (an edge moves
+//     outwards by at most one column per penalty), so it runs a lean copy of the column code: no window history, no
+//     masks, validity of an offset as ONE unsigned comparison (a live offset always has k >= -1 and d+k >= -1), clamped
+//     probe addresses, "full probe with room left" read off one min3;
+//   * the sequence copy starts at LDS offset 0, so a probe address is the byte index itself;
+//   * the first probe of the match extension looks at eight bytes, so the per-lane loop that walks longer runs is entered
+//     for the cells near the alignment path only (a random 4-mer matches in one cell of 256, i.e. in most chunks);
+//   * the per-penalty header is scalar arithmetic on a handful of loop-carried values (chunk indices change only when the
+//     mapping does), the three per-penalty flags travel as one LDS word, rows are loaded only for chunks that are active.
+//     (Measured and dropped: requesting the next chunk's rows while the current one computes, and the next penalty's
+//     first rows before the barrier — 30.8 and 29.3 ms against 28.6 without: the co-resident workgroup already hides
+//     the load latency, the extra registers and code do not pay.)
+// Results are bit-identical to the other kernels (tests/test_gpu_parity.py).
+#include <type_traits>
+#include "mwf_device.h"
+
+namespace mwf {
+
+using namespace dev;
+
+namespace {
+
+extern __shared__ __attribute__((aligned(16))) uint8_t lds2[];
+
+constexpr int kChunk = 256;
+constexpr int32_t kDead16 = -32768;
+constexpr int32_t kDeadPair = (int32_t)0x80008000u;
+
+__device__ __forceinline__ int32_t from_left(int32_t v, int32_t fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int32_t from_right(int32_t v, int32_t fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ int32_t lo16(int32_t v) { return (int32_t)(int16_t)(v & 0xffff); }
+__device__ __forceinline__ int32_t hi16(int32_t v) { return v >> 16; }
+__device__ __forceinline__ int32_t pack2(int32_t a, int32_t b)
+{
+	typedef short short2_t __attribute__((ext_vector_type(2)));
+	const short2_t v = __builtin_amdgcn_cvt_pk_i16(a, b); // saturating
+	return __builtin_bit_cast(int32_t, v);
+}
+__device__ __forceinline__ int32_t both16(int32_t v) { return (int32_t)(((uint32_t)v << 16) | ((uint32_t)v & 0xffffu)); }
+
+// four bytes at byte offset `off` of the sequence copy (which starts at LDS offset 0)
+__device__ __forceinline__ uint32_t seq4(int32_t off)
+{
+	const uint32_t *p = (const uint32_t*)(lds2 + (off & ~3));
+	return __builtin_amdgcn_alignbyte(p[1], p[0], (uint32_t)off);
+}
+
+// leading equal bytes of a 4-byte probe result (0 bits = equal bytes): v_ffbl_b32 yields -1 for x == 0
+__device__ __forceinline__ int32_t lead_eq(uint32_t x)
+{
+	int32_t fb;
+	asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(x));
+	return (int32_t)((uint32_t)fb >> 3);
+}
+
+// Leading equal bytes of t[j..] and q[..] (aq: byte offset of the query base), at most eight looked at: three dwords of
+// each sequence, two v_alignbyte's each.  Returns min(equal bytes, 9 if all eight are equal).
+struct Probe8 { uint32_t t0, t1, t2, q0, q1, q2; };
+__device__ __forceinline__ void probe8_issue(Probe8 &p, int32_t j, int32_t aq)
+{
+	const uint32_t *pt = (const uint32_t*)(lds2 + (j & ~3)), *pq = (const uint32_t*)(lds2 + (aq & ~3));
+	p.t0 = pt[0], p.t1 = pt[1], p.t2 = pt[2], p.q0 = pq[0], p.q1 = pq[1], p.q2 = pq[2];
+}
+__device__ __forceinline__ int32_t probe8_count(const Probe8 &p, int32_t j, int32_t aq)
+{
+	const uint32_t x0 = __builtin_amdgcn_alignbyte(p.t1, p.t0, (uint32_t)j) ^ __builtin_amdgcn_alignbyte(p.q1, p.q0, (uint32_t)aq);
+	const uint32_t x1 = __builtin_amdgcn_alignbyte(p.t2, p.t1, (uint32_t)j) ^ __builtin_amdgcn_alignbyte(p.q2, p.q1, (uint32_t)aq);
+	return min(min(lead_eq(x0), lead_eq(x1) + 4), 9); // lead_eq is huge for "no difference"
+}
+
+__device__ __forceinline__ uint32_t inm_bit(int32_t d, int32_t k, int32_t tl, int32_t ql)
+{
+	return (uint32_t)((uint32_t)(k + 1) < (uint32_t)(tl + 1)) & (uint32_t)((uint32_t)(d + k + 1) < (uint32_t)(ql + 1));
+}
+
+__device__ __forceinline__ unsigned long long lane_mask(int32_t base, int32_t k, int32_t a, int32_t b)
+{
+	int32_t lmin = a - base - k, lmax = b - base - k;
+	if (lmax < 0) return 0ull;
+	lmin = lmin <= 0 ? 0 : (lmin + 3) >> 2;
+	lmax = min(lmax >> 2, 63);
+	if (lmin > lmax) return 0ull;
+	return (~0ull >> (63 - lmax)) & (~0ull << lmin);
+}
+
+// exact-match run t[j..] == q[..] (aq = byte offset of the query base in LDS), at most `room`, the first n0 known equal,
+// walked by all 64 lanes: 256 bytes per trip.  Arguments wave-uniform.
+__device__ __forceinline__ int32_t run_wave2(int32_t j, int32_t aq, int32_t room, int32_t n0)
+{
+	const int32_t lane = threadIdx.x & 63;
+	int32_t n = n0;
+	while (n < room) {
+		const int32_t off = n + 4 * lane;
+		int32_t m = 0;
+		if (off < room) {
+			const uint32_t x = seq4(j + off) ^ seq4(aq + off);
+			m = min(min(lead_eq(x), 4), room - off);
+		}
+		const unsigned long long stop = __ballot(m < 4);
+		if (stop == 0) { n += 256; continue; }
+		const int32_t first = (int32_t)__builtin_ctzll(stop);
+		n += 4 * first + __builtin_amdgcn_readlane(m, first);
+		break;
+	}
+	return min(n, room);
+}
+
+template <int D, int NWK>
+struct alignas(16) Band2Lds {
+	Shared sh;
+	int32_t edge[D][NWK][4]; // per age and chunk slot: {E1 pair (c2,c3), E2 pair (c2,c3)} of lane 63, {F1 pair (c0,c1), F2 pair (c0,c1)} of lane 0
+};
+
+template <int T, int K, int E1, int E2, bool TB>
+__device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &sh, int32_t (*edge)[(T / 64) * K][4], const int32_t qoff, bool trace_band)
+{
+	constexpr int NW = T / 64, NWK = NW * K, D = (E1 > E2 ? E1 : E2) + 1;
+	const int32_t tl = M.tl, ql = M.ql, cmax = tl + ql + 1;
+	const int32_t tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+	const int32_t W = A.W, nH = A.pen.nH, lagx = A.pen.x, lag1 = A.pen.oe1, lag2 = A.pen.oe2;
+	char *const Hb = (char*)M.H; // rows of W int16: (row, column) at byte (row * W + column) * 2
+	auto at = [&](int32_t row, int32_t col) -> char* { return Hb + (size_t)((uint32_t)(row * W + col) << 1); };
+	const int32_t min_lag = min(lagx, min(lag1, lag2));
+	const bool relaxed_stores = min_lag >= 3; // rows written now are first loaded two penalties from now: stores may cross the barrier
+	PassResult R;
+	R.status = ST_OK, R.s = 0, R.info = 0, R.n_snap = 0, R.cells = 0;
+
+	// per-thread wavefront state, two columns per register: [age][slot][pair]; age 0 is the previous penalty
+	int32_t e1h[E1][K][2], f1h[E1][K][2], e2h[E2][K][2], f2h[E2][K][2];
+#pragma unroll
+	for (int k = 0; k < K; ++k)
+#pragma unroll
+		for (int i = 0; i < 2; ++i) {
+#pragma unroll
+			for (int a = 0; a < E1; ++a) e1h[a][k][i] = f1h[a][k][i] = kDeadPair;
+#pragma unroll
+			for (int a = 0; a < E2; ++a) e2h[a][k][i] = f2h[a][k][i] = kDeadPair;
+		}
+
+	// ---- penalty 0 (reference wf_stripe_init, miniwfa.c:103-121) and its extension
+	for (int32_t j = tid; j < D * NWK * 4; j += T) (&edge[0][0][0])[j] = kDeadPair;
+	if (tid == 0) {
+		for (int32_t j = 0; j < nH; ++j) sh.rng_lo[j] = 1, sh.rng_hi[j] = 0;
+		for (int32_t j = 0; j < 12; ++j) (&sh.flags[0][0])[j] = 0;
+		sh.rng_lo[0] = sh.rng_hi[0] = tl + 1;
+	}
+	if (tid < 64) { // the origin's run, walked by the first wave
+		const int32_t k0 = run_wave2(0, qoff, min(tl, ql), 0) - 1;
+		if (tid == 0) {
+			*(int16_t*)at(0, tl + 1) = (int16_t)k0;
+			sh.word[1] = k0;
+		}
+	}
+	__syncthreads();
+	{
+		const int32_t k0 = uni(sh.word[1]);
+		if (k0 == tl - 1 && k0 == ql - 1) return R;
+	}
+
+	int32_t s = 0, wf_lo = tl + 1, wf_hi = tl + 1;
+	int32_t curH = 0, par = 0, dcur = 0;
+	int64_t cells = 0, tb_used = 0;
+
+	// chunk of every slot of this wave under the mapping that starts at chunk gl (changes only when gl does)
+	int32_t gl = (wf_lo > 1 ? wf_lo - 1 : 1) >> 8, gk[K];
+	auto remap = [&](int32_t g_lo) {
+		const int32_t base = g_lo - g_lo % NWK;
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			int32_t g = base + wave + NW * k;
+			if (g < g_lo) g += NWK;
+			gk[k] = g;
+		}
+	};
+	remap(gl);
+
+	// rows of one chunk: H at the three lags (four columns = one 8-byte load each) and the two neighbouring columns
+	struct Rows { int2 hx, o1, o2; int32_t v1, v2; };
+	auto load_rows = [&](Rows &r, int32_t g, int32_t jx, int32_t j1, int32_t j2) {
+		const int32_t c0 = g * kChunk + 4 * lane;
+		r.hx = *(const int2*)at(jx, c0);
+		r.o1 = *(const int2*)at(j1, c0);
+		r.o2 = *(const int2*)at(j2, c0);
+		const int32_t ce = lane == 0 ? max(c0, 1) - 1 : c0 + 4; // lane 0: the column to the left, lane 63: the one to the right
+		r.v1 = *(const int16_t*)at(j1, ce), r.v2 = *(const int16_t*)at(j2, ce);
+	};
+
+	for (;;) {
+		const int32_t lo = wf_lo > 1 ? wf_lo - 1 : 1;       // miniwfa.c:417-418
+		const int32_t hi = wf_hi < cmax ? wf_hi + 1 : cmax;
+		const int32_t s_new = s + 1;
+		const int32_t newH = curH + 1 == nH ? 0 : curH + 1;
+		const int32_t npar = par + 1 == 3 ? 0 : par + 1;
+		const int32_t dnew = dcur + 1 == D ? 0 : dcur + 1;
+		const int32_t origin = lo & ~3;
+		const int32_t row_bytes = (hi | 3) - origin + 1;
+		if (TB) {
+			if (s_new - 1 >= A.rows_slot) { R.status = ST_ROWS_OVERFLOW; break; }
+			if (tb_used + row_bytes > A.tb_slot_bytes) { R.status = ST_TB_OVERFLOW; break; }
+		}
+		// the window of penalty s_new+1 lies inside [lo-1, hi+1] whatever the flags say; it must fit the register span
+		const int32_t gl_next = (lo > 1 ? lo - 1 : 1) >> 8;
+		if (((hi < cmax ? hi + 1 : cmax) >> 8) - gl_next + 1 > NWK - 1) { R.status = ST_BAND_OVERFLOW; break; }
+		int32_t jx = newH - lagx; if (jx < 0) jx += nH;
+		int32_t j1 = newH - lag1; if (j1 < 0) j1 += nH;
+		int32_t j2 = newH - lag2; if (j2 < 0) j2 += nH;
+		const bool track_good = (((256 - (s_new & 255)) & 255) < nH); // a shrink can still see this slice
+		// ages of the edge table to read: penalties s_new-E1 and s_new-E2
+		int32_t d1 = dnew - E1; if (d1 < 0) d1 += D;
+		int32_t d2 = dnew - E2; if (d2 < 0) d2 += D;
+		// chunk ranges: [ga, ga+gspan] meets the window; [gd, gd+dspan] lies nH+1 columns inside it (dspan < 0: none)
+		const int32_t ga = lo >> 8, gspan = (hi >> 8) - ga;
+		const int32_t gd = (lo + nH + 1 + kChunk - 1) >> 8, dspan = ((hi - nH) >> 8) - 1 - gd;
+		const int32_t cfin = ql + 1; // the end cell (tl-1, ql-1) lies on diagonal ql-tl, i.e. in this column
+
+		if (tid == 0) {
+			sh.rng_lo[newH] = lo, sh.rng_hi[newH] = hi;
+			sh.flags[npar + 1 == 3 ? 0 : npar + 1][0] = 0; // the flag word of the NEXT penalty (its last readers passed the previous barrier)
+			if (TB) M.row_off[s_new - 1] = tb_used, M.row_lo[s_new - 1] = origin;
+			if (trace_band && s_new - 1 < A.dbg_cap) M.dbg[2 * (s_new - 1)] = lo, M.dbg[2 * (s_new - 1) + 1] = hi;
+		}
+
+		bool act[K];
+		int n_act = 0;
+#pragma unroll
+		for (int k = 0; k < K; ++k) act[k] = (uint32_t)(gk[k] - ga) <= (uint32_t)gspan, n_act += act[k] ? 1 : 0;
+		// the waves with the most chunks to do set the pace of the penalty: let them issue first
+		if (n_act >= 2) __builtin_amdgcn_s_setprio(3);
+		else __builtin_amdgcn_s_setprio(0);
+
+		// window history: only a chunk near a window edge needs it
+		int32_t xlo = 1, xhi = 0, alo = 1, ahi = 0, blo = 1, bhi = 0;
+		bool hist = false;
+		Rows cur;
+		int n_stores = 0;
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			if (!act[k]) {
+				// a chunk outside the window: its columns were not computed at this penalty, i.e. their E/F are dead
+#pragma unroll
+				for (int i = 0; i < 2; ++i) {
+#pragma unroll
+					for (int a = E1 - 1; a > 0; --a) e1h[a][k][i] = e1h[a - 1][k][i], f1h[a][k][i] = f1h[a - 1][k][i];
+#pragma unroll
+					for (int a = E2 - 1; a > 0; --a) e2h[a][k][i] = e2h[a - 1][k][i], f2h[a][k][i] = f2h[a - 1][k][i];
+					e1h[0][k][i] = f1h[0][k][i] = e2h[0][k][i] = f2h[0][k][i] = kDeadPair;
+				}
+				const int32_t r = wave + NW * k;
+				if (lane == 63) edge[dnew][r][0] = kDeadPair, edge[dnew][r][1] = kDeadPair;
+				if (lane == 0) edge[dnew][r][2] = kDeadPair, edge[dnew][r][3] = kDeadPair;
+				continue;
+			}
+			const int32_t r = wave + NW * k, g = gk[k], cb = g * kChunk, c0 = cb + 4 * lane;
+			load_rows(cur, g, jx, j1, j2);
+
+			const bool deep = (uint32_t)(g - gd) <= (uint32_t)dspan && dspan >= 0 && !track_good; // uniform
+			int32_t hx[4] = {lo16(cur.hx.x), hi16(cur.hx.x), lo16(cur.hx.y), hi16(cur.hx.y)};
+			int32_t o1[6], o2[6]; // o1[i+1] is column c0+i; o1[0], o1[5] the neighbours
+			o1[1] = lo16(cur.o1.x), o1[2] = hi16(cur.o1.x), o1[3] = lo16(cur.o1.y), o1[4] = hi16(cur.o1.y);
+			o2[1] = lo16(cur.o2.x), o2[2] = hi16(cur.o2.x), o2[3] = lo16(cur.o2.y), o2[4] = hi16(cur.o2.y);
+			int32_t v1 = cur.v1, v2 = cur.v2;
+			bool inner = true;
+			if (!deep) {
+				if (!hist) {
+					xlo = uni(sh.rng_lo[jx]), xhi = uni(sh.rng_hi[jx]);
+					alo = uni(sh.rng_lo[j1]), ahi = uni(sh.rng_hi[j1]);
+					blo = uni(sh.rng_lo[j2]), bhi = uni(sh.rng_hi[j2]);
+					hist = true;
+				}
+				// columns whose every H read (c and c+-1) falls inside its source window and that are inside [lo,hi]
+				const int32_t ilo = max(max(lo, xlo), max(alo, blo) + 1), ihi = min(min(hi, xhi), min(ahi, bhi) - 1);
+				inner = cb >= ilo && cb + kChunk - 1 <= ihi;
+				if (!inner) { // reads outside a source window yield "dead" (what the reference's pads supply, miniwfa.c:96-99)
+#pragma unroll
+					for (int i = 0; i < 4; ++i) {
+						const int32_t c = c0 + i;
+						hx[i] = ((c >= xlo) & (c <= xhi)) ? hx[i] : kDead16;
+						o1[i + 1] = ((c >= alo) & (c <= ahi)) ? o1[i + 1] : kDead16;
+						o2[i + 1] = ((c >= blo) & (c <= bhi)) ? o2[i + 1] : kDead16;
+					}
+					const int32_t ce = lane == 0 ? c0 - 1 : c0 + 4;
+					v1 = ((ce >= alo) & (ce <= ahi)) ? v1 : kDead16;
+					v2 = ((ce >= blo) & (ce <= bhi)) ? v2 : kDead16;
+				}
+			}
+			o1[0] = from_left(o1[4], v1), o1[5] = from_right(o1[1], v1);
+			o2[0] = from_left(o2[4], v2), o2[5] = from_right(o2[1], v2);
+			// gap-extension sources: E of column c-1, F of column c+1, e1 (e2) penalties ago.  Lanes shift whole pairs; lane 0 /
+			// lane 63 take the neighbouring wave's pair from the edge table.
+			int32_t g1m[4], g1p[4], g2m[4], g2p[4];
+			{
+				const int32_t rl = r == 0 ? NWK - 1 : r - 1, rr = r + 1 == NWK ? 0 : r + 1;
+				const int32_t E1l = from_left(e1h[E1 - 1][k][1], edge[d1][rl][0]), E2l = from_left(e2h[E2 - 1][k][1], edge[d2][rl][1]);
+				const int32_t F1r = from_right(f1h[E1 - 1][k][0], edge[d1][rr][2]), F2r = from_right(f2h[E2 - 1][k][0], edge[d2][rr][3]);
+				g1m[0] = hi16(E1l), g1m[1] = lo16(e1h[E1 - 1][k][0]), g1m[2] = hi16(e1h[E1 - 1][k][0]), g1m[3] = lo16(e1h[E1 - 1][k][1]);
+				g2m[0] = hi16(E2l), g2m[1] = lo16(e2h[E2 - 1][k][0]), g2m[2] = hi16(e2h[E2 - 1][k][0]), g2m[3] = lo16(e2h[E2 - 1][k][1]);
+				g1p[0] = hi16(f1h[E1 - 1][k][0]), g1p[1] = lo16(f1h[E1 - 1][k][1]), g1p[2] = hi16(f1h[E1 - 1][k][1]), g1p[3] = lo16(F1r);
+				g2p[0] = hi16(f2h[E2 - 1][k][0]), g2p[1] = lo16(f2h[E2 - 1][k][1]), g2p[2] = hi16(f2h[E2 - 1][k][1]), g2p[3] = lo16(F2r);
+			}
+
+			int32_t hv[4], nmat[4], ne1[4], nf1[4], ne2[4], nf2[4];
+			uint32_t tbw = 0, pend = 0, live = 0, fin = 0, gbits = 0;
+			if (deep) {
+				// ---- lean copy: recurrence, then the first 4-byte probe of the match extension, in two phases so that all eight
+				// LDS reads are in flight together
+				const int32_t t0 = ql + tl + 1 - c0, dq0 = c0 - 1 - tl + qoff;
+				int32_t jc[4], aq[4], rj[4], m9[4];
+				Probe8 pr[4];
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					const Cell v = wf_cell<TB>(hx[i], o1[i], g1m[i], o2[i], g2m[i], o1[i + 2], g1p[i], o2[i + 2], g2p[i]);
+					ne1[i] = v.e1, nf1[i] = v.f1, ne2[i] = v.e2, nf2[i] = v.f2;
+					hv[i] = v.h;
+					tbw |= v.tb << (8 * i);
+					rj[i] = min(tl, t0 - i);                                           // min(tl, ql - d): the largest j = k+1 inside the matrix
+					jc[i] = (int32_t)min((uint32_t)(v.h + 1), (uint32_t)rj[i]);        // dead and phantom offsets clamp to it: room 0
+					aq[i] = jc[i] + dq0 + i;                                           // byte offset of q[d + j] in the LDS copy
+					probe8_issue(pr[i], jc[i], aq[i]);
+				}
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					// leading equal bytes, capped at 9 and at the room: 9 <=> all eight equal and more than eight to go
+					m9[i] = min(probe8_count(pr[i], jc[i], aq[i]), rj[i] - jc[i]);
+					nmat[i] = min(m9[i], 8);
+				}
+				if (__ballot(max(max(m9[0], m9[1]), max(m9[2], m9[3])) == 9))
+					pend = (uint32_t)(m9[0] == 9) | (uint32_t)(m9[1] == 9) << 1 | (uint32_t)(m9[2] == 9) << 2 | (uint32_t)(m9[3] == 9) << 3;
+			} else {
+				// ---- general copy: window tests, edge liveness, good bits
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					const int32_t c = c0 + i, d = c - 1 - tl;
+					const uint32_t a = inner ? 1u : (uint32_t)((c >= lo) & (c <= hi));
+					const Cell v = wf_cell<TB>(hx[i], o1[i], g1m[i], o2[i], g2m[i], o1[i + 2], g1p[i], o2[i + 2], g2p[i]);
+					ne1[i] = a ? v.e1 : kDead16, nf1[i] = a ? v.f1 : kDead16;
+					ne2[i] = a ? v.e2 : kDead16, nf2[i] = a ? v.f2 : kDead16;
+					const uint32_t inm = a & inm_bit(d, v.h, tl, ql);
+					if (track_good) // uniform
+						gbits |= (a & (inm | inm_bit(d, v.e1, tl, ql) | inm_bit(d, v.f1, tl, ql) | inm_bit(d, v.e2, tl, ql) | inm_bit(d, v.f2, tl, ql))) << i;
+					const int32_t j = inm ? v.h + 1 : 0, q = inm ? d + v.h + 1 : 0;
+					const int32_t room = inm ? min(tl - j, ql - q) : 0;
+					Probe8 pr;
+					probe8_issue(pr, j, qoff + q);
+					const int32_t m9 = min(probe8_count(pr, j, qoff + q), room);
+					nmat[i] = min(m9, 8);
+					pend |= (uint32_t)(m9 == 9) << i;
+					hv[i] = v.h;
+					tbw |= v.tb << (8 * i);
+					// edge rule (miniwfa.c:325-326): H is the max of the five, so "any live" == "H live"
+					const uint32_t lv = (uint32_t)(v.h >= -1);
+					live |= (lv & (uint32_t)(c == lo)) | ((lv & (uint32_t)(c == hi)) << 1);
+				}
+			}
+			// ---- the new E/F are final: age the registers, publish this chunk's outer pairs for the neighbouring waves
+#pragma unroll
+			for (int i = 0; i < 2; ++i) {
+#pragma unroll
+				for (int a = E1 - 1; a > 0; --a) e1h[a][k][i] = e1h[a - 1][k][i], f1h[a][k][i] = f1h[a - 1][k][i];
+#pragma unroll
+				for (int a = E2 - 1; a > 0; --a) e2h[a][k][i] = e2h[a - 1][k][i], f2h[a][k][i] = f2h[a - 1][k][i];
+				e1h[0][k][i] = pack2(ne1[2 * i], ne1[2 * i + 1]), f1h[0][k][i] = pack2(nf1[2 * i], nf1[2 * i + 1]);
+				e2h[0][k][i] = pack2(ne2[2 * i], ne2[2 * i + 1]), f2h[0][k][i] = pack2(nf2[2 * i], nf2[2 * i + 1]);
+			}
+			if (lane == 63) edge[dnew][r][0] = e1h[0][k][1], edge[dnew][r][1] = e2h[0][k][1];
+			if (lane == 0) edge[dnew][r][2] = f1h[0][k][0], edge[dnew][r][3] = f2h[0][k][0];
+
+			// ---- a run of >= 4 matches continues (one cell in 256 by chance, plus the cells near the alignment path).  Each lane
+			// first walks its own runs 8 bytes per trip, four trips at most; what is still open then the whole wave walks, 256 per trip.
+			if (__ballot(pend != 0)) {
+				uint32_t open = 0;
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					if (__ballot((pend >> i) & 1u) == 0) continue; // uniform
+					if ((pend >> i) & 1u) {
+						int32_t n = 8; // pend is only set for a full first probe of an in-matrix cell with room left
+						const int32_t j = hv[i] + 1, q = c0 + i - 1 - tl + j, rm = min(tl - j, ql - q), aqq = qoff + q;
+						for (int trip = 0; n < rm; ++trip) {
+							if (trip == 4) { open |= 1u << i; break; }
+							const uint32_t xa = seq4(j + n) ^ seq4(aqq + n), xb = seq4(j + n + 4) ^ seq4(aqq + n + 4);
+							if (xa | xb) { n += xa ? min(lead_eq(xa), 4) : 4 + min(lead_eq(xb), 4); break; }
+							n += 8;
+						}
+						nmat[i] = min(n, rm);
+					}
+				}
+				for (unsigned long long owners = __ballot(open != 0); owners; owners &= owners - 1) {
+					const int32_t src = (int32_t)__builtin_ctzll(owners);
+					const int32_t c0s = cb + 4 * src;
+					const uint32_t bits = (uint32_t)__builtin_amdgcn_readlane((int32_t)open, src);
+#pragma unroll
+					for (int i = 0; i < 4; ++i) {
+						if (!((bits >> i) & 1u)) continue; // uniform
+						const int32_t hh = __builtin_amdgcn_readlane(hv[i], src);
+						const int32_t j = hh + 1, q = c0s + i - 1 - tl + j, rm = min(tl - j, ql - q);
+						const int32_t n = run_wave2(j, qoff + q, rm, 40);
+						nmat[i] = lane == src ? n : nmat[i];
+					}
+				}
+			}
+			// ---- termination test of the extension sweep (miniwfa.c:405-409): only column ql+1 can hold the end cell
+			int32_t done_info = 0;
+			unsigned long long fm = 0;
+#pragma unroll
+			for (int i = 0; i < 4; ++i) hv[i] += nmat[i];
+			if ((uint32_t)(cfin - cb) < (uint32_t)kChunk && cfin >= lo && cfin <= hi) { // uniform
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					const uint32_t f = (uint32_t)(c0 + i == cfin) & (uint32_t)(hv[i] == tl - 1) & inm_bit(ql - tl, hv[i] - nmat[i], tl, ql);
+					fin |= f;
+					done_info = f ? (nmat[i] == 0 ? (int32_t)((tbw >> (8 * i)) & 7u) : 0) : done_info;
+				}
+				fm = __ballot(fin != 0);
+			}
+			*(int2*)at(newH, c0) = make_int2(pack2(hv[0], hv[1]), pack2(hv[2], hv[3]));
+			++n_stores;
+			if (TB && c0 >= origin && c0 <= hi) *(uint32_t*)(M.tb + tb_used - origin + c0) = tbw;
+			if (track_good) {
+				unsigned long long *gword = M.good + (int64_t)newH * A.GW + g * 4;
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					const unsigned long long m = __ballot((gbits >> i) & 1u);
+					if (lane == 0) gword[i] = m;
+				}
+			}
+			if (!deep || fm) { // uniform; a deep chunk can only have the end cell to report
+				uint32_t bits = (__ballot(live & 1u) ? 1u : 0u) | (__ballot(live & 2u) ? 2u : 0u);
+				if (fm) bits |= 4u | (uint32_t)__builtin_amdgcn_readlane(done_info, (int32_t)__builtin_ctzll(fm)) << 4;
+				if (bits && lane == 0) atomicOr((unsigned int*)&sh.flags[npar][0], bits);
+			}
+		}
+
+		// Everything older than this penalty's last operations must be complete before another wave may load it (vmcnt retires
+		// in issue order).  With every lag >= 3 the rows written now are first loaded two penalties from now: the youngest store
+		// may stay in flight across the barrier.
+		if (relaxed_stores && n_stores > 0 && !TB && !track_good) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+		else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+		__builtin_amdgcn_s_barrier();
+		asm volatile("" ::: "memory");
+
+		// ---- bookkeeping, identical on every thread
+		const uint32_t fl = (uint32_t)uni(sh.flags[npar][0]);
+		if (fl & 1u) wf_lo = lo;
+		if (fl & 2u) wf_hi = hi;
+		const int32_t done = (int32_t)((fl >> 2) & 1u), payload = (int32_t)((fl >> 4) & 7u);
+		s = s_new, curH = newH, par = npar, dcur = dnew;
+		if (gl_next != gl) gl = gl_next, remap(gl);
+		if (TB) tb_used += row_bytes;
+		if ((s & 0xff) == 0) { // shrink (reference wf_stripe_shrink, miniwfa.c:144-171) on the interleaved good bits
+			if (tid == 0) sh.red[0] = 0x7fffffff, sh.red[1] = -1;
+			__syncthreads();
+			const int32_t gfirst = wf_lo >> 8, n_words = ((wf_hi >> 8) - gfirst + 1) * 4;
+			for (int32_t q = tid; q < n_words; q += T) {
+				const int32_t gg = gfirst + (q >> 2), kq = q & 3, base = gg * kChunk;
+				unsigned long long m = 0;
+				for (int32_t j = 0; j < nH; ++j)
+					if (sh.rng_lo[j] <= sh.rng_hi[j] && sh.rng_lo[j] <= base + kChunk - 1 && sh.rng_hi[j] >= base) m |= M.good[(int64_t)j * A.GW + gg * 4 + kq];
+				m &= lane_mask(base, kq, wf_lo, wf_hi);
+				if (m) {
+					atomicMin(&sh.red[0], base + 4 * (int32_t)__builtin_ctzll(m) + kq);
+					atomicMax(&sh.red[1], base + 4 * (63 - (int32_t)__builtin_clzll(m)) + kq);
+				}
+			}
+			__syncthreads();
+			const int32_t glo = uni(sh.red[0]), ghi = uni(sh.red[1]);
+			if (ghi < 0) { R.status = ST_INTERNAL; break; }
+			wf_lo = glo, wf_hi = ghi;
+		}
+		cells += hi - lo + 1;
+		if ((A.max_iter > 0 && cells > A.max_iter) || (A.max_s > 0 && s > A.max_s)) { // miniwfa.c:422-425
+			R.status = ST_STOPPED;
+			break;
+		}
+		if (done) {
+			R.info = payload;
+			break;
+		}
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	R.s = s, R.cells = cells;
+	return R;
+}
+
+// Workgroups share a CU: 2 x 512, 4 x 256, 8 x 128 or 16 x 64 threads = 4 waves per SIMD, i.e. at most 128 VGPRs; with traceback
+// the smaller ones get 168 (3 per SIMD).  768 threads: one workgroup per CU.
+template <int T, int K, int E1, int E2, bool TB>
+__global__ __launch_bounds__(T, T <= 512 ? ((TB && T < 512) ? 3 : 4) : T == 640 ? 5 : 1) void wfa_band2_kernel(const BatchArgs A)
+{
+	constexpr int NWK = (T / 64) * K, D = (E1 > E2 ? E1 : E2) + 1;
+	// the sequence copy starts at LDS offset 0; the bookkeeping words and the edge table sit behind it
+	Band2Lds<D, NWK> *const L = (Band2Lds<D, NWK>*)(lds2 + A.band_lds_seq);
+	Shared &sh = L->sh;
+	int32_t (*const edge)[NWK][4] = L->edge;
+	for (;;) {
+		if (threadIdx.x == 0) sh.item = (int32_t)atomicAdd(A.queue, 1);
+		__syncthreads();
+		const int32_t item = uni(sh.item);
+		__syncthreads();
+		if (item >= A.n_pairs) break;
+		const int32_t pair = A.order ? A.order[item] : item;
+		PairMem M;
+		pair_mem(A, (int32_t)blockIdx.x, pair, M);
+		const int32_t qoff = ((M.tl + 3) & ~3) + 8; // both sequences start on a dword
+		for (int32_t j = threadIdx.x; j < M.tl; j += T) lds2[j] = M.ts[j];
+		for (int32_t j = threadIdx.x; j < M.ql; j += T) lds2[qoff + j] = M.qs[j];
+		__syncthreads();
+		const bool trace = A.dbg && pair == A.debug_pair;
+		const PassResult R = band2_pass<T, K, E1, E2, TB>(A, M, sh, edge, qoff, trace);
+		finish_pair(A, M, (int32_t)blockIdx.x, pair, R, R.status, 0);
+	}
+}
+
+template <int T, int K, int E1, int E2>
+constexpr int lds_tail() { return (int)sizeof(Band2Lds<(E1 > E2 ? E1 : E2) + 1, (T / 64) * K>); }
+
+template <int T, int K, int E1, int E2>
+int launch_one(const BatchArgs &a0, int grid, int lds_seq, hipStream_t st)
+{
+	BatchArgs a = a0;
+	a.band_lds_seq = lds_seq;
+	const int lds = lds_seq + lds_tail<T, K, E1, E2>();
+	if (a.want_cigar) {
+		static int max_set = 0;
+		if (lds > 48 * 1024 && lds > max_set) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wfa_band2_kernel<T, K, E1, E2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds), max_set = lds;
+		hipLaunchKernelGGL((wfa_band2_kernel<T, K, E1, E2, true>), dim3(grid), dim3(T), lds, st, a);
+	} else {
+		static int max_set = 0;
+		if (lds > 48 * 1024 && lds > max_set) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wfa_band2_kernel<T, K, E1, E2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds), max_set = lds;
+		hipLaunchKernelGGL((wfa_band2_kernel<T, K, E1, E2, false>), dim3(grid), dim3(T), lds, st, a);
+	}
+	return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+template <int T, int K, int E1, int E2>
+int occ_one(int lds_seq, bool tb)
+{
+	const int lds = lds_seq + lds_tail<T, K, E1, E2>();
+	int n = 0;
+	hipError_t e;
+	if (tb) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, true>, T, lds);
+	else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, false>, T, lds);
+	return e == hipSuccess ? n : 0;
+}
+
+} // namespace
+
+// the packed kernel: (e1,e2) instantiated, sequences fit LDS (the host checks), every H lag >= 1
+bool band2_supported(const Penalty &p)
+{
+	return (p.e1 == 2 && p.e2 == 1) || (p.e1 == 2 && p.e2 == 2) || (p.e1 == 1 && p.e2 == 1);
+}
+
+#ifdef MWF_BAND_DEV
+#define MWF_BAND2_REST(FN, ...)
+#else
+#define MWF_BAND2_REST(FN, ...)                                                     \
+	if (g.block == 256) MWF_BAND2_PEN(FN, 256, 3, __VA_ARGS__)                      \
+	if (g.block == 128) MWF_BAND2_PEN(FN, 128, 3, __VA_ARGS__)                      \
+	if (g.block == 64) MWF_BAND2_PEN(FN, 64, 3, __VA_ARGS__)
+#endif
+#ifdef MWF_BAND_DEV
+#define MWF_BAND2_PEN(FN, T, K, ...) { if (a_e1 == 2 && a_e2 == 1) return FN<T, K, 2, 1>(__VA_ARGS__); }
+#else
+#define MWF_BAND2_PEN(FN, T, K, ...)                                                \
+	{                                                                               \
+		if (a_e1 == 2 && a_e2 == 1) return FN<T, K, 2, 1>(__VA_ARGS__);             \
+		if (a_e1 == 2 && a_e2 == 2) return FN<T, K, 2, 2>(__VA_ARGS__);             \
+		if (a_e1 == 1 && a_e2 == 1) return FN<T, K, 1, 1>(__VA_ARGS__);             \
+	}
+#endif
+#define MWF_BAND2_DISPATCH(FN, ...)                                                 \
+	do {                                                                            \
+		if (g.block == 512) MWF_BAND2_PEN(FN, 512, 3, __VA_ARGS__)                  \
+		if (g.block == 768) MWF_BAND2_PEN(FN, 768, 2, __VA_ARGS__)                  \
+		if (g.block == 640) MWF_BAND2_PEN(FN, 640, 2, __VA_ARGS__)                  \
+		MWF_BAND2_REST(FN, __VA_ARGS__)                                             \
+	} while (0)
+
+int launch_band2(const BatchArgs &a, int grid, const BandGeom &g, void *stream)
+{
+	const int a_e1 = a.pen.e1, a_e2 = a.pen.e2;
+	MWF_BAND2_DISPATCH(launch_one, a, grid, g.lds_bytes, (hipStream_t)stream);
+	return -1;
+}
+
+int band2_kernel_occupancy(const Penalty &p, const BandGeom &g, bool cigar)
+{
+	const int a_e1 = p.e1, a_e2 = p.e2;
+	MWF_BAND2_DISPATCH(occ_one, g.lds_bytes, cigar);
+	return 0;
+}
+
+} // namespace mwf

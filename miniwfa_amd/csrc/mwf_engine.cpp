@@ -315,7 +315,9 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 {
 	pl.kind = 0;
 	const bool low_mem = (opt.flag & MWF_F_CIGAR) && opt.step > 0;
-	if (want_kind == 0 || low_mem || !band_supported(P)) return;
+	// packed kernel (mwf_band2.hip): 16-bit offsets; unpacked kernel (mwf_band.hip): every H lag >= 2, long targets
+	const bool can_packed = band2_supported(P) && g->band_pack != 0, can_plain = band_supported(P);
+	if (want_kind == 0 || low_mem || (!can_packed && !can_plain)) return;
 	const int64_t max_window = std::min<int64_t>(max_len + 1, 2 * max_bound + 3);
 	BandGeom bg;
 	bg.packed = 0;
@@ -329,7 +331,8 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 	//                   needs more than its 128 VGPRs then: 52.9 ms against 60.3 ms unpacked on the 1024 x 10 kb batch)
 	// Unpacked (long targets): 256 x 2 up to 1728 columns, 768 x 2 beyond.
 	// (measured alternatives on the 1024 x 10 kb batch: 1024 threads x 2 chunks spills and runs 50 ms, 512 x 3 unpacked 49 ms, 768 x 2 42 ms)
-	const bool range_ok = max_tl + max_bound < 32767 && g->band_pack != 0;
+	const bool range_ok = can_packed && max_tl + max_bound < 32767;
+	if (!range_ok && !can_plain) return;
 	const bool cigar = (opt.flag & MWF_F_CIGAR) != 0;
 	if (range_ok) {
 		bg.packed = 1;
@@ -338,15 +341,20 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 	// forced geometry (tests, tuning): 256 and 768 mean the unpacked variants unless packing is asked for as well
 	if ((g->block == 64 || g->block == 128) && range_ok) bg.block = g->block, bg.packed = 1;
 	if (g->block == 256) bg.block = 256, bg.packed = range_ok && g->band_pack == 1;
-	if (g->block == 768) bg.block = 768, bg.packed = range_ok && cigar;
-	if (g->block == 512 && range_ok) bg.block = 512, bg.packed = 1;
+	if (g->block == 768) bg.block = 768, bg.packed = range_ok && (cigar || g->band_pack == 1);
+	if ((g->block == 512 || g->block == 640) && range_ok) bg.block = g->block, bg.packed = 1;
 	// geometry picked by the caller for a size class (pairs short enough that their window should stay inside a small span)
 	if (g->block == 0 && (geom_block == 64 || geom_block == 128) && range_ok) bg.block = geom_block, bg.packed = 1;
 	if (g->block == 0 && geom_block == 256) bg.block = 256, bg.packed = range_ok;
-	bg.span = bg.block / 64 * (bg.packed && bg.block != 768 ? 3 : 2) * 256;
+	bg.span = bg.block / 64 * (bg.packed && bg.block != 768 && bg.block != 640 ? 3 : 2) * 256;
 	if (want_kind != 2 && max_len + 1 > 4 * (int64_t)bg.span) return; // windows will mostly outgrow the span: go generic at once
-	const int64_t lds_cap = bg.block >= 768 ? 140 * 1024 : bg.block == 512 ? 70 * 1024 : bg.block == 256 ? 36 * 1024 : bg.block == 128 ? 18 * 1024 : 9 * 1024;
+	const int64_t lds_cap = bg.block >= 768 ? 140 * 1024 : bg.block >= 512 ? 70 * 1024 : bg.block == 256 ? 36 * 1024 : bg.block == 128 ? 18 * 1024 : 9 * 1024;
 	bg.lds_bytes = max_seq_lds <= lds_cap ? (int)((max_seq_lds + 15) / 16 * 16) : 0;
+	if (bg.packed && bg.lds_bytes == 0) { // the packed kernel keeps the sequences in LDS
+		if (!can_plain) return;
+		bg.packed = 0, bg.block = max_window <= 8 * 256 - 256 - 64 ? 256 : 768, bg.span = bg.block / 64 * 2 * 256;
+	}
+	if (!bg.packed && !can_plain) return;
 	pl.kind = 2, pl.band = bg;
 }
 
@@ -360,7 +368,8 @@ int cached_occupancy(mwf_gpu_t *g, const Penalty &P, const Plan &pl, int lds_e2_
 	else key = 2ull | (uint64_t)pl.block << 4 | (uint64_t)stream_pass << 16 | (uint64_t)lds_e2_cols << 20;
 	auto it = g->occ_cache.find(key);
 	if (it != g->occ_cache.end()) return it->second;
-	const int per = pl.kind == 2 ? band_kernel_occupancy(P, pl.band, pl.cigar) : batch_kernel_occupancy(pl.block, stream_pass, lds_e2_cols);
+	const int per = pl.kind == 2 ? (pl.band.packed ? band2_kernel_occupancy(P, pl.band, pl.cigar) : band_kernel_occupancy(P, pl.band, pl.cigar))
+	                             : batch_kernel_occupancy(pl.block, stream_pass, lds_e2_cols);
 	g->occ_cache[key] = per;
 	return per;
 }
@@ -490,7 +499,8 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 
 	// HIP events bracket the kernel only: every workspace allocation above is already done
 	if (timed) HIP_TRY(g, hipEventRecord(g->ev0, g->stream));
-	const int lrc = pl.kind == 2 ? launch_band(a, pl.grid, pl.band, g->stream) : launch_batch(a, pl.grid, pl.block, g->stream);
+	const int lrc = pl.kind == 2 ? (pl.band.packed ? launch_band2(a, pl.grid, pl.band, g->stream) : launch_band(a, pl.grid, pl.band, g->stream))
+	                             : launch_batch(a, pl.grid, pl.block, g->stream);
 	if (lrc != 0) {
 		g->err = "kernel launch failed";
 		return -1;
@@ -501,6 +511,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	}
 	g->stats.n_launches += 1;
 	g->stats.grid = std::max(g->stats.grid, pl.grid), g->stats.block = pl.block, g->stats.kernel_kind = pl.kind;
+	g->stats.packed = pl.kind == 2 && pl.band.packed;
 	if (ran_kind) *ran_kind = pl.kind;
 	return 0;
 }
@@ -859,7 +870,7 @@ int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value)
 {
 	if (!g || !name) return -1;
 	if (!strcmp(name, "block")) {
-		if (value != 0 && value != 64 && value != 128 && value != 256 && value != 384 && value != 512 && value != 768 && value != 1024) return -1;
+		if (value != 0 && value != 64 && value != 128 && value != 256 && value != 384 && value != 512 && value != 640 && value != 768 && value != 1024) return -1;
 		g->block = (int)value;
 	} else if (!strcmp(name, "slots_per_cu")) g->slots_per_cu = (int)value;
 	else if (!strcmp(name, "coop_min_len")) g->coop_min_len = value;
@@ -999,7 +1010,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	// gap fills of mwf_wfa_auto's chain fallback, which inherit step = 5000) run in the classes as high-memory pairs; only
 	// genuinely long pairs go through the two-pass kernel (group 5).
 	const bool low_mem = cigar && opt->step > 0;
-	const bool classes = g->force_kind < 0 && g->block == 0 && band_supported(P0);
+	const bool classes = g->force_kind < 0 && g->block == 0 && (band_supported(P0) || (band2_supported(P0) && g->band_pack != 0));
 	struct Group { std::vector<int32_t> ids; int64_t max_len = 0, max_bound = 0, max_bound1 = 0, max_tl = 0, max_seq_lds = 0; } grp[6];
 	for (int32_t i = 0; i < b->n; ++i) {
 		const int64_t len = (int64_t)b->h_tl[i] + b->h_ql[i], bound = penalty_bound(*opt, b->h_tl[i], b->h_ql[i], true);
@@ -1008,14 +1019,15 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		int c = low_mem && !step0 ? 5 : 0;
 		if (classes && c == 0) {
 			const int64_t window = std::min<int64_t>(len + 1, 2 * bound + 3);
-			const bool packable = (int64_t)b->h_tl[i] + bound < 32767 && g->band_pack != 0;
+			const bool packable = (int64_t)b->h_tl[i] + bound < 32767 && g->band_pack != 0 && band2_supported(P0);
+			const bool plain_ok = band_supported(P0);
 			// A window cannot outgrow min(tl+ql+1, 2 x penalty bound + 3); in practice it stays far below tl+ql (a quarter of
 			// it at 5 % divergence), so a pair is also given to a small kernel when it is merely short — if its window does
 			// outgrow that span, finalize() moves it to the wide band kernel, and from there to the generic one.
 			if (packable && (window <= kBandMicroWindow || len + 1 <= 2 * (int64_t)(1 * 3 * 256))) c = 4;
 			else if (packable && (window <= kBandTinyWindow || len + 1 <= 3 * (int64_t)(2 * 3 * 256))) c = 3;
-			else if (packable ? (window <= kBandSmallWindow || len + 1 <= 3 * (int64_t)(4 * 3 * 256)) : window <= 8 * 256 - 256 - 64) c = 2;
-			else if (len + 1 <= 4 * (int64_t)(8 * 3 * 256)) c = 1;
+			else if (packable ? (window <= kBandSmallWindow || len + 1 <= 3 * (int64_t)(4 * 3 * 256)) : (plain_ok && window <= 8 * 256 - 256 - 64)) c = 2;
+			else if ((packable || plain_ok) && len + 1 <= 4 * (int64_t)(8 * 3 * 256)) c = 1;
 		}
 		b->h_class[i] = (int8_t)(c == 5 ? 0 : c);
 		b->h_flags[i] = (int8_t)(step0 ? 1 : 0);

@@ -88,6 +88,7 @@ struct BatchArgs {
 	int32_t coop_pair;         // the one pair this launch aligns
 	int32_t lds_e2_cols;       // generic kernel, 512 threads, e2 == 1: columns of E2/F2 kept in LDS (power of two; 0 = all in HBM)
 	int32_t scalar_generic;    // generic kernel: 1 = one column per lane (forward_pass) also where the four-columns-per-lane pass applies
+	int32_t band_lds_seq;      // band kernel with the sequences in LDS: bytes of the sequence copy (bookkeeping words and edge table sit behind it)
 	int32_t coop_groups, coop_group_size; // pairs side by side on the whole-device kernel and workgroups per pair (grid = product)
 	int64_t coop_edge_stride;  // ints between two groups' granule arrays
 	int64_t coop_misc_stride;  // bytes between two groups' flags / barrier words / pass state / flag ring
@@ -121,6 +122,10 @@ int  launch_coop_walk(const BatchArgs &a, void *stream);                 // chec
 int  launch_coop_finish(const BatchArgs &a, void *stream);               // traceback + per-pair outputs
 
 bool band_supported(const Penalty &p);                       // (e1,e2) instantiated and every H lag >= 2
+// launch wrappers implemented in mwf_band2.hip (packed band kernel: 16-bit offsets, sequences in LDS; BandGeom::packed)
+bool band2_supported(const Penalty &p);
+int  launch_band2(const BatchArgs &a, int grid, const BandGeom &g, void *stream);
+int  band2_kernel_occupancy(const Penalty &p, const BandGeom &g, bool cigar);
 int  launch_band(const BatchArgs &a, int grid, const BandGeom &g, void *stream);
 int  band_kernel_occupancy(const Penalty &p, const BandGeom &g, bool cigar);
 
