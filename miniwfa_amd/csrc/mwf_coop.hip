@@ -202,6 +202,9 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 	const int64_t W = A.W;
 	const int32_t nH = A.pen.nH, lagx = A.pen.x, lag1 = A.pen.oe1, lag2 = A.pen.oe2;
 	const bool relaxed_stores = min(lagx, min(lag1, lag2)) >= 3;
+	// some H lag is 1 (edit-distance preset: x = o+e = 1): the rows of the next penalty include the one this penalty writes,
+	// so a chunk's next rows are requested only after its own store has completed
+	const bool lag_one = min(lagx, min(lag1, lag2)) < 2;
 	int32_t *const H = M.H;
 	// What crosses waves.  granule(row, r, side, which): per H slot (= penalty mod nH), chunk slot r and side (0: the chunk's
 	// last column, written by lane 63; 1: its first column, lane 0): which 0 = E1 | F1, 1 = E2 | F2, 2 = H after extension.
@@ -453,7 +456,7 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 					const int32_t lv = __ballot(live & 2u) != 0;
 					if (lane < kFlagCopies) st_ag(flag_entry(s_new, lane) + 1, s_new << 4 | lv);
 				}
-				prefetch(k, nextH, phi, gl_next); // the next penalty's rows: only now, so that nothing queues in front of what was just published
+				if (!lag_one) prefetch(k, nextH, phi, gl_next); // the next penalty's rows: only now, so that nothing queues in front of what was just published
 				// a run of >= 4 matches continues: the wave walks it together, one owning lane and column at a time
 				unsigned long long owners = __ballot(pend != 0);
 				while (owners) {
@@ -500,6 +503,10 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 					int32_t val = 0;
 					if (fm) val = 1 | __builtin_amdgcn_readlane(done_info, (int32_t)__builtin_ctzll(fm)) << 1;
 					if (lane < kFlagCopies) st_ag(flag_entry(s_new, lane) + 2, s_new << 4 | val);
+				}
+				if (lag_one) {
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+					prefetch(k, nextH, phi, gl_next);
 				}
 
 			} else {
@@ -743,8 +750,7 @@ int launch_pass(const BatchArgs &a, int grid, hipStream_t st)
 
 bool coop_supported(const Penalty &p)
 {
-	const bool inst = (p.e1 == 2 && p.e2 == 1) || (p.e1 == 2 && p.e2 == 2);
-	return inst && p.x >= 2 && p.oe1 >= 2 && p.oe2 >= 2;
+	return (p.e1 == 2 && p.e2 == 1) || (p.e1 == 2 && p.e2 == 2) || (p.e1 == 1 && p.e2 == 1);
 }
 
 int64_t coop_chunk_slots(int grid) { return (int64_t)grid * kNW * kK; }
@@ -762,6 +768,7 @@ int launch_coop_pass(const BatchArgs &a, int grid, void *stream)
 {
 	if (a.pen.e1 == 2 && a.pen.e2 == 1) return launch_pass<2, 1>(a, grid, (hipStream_t)stream);
 	if (a.pen.e1 == 2 && a.pen.e2 == 2) return launch_pass<2, 2>(a, grid, (hipStream_t)stream);
+	if (a.pen.e1 == 1 && a.pen.e2 == 1) return launch_pass<1, 1>(a, grid, (hipStream_t)stream);
 	return -1;
 }
 

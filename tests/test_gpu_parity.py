@@ -617,3 +617,35 @@ def test_repeated_calls_recycle_device_memory():
     eng.set("trim", 0)
     assert eng.stats().dev_bytes < sizes[-1]
     eng.close()
+
+
+@pytest.mark.parametrize("kind", [2, 1])
+def test_edit_distance_and_single_affine_presets_on_the_fast_kernels(kind, oracle):
+    """The reference CLI's -e (x=1, o=0, e=1: every wavefront lag is 1, a ring of two slices) and -a (o2=o1, e2=e1)
+    presets (main.c:34-35) are legal mwf_opt_t values: both must run on the band kernel (kind 2) and on the whole-device
+    kernel (kind 1), not only on the generic one.  Score, CIGAR and, on the whole-device kernel, the low-memory mode."""
+    EDIT = dict(x=1, o1=0, e1=1, o2=0, e2=1)
+    AFFINE = dict(x=4, o1=4, e1=2, o2=4, e2=2)
+    eng = mw.Engine(0)
+    eng.set("force_kind", kind)
+    pairs = [synth_pair(94000 + i, (50, 700, 2500, 6000)[i % 4], (0.01, 0.06, 0.2)[i % 3]) for i in range(12)]
+    pairs += [(b"", b"ACGT"), (b"GATTACA", b"GATTACA"), (b"A" * 900, b"C" * 800)]
+    if kind == 1:
+        pairs = pairs[:6] + pairs[-3:] + [synth_pair(94100, 25000, 0.03, 2, 1500)]
+    modes = [dict(flag=0), dict(flag=1)] + ([dict(flag=1, step=300)] if kind == 1 else [])
+    for pen in (EDIT, AFFINE):
+        for kw in modes:
+            o = make_opt(**pen, **kw)
+            for lo in range(0, len(pairs), 4 if kind == 1 else len(pairs)):
+                chunk = pairs[lo:lo + (4 if kind == 1 else len(pairs))]
+                b = eng.upload(PackedBatch(chunk))
+                b.align(mw.opt_init(**pen, **kw))
+                assert eng.stats().kernel_kind == kind, (pen, kw)
+                s, it, nc = b.results()
+                for i, (t, q) in enumerate(chunk):
+                    es, eit, ecig = oracle.align(t, q, o)
+                    assert (int(s[i]), int(it[i])) == (es, eit), (kind, pen["x"], kw, lo + i, len(t))
+                    if ecig is not None:
+                        assert b.cigar(i, int(nc[i])).tolist() == ecig, (kind, pen["x"], kw, lo + i)
+                b.free()
+    eng.close()
