@@ -17,9 +17,10 @@
 //     for the cells near the alignment path only (a random 4-mer matches in one cell of 256, i.e. in most chunks);
 //   * the per-penalty header is scalar arithmetic on a handful of loop-carried values (chunk indices change only when the
 //     mapping does), the three per-penalty flags travel as one LDS word, rows are loaded only for chunks that are active.
-//     (Measured and dropped: requesting the next chunk's rows while the current one computes, and the next penalty's
-//     first rows before the barrier — 30.8 and 29.3 ms against 28.6 without: the co-resident workgroup already hides
-//     the load latency, the extra registers and code do not pay.)
+//     (Measured and dropped: requesting the next chunk's rows while the current one computes, the next penalty's first
+//     rows before the barrier, all active chunks' rows at the start of the penalty — 30.8, 29.3 and 38.6 ms against 28.6
+//     without: the co-resident workgroup already hides the load latency; registers are what is scarce — the 512-thread
+//     variant lives in 128 VGPRs so that two workgroups share a CU.)
 // Results are bit-identical to the other kernels (tests/test_gpu_parity.py).
 #include <type_traits>
 #include "mwf_device.h"
@@ -314,51 +315,64 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 				// ---- lean copy: recurrence, then the first 4-byte probe of the match extension, in two phases so that all eight
 				// LDS reads are in flight together
 				const int32_t t0 = ql + tl + 1 - c0, dq0 = c0 - 1 - tl + qoff;
-				int32_t jc[4], aq[4], rj[4], m9[4];
-				Probe8 pr[4];
+				int32_t m9[4];
 #pragma unroll
-				for (int i = 0; i < 4; ++i) {
-					const Cell v = wf_cell<TB>(hx[i], o1[i], g1m[i], o2[i], g2m[i], o1[i + 2], g1p[i], o2[i + 2], g2p[i]);
-					ne1[i] = v.e1, nf1[i] = v.f1, ne2[i] = v.e2, nf2[i] = v.f2;
-					hv[i] = v.h;
-					tbw |= v.tb << (8 * i);
-					rj[i] = min(tl, t0 - i);                                           // min(tl, ql - d): the largest j = k+1 inside the matrix
-					jc[i] = (int32_t)min((uint32_t)(v.h + 1), (uint32_t)rj[i]);        // dead and phantom offsets clamp to it: room 0
-					aq[i] = jc[i] + dq0 + i;                                           // byte offset of q[d + j] in the LDS copy
-					probe8_issue(pr[i], jc[i], aq[i]);
-				}
+				for (int h2 = 0; h2 < 2; ++h2) { // two columns at a time: half the probe words in flight, the new pair packed at once
+					int32_t jc[2], aq[2], rj[2];
+					Probe8 pr[2];
 #pragma unroll
-				for (int i = 0; i < 4; ++i) {
-					// leading equal bytes, capped at 9 and at the room: 9 <=> all eight equal and more than eight to go
-					m9[i] = min(probe8_count(pr[i], jc[i], aq[i]), rj[i] - jc[i]);
-					nmat[i] = min(m9[i], 8);
+					for (int u = 0; u < 2; ++u) {
+						const int i = 2 * h2 + u;
+						const Cell v = wf_cell<TB>(hx[i], o1[i], g1m[i], o2[i], g2m[i], o1[i + 2], g1p[i], o2[i + 2], g2p[i]);
+						ne1[i] = v.e1, nf1[i] = v.f1, ne2[i] = v.e2, nf2[i] = v.f2;
+						hv[i] = v.h;
+						tbw |= v.tb << (8 * i);
+						rj[u] = min(tl, t0 - i);
+						jc[u] = (int32_t)min((uint32_t)(v.h + 1), (uint32_t)rj[u]);
+						aq[u] = jc[u] + dq0 + i;
+						probe8_issue(pr[u], jc[u], aq[u]);
+					}
+#pragma unroll
+					for (int u = 0; u < 2; ++u) {
+						const int i = 2 * h2 + u;
+						m9[i] = min(probe8_count(pr[u], jc[u], aq[u]), rj[u] - jc[u]);
+						nmat[i] = min(m9[i], 8);
+					}
 				}
 				if (__ballot(max(max(m9[0], m9[1]), max(m9[2], m9[3])) == 9))
 					pend = (uint32_t)(m9[0] == 9) | (uint32_t)(m9[1] == 9) << 1 | (uint32_t)(m9[2] == 9) << 2 | (uint32_t)(m9[3] == 9) << 3;
 			} else {
-				// ---- general copy: window tests, edge liveness, good bits
+				// ---- general copy: window tests, edge liveness, good bits; the probe as in the lean copy (a column outside the
+				// window probes as a dead offset: room 0)
+				const int32_t t0 = ql + tl + 1 - c0, dq0 = c0 - 1 - tl + qoff;
+				int32_t jc[4], aq[4], rj[4];
+				Probe8 pr[4];
 #pragma unroll
 				for (int i = 0; i < 4; ++i) {
-					const int32_t c = c0 + i, d = c - 1 - tl;
+					const int32_t c = c0 + i;
 					const uint32_t a = inner ? 1u : (uint32_t)((c >= lo) & (c <= hi));
 					const Cell v = wf_cell<TB>(hx[i], o1[i], g1m[i], o2[i], g2m[i], o1[i + 2], g1p[i], o2[i + 2], g2p[i]);
 					ne1[i] = a ? v.e1 : kDead16, nf1[i] = a ? v.f1 : kDead16;
 					ne2[i] = a ? v.e2 : kDead16, nf2[i] = a ? v.f2 : kDead16;
-					const uint32_t inm = a & inm_bit(d, v.h, tl, ql);
-					if (track_good) // uniform
-						gbits |= (a & (inm | inm_bit(d, v.e1, tl, ql) | inm_bit(d, v.f1, tl, ql) | inm_bit(d, v.e2, tl, ql) | inm_bit(d, v.f2, tl, ql))) << i;
-					const int32_t j = inm ? v.h + 1 : 0, q = inm ? d + v.h + 1 : 0;
-					const int32_t room = inm ? min(tl - j, ql - q) : 0;
-					Probe8 pr;
-					probe8_issue(pr, j, qoff + q);
-					const int32_t m9 = min(probe8_count(pr, j, qoff + q), room);
-					nmat[i] = min(m9, 8);
-					pend |= (uint32_t)(m9 == 9) << i;
+					if (track_good) { // uniform
+						const int32_t d = c - 1 - tl;
+						gbits |= (a & (inm_bit(d, v.h, tl, ql) | inm_bit(d, v.e1, tl, ql) | inm_bit(d, v.f1, tl, ql) | inm_bit(d, v.e2, tl, ql) | inm_bit(d, v.f2, tl, ql))) << i;
+					}
 					hv[i] = v.h;
 					tbw |= v.tb << (8 * i);
 					// edge rule (miniwfa.c:325-326): H is the max of the five, so "any live" == "H live"
 					const uint32_t lv = (uint32_t)(v.h >= -1);
 					live |= (lv & (uint32_t)(c == lo)) | ((lv & (uint32_t)(c == hi)) << 1);
+					rj[i] = min(tl, t0 - i);
+					jc[i] = (int32_t)min((uint32_t)((a ? v.h : kDead16) + 1), (uint32_t)rj[i]);
+					aq[i] = jc[i] + dq0 + i;
+					probe8_issue(pr[i], jc[i], aq[i]);
+				}
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					const int32_t m9 = min(probe8_count(pr[i], jc[i], aq[i]), rj[i] - jc[i]);
+					nmat[i] = min(m9, 8);
+					pend |= (uint32_t)(m9 == 9) << i;
 				}
 			}
 			// ---- the new E/F are final: age the registers, publish this chunk's outer pairs for the neighbouring waves

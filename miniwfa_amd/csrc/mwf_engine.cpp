@@ -71,7 +71,8 @@ struct mwf_gpu_s {
 	int lds_e2 = 1;            // generic kernel: keep E2/F2 in LDS where that applies (0: never)
 	int scalar_generic = 0;    // 1: the generic kernel's original one-column-per-lane pass everywhere (comparison / fallback)
 	int64_t coop_spin_limit = 1 << 23; // polls (about a microsecond each) before the whole-device kernel gives up on a workgroup
-	int64_t coop_tb_cap = (int64_t)96 << 30; // whole-device traceback arena: covers the 5 Mb pairs; doubles on overflow
+	int64_t coop_tb_cap = (int64_t)96 << 30; // whole-device traceback arena: first allocation never above this ...
+	int64_t coop_tb_mult = 1;                // ... times this; doubled after an overflow while memory lasts
 	int64_t lowmem_budget_mb = 0; // whole-device low-memory mode: first-pass traceback above this many MB -> true two-pass (0: automatic)
 	// workspace (per-stream pool)
 	DevBuf ring, sring, good, tb, row_off, row_lo, cig_scratch, snap, snap_meta, seg, queue, dbg, coop_edge, coop_misc;
@@ -577,8 +578,11 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 		// Arena: the worst case (every row as wide as the matrix) is out of reach for long pairs, so start from a cap that
 		// holds the real ones (s^2 bytes: 51 GB for the MHC pair) and let finalize() double it after an overflow.  An
 		// arena that is already large enough is reused as is, so repeated calls never re-allocate.
+		// (first guess: 6000 bytes per column of the matrix' perimeter — 1.8 GB for a 150 kb pair that needs 0.7, 60 GB for the
+		// 5 Mb pair that needs 55: a traceback of s^2 bytes with s about 2.5 % of tl+ql)
 		const int64_t worst = NG * (rows_slot + 1) * (len + 8);
-		int64_t want = std::min(worst, g->tb_budget_mb > 0 ? (g->tb_budget_mb << 20) : g->coop_tb_cap);
+		const int64_t guess = std::min<int64_t>(g->coop_tb_cap, std::max<int64_t>((int64_t)1 << 30, 6000 * len) * (int64_t)NG);
+		int64_t want = std::min(worst, g->tb_budget_mb > 0 ? (g->tb_budget_mb << 20) : guess * g->coop_tb_mult);
 		if ((int64_t)g->tb.bytes >= want) want = (int64_t)g->tb.bytes;
 		else {
 			size_t fr = 0, tot = 0;
@@ -679,7 +683,7 @@ bool coop_can_grow(mwf_gpu_t *g)
 {
 	size_t fr = 0, tot = 0;
 	if (hipMemGetInfo(&fr, &tot) != hipSuccess) return false;
-	return (int64_t)(fr / 10 * 9) > ((int64_t)1 << 30) && (int64_t)g->tb.bytes >= g->coop_tb_cap / 4 * 3;
+	return (int64_t)(fr / 10 * 9) > (int64_t)g->tb.bytes / 2; // room for at least half as much again
 }
 
 int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b);
@@ -1128,7 +1132,7 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 					if (!coop_warned) fprintf(stderr, "[libmwf_hip] warning: wavefront of pair %d outgrew the whole-device kernel's span; re-running it on one workgroup (slow)\n", (int)i);
 					coop_warned = true;
 					to_generic[step0].push_back((int32_t)i);
-				} else if (g->tb_budget_mb == 0 && g->coop_tb_cap < ((int64_t)1 << 40) && coop_can_grow(g)) grow_coop = true, coop_alone.push_back((int32_t)i);
+				} else if (g->tb_budget_mb == 0 && g->coop_tb_mult < ((int64_t)1 << 20) && coop_can_grow(g)) grow_coop = true, coop_alone.push_back((int32_t)i);
 				else if (b->opt.step > 0 && !step0) to_generic[0].push_back((int32_t)i); // the first-pass traceback does not fit: true two-pass mode
 				else fail = "traceback";
 			} else if (st == ST_TB_OVERFLOW || st == ST_SNAP_OVERFLOW) {
@@ -1148,7 +1152,7 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 		for (int z = 0; z < 2; ++z) n_redo += to_generic[z].size() + to_band_wide[z].size() + same_fewer[0][z].size() + same_fewer[2][z].size();
 		if (n_redo == 0) break;
 		g->stats.n_retries += (int32_t)n_redo;
-		if (grow_coop) g->coop_tb_cap *= 2;
+		if (grow_coop) g->coop_tb_mult *= 2;
 		for (int32_t i : coop_alone)
 			if (run_coop_pair(g, b, b->opt, i, false, false)) return -1;
 		const bool shrink = !same_fewer[0][0].empty() || !same_fewer[0][1].empty() || !same_fewer[2][0].empty() || !same_fewer[2][1].empty();
