@@ -40,7 +40,7 @@ class MwfRst(C.Structure):
 class GpuStats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("cells", C.c_int64), ("cells_pass1", C.c_int64), ("n_launches", C.c_int32),
                 ("n_retries", C.c_int32), ("grid", C.c_int32), ("block", C.c_int32), ("kernel_kind", C.c_int32),
-                ("dev_bytes", C.c_int64), ("dev_bytes_peak", C.c_int64), ("packed", C.c_int32), ("reserved_", C.c_int32)]
+                ("dev_bytes", C.c_int64), ("dev_bytes_peak", C.c_int64), ("packed", C.c_int32), ("lowmem_two_pass", C.c_int32)]
 
 
 class KmStat(C.Structure):

@@ -190,9 +190,15 @@ __device__ __forceinline__ bool grid_sync(const BatchArgs &A, unsigned *sync, un
 
 // grp / lb / G: this pair's group of workgroups, this workgroup's index in it, the group's size (the whole grid when one pair
 // has the device to itself)
-template <int E1, int E2, bool TB>
+// SEG: first pass of the true low-memory mode (reference mwf_wfa_seg, miniwfa.c:551-601): no traceback bytes are stored;
+// every wavefront value carries the index of the cell its optimal predecessor chain went through at the last snapshot
+// (shadow registers / shadow H rows / shadow granules, moved by the choices the traceback byte records, :495-526), and
+// every `step` penalties the shadow ring is flattened into a snapshot and renumbered (:451-474), see coop_snapshot().
+template <int E1, int E2, bool TB, bool SEG = false>
 __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh, int32_t n_seg, int32_t grp, int32_t lb, int32_t G)
 {
+	static_assert(!(TB && SEG), "the first pass of the low-memory mode stores no traceback");
+	constexpr bool WTB = TB || SEG; // the recurrence yields the traceback byte
 	const int32_t NWt = G * kNW, TC = NWt * kK;
 	const int32_t tl = M.tl, ql = M.ql, cmax = tl + ql + 1;
 	const int32_t tid = threadIdx.x, lane = tid & 63, gw = uni(lb * kNW + (tid >> 6));
@@ -210,6 +216,10 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 	// last column, written by lane 63; 1: its first column, lane 0): which 0 = E1 | F1, 1 = E2 | F2, 2 = H after extension.
 	gran_t *const grans = (gran_t*)(A.coop_edge + (int64_t)grp * A.coop_edge_stride);
 	auto granule = [&](int32_t row, int32_t r, int32_t side, int32_t which) -> gran_t* { return grans + ((((int64_t)row * TC + r) * 2 + side) * 4 + which); };
+	// SEG: the same for the provenance values, in a second array of the same shape
+	gran_t *const sgrans = (gran_t*)(A.coop_edge + (int64_t)grp * A.coop_edge_stride + A.coop_sedge_off);
+	auto sgranule = [&](int32_t row, int32_t r, int32_t side, int32_t which) -> gran_t* { return sgrans + ((((int64_t)row * TC + r) * 2 + side) * 4 + which); };
+	int32_t *const sH = M.sH;
 	int32_t *const gflags = (int32_t*)misc;                // [12..14]: origin offset, shrink reduction; [15]: set by the first workgroup that gives up a wait
 	// Per penalty (mod kFlagRing): "new low edge live", "new high edge live", "end cell reached | last state << 1", each as
 	// penalty << 4 | value, written by the one wave that owns the column in question.
@@ -232,6 +242,21 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 		}
 	int4 phx[kK], po1[kK], po2[kK];
 	gran_t ph1[kK], ph2[kK];       // lanes 0 / 63: H granules of the neighbouring chunk's adjacent column for lags o1+e1, o2+e2
+	// SEG: provenance of the same values (dead code otherwise)
+	int32_t se1h[E1][kK][4], sf1h[E1][kK][4], se2h[E2][kK][4], sf2h[E2][kK][4];
+	int4 sphx[kK], spo1[kK], spo2[kK];
+	gran_t sph1[kK], sph2[kK];
+	if (SEG) {
+#pragma unroll
+		for (int k = 0; k < kK; ++k)
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+#pragma unroll
+				for (int a = 0; a < E1; ++a) se1h[a][k][i] = sf1h[a][k][i] = kNegInf;
+#pragma unroll
+				for (int a = 0; a < E2; ++a) se2h[a][k][i] = sf2h[a][k][i] = kNegInf;
+			}
+	}
 
 	// ---- penalty 0: origin and its extension (the first wave of workgroup 0 walks it cooperatively)
 	if (tid == 0) {
@@ -249,18 +274,25 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 			const int32_t r0 = (c0 >> 8) % TC;
 			if ((c0 & 255) == 0) st_gran(granule(0, r0, 1, 2), k0, 0);
 			if ((c0 & 255) == 255) st_gran(granule(0, r0, 0, 2), k0, 0);
+			if (SEG) { // the origin's provenance is -1 (miniwfa.c:119, :542)
+				st_ag(&sH[c0], -1);
+				if ((c0 & 255) == 0) st_gran(sgranule(0, r0, 1, 2), -1, 0);
+				if ((c0 & 255) == 255) st_gran(sgranule(0, r0, 0, 2), -1, 0);
+			}
 		}
 	}
 	if (tid == 0) for (int32_t j = 0; j < 12; ++j) (&sh.flags[0][0])[j] = 0;
 	if (!grid_sync<false>(A, sync, (unsigned)lb, sh, epoch, G, nullptr, cum, 0)) { R.status = ST_INTERNAL; return R; }
 	{
 		const int32_t k0 = uni(ld_ag(&gflags[12]));
-		if (k0 == tl - 1 && k0 == ql - 1) { R.cells = 0; return R; }
+		if (k0 == tl - 1 && k0 == ql - 1) { R.cells = 0; R.info = SEG ? -1 : 0; return R; }
 	}
 
 	int32_t s = 0, wf_lo = tl + 1, wf_hi = tl + 1;
 	int32_t curH = 0, par = 0, sid = 0;
 	int64_t cells = 0, tb_used = 0;
+	int32_t snap_ctr = A.step == 1 ? 0 : 1, n_snap = 0; // SEG: (s+1) % step, snapshots taken
+	int64_t snap_used = 0;
 
 	auto prefetch = [&](int k, int32_t slotH, int32_t phi, int32_t g_lo) {
 		int32_t jx = slotH - lagx; if (jx < 0) jx += nH;
@@ -279,6 +311,13 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 		const int32_t side = lane == 0 ? 0 : 1;
 		ph1[k] = ld_gran(granule(j1, rn, side, 2));
 		ph2[k] = ld_gran(granule(j2, rn, side, 2));
+		if (SEG) {
+			sphx[k] = *(const int4*)(sH + (jx * W + c0));
+			spo1[k] = *(const int4*)(sH + (j1 * W + c0));
+			spo2[k] = *(const int4*)(sH + (j2 * W + c0));
+			sph1[k] = ld_gran(sgranule(j1, rn, side, 2));
+			sph2[k] = ld_gran(sgranule(j2, rn, side, 2));
+		}
 	};
 	int32_t gl;
 	{
@@ -302,6 +341,90 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 				wf_lo = wf_hi = c;
 				++sid;
 			}
+		}
+		if (SEG) { // snapshot when (s+1) % step == 0, before slice s+1 is computed (miniwfa.c:585-586)
+			if (snap_ctr == 0) {
+				// ---- flatten the shadow ring and renumber it (reference wf_snapshot1, miniwfa.c:451-474).  Index of a cell:
+				// slice id * Wspan + (column - slo), slice ids: H ring slot j -> j, then E1, F1, E2, F2 by age.
+				if (!grid_sync<true>(A, sync, (unsigned)lb, sh, epoch, G, nullptr, cum, 0)) { R.status = ST_INTERNAL; break; }
+				int32_t slo = 0x7fffffff, shi = -1;
+				for (int32_t j = 0; j < nH; ++j) {
+					const int32_t l = uni(sh.rng_lo[j]), h = uni(sh.rng_hi[j]);
+					if (l <= h) slo = min(slo, l), shi = max(shi, h);
+				}
+				const int32_t Wspan = shi - slo + 1;
+				constexpr int32_t NS_EF = 2 * E1 + 2 * E2;
+				const int64_t total = (int64_t)(nH + NS_EF) * Wspan;
+				if ((int64_t)(n_snap + 1) * 8 > A.snap_meta_slot || snap_used + total > A.snap_slot_ints || total > 0x7fffffffLL) { R.status = ST_SNAP_OVERFLOW; break; }
+				int32_t *const x = M.snap + snap_used;
+				if (lead) {
+					int32_t *meta = M.snap_meta + (int64_t)n_snap * 8;
+					meta[0] = (int32_t)(snap_used & 0xffffffff), meta[1] = (int32_t)(snap_used >> 32);
+					meta[2] = s, meta[3] = curH, meta[4] = slo, meta[5] = Wspan;
+				}
+				const int32_t gbase_s = gl - gl % TC;
+#pragma unroll
+				for (int k = 0; k < kK; ++k) {
+					const int32_t r = gw + NWt * k;
+					int32_t g = gbase_s + r;
+					if (g < gl) g += TC;
+					const int32_t cb = g * kChunk, c0 = cb + 4 * lane;
+					if (cb > shi || cb + kChunk - 1 < slo) continue; // uniform
+					// H rows of the ring
+					for (int32_t j = 0; j < nH; ++j) {
+						const int32_t l = uni(sh.rng_lo[j]), h = uni(sh.rng_hi[j]);
+						if (l > h || cb > h || cb + kChunk - 1 < l) continue; // uniform
+						int32_t age = curH - j; if (age < 0) age += nH;
+						int4 v = *(const int4*)(sH + (j * W + c0));
+						int32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+						for (int i = 0; i < 4; ++i) {
+							const int32_t c = c0 + i;
+							if (c >= l && c <= h) {
+								const int32_t t = j * Wspan + (c - slo);
+								x[t] = vv[i];
+								vv[i] = t;
+							}
+						}
+						*(int4*)(sH + (j * W + c0)) = make_int4(vv[0], vv[1], vv[2], vv[3]);
+						// the copies of the outer columns the neighbouring waves read
+						if (lane == 63 && c0 + 3 >= l && c0 + 3 <= h) st_gran(sgranule(j, r, 0, 2), vv[3], s - age);
+						if (lane == 0 && c0 >= l && c0 <= h) st_gran(sgranule(j, r, 1, 2), vv[0], s - age);
+					}
+					// E/F registers: age a holds penalty s - a, whose window is that of H ring slot curH - a
+					auto flat = [&](int32_t (&reg)[4], int32_t id, int32_t a, int32_t which, bool is_e) {
+						int32_t j = curH - a; if (j < 0) j += nH;
+						if (s - a < 0) return;
+						const int32_t l = uni(sh.rng_lo[j]), h = uni(sh.rng_hi[j]);
+#pragma unroll
+						for (int i = 0; i < 4; ++i) {
+							const int32_t c = c0 + i;
+							if (c >= l && c <= h) {
+								const int32_t t = id * Wspan + (c - slo);
+								x[t] = reg[i];
+								reg[i] = t;
+							}
+						}
+						if (is_e && lane == 63 && c0 + 3 >= l && c0 + 3 <= h) st_gran(sgranule(j, r, 0, which), reg[3], s - a);
+						if (!is_e && lane == 0 && c0 >= l && c0 <= h) st_gran(sgranule(j, r, 1, which), reg[0], s - a);
+					};
+#pragma unroll
+					for (int a = 0; a < E1; ++a) flat(se1h[a][k], nH + a, a, 0, true), flat(sf1h[a][k], nH + E1 + a, a, 0, false);
+#pragma unroll
+					for (int a = 0; a < E2; ++a) flat(se2h[a][k], nH + 2 * E1 + a, a, 1, true), flat(sf2h[a][k], nH + 2 * E1 + E2 + a, a, 1, false);
+				}
+				snap_used += total, ++n_snap;
+				if (!grid_sync<true>(A, sync, (unsigned)lb, sh, epoch, G, nullptr, cum, 0)) { R.status = ST_INTERNAL; break; }
+				// what was requested for the next penalty before the renumbering is stale: request it again
+				{
+					const int32_t lo_n = wf_lo > 1 ? wf_lo - 1 : 1, hi_n = wf_hi < cmax ? wf_hi + 1 : cmax;
+					const int32_t nH1 = curH + 1 == nH ? 0 : curH + 1;
+#pragma unroll
+					for (int k = 0; k < kK; ++k) prefetch(k, nH1, hi_n, gl);
+					(void)lo_n;
+				}
+			}
+			snap_ctr = snap_ctr + 1 == A.step ? 0 : snap_ctr + 1;
 		}
 		const int32_t lo = wf_lo > 1 ? wf_lo - 1 : 1;
 		const int32_t hi = wf_hi < cmax ? wf_hi + 1 : cmax;
@@ -355,6 +478,7 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 			const int32_t cb = g * kChunk;
 			const bool active = cb <= hi && cb + kChunk - 1 >= lo;
 			int32_t ne1[4], nf1[4], ne2[4], nf2[4];
+			int32_t sne1s[4], snf1s[4], sne2s[4], snf2s[4]; // SEG: the new provenance values of this chunk
 			if (active) {
 				if (k == 0) act0 = true; else act1 = true;
 				const int32_t c0 = cb + 4 * lane;
@@ -364,12 +488,21 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 				o1[1] = po1[k].x, o1[2] = po1[k].y, o1[3] = po1[k].z, o1[4] = po1[k].w;
 				o2[1] = po2[k].x, o2[2] = po2[k].y, o2[3] = po2[k].z, o2[4] = po2[k].w;
 				gran_t gh1 = ph1[k], gh2 = ph2[k];
+				int32_t shx[4], so1[6], so2[6];
+				gran_t sgh1 = 0, sgh2 = 0;
+				if (SEG) {
+					shx[0] = sphx[k].x, shx[1] = sphx[k].y, shx[2] = sphx[k].z, shx[3] = sphx[k].w;
+					so1[1] = spo1[k].x, so1[2] = spo1[k].y, so1[3] = spo1[k].z, so1[4] = spo1[k].w;
+					so2[1] = spo2[k].x, so2[2] = spo2[k].y, so2[3] = spo2[k].z, so2[4] = spo2[k].w;
+					sgh1 = sph1[k], sgh2 = sph2[k];
+				}
 				// What the neighbouring chunks computed for the column next to this chunk (lane 0: left neighbour's last column,
 				// lane 63: right neighbour's first): E1|F1 of penalty s_new-e1, E2|F2 of s_new-e2, H of s_new-lag1 and s_new-lag2.
 				// A neighbour column outside the window of that penalty was never computed: NEG_INF.  Otherwise wait for the
 				// granule carrying that penalty's tag — this wait is the only synchronisation between neighbouring waves.
 				const int32_t rl = r == 0 ? TC - 1 : r - 1, rr = r + 1 == TC ? 0 : r + 1;
 				int32_t xg1, xg2, v1, v2;
+				int32_t sxg1 = kNegInf, sxg2 = kNegInf, sv1 = kNegInf, sv2 = kNegInf;
 				{
 					const int32_t nb = lane == 0 ? rl : rr, side = lane == 0 ? 0 : 1, cn = lane == 0 ? cb - 1 : cb + kChunk;
 					const bool edge_lane = lane == 0 || lane == 63;
@@ -381,9 +514,13 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 					const unsigned long long t_g0 = __builtin_readcyclecounter();
 #endif
 					gran_t ge1 = ld_gran(granule(jg1, nb, side, 0)), ge2 = ld_gran(granule(jg2, nb, side, 1));
+					gran_t sge1 = 0, sge2 = 0;
+					if (SEG) sge1 = ld_gran(sgranule(jg1, nb, side, 0)), sge2 = ld_gran(sgranule(jg2, nb, side, 1));
 					for (unsigned spins = 0;; ++spins) {
-						const bool late = (need_e1 && gran_tag(ge1) != s_new - E1) || (need_e2 && gran_tag(ge2) != s_new - E2) ||
-						                  (need_h1 && gran_tag(gh1) != s_new - lag1) || (need_h2 && gran_tag(gh2) != s_new - lag2);
+						bool late = (need_e1 && gran_tag(ge1) != s_new - E1) || (need_e2 && gran_tag(ge2) != s_new - E2) ||
+						            (need_h1 && gran_tag(gh1) != s_new - lag1) || (need_h2 && gran_tag(gh2) != s_new - lag2);
+						if (SEG) late = late || (need_e1 && gran_tag(sge1) != s_new - E1) || (need_e2 && gran_tag(sge2) != s_new - E2) ||
+						                (need_h1 && gran_tag(sgh1) != s_new - lag1) || (need_h2 && gran_tag(sgh2) != s_new - lag2);
 						if (!__ballot(late)) break;
 						if (spins > A.coop_spin_limit || ((spins & 255u) == 255u && uni(ld_ag(&gflags[15])))) {
 							if (lane == 0) sh.red[0] = 1, st_ag(&gflags[15], 1);
@@ -392,12 +529,20 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 						__builtin_amdgcn_s_sleep(1);
 						ge1 = ld_gran(granule(jg1, nb, side, 0)), ge2 = ld_gran(granule(jg2, nb, side, 1));
 						gh1 = ld_gran(granule(j1, nb, side, 2)), gh2 = ld_gran(granule(j2, nb, side, 2));
+						if (SEG) {
+							sge1 = ld_gran(sgranule(jg1, nb, side, 0)), sge2 = ld_gran(sgranule(jg2, nb, side, 1));
+							sgh1 = ld_gran(sgranule(j1, nb, side, 2)), sgh2 = ld_gran(sgranule(j2, nb, side, 2));
+						}
 					}
 #ifdef MWF_BAND_TIMING
 					if (__ballot(gran_tag(ge1) == 0x7fffffff) == 0) t_acc[3] += __builtin_readcyclecounter() - t_g0; // (forces the wait here)
 #endif
 					xg1 = need_e1 ? gran_val(ge1) : kNegInf, xg2 = need_e2 ? gran_val(ge2) : kNegInf;
 					v1 = need_h1 ? gran_val(gh1) : kNegInf, v2 = need_h2 ? gran_val(gh2) : kNegInf;
+					if (SEG) {
+						sxg1 = need_e1 ? gran_val(sge1) : kNegInf, sxg2 = need_e2 ? gran_val(sge2) : kNegInf;
+						sv1 = need_h1 ? gran_val(sgh1) : kNegInf, sv2 = need_h2 ? gran_val(sgh2) : kNegInf;
+					}
 				}
 				if (!inner) {
 #pragma unroll
@@ -406,6 +551,11 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 						hx[i] = ((c >= xlo) & (c <= xhi)) ? hx[i] : kNegInf;
 						o1[i + 1] = ((c >= alo) & (c <= ahi)) ? o1[i + 1] : kNegInf;
 						o2[i + 1] = ((c >= blo) & (c <= bhi)) ? o2[i + 1] : kNegInf;
+						if (SEG) {
+							shx[i] = ((c >= xlo) & (c <= xhi)) ? shx[i] : kNegInf;
+							so1[i + 1] = ((c >= alo) & (c <= ahi)) ? so1[i + 1] : kNegInf;
+							so2[i + 1] = ((c >= blo) & (c <= bhi)) ? so2[i + 1] : kNegInf;
+						}
 					}
 				}
 				o1[0] = from_left(o1[4], v1), o1[5] = from_right(o1[1], v1);
@@ -419,16 +569,34 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 				for (int i = 1; i < 4; ++i) g1m[i] = e1h[E1 - 1][k][i - 1], g2m[i] = e2h[E2 - 1][k][i - 1];
 #pragma unroll
 				for (int i = 0; i < 3; ++i) g1p[i] = f1h[E1 - 1][k][i + 1], g2p[i] = f2h[E2 - 1][k][i + 1];
+				int32_t sg1m[4], sg1p[4], sg2m[4], sg2p[4];
+				if (SEG) {
+					so1[0] = from_left(so1[4], sv1), so1[5] = from_right(so1[1], sv1);
+					so2[0] = from_left(so2[4], sv2), so2[5] = from_right(so2[1], sv2);
+					sg1m[0] = from_left(se1h[E1 - 1][k][3], sxg1), sg2m[0] = from_left(se2h[E2 - 1][k][3], sxg2);
+					sg1p[3] = from_right(sf1h[E1 - 1][k][0], sxg1), sg2p[3] = from_right(sf2h[E2 - 1][k][0], sxg2);
+#pragma unroll
+					for (int i = 1; i < 4; ++i) sg1m[i] = se1h[E1 - 1][k][i - 1], sg2m[i] = se2h[E2 - 1][k][i - 1];
+#pragma unroll
+					for (int i = 0; i < 3; ++i) sg1p[i] = sf1h[E1 - 1][k][i + 1], sg2p[i] = sf2h[E2 - 1][k][i + 1];
+				}
 
 				int32_t hv[4], room[4], nmat[4];
+				int32_t sne1[4], snf1[4], sne2[4], snf2[4], shv[4];
 				uint32_t tbw = 0, pend = 0, live = 0, fin = 0, gbits = 0;
 #pragma unroll
 				for (int i = 0; i < 4; ++i) {
 					const int32_t c = c0 + i, d = c - 1 - tl;
 					const uint32_t act = inner ? 1u : (uint32_t)((c >= lo) & (c <= hi));
-					const Cell v = wf_cell<TB>(hx[i], o1[i], g1m[i], o2[i], g2m[i], o1[i + 2], g1p[i], o2[i + 2], g2p[i]);
+					const Cell v = wf_cell<WTB>(hx[i], o1[i], g1m[i], o2[i], g2m[i], o1[i + 2], g1p[i], o2[i + 2], g2p[i]);
 					ne1[i] = act ? v.e1 : kNegInf, nf1[i] = act ? v.f1 : kNegInf;
 					ne2[i] = act ? v.e2 : kNegInf, nf2[i] = act ? v.f2 : kNegInf;
+					if (SEG) { // provenance follows the choices the traceback byte records (miniwfa.c:504-523)
+						const Cell u = shadow_cell(v.tb, shx[i], so1[i], sg1m[i], so2[i], sg2m[i], so1[i + 2], sg1p[i], so2[i + 2], sg2p[i]);
+						sne1[i] = act ? u.e1 : kNegInf, snf1[i] = act ? u.f1 : kNegInf;
+						sne2[i] = act ? u.e2 : kNegInf, snf2[i] = act ? u.f2 : kNegInf;
+						shv[i] = act ? u.h : kNegInf;
+					}
 					const uint32_t inm = act & inm_bit(d, v.h, tl, ql);
 					if (track_good)
 						gbits |= (act & (inm | inm_bit(d, v.e1, tl, ql) | inm_bit(d, v.f1, tl, ql) | inm_bit(d, v.e2, tl, ql) | inm_bit(d, v.f2, tl, ql))) << i;
@@ -445,6 +613,12 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 				// E/F of the outer columns and the edge flags are final: publish them now, the write-through overlaps the probes
 				if (lane == 63) st_gran(granule(newH, r, 0, 0), ne1[3], s_new), st_gran(granule(newH, r, 0, 1), ne2[3], s_new);
 				if (lane == 0) st_gran(granule(newH, r, 1, 0), nf1[0], s_new), st_gran(granule(newH, r, 1, 1), nf2[0], s_new);
+				if (SEG) {
+					if (lane == 63) st_gran(sgranule(newH, r, 0, 0), sne1[3], s_new), st_gran(sgranule(newH, r, 0, 1), sne2[3], s_new);
+					if (lane == 0) st_gran(sgranule(newH, r, 1, 0), snf1[0], s_new), st_gran(sgranule(newH, r, 1, 1), snf2[0], s_new);
+#pragma unroll
+					for (int i = 0; i < 4; ++i) sne1s[i] = sne1[i], snf1s[i] = snf1[i], sne2s[i] = sne2[i], snf2s[i] = snf2[i];
+				}
 				if ((uint32_t)(lo - cb) < (uint32_t)kChunk) { // this chunk holds the low edge column
 					const int32_t lv = __ballot(live & 1u) != 0;
 					if (lane < kFlagCopies) st_ag(flag_entry(s_new, lane) + 0, s_new << 4 | lv);
@@ -482,10 +656,15 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 					const uint32_t act = inner ? 1u : (uint32_t)((c0 + i >= lo) & (c0 + i <= hi));
 					const uint32_t f = act & inm_bit(d, hv[i], tl, ql) & (uint32_t)(kk == tl - 1) & (uint32_t)(d + kk == ql - 1);
 					fin |= f;
-					done_info = f ? (nmat[i] == 0 ? (int32_t)((tbw >> (8 * i)) & 7u) : 0) : done_info;
+					done_info = f ? (SEG ? shv[i] : (nmat[i] == 0 ? (int32_t)((tbw >> (8 * i)) & 7u) : 0)) : done_info;
 					hv[i] = kk;
 				}
 				*(int4*)(H + (newH * W + c0)) = make_int4(hv[0], hv[1], hv[2], hv[3]);
+				if (SEG) {
+					*(int4*)(sH + (newH * W + c0)) = make_int4(shv[0], shv[1], shv[2], shv[3]);
+					if (lane == 63) st_gran(sgranule(newH, r, 0, 2), shv[3], s_new);
+					if (lane == 0) st_gran(sgranule(newH, r, 1, 2), shv[0], s_new);
+				}
 				if (TB && c0 >= origin && c0 <= hi) *(uint32_t*)(M.tb + tb_used - origin + c0) = tbw;
 				if (track_good) {
 					unsigned long long *gword = M.good + (int64_t)newH * A.GW + (int64_t)g * 4;
@@ -501,7 +680,13 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 				if ((uint32_t)(cfin - cb) < (uint32_t)kChunk && cfin >= lo && cfin <= hi) { // this chunk holds the end diagonal
 					const unsigned long long fm = __ballot(fin);
 					int32_t val = 0;
-					if (fm) val = 1 | __builtin_amdgcn_readlane(done_info, (int32_t)__builtin_ctzll(fm)) << 1;
+					if (fm && SEG) { // the end cell's provenance does not fit the flag word: its own word, visible before the flag is
+						const int32_t prov = __builtin_amdgcn_readlane(done_info, (int32_t)__builtin_ctzll(fm));
+						if (lane == 0) st_ag(&gflags[16], prov);
+						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+						asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+						val = 1;
+					} else if (fm) val = 1 | __builtin_amdgcn_readlane(done_info, (int32_t)__builtin_ctzll(fm)) << 1;
 					if (lane < kFlagCopies) st_ag(flag_entry(s_new, lane) + 2, s_new << 4 | val);
 				}
 				if (lag_one) {
@@ -513,6 +698,17 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 				prefetch(k, nextH, phi, gl_next);
 #pragma unroll
 				for (int i = 0; i < 4; ++i) ne1[i] = nf1[i] = ne2[i] = nf2[i] = kNegInf;
+			}
+			if (SEG) {
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+#pragma unroll
+					for (int a = E1 - 1; a > 0; --a) se1h[a][k][i] = se1h[a - 1][k][i], sf1h[a][k][i] = sf1h[a - 1][k][i];
+#pragma unroll
+					for (int a = E2 - 1; a > 0; --a) se2h[a][k][i] = se2h[a - 1][k][i], sf2h[a][k][i] = sf2h[a - 1][k][i];
+					se1h[0][k][i] = active ? sne1s[i] : kNegInf, sf1h[0][k][i] = active ? snf1s[i] : kNegInf;
+					se2h[0][k][i] = active ? sne2s[i] : kNegInf, sf2h[0][k][i] = active ? snf2s[i] : kNegInf;
+				}
 			}
 
 #pragma unroll
@@ -530,7 +726,7 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 		// operations of the wave, except that an idle second chunk still issues its 5 dummy prefetch loads
 		// after them.  (A smaller count than the truth only waits for more.)
 		int32_t vm_keep = 0;
-		if (relaxed_stores && !track_good) {
+		if (relaxed_stores && !track_good && !SEG) {
 			if (act1) vm_keep = 3 + (TB ? 1 : 0);
 			else if (act0) vm_keep = 8 + (TB ? 1 : 0);
 		}
@@ -634,15 +830,20 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 		}
 		cells += hi - lo + 1;
 		// the low-memory first pass has no stop rules and is not counted in n_iter (miniwfa.c:569-589)
-		if (A.coop_pass != 1 && ((A.max_iter > 0 && cells > A.max_iter) || (A.max_s > 0 && s > A.max_s))) {
+		if (A.coop_pass != 1 && A.coop_pass != 3 && ((A.max_iter > 0 && cells > A.max_iter) || (A.max_s > 0 && s > A.max_s))) {
 			R.status = ST_STOPPED;
 			break;
 		}
 		if (done) {
 			R.info = payload;
+			if (SEG) {
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+				R.info = uni(ld_ag(&gflags[16]));
+			}
 			break;
 		}
 	}
+	R.n_snap = n_snap;
 #ifdef MWF_BAND_TIMING
 	if (lane == 0 && ((tid >> 6) < 2 || (tid >> 6) == 7) && (blockIdx.x == 0 || blockIdx.x == 72 || blockIdx.x == 73 || blockIdx.x == 74 || blockIdx.x == 200))
 		printf("wg %3d wave %d steps %llu active-slots %llu | per step: header %.0f  slots %.0f  drain+flags+barrier %.0f cycles; granule wait per active slot %.0f (watcher: polls per step %.2f)\n", (int)blockIdx.x, tid >> 6,
@@ -677,6 +878,24 @@ __global__ __launch_bounds__(kT) void wfa_coop_kernel(const BatchArgs A)
 		int32_t *st = state + (A.coop_pass == 2 ? 8 : 0);
 		st[0] = R.status, st[1] = R.s, st[2] = R.info;
 		st[4] = (int32_t)(R.cells & 0xffffffff), st[5] = (int32_t)(R.cells >> 32);
+		st[6] = R.n_snap;
+	}
+}
+
+// The first pass of the true low-memory mode: a kernel of its own, so that the other passes keep their register allocation.
+template <int E1, int E2>
+__global__ __launch_bounds__(kT) void wfa_coop_seg_kernel(const BatchArgs A)
+{
+	__shared__ Shared sh;
+	const int32_t G = A.coop_group_size, grp = (int32_t)blockIdx.x / G, lb = (int32_t)blockIdx.x % G;
+	PairMem M;
+	pair_mem(A, grp, group_pair(A, grp), M);
+	const PassResult R = coop_pass<E1, E2, false, true>(A, M, sh, 0, grp, lb, G);
+	if (lb == 0 && threadIdx.x == 0) {
+		int32_t *st = group_state(A, grp);
+		st[0] = R.status, st[1] = R.s, st[2] = R.info;
+		st[4] = (int32_t)(R.cells & 0xffffffff), st[5] = (int32_t)(R.cells >> 32);
+		st[6] = R.n_snap;
 	}
 }
 
@@ -724,6 +943,45 @@ __global__ void coop_walk_kernel(const BatchArgs A)
 	st[3] = n_seg;
 }
 
+// Checkpoints of the true low-memory mode: chase the provenance of the end cell back through the snapshots (reference
+// wf_traceback_seg, miniwfa.c:528-549).  An index decodes to (slice id, column) with the snapshot's Wspan and slo; the
+// slice id gives the penalty: H ring slot j held penalty S - ((curH - j) mod nH), an E/F register of age a penalty S - a.
+__global__ void coop_trace_kernel(const BatchArgs A)
+{
+	if (threadIdx.x != 0) return;
+	const int32_t grp = (int32_t)blockIdx.x; // one block per pair
+	int32_t *st = group_state(A, grp);
+	st[3] = 0;
+	if (st[0] != ST_OK) return;
+	const Penalty &P = A.pen;
+	PairMem M;
+	pair_mem(A, grp, group_pair(A, grp), M);
+	const int32_t n_snap = st[6];
+	if (n_snap > A.seg_slot) { st[0] = ST_SNAP_OVERFLOW; return; }
+	int32_t last = st[2];
+	for (int32_t j = n_snap - 1; j >= 0; --j) {
+		const int32_t *meta = M.snap_meta + (int64_t)j * 8;
+		const int64_t base = (int64_t)(uint32_t)meta[0] | (int64_t)meta[1] << 32;
+		const int32_t S = meta[2], curH = meta[3], slo = meta[4], Wspan = meta[5];
+		if (last < 0 || Wspan <= 0) { st[0] = ST_INTERNAL; return; }
+		const int32_t id = last / Wspan, col = slo + last % Wspan;
+		int32_t age;
+		if (id < P.nH) { age = curH - id; if (age < 0) age += P.nH; }
+		else {
+			const int32_t q = id - P.nH;
+			if (q < P.e1) age = q;
+			else if (q < 2 * P.e1) age = q - P.e1;
+			else if (q < 2 * P.e1 + P.e2) age = q - 2 * P.e1;
+			else if (q < 2 * P.e1 + 2 * P.e2) age = q - 2 * P.e1 - P.e2;
+			else { st[0] = ST_INTERNAL; return; }
+		}
+		M.seg[2 * j] = S - age, M.seg[2 * j + 1] = col;
+		last = M.snap[base + last];
+	}
+	if (last != -1) { st[0] = ST_INTERNAL; return; } // the chain must end at the origin (reference asserts, miniwfa.c:542,547)
+	st[3] = n_snap;
+}
+
 __global__ __launch_bounds__(64) void coop_finish_kernel(const BatchArgs A)
 {
 	const int32_t grp = (int32_t)blockIdx.x; // one block per pair
@@ -742,7 +1000,8 @@ __global__ __launch_bounds__(64) void coop_finish_kernel(const BatchArgs A)
 template <int E1, int E2>
 int launch_pass(const BatchArgs &a, int grid, hipStream_t st)
 {
-	hipLaunchKernelGGL((wfa_coop_kernel<E1, E2>), dim3(grid), dim3(kT), 0, st, a);
+	if (a.coop_pass == 3) hipLaunchKernelGGL((wfa_coop_seg_kernel<E1, E2>), dim3(grid), dim3(kT), 0, st, a);
+	else hipLaunchKernelGGL((wfa_coop_kernel<E1, E2>), dim3(grid), dim3(kT), 0, st, a);
 	return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -775,6 +1034,12 @@ int launch_coop_pass(const BatchArgs &a, int grid, void *stream)
 int launch_coop_walk(const BatchArgs &a, void *stream)
 {
 	hipLaunchKernelGGL(coop_walk_kernel, dim3(a.coop_groups > 0 ? a.coop_groups : 1), dim3(64), 0, (hipStream_t)stream, a);
+	return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_coop_trace(const BatchArgs &a, void *stream)
+{
+	hipLaunchKernelGGL(coop_trace_kernel, dim3(a.coop_groups > 0 ? a.coop_groups : 1), dim3(64), 0, (hipStream_t)stream, a);
 	return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -513,6 +513,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	g->stats.n_launches += 1;
 	g->stats.grid = std::max(g->stats.grid, pl.grid), g->stats.block = pl.block, g->stats.kernel_kind = pl.kind;
 	g->stats.packed = pl.kind == 2 && pl.band.packed;
+	g->stats.lowmem_two_pass = pl.low_mem ? 1 : 0;
 	if (ran_kind) *ran_kind = pl.kind;
 	return 0;
 }
@@ -565,8 +566,20 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 	const size_t NG = (size_t)n_groups;
 	if (ensure(g, g->ring, NG * (size_t)P.nH * W * 4 + 4096)) return -1;
 	if (ensure(g, g->good, NG * (size_t)P.nH * GW * 8)) return -1;
-	// granules crossing waves: [nH][TC][2 sides][4] x 8 bytes; misc: flags, barrier words, pass state, then the flag ring
-	const size_t gran_bytes = (size_t)P.nH * TC * 2 * 4 * 8;
+	// Low-memory mode (opt.step > 0), two ways to the checkpoints:
+	//   walk     — the first pass stores its whole traceback (s^2 bytes: 55 GB for the 5 Mb pair) and the checkpoints are
+	//              read off it by walking the recorded choices back (fast while that fits the budget);
+	//   two-pass — the reference's way (miniwfa.c:551-601): the first pass stores no traceback, carries provenance through
+	//              shadow registers / rows and takes a snapshot every `step` penalties: a few GB for the 5 Mb pair.
+	// Chosen by what the walk variant's arena would be against the budget ("lowmem_budget_mb", default 8 GB).
+	bool two_pass = false;
+	if (low_mem) {
+		const int64_t budget = (g->lowmem_budget_mb > 0 ? g->lowmem_budget_mb : 8192) << 20;
+		two_pass = std::max<int64_t>((int64_t)1 << 30, 6000 * len) * (int64_t)NG * g->coop_tb_mult > budget;
+	}
+	// granules crossing waves: [nH][TC][2 sides][4] x 8 bytes (twice for the two-pass mode: values and their provenance);
+	// misc: flags, barrier words, pass state, then the flag ring
+	const size_t gran_bytes = (size_t)P.nH * TC * 2 * 4 * 8 * (two_pass ? 2 : 1);
 	const size_t flag_ring_bytes = (size_t)64 * 32 * 128; // mwf_coop.hip: kFlagRing x kFlagCopies lines of 128 bytes
 	const size_t misc_bytes = 4096 + flag_ring_bytes;
 	if (ensure(g, g->coop_edge, NG * gran_bytes)) return -1;
@@ -581,7 +594,10 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 		// (first guess: 6000 bytes per column of the matrix' perimeter — 1.8 GB for a 150 kb pair that needs 0.7, 60 GB for the
 		// 5 Mb pair that needs 55: a traceback of s^2 bytes with s about 2.5 % of tl+ql)
 		const int64_t worst = NG * (rows_slot + 1) * (len + 8);
-		const int64_t guess = std::min<int64_t>(g->coop_tb_cap, std::max<int64_t>((int64_t)1 << 30, 6000 * len) * (int64_t)NG);
+		int64_t guess = std::min<int64_t>(g->coop_tb_cap, std::max<int64_t>((int64_t)1 << 30, 6000 * len) * (int64_t)NG);
+		// two-pass: only the second pass stores traceback, and its rows are at most about 2*(step+nH) wide (the band collapses
+		// to one diagonal at every checkpoint, miniwfa.c:413-416); s is guessed as 3 % of tl+ql
+		if (two_pass) guess = std::min<int64_t>(guess, std::max<int64_t>((int64_t)64 << 20, (len * 3 / 100 + 1024) * std::min<int64_t>(len + 1, 2 * (int64_t)(opt.step + 2 * P.nH) + 8)) * (int64_t)NG);
 		int64_t want = std::min(worst, g->tb_budget_mb > 0 ? (g->tb_budget_mb << 20) : guess * g->coop_tb_mult);
 		if ((int64_t)g->tb.bytes >= want) want = (int64_t)g->tb.bytes;
 		else {
@@ -598,6 +614,18 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 			if (ensure(g, g->seg, NG * (size_t)seg_slot * 8)) return -1;
 		}
 		if (ensure(g, g->tb, NG * (size_t)tb_bytes)) return -1;
+	}
+	int64_t snap_slot_ints = 0, snap_meta_slot = 0;
+	if (two_pass) {
+		// shadow H rows; snapshots: (nH + 2 e1 + 2 e2) array-slices x the window at every `step` penalties, windows about as
+		// wide as the penalty: ~ NS * s^2 / step ints with s guessed as 3 % of tl+ql (doubled with the arena after an overflow)
+		const int64_t NS = P.nH + 2 * P.e1 + 2 * P.e2, s_guess = len * 3 / 100 + 1024;
+		snap_meta_slot = (bound1 / opt.step + 2) * 8;
+		snap_slot_ints = std::min<int64_t>(std::max<int64_t>((int64_t)4 << 20, NS * (s_guess / opt.step + 2) * std::min<int64_t>(len + 1, s_guess)) * g->coop_tb_mult,
+		                                   ((int64_t)48 << 30) / 4);
+		if (ensure(g, g->sring, NG * (size_t)P.nH * W * 4 + 4096)) return -1;
+		if (ensure(g, g->snap, NG * (size_t)snap_slot_ints * 4)) return -1;
+		if (ensure(g, g->snap_meta, NG * (size_t)snap_meta_slot * 4)) return -1;
 	}
 	if (traced) {
 		if (ensure(g, g->dbg, (size_t)8 * (bound + 2))) return -1;
@@ -620,6 +648,9 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 	a.cig_scratch = cigar ? (uint32_t*)g->cig_scratch.p : nullptr, a.cig_scratch_slot = cig_scratch;
 	a.cig_pool = b->d_cig_pool, a.cig_head = b->d_cig_head, a.cig_pool_words = b->cig_pool_words;
 	a.seg = low_mem ? (int32_t*)g->seg.p : nullptr, a.seg_slot = seg_slot;
+	a.sring = two_pass ? (int32_t*)g->sring.p : nullptr;
+	a.snap = two_pass ? (int32_t*)g->snap.p : nullptr, a.snap_slot_ints = snap_slot_ints;
+	a.snap_meta = two_pass ? (int32_t*)g->snap_meta.p : nullptr, a.snap_meta_slot = snap_meta_slot;
 	a.out_s = b->d_s, a.out_iter = b->d_iter, a.out_ncig = b->d_ncig, a.out_cigoff = b->d_cigoff;
 	a.out_status = b->d_status, a.out_cells1 = b->d_cells1, a.out_dbg = b->d_dbg4;
 	a.dbg = traced && n_groups == 1 ? (int32_t*)g->dbg.p : nullptr; // the band trace is a single-pair diagnostic
@@ -628,6 +659,7 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 	a.coop_spin_limit = (uint32_t)g->coop_spin_limit;
 	a.coop_groups = n_groups, a.coop_group_size = Gs;
 	a.coop_edge = (int32_t*)g->coop_edge.p, a.coop_edge_stride = (int64_t)(gran_bytes / 4);
+	a.coop_sedge_off = two_pass ? (int64_t)(gran_bytes / 8) : 0;
 	a.coop_flags = (int32_t*)g->coop_misc.p, a.coop_misc_stride = (int64_t)misc_bytes; // per group: flags | +1024 barrier words | +2048 pass state | +4096 flag ring
 	a.coop_sync = (unsigned int*)((char*)g->coop_misc.p + 1024);
 	a.coop_state = (int32_t*)((char*)g->coop_misc.p + 2048);
@@ -648,11 +680,12 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 	std::lock_guard<std::mutex> lock(g_coop_mutex[g->device % kMaxDevices]);
 	if (reset_sync(true)) return -1;
 	if (first) HIP_TRY(g, hipEventRecord(g->ev0, g->stream));
-	a.coop_pass = low_mem ? 1 : 0;
+	a.coop_pass = two_pass ? 3 : low_mem ? 1 : 0;
+	g->stats.lowmem_two_pass = two_pass ? 1 : 0;
 	if (launch_coop_pass(a, Gs * n_groups, g->stream)) { g->err = "kernel launch failed (whole-device pass)"; return -1; }
 	g->stats.n_launches += 1;
 	if (low_mem) {
-		if (launch_coop_walk(a, g->stream)) { g->err = "kernel launch failed (checkpoint walk)"; return -1; }
+		if (two_pass ? launch_coop_trace(a, g->stream) : launch_coop_walk(a, g->stream)) { g->err = "kernel launch failed (checkpoints)"; return -1; }
 		if (reset_sync(false)) return -1; // barrier counters, flag ring and granules of the second pass
 		a.coop_pass = 2;
 		// the second pass is not traced: the band trace of a low-memory run is that of its second pass, traced below

@@ -91,10 +91,11 @@ struct BatchArgs {
 	int32_t band_lds_seq;      // band kernel with the sequences in LDS: bytes of the sequence copy (bookkeeping words and edge table sit behind it)
 	int32_t coop_groups, coop_group_size; // pairs side by side on the whole-device kernel and workgroups per pair (grid = product)
 	int64_t coop_edge_stride;  // ints between two groups' granule arrays
+	int64_t coop_sedge_off;    // ints from a group's granule array to its array of provenance granules (true low-memory first pass)
 	int64_t coop_misc_stride;  // bytes between two groups' flags / barrier words / pass state / flag ring
 	const int32_t *coop_pair_ids; // [coop_groups] pair of every group (null: coop_pair)
 	uint32_t coop_spin_limit;  // polls after which a wait for another workgroup gives up (ST_INTERNAL)
-	int32_t coop_pass;         // 0: plain pass; 1: pass whose traceback feeds the checkpoint walk; 2: second pass (uses seg)
+	int32_t coop_pass;         // 0: plain pass; 1: pass whose traceback feeds the checkpoint walk; 2: second pass (uses seg); 3: first pass with provenance and snapshots
 	int32_t *coop_edge;        // granules [nH][waves*2][2][4] x 8 B: E/F/H of every chunk's outer columns, tagged with their penalty
 	int32_t *coop_flags;       // [12..14] origin offset and shrink reduction; [1024 + 4*(penalty mod 64) ..] edge-live / end-cell flag ring
 	unsigned int *coop_sync;   // [0..1]: arrivals of the full barrier, [16+8g]: per-group arrivals, [96+8g]: per-group generation, [200..201]: workgroup-penalties finished
@@ -119,6 +120,7 @@ int  coop_max_grid(bool cigar);
 int64_t coop_chunk_slots(int grid);                  // 256-column chunks a launch of `grid` workgroups holds (window capacity + 1)                      // co-resident workgroups the kernel may be launched with
 int  launch_coop_pass(const BatchArgs &a, int grid, void *stream);       // forward pass (score / traceback bytes)
 int  launch_coop_walk(const BatchArgs &a, void *stream);                 // checkpoints from the traceback matrix
+int  launch_coop_trace(const BatchArgs &a, void *stream);                // checkpoints from the snapshots of a provenance pass
 int  launch_coop_finish(const BatchArgs &a, void *stream);               // traceback + per-pair outputs
 
 bool band_supported(const Penalty &p);                       // (e1,e2) instantiated and every H lag >= 2

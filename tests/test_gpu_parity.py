@@ -649,3 +649,62 @@ def test_edit_distance_and_single_affine_presets_on_the_fast_kernels(kind, oracl
                         assert b.cigar(i, int(nc[i])).tolist() == ecig, (kind, pen["x"], kw, lo + i)
                 b.free()
     eng.close()
+
+
+def test_whole_device_kernel_true_low_memory_mode(oracle):
+    """The whole-device kernel's two-pass low-memory mode (reference mwf_wfa_seg, miniwfa.c:551-601): the first pass stores no
+    traceback — provenance travels through shadow registers, shadow H rows and shadow granules, a snapshot every `step`
+    penalties — and must yield the reference's checkpoints, i.e. its second-pass n_iter and CIGAR.  Forced by a 1 MB budget
+    for the walk variant; steps from 1 (a snapshot at every penalty) to beyond the penalty."""
+    eng = mw.Engine(0)
+    eng.set("force_kind", 1)
+    eng.set("lowmem_budget_mb", 1)
+    cases = [synth_pair(95000, 300, 0.1), synth_pair(95001, 3000, 0.05), synth_pair(95002, 20000, 0.04),
+             synth_pair(95003, 9000, 0.2), synth_pair(95004, 15000, 0.01, 3, 2000), synth_pair(95005, 30000, 0.03, 1, 4000),
+             (b"", b"ACGT"), (b"ACGT", b""), (b"A" * 7000, b"A" * 7000), (b"A" * 1200, b"C" * 1100)]
+    cases += [(q, t) for t, q in cases[1:4]]
+    opts = [make_opt(flag=1, step=100), make_opt(flag=1, step=700), make_opt(flag=1, step=5000), make_opt(flag=1, step=1), make_opt(flag=1, step=7),
+            make_opt(flag=1, step=256), make_opt(flag=1, o2=4, e2=2, step=300), make_opt(flag=1, x=1, o1=0, e1=1, o2=0, e2=1, step=150)]
+    for o in opts:
+        go = mw.opt_init(**{k: getattr(o, k) for k in OPT_KEYS})
+        for lo in range(0, len(cases), 3):
+            pairs = cases[lo:lo + 3]
+            if o.step < 10:
+                pairs = [p for p in pairs if len(p[0]) <= 9000]   # (a snapshot per penalty: keep it to seconds)
+                if not pairs:
+                    continue
+            b = eng.upload(PackedBatch(pairs))
+            b.align(go)
+            st = eng.stats()
+            assert st.kernel_kind == 1 and st.lowmem_two_pass == 1
+            s, it, nc = b.results()
+            for i, (t, q) in enumerate(pairs):
+                es, eit, ecig = oracle.align(t, q, o)
+                assert (int(s[i]), int(it[i])) == (es, eit), (lo + i, len(t), len(q), o.step, o.o2, o.x)
+                assert b.cigar(i, int(nc[i])).tolist() == ecig, (lo + i, o.step)
+            b.free()
+    assert eng.stats().n_retries == 0
+    # stop rules apply to the second pass only (miniwfa.c:569-589 has none)
+    t, q = cases[2]
+    full = oracle.align(t, q, make_opt(flag=1, step=700))
+    for kw in (dict(max_s=full[0] - 1), dict(max_s=full[0]), dict(max_iter=full[1] - 1), dict(max_iter=full[1]), dict(max_s=500)):
+        b = eng.upload(PackedBatch([(t, q)]))
+        b.align(mw.opt_init(flag=1, step=700, **kw))
+        s, it, nc = b.results()
+        assert (int(s[0]), int(it[0])) == oracle.align(t, q, make_opt(flag=1, step=700, **kw))[:2], kw
+        b.free()
+    # memory: the 30 kb pair's first pass in both variants
+    t, q = cases[5]
+    peaks = {}
+    for budget in (1, 1 << 20):
+        e2 = mw.Engine(0)
+        e2.set("force_kind", 1)
+        e2.set("lowmem_budget_mb", budget)
+        b = e2.upload(PackedBatch([(t, q)]))
+        b.align(mw.opt_init(flag=1, step=1000))
+        b.results()
+        peaks[e2.stats().lowmem_two_pass] = e2.stats().dev_bytes_peak
+        b.free()
+        e2.close()
+    assert set(peaks) == {0, 1} and peaks[1] < peaks[0], peaks
+    eng.close()
