@@ -41,7 +41,7 @@ template <int W>
 void run(const char *name, int waves_per_simd)
 {
 	int *out; long long *cyc;
-	const int grid = 256, block = 256 * waves_per_simd;
+	const int grid = waves_per_simd > 4 ? 512 : 256, block = waves_per_simd > 4 ? 1024 : 256 * waves_per_simd; // 8 waves per SIMD: two 1024-thread workgroups per CU
 	hipMalloc(&out, grid * block * 4); hipMalloc(&cyc, grid * 8);
 	k<W><<<grid, block>>>(out, cyc, 1);
 	hipDeviceSynchronize();
@@ -57,7 +57,7 @@ void run(const char *name, int waves_per_simd)
 
 int main()
 {
-	for (int w : {1, 2, 4}) {
+	for (int w : {1, 2, 4, 8}) {
 		run<0>("v_add_u32", w); run<1>("v_max_i32", w); run<2>("v_max3_i32", w); run<3>("v_cmp(vcc)+v_cndmask pairs", w);
 		run<4>("v_cmp_gt_u32 -> sgpr pair", w); run<5>("v_max_i32_sdwa (sext word)", w); run<6>("v_mov_b32_dpp wave_shr:1", w);
 		run<7>("v_alignbyte_b32", w); run<8>("v_pk_max_i16 / v_pk_add_i16", w); run<9>("ffbl/lshr/min3/xor mix", w);
