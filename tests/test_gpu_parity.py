@@ -708,3 +708,30 @@ def test_whole_device_kernel_true_low_memory_mode(oracle):
         e2.close()
     assert set(peaks) == {0, 1} and peaks[1] < peaks[0], peaks
     eng.close()
+
+
+def test_two_threads_on_the_whole_device_kernel(oracle, capfd):
+    """Two host threads, each aligning long pairs through the drop-in API at the same time: both land on the whole-device
+    kernel, whose workgroups wait for one another and therefore must all be resident — launches are serialised per device,
+    so neither starves the other (no wait gives up, nothing falls back to the one-workgroup kernel)."""
+    import threading
+    pairs = [synth_pair(96000 + i, 70000 + 5000 * i, 0.02) for i in range(4)]
+    expect = [oracle.align(t, q, make_opt(flag=1)) for t, q in pairs]
+    errors = []
+
+    def worker(tid):
+        try:
+            for i in range(tid, len(pairs), 2):
+                got = mw.wfa_exact(pairs[i][0], pairs[i][1], mw.opt_init(flag=mw.MWF_F_CIGAR))
+                if got != expect[i]:
+                    errors.append((tid, i, got[:2], expect[i][:2]))
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t_ in ts:
+        t_.start()
+    for t_ in ts:
+        t_.join()
+    assert not errors, errors[:3]
+    assert "gave up waiting" not in capfd.readouterr().err
