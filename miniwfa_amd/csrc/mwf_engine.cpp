@@ -411,7 +411,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 			lds_e2_cols = 16384;
 			pl.block = 768; // one workgroup per CU either way (128 KB of LDS): twelve waves fit its 168-VGPR budget, 490 ms against 519 ms with eight
 		}
-		per_cu = g->slots_per_cu > 0 ? g->slots_per_cu : cached_occupancy(g, P, pl, lds_e2_cols, !g->scalar_generic && !pl.low_mem);
+		per_cu = g->slots_per_cu > 0 ? g->slots_per_cu : cached_occupancy(g, P, pl, lds_e2_cols, !g->scalar_generic);
 	}
 	slots = std::max(1, std::min(slots, g->n_cu * std::max(1, per_cu)));
 	if (getenv("MWF_DEBUG"))

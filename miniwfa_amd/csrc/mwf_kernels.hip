@@ -391,9 +391,13 @@ __device__ __forceinline__ int32_t run_wave_g(const PairMem &M, int32_t j, int32
 // per penalty parity.  When the window outgrows the LDS span the pass carries on in the HBM rows (and comes back).
 extern __shared__ __attribute__((aligned(16))) int32_t lds_e2f2[];
 
-template <int T, bool TB, bool LDS2>
+// SEG: the low-memory first pass (shadow ring + snapshots, no traceback bytes, no stop rules, miniwfa.c:569-589) in the same
+// four-columns-per-lane form: every shadow array-slice is one 16-byte load or store per lane as well.
+template <int T, bool TB, bool LDS2, bool SEG = false>
 __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &sh, int32_t n_seg, bool trace_band)
 {
+	static_assert(!(SEG && (TB || LDS2)), "the low-memory first pass stores no traceback and keeps every array in HBM");
+	constexpr bool WTB = TB || SEG;
 	constexpr int NW = T / 64;
 	constexpr int32_t kChunk = 256;
 	__shared__ int32_t e2_edge[2][64][2]; // [penalty parity][chunk mod 64]{first column's F2, last column's E2}
@@ -415,18 +419,23 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 		const int32_t k0 = extend_run(M.ts, M.qs, tl, ql, -1, 0);
 		M.H[c0] = k0;
 		M.E1[c0] = M.F1[c0] = M.E2[c0] = M.F2[c0] = kNegInf;
+		if (SEG) {
+			M.sH[c0] = -1;
+			M.sE1[c0] = M.sF1[c0] = M.sE2[c0] = M.sF2[c0] = kNegInf;
+		}
 		sh.rng_lo[0] = sh.rng_hi[0] = c0;
 		sh.word[1] = k0;
 	}
 	__syncthreads();
 	{
 		const int32_t k0 = uni(sh.word[1]);
-		if (k0 == tl - 1 && k0 == ql - 1) return R;
+		if (k0 == tl - 1 && k0 == ql - 1) { R.info = SEG ? -1 : 0; return R; }
 	}
 
 	int32_t s = 0, wf_lo = tl + 1, wf_hi = tl + 1;
 	int32_t curH = 0, cur1 = 0, cur2 = 0, par = 0, sid = 0;
-	int64_t cells = 0, tb_used = 0;
+	int64_t cells = 0, tb_used = 0, snap_used = 0;
+	int32_t snap_ctr = A.step == 1 ? 0 : 1, n_snap = 0; // SEG: (s+1) % step, snapshots taken
 	const int32_t cfin = ql + 1; // the end cell (tl-1, ql-1) lies on diagonal ql-tl, i.e. in this column
 
 	for (;;) {
@@ -440,6 +449,13 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 		}
 		const int32_t lo = wf_lo > 1 ? wf_lo - 1 : 1;       // miniwfa.c:417-418
 		const int32_t hi = wf_hi < cmax ? wf_hi + 1 : cmax;
+		if (SEG) {
+			if (snap_ctr == 0) {
+				if (!take_snapshot<T>(A, M, sh, n_snap, snap_used, s, curH, cur1, cur2)) { R.status = ST_SNAP_OVERFLOW; break; }
+				++n_snap;
+			}
+			snap_ctr = snap_ctr + 1 == A.step ? 0 : snap_ctr + 1;
+		}
 		const int32_t s_new = s + 1;
 		const int32_t newH = curH + 1 == P.nH ? 0 : curH + 1;
 		const int32_t new1 = cur1 + 1 == P.n1 ? 0 : cur1 + 1;
@@ -469,6 +485,14 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 		const int32_t *sHx = M.H + jx * W, *sHa = M.H + j1 * W, *sHb = M.H + j2 * W;
 		const int32_t *sE1 = M.E1 + r1 * W, *sF1 = M.F1 + r1 * W, *sE2 = M.E2 + r2 * W, *sF2 = M.F2 + r2 * W;
 		int32_t *dH = M.H + newH * W, *dE1 = M.E1 + new1 * W, *dF1 = M.F1 + new1 * W, *dE2 = M.E2 + new2 * W, *dF2 = M.F2 + new2 * W;
+		// SEG: the shadow ring, same rows
+		const int32_t *tHx = 0, *tHa = 0, *tHb = 0, *tE1 = 0, *tF1 = 0, *tE2 = 0, *tF2 = 0;
+		int32_t *uH = 0, *uE1 = 0, *uF1 = 0, *uE2 = 0, *uF2 = 0;
+		if (SEG) {
+			tHx = M.sH + jx * W, tHa = M.sH + j1 * W, tHb = M.sH + j2 * W;
+			tE1 = M.sE1 + r1 * W, tF1 = M.sF1 + r1 * W, tE2 = M.sE2 + r2 * W, tF2 = M.sF2 + r2 * W;
+			uH = M.sH + newH * W, uE1 = M.sE1 + new1 * W, uF1 = M.sF1 + new1 * W, uE2 = M.sE2 + new2 * W, uF2 = M.sF2 + new2 * W;
+		}
 		const bool track_good = (((256 - (s_new & 255)) & 255) < P.nH);
 		// every chunk the window touches is stored whole: those columns must map to distinct LDS slots (and at most 64 chunks)
 		const bool cur_in_lds = LDS2 && ((hi | 255) - (lo & ~255) + 1) <= cap;
@@ -538,9 +562,47 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 			for (int i = 1; i < 4; ++i) g1m[i] = e1s[i - 1], g2m[i] = e2s[i - 1];
 #pragma unroll
 			for (int i = 0; i < 3; ++i) g1p[i] = f1s[i + 1], g2p[i] = f2s[i + 1];
+			// SEG: the provenance of the same nine sources
+			int32_t thx[4], to1[6], to2[6], tg1m[4], tg1p[4], tg2m[4], tg2p[4];
+			if (SEG) {
+				const int4 x4 = *(const int4*)(tHx + c0), a4s = *(const int4*)(tHa + c0), b4s = *(const int4*)(tHb + c0);
+				const int4 e1q = *(const int4*)(tE1 + c0), f1q = *(const int4*)(tF1 + c0), e2q = *(const int4*)(tE2 + c0), f2q = *(const int4*)(tF2 + c0);
+				int32_t wa = tHa[ce], wb = tHb[ce], wg1 = (lane == 0 ? tE1 : tF1)[ce], wg2 = (lane == 0 ? tE2 : tF2)[ce];
+				thx[0] = x4.x, thx[1] = x4.y, thx[2] = x4.z, thx[3] = x4.w;
+				to1[1] = a4s.x, to1[2] = a4s.y, to1[3] = a4s.z, to1[4] = a4s.w;
+				to2[1] = b4s.x, to2[2] = b4s.y, to2[3] = b4s.z, to2[4] = b4s.w;
+				int32_t te1[4] = {e1q.x, e1q.y, e1q.z, e1q.w}, tf1[4] = {f1q.x, f1q.y, f1q.z, f1q.w};
+				int32_t te2[4] = {e2q.x, e2q.y, e2q.z, e2q.w}, tf2[4] = {f2q.x, f2q.y, f2q.z, f2q.w};
+				if (!inner) {
+#pragma unroll
+					for (int i = 0; i < 4; ++i) {
+						const int32_t c = c0 + i;
+						thx[i] = ((c >= xlo) & (c <= xhi)) ? thx[i] : kNegInf;
+						to1[i + 1] = ((c >= alo) & (c <= ahi)) ? to1[i + 1] : kNegInf;
+						to2[i + 1] = ((c >= blo) & (c <= bhi)) ? to2[i + 1] : kNegInf;
+						const bool in1 = (c >= p1lo) & (c <= p1hi), in2 = (c >= p2lo) & (c <= p2hi);
+						te1[i] = in1 ? te1[i] : kNegInf, tf1[i] = in1 ? tf1[i] : kNegInf;
+						te2[i] = in2 ? te2[i] : kNegInf, tf2[i] = in2 ? tf2[i] : kNegInf;
+					}
+					const int32_t cn = lane == 0 ? c0 - 1 : c0 + 4;
+					wa = ((cn >= alo) & (cn <= ahi)) ? wa : kNegInf;
+					wb = ((cn >= blo) & (cn <= bhi)) ? wb : kNegInf;
+					wg1 = ((cn >= p1lo) & (cn <= p1hi)) ? wg1 : kNegInf;
+					wg2 = ((cn >= p2lo) & (cn <= p2hi)) ? wg2 : kNegInf;
+				}
+				to1[0] = from_left(to1[4], wa), to1[5] = from_right(to1[1], wa);
+				to2[0] = from_left(to2[4], wb), to2[5] = from_right(to2[1], wb);
+				tg1m[0] = from_left(te1[3], wg1), tg2m[0] = from_left(te2[3], wg2);
+				tg1p[3] = from_right(tf1[0], wg1), tg2p[3] = from_right(tf2[0], wg2);
+#pragma unroll
+				for (int i = 1; i < 4; ++i) tg1m[i] = te1[i - 1], tg2m[i] = te2[i - 1];
+#pragma unroll
+				for (int i = 0; i < 3; ++i) tg1p[i] = tf1[i + 1], tg2p[i] = tf2[i + 1];
+			}
 
 			// ---- the recurrence, then the first 4-byte probe of the match extension, branch-free for all 4 columns
 			int32_t hv[4], nmat[4], ne1[4], nf1[4], ne2[4], nf2[4];
+			int32_t uh[4], ue1[4], uf1[4], ue2[4], uf2[4]; // SEG: new provenance values
 			uint32_t tbw = 0, pend = 0, live = 0, fin = 0, gbits = 0;
 			auto columns = [&](auto inner_c) {
 				constexpr bool INNER = decltype(inner_c)::value;
@@ -548,9 +610,13 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 				for (int i = 0; i < 4; ++i) {
 					const int32_t c = c0 + i, d = c - 1 - tl;
 					const uint32_t act = INNER ? 1u : (uint32_t)((c >= lo) & (c <= hi));
-					const Cell v = wf_cell<TB>(hx[i], o1[i], g1m[i], o2[i], g2m[i], o1[i + 2], g1p[i], o2[i + 2], g2p[i]);
+					const Cell v = wf_cell<WTB>(hx[i], o1[i], g1m[i], o2[i], g2m[i], o1[i + 2], g1p[i], o2[i + 2], g2p[i]);
 					ne1[i] = act ? v.e1 : kNegInf, nf1[i] = act ? v.f1 : kNegInf;
 					ne2[i] = act ? v.e2 : kNegInf, nf2[i] = act ? v.f2 : kNegInf;
+					if (SEG) { // provenance follows the choices the traceback byte records (miniwfa.c:504-523)
+						const Cell u = shadow_cell(v.tb, thx[i], to1[i], tg1m[i], to2[i], tg2m[i], to1[i + 2], tg1p[i], to2[i + 2], tg2p[i]);
+						uh[i] = u.h, ue1[i] = u.e1, uf1[i] = u.f1, ue2[i] = u.e2, uf2[i] = u.f2;
+					}
 					const uint32_t inm = act & inm_bit(d, v.h, tl, ql);
 					if (track_good) // uniform
 						gbits |= (act & (inm | inm_bit(d, v.e1, tl, ql) | inm_bit(d, v.f1, tl, ql) | inm_bit(d, v.e2, tl, ql) | inm_bit(d, v.f2, tl, ql))) << i;
@@ -568,6 +634,13 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 			// E/F of this penalty: final, store now
 			*(int4*)(dE1 + c0) = make_int4(ne1[0], ne1[1], ne1[2], ne1[3]);
 			*(int4*)(dF1 + c0) = make_int4(nf1[0], nf1[1], nf1[2], nf1[3]);
+			if (SEG) { // (whole chunks are stored: columns outside the window are never read back as anything but NEG_INF)
+				*(int4*)(uH + c0) = make_int4(uh[0], uh[1], uh[2], uh[3]);
+				*(int4*)(uE1 + c0) = make_int4(ue1[0], ue1[1], ue1[2], ue1[3]);
+				*(int4*)(uF1 + c0) = make_int4(uf1[0], uf1[1], uf1[2], uf1[3]);
+				*(int4*)(uE2 + c0) = make_int4(ue2[0], ue2[1], ue2[2], ue2[3]);
+				*(int4*)(uF2 + c0) = make_int4(uf2[0], uf2[1], uf2[2], uf2[3]);
+			}
 			if (LDS2 && cur_in_lds) {
 				*(int4*)(lE2 + (c0 & cap_mask)) = make_int4(ne2[0], ne2[1], ne2[2], ne2[3]);
 				*(int4*)(lF2 + (c0 & cap_mask)) = make_int4(nf2[0], nf2[1], nf2[2], nf2[3]);
@@ -624,7 +697,7 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 				for (int i = 0; i < 4; ++i) {
 					const uint32_t f = (uint32_t)(c0 + i == cfin) & (uint32_t)(hv[i] == tl - 1) & inm_bit(ql - tl, hv[i] - nmat[i], tl, ql);
 					fin |= f;
-					done_info = f ? (nmat[i] == 0 ? (int32_t)((tbw >> (8 * i)) & 7u) : 0) : done_info;
+					done_info = f ? (SEG ? uh[i] : (nmat[i] == 0 ? (int32_t)((tbw >> (8 * i)) & 7u) : 0)) : done_info;
 				}
 			}
 			*(int4*)(dH + c0) = make_int4(hv[0], hv[1], hv[2], hv[3]);
@@ -675,7 +748,7 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 			wf_lo = glo, wf_hi = ghi;
 		}
 		cells += hi - lo + 1;
-		if ((A.max_iter > 0 && cells > A.max_iter) || (A.max_s > 0 && s > A.max_s)) { // miniwfa.c:422-425
+		if (!SEG && ((A.max_iter > 0 && cells > A.max_iter) || (A.max_s > 0 && s > A.max_s))) { // miniwfa.c:422-425
 			R.status = ST_STOPPED;
 			break;
 		}
@@ -684,12 +757,11 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 			break;
 		}
 	}
-	R.s = s, R.cells = cells;
+	R.s = s, R.cells = cells, R.n_snap = n_snap;
 	return R;
 }
 
-// STREAM: the four-columns-per-lane pass for everything but the low-memory mode (two kernels rather than one, so that
-// neither pays for the other's registers)
+// STREAM: the four-columns-per-lane passes (two kernels rather than one, so that neither pays for the other's registers)
 template <int T, bool STREAM, bool LDS2>
 __device__ void align_pair(const BatchArgs &A, Shared &sh, int32_t slot, int32_t pair)
 {
@@ -700,8 +772,10 @@ __device__ void align_pair(const BatchArgs &A, Shared &sh, int32_t slot, int32_t
 	int64_t cells1 = 0;
 	PassResult R;
 	R.status = ST_OK, R.s = 0, R.info = 0, R.n_snap = 0, R.cells = 0;
-	if (!STREAM && A.step > 0 && A.want_cigar) { // low-memory first pass (reference mwf_wfa_exact, miniwfa.c:610-611)
-		PassResult R1 = forward_pass<T, false, true>(A, M, sh, 0, false);
+	if (!LDS2 && A.step > 0 && A.want_cigar) { // low-memory first pass (reference mwf_wfa_exact, miniwfa.c:610-611)
+		PassResult R1;
+		if constexpr (STREAM && !LDS2) R1 = stream_pass<T, false, false, true>(A, M, sh, 0, false);
+		else R1 = forward_pass<T, false, true>(A, M, sh, 0, false);
 		cells1 = R1.cells;
 		status = R1.status;
 		if (status == ST_OK) {
@@ -713,7 +787,7 @@ __device__ void align_pair(const BatchArgs &A, Shared &sh, int32_t slot, int32_t
 		__syncthreads();
 	}
 	if (status == ST_OK) {
-		if (STREAM) R = A.want_cigar ? stream_pass<T, true, LDS2>(A, M, sh, 0, trace) : stream_pass<T, false, LDS2>(A, M, sh, 0, trace);
+		if (STREAM) R = A.want_cigar ? stream_pass<T, true, LDS2>(A, M, sh, n_seg, trace) : stream_pass<T, false, LDS2>(A, M, sh, 0, trace);
 		else R = A.want_cigar ? forward_pass<T, true, false>(A, M, sh, n_seg, trace) : forward_pass<T, false, false>(A, M, sh, 0, trace);
 		status = R.status;
 	}
@@ -754,8 +828,8 @@ int launch_reset(int32_t *status, int32_t *s, int32_t n, unsigned long long *cig
 	return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-// the low-memory mode (and scalar_generic, for comparison) runs the one-column-per-lane kernel
-static bool wants_stream(const BatchArgs &a) { return !a.scalar_generic && !(a.step > 0 && a.want_cigar); }
+// scalar_generic (comparison / fallback) runs the one-column-per-lane kernel, low-memory mode included
+static bool wants_stream(const BatchArgs &a) { return !a.scalar_generic; }
 
 template <bool STREAM>
 static int launch_batch_as(const BatchArgs &a, int grid, int block, hipStream_t st)
