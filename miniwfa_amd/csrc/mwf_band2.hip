@@ -64,6 +64,28 @@ __device__ __forceinline__ int32_t lead_eq(uint32_t x)
 	return (int32_t)((uint32_t)fb >> 3);
 }
 
+// The recurrence with its traceback byte (dev::wf_cell, miniwfa.c:267-278, :289-306) written for few live registers.
+template <bool WANT_TB>
+__device__ __forceinline__ Cell cell16(int32_t hx, int32_t o1m, int32_t g1m, int32_t o2m, int32_t g2m,
+                                       int32_t o1p, int32_t g1p, int32_t o2p, int32_t g2p)
+{
+	if (!WANT_TB) return wf_cell<false>(hx, o1m, g1m, o2m, g2m, o1p, g1p, o2p, g2p);
+	Cell c;
+	c.e1 = max(o1m, g1m);
+	c.e2 = max(o2m, g2m);
+	c.f1 = max(o1p, g1p) + 1;
+	c.f2 = max(o2p, g2p) + 1;
+	const int32_t e = max(c.e1, c.e2), f = max(c.f1, c.f2), g = max(e, f), m = hx + 1;
+	c.h = max(m, g);
+	// The byte from the RESULTS (so that the gap sources are read once and can stay 16-bit operands): H is the maximum of
+	// m, e1, e2, f1, f2 and the reference's tie-breaking (mismatch, then E1, E2, F1, F2) is the first of them that equals it;
+	// a gap state was extended iff it differs from what opening it would have given.
+	const uint32_t z = c.h == m ? 0u : c.h == c.e1 ? 1u : c.h == c.e2 ? 3u : c.h == c.f1 ? 2u : 4u;
+	c.tb = z | ((uint32_t)(c.e1 != o1m) << 3) | ((uint32_t)(c.f1 != o1p + 1) << 4) | ((uint32_t)(c.e2 != o2m) << 5) | ((uint32_t)(c.f2 != o2p + 1) << 6);
+	(void)e, (void)f, (void)g;
+	return c;
+}
+
 // Leading equal bytes of t[j..] and q[..] (aq: byte offset of the query base), at most eight looked at: three dwords of
 // each sequence, two v_alignbyte's each.  Returns min(equal bytes, 9 if all eight are equal).
 struct Probe8 { uint32_t t0, t1, t2, q0, q1, q2; };
@@ -310,70 +332,57 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 			}
 
 			int32_t hv[4], nmat[4], ne1[4], nf1[4], ne2[4], nf2[4];
+			int32_t pe1[2], pf1[2], pe2[2], pf2[2]; // the new E/F, packed as soon as a pair of columns is done
 			uint32_t tbw = 0, pend = 0, live = 0, fin = 0, gbits = 0;
-			if (deep) {
-				// ---- lean copy: recurrence, then the first 4-byte probe of the match extension, in two phases so that all eight
-				// LDS reads are in flight together
+			{
+				// ---- recurrence, then the first probe of the match extension (8 bytes), two columns at a time: half the probe words
+				// in flight, the new pair packed at once.  A chunk deep inside the window needs nothing else; an edge chunk masks
+				// the columns outside the window (their offsets probe as dead: room 0), notes edge liveness and the good bits.
 				const int32_t t0 = ql + tl + 1 - c0, dq0 = c0 - 1 - tl + qoff;
 				int32_t m9[4];
 #pragma unroll
-				for (int h2 = 0; h2 < 2; ++h2) { // two columns at a time: half the probe words in flight, the new pair packed at once
+				for (int h2 = 0; h2 < 2; ++h2) {
 					int32_t jc[2], aq[2], rj[2];
 					Probe8 pr[2];
 #pragma unroll
 					for (int u = 0; u < 2; ++u) {
 						const int i = 2 * h2 + u;
-						const Cell v = wf_cell<TB>(hx[i], o1[i], g1m[i], o2[i], g2m[i], o1[i + 2], g1p[i], o2[i + 2], g2p[i]);
+						const Cell v = cell16<TB>(hx[i], o1[i], g1m[i], o2[i], g2m[i], o1[i + 2], g1p[i], o2[i + 2], g2p[i]);
 						ne1[i] = v.e1, nf1[i] = v.f1, ne2[i] = v.e2, nf2[i] = v.f2;
 						hv[i] = v.h;
 						tbw |= v.tb << (8 * i);
-						rj[u] = min(tl, t0 - i);
-						jc[u] = (int32_t)min((uint32_t)(v.h + 1), (uint32_t)rj[u]);
-						aq[u] = jc[u] + dq0 + i;
+						int32_t hq = v.h;
+						if (!deep) { // uniform
+							const int32_t c = c0 + i;
+							const uint32_t a = inner ? 1u : (uint32_t)((c >= lo) & (c <= hi));
+							ne1[i] = a ? v.e1 : kDead16, nf1[i] = a ? v.f1 : kDead16;
+							ne2[i] = a ? v.e2 : kDead16, nf2[i] = a ? v.f2 : kDead16;
+							hq = a ? v.h : kDead16;
+							if (track_good) { // uniform
+								const int32_t d = c - 1 - tl;
+								gbits |= (a & (inm_bit(d, v.h, tl, ql) | inm_bit(d, v.e1, tl, ql) | inm_bit(d, v.f1, tl, ql) | inm_bit(d, v.e2, tl, ql) | inm_bit(d, v.f2, tl, ql))) << i;
+							}
+							// edge rule (miniwfa.c:325-326): H is the max of the five, so "any live" == "H live"
+							const uint32_t lv = (uint32_t)(v.h >= -1);
+							live |= (lv & (uint32_t)(c == lo)) | ((lv & (uint32_t)(c == hi)) << 1);
+						}
+						rj[u] = min(tl, t0 - i);                                           // min(tl, ql - d): the largest j = k+1 inside the matrix
+						jc[u] = (int32_t)min((uint32_t)(hq + 1), (uint32_t)rj[u]);         // dead and phantom offsets clamp to it: room 0
+						aq[u] = jc[u] + dq0 + i;                                           // byte offset of q[d + j] in the LDS copy
 						probe8_issue(pr[u], jc[u], aq[u]);
 					}
+					pe1[h2] = pack2(ne1[2 * h2], ne1[2 * h2 + 1]), pf1[h2] = pack2(nf1[2 * h2], nf1[2 * h2 + 1]);
+					pe2[h2] = pack2(ne2[2 * h2], ne2[2 * h2 + 1]), pf2[h2] = pack2(nf2[2 * h2], nf2[2 * h2 + 1]);
 #pragma unroll
 					for (int u = 0; u < 2; ++u) {
 						const int i = 2 * h2 + u;
+						// leading equal bytes, capped at 9 and at the room: 9 <=> all eight equal and more than eight to go
 						m9[i] = min(probe8_count(pr[u], jc[u], aq[u]), rj[u] - jc[u]);
 						nmat[i] = min(m9[i], 8);
 					}
 				}
 				if (__ballot(max(max(m9[0], m9[1]), max(m9[2], m9[3])) == 9))
 					pend = (uint32_t)(m9[0] == 9) | (uint32_t)(m9[1] == 9) << 1 | (uint32_t)(m9[2] == 9) << 2 | (uint32_t)(m9[3] == 9) << 3;
-			} else {
-				// ---- general copy: window tests, edge liveness, good bits; the probe as in the lean copy (a column outside the
-				// window probes as a dead offset: room 0)
-				const int32_t t0 = ql + tl + 1 - c0, dq0 = c0 - 1 - tl + qoff;
-				int32_t jc[4], aq[4], rj[4];
-				Probe8 pr[4];
-#pragma unroll
-				for (int i = 0; i < 4; ++i) {
-					const int32_t c = c0 + i;
-					const uint32_t a = inner ? 1u : (uint32_t)((c >= lo) & (c <= hi));
-					const Cell v = wf_cell<TB>(hx[i], o1[i], g1m[i], o2[i], g2m[i], o1[i + 2], g1p[i], o2[i + 2], g2p[i]);
-					ne1[i] = a ? v.e1 : kDead16, nf1[i] = a ? v.f1 : kDead16;
-					ne2[i] = a ? v.e2 : kDead16, nf2[i] = a ? v.f2 : kDead16;
-					if (track_good) { // uniform
-						const int32_t d = c - 1 - tl;
-						gbits |= (a & (inm_bit(d, v.h, tl, ql) | inm_bit(d, v.e1, tl, ql) | inm_bit(d, v.f1, tl, ql) | inm_bit(d, v.e2, tl, ql) | inm_bit(d, v.f2, tl, ql))) << i;
-					}
-					hv[i] = v.h;
-					tbw |= v.tb << (8 * i);
-					// edge rule (miniwfa.c:325-326): H is the max of the five, so "any live" == "H live"
-					const uint32_t lv = (uint32_t)(v.h >= -1);
-					live |= (lv & (uint32_t)(c == lo)) | ((lv & (uint32_t)(c == hi)) << 1);
-					rj[i] = min(tl, t0 - i);
-					jc[i] = (int32_t)min((uint32_t)((a ? v.h : kDead16) + 1), (uint32_t)rj[i]);
-					aq[i] = jc[i] + dq0 + i;
-					probe8_issue(pr[i], jc[i], aq[i]);
-				}
-#pragma unroll
-				for (int i = 0; i < 4; ++i) {
-					const int32_t m9 = min(probe8_count(pr[i], jc[i], aq[i]), rj[i] - jc[i]);
-					nmat[i] = min(m9, 8);
-					pend |= (uint32_t)(m9 == 9) << i;
-				}
 			}
 			// ---- the new E/F are final: age the registers, publish this chunk's outer pairs for the neighbouring waves
 #pragma unroll
@@ -382,8 +391,7 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 				for (int a = E1 - 1; a > 0; --a) e1h[a][k][i] = e1h[a - 1][k][i], f1h[a][k][i] = f1h[a - 1][k][i];
 #pragma unroll
 				for (int a = E2 - 1; a > 0; --a) e2h[a][k][i] = e2h[a - 1][k][i], f2h[a][k][i] = f2h[a - 1][k][i];
-				e1h[0][k][i] = pack2(ne1[2 * i], ne1[2 * i + 1]), f1h[0][k][i] = pack2(nf1[2 * i], nf1[2 * i + 1]);
-				e2h[0][k][i] = pack2(ne2[2 * i], ne2[2 * i + 1]), f2h[0][k][i] = pack2(nf2[2 * i], nf2[2 * i + 1]);
+				e1h[0][k][i] = pe1[i], f1h[0][k][i] = pf1[i], e2h[0][k][i] = pe2[i], f2h[0][k][i] = pf2[i];
 			}
 			if (lane == 63) edge[dnew][r][0] = e1h[0][k][1], edge[dnew][r][1] = e2h[0][k][1];
 			if (lane == 0) edge[dnew][r][2] = f1h[0][k][0], edge[dnew][r][3] = f2h[0][k][0];

@@ -328,8 +328,8 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 	//   window <=  448:  64 threads x 3 chunks, sixteen pairs per CU (twelve with traceback): short reads
 	//   window <= 1216: 128 threads x 3 chunks, eight pairs per CU (six with traceback)
 	//   window <= 2752: 256 threads x 3 chunks, four (three)
-	//   wider:          512 x 3, two per CU, score-only; with traceback 768 x 2 packed, one per CU (the 512-thread variant
-	//                   needs more than its 128 VGPRs then: 52.9 ms against 60.3 ms unpacked on the 1024 x 10 kb batch)
+	//   wider:          512 x 3, two per CU — with traceback too (35.4 ms on the 1024 x 10 kb batch with ~100 bytes of scratch per
+	//                   lane, against 43.4 ms for 768 x 2 with one workgroup per CU)
 	// Unpacked (long targets): 256 x 2 up to 1728 columns, 768 x 2 beyond.
 	// (measured alternatives on the 1024 x 10 kb batch: 1024 threads x 2 chunks spills and runs 50 ms, 512 x 3 unpacked 49 ms, 768 x 2 42 ms)
 	const bool range_ok = can_packed && max_tl + max_bound < 32767;
@@ -337,7 +337,7 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 	const bool cigar = (opt.flag & MWF_F_CIGAR) != 0;
 	if (range_ok) {
 		bg.packed = 1;
-		bg.block = max_window <= kBandMicroWindow ? 64 : max_window <= kBandTinyWindow ? 128 : max_window <= kBandSmallWindow ? 256 : cigar ? 768 : 512;
+		bg.block = max_window <= kBandMicroWindow ? 64 : max_window <= kBandTinyWindow ? 128 : max_window <= kBandSmallWindow ? 256 : 512;
 	} else bg.block = max_window <= 8 * 256 - 256 - 64 ? 256 : 768;
 	// forced geometry (tests, tuning): 256 and 768 mean the unpacked variants unless packing is asked for as well
 	if ((g->block == 64 || g->block == 128) && range_ok) bg.block = g->block, bg.packed = 1;

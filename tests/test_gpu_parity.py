@@ -572,11 +572,15 @@ def test_low_memory_mode_sends_short_pairs_to_the_band_kernel(oracle):
 def test_device_results_carry_a_not_final_sentinel(oracle):
     """Zero-copy consumers of the device result arrays: a pair that still needs a re-run reads s == -2 and status != 0
     until mwf_gpu_batch_results() has run it again (-1 stays the reference's "stopped" answer)."""
-    import torch
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
 
-    class DevPtr:
-        def __init__(self, ptr, n, typestr):
-            self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+    def peek(ptr, n):
+        """n int32 words of device memory, after everything enqueued on the device has finished"""
+        assert hip.hipDeviceSynchronize() == 0
+        out = (ctypes.c_int32 * n)()
+        assert hip.hipMemcpy(out, ctypes.c_void_p(ptr), ctypes.c_size_t(4 * n), 2) == 0   # hipMemcpyDeviceToHost
+        return list(out)
 
     eng = mw.Engine(0)
     eng.set("force_kind", 2)
@@ -584,16 +588,13 @@ def test_device_results_carry_a_not_final_sentinel(oracle):
     pairs = [synth_pair(93200, 200, 0.05), synth_pair(93201, 3000, 0.3), synth_pair(93202, 300, 0.05)]
     b = eng.upload(PackedBatch(pairs))
     b.align(mw.opt_init(max_s=0))
-    torch.cuda.synchronize()
-    d_s = torch.as_tensor(DevPtr(b.dev_scores_ptr(), 3, "<i4"), device="cuda:0").cpu().tolist()
-    d_st = torch.as_tensor(DevPtr(b.dev_status_ptr(), 3, "<i4"), device="cuda:0").cpu().tolist()
+    d_s, d_st = peek(b.dev_scores_ptr(), 3), peek(b.dev_status_ptr(), 3)
     exp = [oracle.align(t, q, make_opt())[0] for t, q in pairs]
     assert d_s[0] == exp[0] and d_s[2] == exp[2] and d_st[0] == 0 and d_st[2] == 0
     assert d_s[1] == -2 and d_st[1] != 0                     # its window outgrew the 64-thread kernel's span
     s, it, nc = b.results()
     assert s.tolist() == exp and eng.stats().n_retries >= 1
-    d_s = torch.as_tensor(DevPtr(b.dev_scores_ptr(), 3, "<i4"), device="cuda:0").cpu().tolist()
-    assert d_s == exp
+    assert peek(b.dev_scores_ptr(), 3) == exp
     b.align(mw.opt_init(max_s=40))                           # stopped pairs read -1, as in the reference
     s, _, _ = b.results()
     assert s.tolist() == [oracle.align(t, q, make_opt(max_s=40))[0] for t, q in pairs] and -1 in s.tolist()
