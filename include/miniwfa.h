@@ -141,7 +141,7 @@ typedef struct {
 	int32_t kernel_kind;   /* 0: one workgroup per pair (generic); 1: one pair across the whole device; 2: one workgroup per pair (band) */
 	int64_t dev_bytes;     /* device memory the engine holds now: workspace pools + recycled batch allocations (live batches hold their own) */
 	int64_t dev_bytes_peak;/* ... and the most it held since creation or the last mwf_gpu_set(g, "trim", 0) */
-	int32_t packed;        /* band kernel: 1 = the 16-bit variant (mwf_band2.hip: 8 bytes of H traffic per cell instead of 16) */
+	int32_t packed;        /* band kernel: 1 = the 16-bit variant (mwf_band2.hip), 2 = the balanced kernel with E/F in LDS and 2-bit sequences (mwf_band3.hip) */
 	int32_t lowmem_two_pass; /* low-memory mode: 1 = the first pass stored no traceback (provenance + snapshots), 0 = checkpoints walked off a full traceback */
 } mwf_gpu_stats_t;
 void mwf_gpu_get_stats(const mwf_gpu_t *g, mwf_gpu_stats_t *st);

@@ -101,6 +101,86 @@ __device__ __forceinline__ int32_t probe8_count(const Probe8 &p, int32_t j, int3
 	return min(min(lead_eq(x0), lead_eq(x1) + 4), 9); // lead_eq is huge for "no difference"
 }
 
+// ---- 2-bit sequence copy (pairs of plain A/C/G/T): sixteen bases per dword, base j at bits 2*(j & 15) of dword j >> 4.
+// One ds_read2_b32 and one v_alignbit per sequence give SIXTEEN bases from any position: the first probe of the match
+// extension needs two LDS instructions instead of four (a wave issues one LDS instruction every 15-40 cycles,
+// profiles/r02/lds_issue_rates_microbench.txt) and a run must be twice as long before the per-lane loop is entered.
+__device__ __forceinline__ uint32_t seq16(int32_t base, int32_t j)
+{
+	const uint32_t *p = (const uint32_t*)(lds2 + base + ((j >> 4) << 2));
+	return __builtin_amdgcn_alignbit(p[1], p[0], (uint32_t)j << 1);
+}
+// leading equal bases of a 16-base probe result (0 bits = equal); huge for "no difference"
+__device__ __forceinline__ int32_t lead_eq2(uint32_t x)
+{
+	int32_t fb;
+	asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(x));
+	return (int32_t)((uint32_t)fb >> 1);
+}
+struct Probe16 { uint32_t t0, t1, q0, q1; };
+__device__ __forceinline__ void probe16_issue(Probe16 &p, int32_t qbase, int32_t j, int32_t iq)
+{
+	const uint32_t *pt = (const uint32_t*)(lds2 + ((j >> 4) << 2)), *pq = (const uint32_t*)(lds2 + qbase + ((iq >> 4) << 2));
+	p.t0 = pt[0], p.t1 = pt[1], p.q0 = pq[0], p.q1 = pq[1];
+}
+// min(equal bases, 17 if all sixteen are equal)
+__device__ __forceinline__ int32_t probe16_count(const Probe16 &p, int32_t j, int32_t iq)
+{
+	return min(lead_eq2(__builtin_amdgcn_alignbit(p.t1, p.t0, (uint32_t)j << 1) ^ __builtin_amdgcn_alignbit(p.q1, p.q0, (uint32_t)iq << 1)), 17);
+}
+// exact-match run t[j..] == q[iq..] on the 2-bit copies, at most `room`, the first n0 known equal, walked by all 64 lanes:
+// 1024 bases per trip.  Arguments wave-uniform.
+__device__ __forceinline__ int32_t run_wave16(int32_t qbase, int32_t j, int32_t iq, int32_t room, int32_t n0)
+{
+	const int32_t lane = threadIdx.x & 63;
+	int32_t n = n0;
+	while (n < room) {
+		const int32_t off = n + 16 * lane;
+		int32_t m = 0;
+		if (off < room) m = min(min(lead_eq2(seq16(0, j + off) ^ seq16(qbase, iq + off)), 16), room - off);
+		const unsigned long long stop = __ballot(m < 16);
+		if (stop == 0) { n += 1024; continue; }
+		const int32_t first = (int32_t)__builtin_ctzll(stop);
+		n += 16 * first + __builtin_amdgcn_readlane(m, first);
+		break;
+	}
+	return min(n, room);
+}
+// Bytes -> 2 bits per base into LDS at `base` (two dwords of slack behind the last base).  Returns nonzero when a byte is not
+// one of A, C, G, T.  code = (byte >> 1) & 3: A 0, C 1, T 2, G 3.
+template <int T>
+__device__ __forceinline__ uint32_t pack2bit(const uint8_t *src, int32_t len, int32_t base)
+{
+	uint32_t bad = 0;
+	const int32_t n_dw = (len >> 4) + 2;
+	for (int32_t w = threadIdx.x; w < n_dw; w += T) {
+		uint32_t out = 0;
+		const int32_t b0 = w << 4;
+		if (b0 + 16 <= len) {
+			uint32_t q[4];
+			__builtin_memcpy(q, src + b0, 16);
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const uint32_t x = q[k], code = (x >> 1) & 0x03030303u;
+				// the byte each code stands for: 0 'A' 0x41, 1 'C' 0x43, 2 'T' 0x54, 3 'G' 0x47
+				const uint32_t lo1 = code & 0x01010101u, hi1 = (code >> 1) & 0x01010101u;
+				const uint32_t expect = 0x41414141u + (lo1 & ~hi1) * 0x02u + (hi1 & ~lo1) * 0x13u + (hi1 & lo1) * 0x06u;
+				bad |= x ^ expect;
+				out |= ((code | code >> 6 | code >> 12 | code >> 18) & 0xffu) << (8 * k);
+			}
+		} else {
+#pragma unroll 1
+			for (int32_t k = 0; k < 16 && b0 + k < len; ++k) {
+				const uint32_t x = src[b0 + k], code = (x >> 1) & 3u;
+				bad |= x ^ ((0x47544341u >> (8 * code)) & 0xffu);
+				out |= code << (2 * k);
+			}
+		}
+		*(uint32_t*)(lds2 + base + 4 * w) = out;
+	}
+	return bad;
+}
+
 __device__ __forceinline__ uint32_t inm_bit(int32_t d, int32_t k, int32_t tl, int32_t ql)
 {
 	return (uint32_t)((uint32_t)(k + 1) < (uint32_t)(tl + 1)) & (uint32_t)((uint32_t)(d + k + 1) < (uint32_t)(ql + 1));
@@ -144,7 +224,7 @@ struct alignas(16) Band2Lds {
 	int32_t edge[D][NWK][4]; // per age and chunk slot: {E1 pair (c2,c3), E2 pair (c2,c3)} of lane 63, {F1 pair (c0,c1), F2 pair (c0,c1)} of lane 0
 };
 
-template <int T, int K, int E1, int E2, bool TB>
+template <int T, int K, int E1, int E2, bool TB, bool S2>
 __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &sh, int32_t (*edge)[(T / 64) * K][4], const int32_t qoff, bool trace_band)
 {
 	constexpr int NW = T / 64, NWK = NW * K, D = (E1 > E2 ? E1 : E2) + 1;
@@ -178,7 +258,7 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 		sh.rng_lo[0] = sh.rng_hi[0] = tl + 1;
 	}
 	if (tid < 64) { // the origin's run, walked by the first wave
-		const int32_t k0 = run_wave2(0, qoff, min(tl, ql), 0) - 1;
+		const int32_t k0 = (S2 ? run_wave16(qoff, 0, 0, min(tl, ql), 0) : run_wave2(0, qoff, min(tl, ql), 0)) - 1;
 		if (tid == 0) {
 			*(int16_t*)at(0, tl + 1) = (int16_t)k0;
 			sh.word[1] = k0;
@@ -338,12 +418,15 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 				// ---- recurrence, then the first probe of the match extension (8 bytes), two columns at a time: half the probe words
 				// in flight, the new pair packed at once.  A chunk deep inside the window needs nothing else; an edge chunk masks
 				// the columns outside the window (their offsets probe as dead: room 0), notes edge liveness and the good bits.
-				const int32_t t0 = ql + tl + 1 - c0, dq0 = c0 - 1 - tl + qoff;
+				// (2-bit copy: aq is the query INDEX d + j, the copy's offset is added where it is read; FULL bases per first probe)
+				constexpr int FULL = S2 ? 16 : 8;
+				const int32_t t0 = ql + tl + 1 - c0, dq0 = c0 - 1 - tl + (S2 ? 0 : qoff);
 				int32_t m9[4];
 #pragma unroll
 				for (int h2 = 0; h2 < 2; ++h2) {
 					int32_t jc[2], aq[2], rj[2];
 					Probe8 pr[2];
+					Probe16 ps[2];
 #pragma unroll
 					for (int u = 0; u < 2; ++u) {
 						const int i = 2 * h2 + u;
@@ -369,7 +452,8 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 						rj[u] = min(tl, t0 - i);                                           // min(tl, ql - d): the largest j = k+1 inside the matrix
 						jc[u] = (int32_t)min((uint32_t)(hq + 1), (uint32_t)rj[u]);         // dead and phantom offsets clamp to it: room 0
 						aq[u] = jc[u] + dq0 + i;                                           // byte offset of q[d + j] in the LDS copy
-						probe8_issue(pr[u], jc[u], aq[u]);
+						if (S2) probe16_issue(ps[u], qoff, jc[u], aq[u]);
+						else probe8_issue(pr[u], jc[u], aq[u]);
 					}
 					pe1[h2] = pack2(ne1[2 * h2], ne1[2 * h2 + 1]), pf1[h2] = pack2(nf1[2 * h2], nf1[2 * h2 + 1]);
 					pe2[h2] = pack2(ne2[2 * h2], ne2[2 * h2 + 1]), pf2[h2] = pack2(nf2[2 * h2], nf2[2 * h2 + 1]);
@@ -377,12 +461,12 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 					for (int u = 0; u < 2; ++u) {
 						const int i = 2 * h2 + u;
 						// leading equal bytes, capped at 9 and at the room: 9 <=> all eight equal and more than eight to go
-						m9[i] = min(probe8_count(pr[u], jc[u], aq[u]), rj[u] - jc[u]);
-						nmat[i] = min(m9[i], 8);
+						m9[i] = min(S2 ? probe16_count(ps[u], jc[u], aq[u]) : probe8_count(pr[u], jc[u], aq[u]), rj[u] - jc[u]);
+						nmat[i] = min(m9[i], FULL);
 					}
 				}
-				if (__ballot(max(max(m9[0], m9[1]), max(m9[2], m9[3])) == 9))
-					pend = (uint32_t)(m9[0] == 9) | (uint32_t)(m9[1] == 9) << 1 | (uint32_t)(m9[2] == 9) << 2 | (uint32_t)(m9[3] == 9) << 3;
+				if (__ballot(max(max(m9[0], m9[1]), max(m9[2], m9[3])) == FULL + 1))
+					pend = (uint32_t)(m9[0] == FULL + 1) | (uint32_t)(m9[1] == FULL + 1) << 1 | (uint32_t)(m9[2] == FULL + 1) << 2 | (uint32_t)(m9[3] == FULL + 1) << 3;
 			}
 			// ---- the new E/F are final: age the registers, publish this chunk's outer pairs for the neighbouring waves
 #pragma unroll
@@ -404,13 +488,19 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 				for (int i = 0; i < 4; ++i) {
 					if (__ballot((pend >> i) & 1u) == 0) continue; // uniform
 					if ((pend >> i) & 1u) {
-						int32_t n = 8; // pend is only set for a full first probe of an in-matrix cell with room left
+						int32_t n = S2 ? 16 : 8; // pend is only set for a full first probe of an in-matrix cell with room left
 						const int32_t j = hv[i] + 1, q = c0 + i - 1 - tl + j, rm = min(tl - j, ql - q), aqq = qoff + q;
 						for (int trip = 0; n < rm; ++trip) {
 							if (trip == 4) { open |= 1u << i; break; }
-							const uint32_t xa = seq4(j + n) ^ seq4(aqq + n), xb = seq4(j + n + 4) ^ seq4(aqq + n + 4);
-							if (xa | xb) { n += xa ? min(lead_eq(xa), 4) : 4 + min(lead_eq(xb), 4); break; }
-							n += 8;
+							if (S2) {
+								const int32_t m = min(lead_eq2(seq16(0, j + n) ^ seq16(qoff, q + n)), 16);
+								n += m;
+								if (m < 16) break;
+							} else {
+								const uint32_t xa = seq4(j + n) ^ seq4(aqq + n), xb = seq4(j + n + 4) ^ seq4(aqq + n + 4);
+								if (xa | xb) { n += xa ? min(lead_eq(xa), 4) : 4 + min(lead_eq(xb), 4); break; }
+								n += 8;
+							}
 						}
 						nmat[i] = min(n, rm);
 					}
@@ -424,7 +514,7 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 						if (!((bits >> i) & 1u)) continue; // uniform
 						const int32_t hh = __builtin_amdgcn_readlane(hv[i], src);
 						const int32_t j = hh + 1, q = c0s + i - 1 - tl + j, rm = min(tl - j, ql - q);
-						const int32_t n = run_wave2(j, qoff + q, rm, 40);
+						const int32_t n = S2 ? run_wave16(qoff, j, q, rm, 80) : run_wave2(j, qoff + q, rm, 40);
 						nmat[i] = lane == src ? n : nmat[i];
 					}
 				}
@@ -514,7 +604,7 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 
 // Workgroups share a CU: 2 x 512, 4 x 256, 8 x 128 or 16 x 64 threads = 4 waves per SIMD, i.e. at most 128 VGPRs; with traceback
 // the smaller ones get 168 (3 per SIMD).  768 threads: one workgroup per CU.
-template <int T, int K, int E1, int E2, bool TB>
+template <int T, int K, int E1, int E2, bool TB, bool S2>
 __global__ __launch_bounds__(T, T <= 512 ? ((TB && T < 512) ? 3 : 4) : T == 640 ? 5 : 1) void wfa_band2_kernel(const BatchArgs A)
 {
 	constexpr int NWK = (T / 64) * K, D = (E1 > E2 ? E1 : E2) + 1;
@@ -531,12 +621,21 @@ __global__ __launch_bounds__(T, T <= 512 ? ((TB && T < 512) ? 3 : 4) : T == 640 
 		const int32_t pair = A.order ? A.order[item] : item;
 		PairMem M;
 		pair_mem(A, (int32_t)blockIdx.x, pair, M);
-		const int32_t qoff = ((M.tl + 3) & ~3) + 8; // both sequences start on a dword
-		for (int32_t j = threadIdx.x; j < M.tl; j += T) lds2[j] = M.ts[j];
-		for (int32_t j = threadIdx.x; j < M.ql; j += T) lds2[qoff + j] = M.qs[j];
-		__syncthreads();
+		const int32_t qoff = S2 ? ((M.tl >> 4) + 2) * 4 : ((M.tl + 3) & ~3) + 8; // both sequences start on a dword
+		PassResult R;
+		R.status = ST_OK, R.s = 0, R.info = 0, R.n_snap = 0, R.cells = 0;
+		if (S2) {
+			uint32_t bad = pack2bit<T>(M.ts, M.tl, 0);
+			bad |= pack2bit<T>(M.qs, M.ql, qoff);
+			// a base other than A/C/G/T: the host re-runs the pair on the byte-wise copy of this kernel
+			if (__syncthreads_or(bad != 0)) R.status = ST_ALPHABET;
+		} else {
+			for (int32_t j = threadIdx.x; j < M.tl; j += T) lds2[j] = M.ts[j];
+			for (int32_t j = threadIdx.x; j < M.ql; j += T) lds2[qoff + j] = M.qs[j];
+			__syncthreads();
+		}
 		const bool trace = A.dbg && pair == A.debug_pair;
-		const PassResult R = band2_pass<T, K, E1, E2, TB>(A, M, sh, edge, qoff, trace);
+		if (R.status == ST_OK) R = band2_pass<T, K, E1, E2, TB, S2>(A, M, sh, edge, qoff, trace);
 		finish_pair(A, M, (int32_t)blockIdx.x, pair, R, R.status, 0);
 	}
 }
@@ -544,32 +643,40 @@ __global__ __launch_bounds__(T, T <= 512 ? ((TB && T < 512) ? 3 : 4) : T == 640 
 template <int T, int K, int E1, int E2>
 constexpr int lds_tail() { return (int)sizeof(Band2Lds<(E1 > E2 ? E1 : E2) + 1, (T / 64) * K>); }
 
+template <int T, int K, int E1, int E2, bool TB, bool S2>
+void launch_variant(const BatchArgs &a, int grid, int lds, hipStream_t st)
+{
+	static int max_set = 0;
+	if (lds > 48 * 1024 && lds > max_set) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wfa_band2_kernel<T, K, E1, E2, TB, S2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds), max_set = lds;
+	hipLaunchKernelGGL((wfa_band2_kernel<T, K, E1, E2, TB, S2>), dim3(grid), dim3(T), lds, st, a);
+}
+
 template <int T, int K, int E1, int E2>
-int launch_one(const BatchArgs &a0, int grid, int lds_seq, hipStream_t st)
+int launch_one(const BatchArgs &a0, int grid, int lds_seq, bool seq2, hipStream_t st)
 {
 	BatchArgs a = a0;
 	a.band_lds_seq = lds_seq;
 	const int lds = lds_seq + lds_tail<T, K, E1, E2>();
 	if (a.want_cigar) {
-		static int max_set = 0;
-		if (lds > 48 * 1024 && lds > max_set) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wfa_band2_kernel<T, K, E1, E2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds), max_set = lds;
-		hipLaunchKernelGGL((wfa_band2_kernel<T, K, E1, E2, true>), dim3(grid), dim3(T), lds, st, a);
+		if (seq2) launch_variant<T, K, E1, E2, true, true>(a, grid, lds, st);
+		else launch_variant<T, K, E1, E2, true, false>(a, grid, lds, st);
 	} else {
-		static int max_set = 0;
-		if (lds > 48 * 1024 && lds > max_set) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wfa_band2_kernel<T, K, E1, E2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds), max_set = lds;
-		hipLaunchKernelGGL((wfa_band2_kernel<T, K, E1, E2, false>), dim3(grid), dim3(T), lds, st, a);
+		if (seq2) launch_variant<T, K, E1, E2, false, true>(a, grid, lds, st);
+		else launch_variant<T, K, E1, E2, false, false>(a, grid, lds, st);
 	}
 	return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 template <int T, int K, int E1, int E2>
-int occ_one(int lds_seq, bool tb)
+int occ_one(int lds_seq, bool seq2, bool tb)
 {
 	const int lds = lds_seq + lds_tail<T, K, E1, E2>();
 	int n = 0;
 	hipError_t e;
-	if (tb) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, true>, T, lds);
-	else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, false>, T, lds);
+	if (tb) e = seq2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, true, true>, T, lds)
+	                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, true, false>, T, lds);
+	else e = seq2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, false, true>, T, lds)
+	              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, false, false>, T, lds);
 	return e == hipSuccess ? n : 0;
 }
 
@@ -610,14 +717,14 @@ bool band2_supported(const Penalty &p)
 int launch_band2(const BatchArgs &a, int grid, const BandGeom &g, void *stream)
 {
 	const int a_e1 = a.pen.e1, a_e2 = a.pen.e2;
-	MWF_BAND2_DISPATCH(launch_one, a, grid, g.lds_bytes, (hipStream_t)stream);
+	MWF_BAND2_DISPATCH(launch_one, a, grid, g.lds_bytes, g.seq2 != 0, (hipStream_t)stream);
 	return -1;
 }
 
 int band2_kernel_occupancy(const Penalty &p, const BandGeom &g, bool cigar)
 {
 	const int a_e1 = p.e1, a_e2 = p.e2;
-	MWF_BAND2_DISPATCH(occ_one, g.lds_bytes, cigar);
+	MWF_BAND2_DISPATCH(occ_one, g.lds_bytes, g.seq2 != 0, cigar);
 	return 0;
 }
 

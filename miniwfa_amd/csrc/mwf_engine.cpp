@@ -68,6 +68,10 @@ struct mwf_gpu_s {
 	int64_t tb_budget_mb = 0;   // 0: automatic
 	int force_kind = -1;
 	int band_pack = -1;        // int16-packed E/F registers in the band kernel: 0 never, otherwise whenever the value ranges allow
+	int seq2bit = 1;           // packed band kernel: 2-bit sequence copy in LDS for pairs of plain A/C/G/T (0: always bytes)
+	int band3 = 0;             // 1: the balanced band kernel (mwf_band3.hip: E/F in LDS, one column per lane) for the wide class — an experiment, slower than the packed kernel
+	int band3_block = 512;     // its threads per workgroup (512, 768 or 1024)
+	bool acgt_off_once = false; // set around the re-run of pairs that are not plain ACGT
 	int lds_e2 = 1;            // generic kernel: keep E2/F2 in LDS where that applies (0: never)
 	int scalar_generic = 0;    // 1: the generic kernel's original one-column-per-lane pass everywhere (comparison / fallback)
 	int64_t coop_spin_limit = 1 << 23; // polls (about a microsecond each) before the whole-device kernel gives up on a workgroup
@@ -301,7 +305,7 @@ constexpr int64_t kBandMicroWindow = (1 * 3 - 1) * 256 - 64, kBandTinyWindow = (
 
 struct Plan {
 	int kind = 0;              // 0: generic kernel, 2: band kernel
-	BandGeom band{0, 0, 0, 0};
+	BandGeom band{0, 0, 0, 0, 0};
 	int block = 256, grid = 1;
 	int32_t W = 0, GW = 0;
 	int64_t ring_slot_ints = 0, rows_slot = 0, tb_slot_bytes = 0, cig_scratch_slot = 0;
@@ -321,7 +325,7 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 	if (want_kind == 0 || low_mem || (!can_packed && !can_plain)) return;
 	const int64_t max_window = std::min<int64_t>(max_len + 1, 2 * max_bound + 3);
 	BandGeom bg;
-	bg.packed = 0;
+	bg.packed = 0, bg.seq2 = 0;
 	// Packed variants (E/F registers as int16 pairs): valid when no offset (a target index, plus at most one per penalty for
 	// offsets that ran past the matrix) and no penalty count can reach 32767.  They halve the state registers, which is
 	// what lets several workgroups share a CU — one pair's barrier phase then overlaps another's compute:
@@ -350,12 +354,30 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 	bg.span = bg.block / 64 * (bg.packed && bg.block != 768 && bg.block != 640 ? 3 : 2) * 256;
 	if (want_kind != 2 && max_len + 1 > 4 * (int64_t)bg.span) return; // windows will mostly outgrow the span: go generic at once
 	const int64_t lds_cap = bg.block >= 768 ? 140 * 1024 : bg.block >= 512 ? 70 * 1024 : bg.block == 256 ? 36 * 1024 : bg.block == 128 ? 18 * 1024 : 9 * 1024;
-	bg.lds_bytes = max_seq_lds <= lds_cap ? (int)((max_seq_lds + 15) / 16 * 16) : 0;
+	// the packed kernel's sequence copy holds 2 bits per base unless that is switched off (or this is the re-run of pairs that
+	// are not plain ACGT): a quarter of the LDS, half the LDS instructions per probe
+	const bool seq2 = bg.packed && g->seq2bit != 0 && !g->acgt_off_once;
+	const int64_t need_lds = seq2 ? ((max_len >> 4) + 4) * 4 : max_seq_lds;
+	bg.lds_bytes = need_lds <= lds_cap ? (int)((need_lds + 15) / 16 * 16) : 0;
+	bg.seq2 = seq2 && bg.lds_bytes > 0;
 	if (bg.packed && bg.lds_bytes == 0) { // the packed kernel keeps the sequences in LDS
+		bg.lds_bytes = max_seq_lds <= lds_cap ? (int)((max_seq_lds + 15) / 16 * 16) : 0; // (the unpacked kernel's copy is byte-wise)
 		if (!can_plain) return;
 		bg.packed = 0, bg.block = max_window <= 8 * 256 - 256 - 64 ? 256 : 768, bg.span = bg.block / 64 * 2 * 256;
 	}
 	if (!bg.packed && !can_plain) return;
+	// Wide class: the balanced kernel (mwf_band3.hip) keeps E/F in LDS (12 bytes per column with the default penalties) next to a
+	// 2-bit copy of the sequences; two workgroups share a CU, so each may use half of its 160 KB.  The state ring is sized for
+	// the widest window the pairs can reach when that fits, else for what fits (a pair that outgrows it goes to the generic
+	// kernel, as with the other band kernels).  A pair with bases other than A/C/G/T comes back as ST_ALPHABET and is re-run
+	// on the byte-wise packed kernel.
+	if (bg.packed == 1 && bg.block == 512 && band3_supported(P) && !g->acgt_off_once && g->band3 == 1) {
+		const int lds_seq = (int)((((max_len >> 4) + 4) * 4 + 15) / 16 * 16);
+		const int budget = 80 * 1024;
+		int nch = (int)std::min<int64_t>((max_window + 2) / 64 + 3, 4096);
+		while (nch > 8 && band3_lds_bytes(P, lds_seq, nch * 64) > budget) --nch;
+		if (band3_lds_bytes(P, lds_seq, nch * 64) <= budget && nch * 64 >= 1024) bg.packed = 2, bg.span = nch * 64, bg.lds_bytes = lds_seq, bg.block = g->band3_block, bg.seq2 = 1;
+	}
 	pl.kind = 2, pl.band = bg;
 }
 
@@ -364,12 +386,13 @@ int cached_occupancy(mwf_gpu_t *g, const Penalty &P, const Plan &pl, int lds_e2_
 {
 	uint64_t key;
 	if (pl.kind == 2)
-		key = 1ull | (uint64_t)pl.band.block << 4 | (uint64_t)pl.band.packed << 16 | (uint64_t)(pl.band.lds_bytes > 0) << 17 | (uint64_t)pl.cigar << 18 |
-		      (uint64_t)P.e1 << 20 | (uint64_t)P.e2 << 28 | (uint64_t)pl.band.lds_bytes << 36;
+		key = 1ull | (uint64_t)pl.band.block << 4 | (uint64_t)(pl.band.packed == 1) << 16 | (uint64_t)(pl.band.lds_bytes > 0) << 17 | (uint64_t)pl.cigar << 18 |
+		      (uint64_t)(pl.band.packed == 2) << 19 | (uint64_t)(pl.band.seq2 != 0) << 3 | (uint64_t)P.e1 << 20 | (uint64_t)P.e2 << 28 |
+		      (uint64_t)(pl.band.packed == 2 ? band3_lds_bytes(P, pl.band.lds_bytes, pl.band.span) : pl.band.lds_bytes) << 36;
 	else key = 2ull | (uint64_t)pl.block << 4 | (uint64_t)stream_pass << 16 | (uint64_t)lds_e2_cols << 20;
 	auto it = g->occ_cache.find(key);
 	if (it != g->occ_cache.end()) return it->second;
-	const int per = pl.kind == 2 ? (pl.band.packed ? band2_kernel_occupancy(P, pl.band, pl.cigar) : band_kernel_occupancy(P, pl.band, pl.cigar))
+	const int per = pl.kind == 2 ? (pl.band.packed == 2 ? band3_kernel_occupancy(P, pl.band, pl.cigar) : pl.band.packed ? band2_kernel_occupancy(P, pl.band, pl.cigar) : band_kernel_occupancy(P, pl.band, pl.cigar))
 	                             : batch_kernel_occupancy(pl.block, stream_pass, lds_e2_cols);
 	g->occ_cache[key] = per;
 	return per;
@@ -500,7 +523,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 
 	// HIP events bracket the kernel only: every workspace allocation above is already done
 	if (timed) HIP_TRY(g, hipEventRecord(g->ev0, g->stream));
-	const int lrc = pl.kind == 2 ? (pl.band.packed ? launch_band2(a, pl.grid, pl.band, g->stream) : launch_band(a, pl.grid, pl.band, g->stream))
+	const int lrc = pl.kind == 2 ? (pl.band.packed == 2 ? launch_band3(a, pl.grid, pl.band, g->stream) : pl.band.packed ? launch_band2(a, pl.grid, pl.band, g->stream) : launch_band(a, pl.grid, pl.band, g->stream))
 	                             : launch_batch(a, pl.grid, pl.block, g->stream);
 	if (lrc != 0) {
 		g->err = "kernel launch failed";
@@ -512,7 +535,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	}
 	g->stats.n_launches += 1;
 	g->stats.grid = std::max(g->stats.grid, pl.grid), g->stats.block = pl.block, g->stats.kernel_kind = pl.kind;
-	g->stats.packed = pl.kind == 2 && pl.band.packed;
+	g->stats.packed = pl.kind == 2 ? pl.band.packed : 0;
 	g->stats.lowmem_two_pass = pl.low_mem ? 1 : 0;
 	if (ran_kind) *ran_kind = pl.kind;
 	return 0;
@@ -864,6 +887,7 @@ mwf_gpu_t *mwf_gpu_create(int device, void *stream)
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete g; return nullptr; }
 	g->n_cu = prop.multiProcessorCount;
+	if (const char *e = getenv("MWF_BAND3_BLOCK")) { const int v = atoi(e); if (v == 512 || v == 768 || v == 1024) g->band3_block = v; } // experiments
 	g->total_mem = prop.totalGlobalMem;
 	if (stream) g->stream = (hipStream_t)stream;
 	else {
@@ -913,6 +937,9 @@ int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value)
 	else if (!strcmp(name, "coop_min_len")) g->coop_min_len = value;
 	else if (!strcmp(name, "tb_budget_mb")) g->tb_budget_mb = value;
 	else if (!strcmp(name, "force_kind")) g->force_kind = (int)value;
+	else if (!strcmp(name, "band3")) g->band3 = (int)value;
+	else if (!strcmp(name, "seq2bit")) g->seq2bit = (int)value;
+	else if (!strcmp(name, "band3_block") && (value == 512 || value == 768 || value == 1024)) g->band3_block = (int)value;
 	else if (!strcmp(name, "band_pack")) g->band_pack = (int)value;
 	else if (!strcmp(name, "lds_e2")) g->lds_e2 = value != 0;
 	else if (!strcmp(name, "scalar_generic")) g->scalar_generic = value != 0;
@@ -1144,13 +1171,15 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 	const char *fail = nullptr;
 	for (int round = 0; round < 16 && !fail; ++round) {
 		// where every unfinished pair goes next: route = kind (0 generic, 1 whole-device alone, 2 band) and, for the band kernel, the class
-		std::vector<int32_t> to_generic[2], to_band_wide[2], same_fewer[3][2], coop_alone;
+		std::vector<int32_t> to_generic[2], to_band_wide[2], to_band_bytes[2], same_fewer[3][2], coop_alone;
 		bool grow_coop = false;
 		for (size_t i = 0; i < n; ++i) {
 			const int32_t st = b->h_status[i];
 			if (st == ST_OK || st == ST_STOPPED) continue;
 			const int kind = b->h_kind[i], step0 = b->h_flags[i] & 1;
-			if (st == ST_BAND_OVERFLOW && kind == 2) {
+			if (st == ST_ALPHABET && kind == 2) {
+				to_band_bytes[step0].push_back((int32_t)i); // not plain ACGT: the byte-wise band kernel of the same class
+			} else if (st == ST_BAND_OVERFLOW && kind == 2) {
 				if (b->h_class[i] >= 2) b->h_class[i] = 1, to_band_wide[step0].push_back((int32_t)i);
 				else b->h_class[i] = 0, to_generic[step0].push_back((int32_t)i);
 			} else if (kind == 1 && st == ST_INTERNAL && !(b->h_flags[i] & 8)) {
@@ -1182,7 +1211,7 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 			}
 		}
 		size_t n_redo = coop_alone.size();
-		for (int z = 0; z < 2; ++z) n_redo += to_generic[z].size() + to_band_wide[z].size() + same_fewer[0][z].size() + same_fewer[2][z].size();
+		for (int z = 0; z < 2; ++z) n_redo += to_generic[z].size() + to_band_wide[z].size() + to_band_bytes[z].size() + same_fewer[0][z].size() + same_fewer[2][z].size();
 		if (n_redo == 0) break;
 		g->stats.n_retries += (int32_t)n_redo;
 		if (grow_coop) g->coop_tb_mult *= 2;
@@ -1218,6 +1247,10 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 		for (int z = 0; z < 2; ++z) {
 			if (rerun(to_generic[z], z, 0, std::max(1, g->stats.grid))) return -1;
 			if (rerun(to_band_wide[z], z, 2, wide)) return -1;
+			g->acgt_off_once = true;
+			const int rc_bytes = rerun(to_band_bytes[z], z, 2, wide);
+			g->acgt_off_once = false;
+			if (rc_bytes) return -1;
 			if (rerun(same_fewer[0][z], z, 0, std::max(1, std::min<int>(tb_slots, (int)same_fewer[0][z].size())))) return -1;
 			if (rerun(same_fewer[2][z], z, 2, std::max(1, std::min<int>(tb_slots, (int)same_fewer[2][z].size())))) return -1;
 		}

@@ -18,7 +18,8 @@ enum : int32_t {
 	ST_SNAP_OVERFLOW = 5,  // low-memory snapshot arena too small
 	ST_INTERNAL = 6,       // an invariant the reference asserts on failed
 	ST_PENDING = 7,        // not produced yet
-	ST_BAND_OVERFLOW = 8   // band kernel: window outgrew the register-resident span; host re-runs on the generic kernel
+	ST_BAND_OVERFLOW = 8,  // band kernel: window outgrew the register-resident span; host re-runs on the generic kernel
+	ST_ALPHABET = 9        // band kernels with a 2-bit sequence copy: a base other than A/C/G/T; host re-runs the pair on the byte-wise copy
 };
 
 // Penalties in the form the recurrence uses them (reference miniwfa.c:252-256): lags into the ring.
@@ -89,6 +90,7 @@ struct BatchArgs {
 	int32_t lds_e2_cols;       // generic kernel, 512 threads, e2 == 1: columns of E2/F2 kept in LDS (power of two; 0 = all in HBM)
 	int32_t scalar_generic;    // generic kernel: 1 = one column per lane (forward_pass) also where the four-columns-per-lane pass applies
 	int32_t band_lds_seq;      // band kernel with the sequences in LDS: bytes of the sequence copy (bookkeeping words and edge table sit behind it)
+	int32_t band3_cap;         // balanced band kernel: columns of E/F state its LDS ring holds (a multiple of 64)
 	int32_t coop_groups, coop_group_size; // pairs side by side on the whole-device kernel and workgroups per pair (grid = product)
 	int64_t coop_edge_stride;  // ints between two groups' granule arrays
 	int64_t coop_sedge_off;    // ints from a group's granule array to its array of provenance granules (true low-memory first pass)
@@ -110,9 +112,10 @@ int  batch_kernel_occupancy(int block, bool stream_pass, int lds_e2_cols);   // 
 // launch wrappers implemented in mwf_band.hip (band kernel: E/F wavefronts live in registers)
 struct BandGeom {
 	int block;        // threads per workgroup: 256 (x2 chunks), 768 (x2 chunks) or 512 (x3 chunks, packed state)
-	int packed;       // E/F register state held as int16 pairs (two workgroups fit a CU)
-	int span;         // columns the workgroup can hold: waves * chunks * 256
+	int packed;       // 1: E/F register state held as int16 pairs (mwf_band2.hip); 2: the balanced kernel, E/F in LDS (mwf_band3.hip)
+	int span;         // columns the workgroup can hold: waves * chunks * 256 (balanced kernel: columns of its LDS state ring)
 	int lds_bytes;    // dynamic LDS for the sequence copy (0: read sequences from global memory)
+	int seq2;         // packed kernel: the sequence copy holds 2 bits per base (pairs of plain A/C/G/T; others come back as ST_ALPHABET)
 };
 // launch wrappers implemented in mwf_coop.hip (one pair across the whole device)
 bool coop_supported(const Penalty &p);
@@ -128,6 +131,11 @@ bool band_supported(const Penalty &p);                       // (e1,e2) instanti
 bool band2_supported(const Penalty &p);
 int  launch_band2(const BatchArgs &a, int grid, const BandGeom &g, void *stream);
 int  band2_kernel_occupancy(const Penalty &p, const BandGeom &g, bool cigar);
+// launch wrappers implemented in mwf_band3.hip (balanced band kernel: one column per lane, E/F in LDS, 2-bit sequences; BandGeom::packed == 2)
+bool band3_supported(const Penalty &p);
+int  band3_lds_bytes(const Penalty &p, int lds_seq, int cap);
+int  launch_band3(const BatchArgs &a, int grid, const BandGeom &g, void *stream);
+int  band3_kernel_occupancy(const Penalty &p, const BandGeom &g, bool cigar);
 int  launch_band(const BatchArgs &a, int grid, const BandGeom &g, void *stream);
 int  band_kernel_occupancy(const Penalty &p, const BandGeom &g, bool cigar);
 

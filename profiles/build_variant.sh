@@ -8,10 +8,10 @@ NAME=$1; shift
 C=miniwfa_amd/csrc
 [ -f $C/build/mwf_engine.cpp.o ] || python miniwfa_amd/build.py > /dev/null
 mkdir -p /tmp/mwf_variant_$NAME
-for f in mwf_band.hip mwf_band2.hip mwf_coop.hip; do
+for f in mwf_band.hip mwf_band2.hip mwf_band3.hip mwf_coop.hip; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-unused-value -I include -I $C "$@" -c $C/$f -o /tmp/mwf_variant_$NAME/$f.o &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared /tmp/mwf_variant_$NAME/mwf_band.hip.o /tmp/mwf_variant_$NAME/mwf_band2.hip.o /tmp/mwf_variant_$NAME/mwf_coop.hip.o \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared /tmp/mwf_variant_$NAME/mwf_band.hip.o /tmp/mwf_variant_$NAME/mwf_band2.hip.o /tmp/mwf_variant_$NAME/mwf_band3.hip.o /tmp/mwf_variant_$NAME/mwf_coop.hip.o \
   $C/build/mwf_kernels.hip.o $C/build/mwf_engine.cpp.o $C/build/mwf_chain.cpp.o $C/build/kalloc.cpp.o $C/build/mwf_dbg.cpp.o -o profiles/_${NAME}_libmwf_hip.so -lpthread
 echo profiles/_${NAME}_libmwf_hip.so
