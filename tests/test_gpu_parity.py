@@ -233,6 +233,49 @@ def test_band_kernel_against_oracle(block, pack, oracle):
     eng.close()
 
 
+@pytest.mark.parametrize("mode", ["bytes", "2bit", "band3"])
+def test_sequence_copy_modes_and_alphabet_fallback(mode, oracle):
+    """The packed band kernel with its byte-wise sequence copy (seq2bit = 0), with the 2-bit copy (the default) and the
+    opt-in balanced band kernel (band3 = 1, mwf_band3.hip) on one batch: plain ACGT pairs of every size class plus pairs
+    the 2-bit copy cannot hold (an N, lower case, arbitrary bytes, a lone non-ACGT last base) — those come back as
+    ST_ALPHABET and are re-run byte-wise; every result equals the oracle's."""
+    eng = mw.Engine(0)
+    eng.set("seq2bit", 0 if mode == "bytes" else 1)
+    eng.set("band3", 1 if mode == "band3" else 0)
+    pairs = [synth_pair(91000 + i, (150, 900, 3000, 6500)[i % 4], (0.02, 0.06, 0.12)[i % 3]) for i in range(24)]
+    odd = []
+    t, q = synth_pair(91100, 6500, 0.05); odd.append((t[:3000] + b"N" + t[3001:], q))
+    t, q = synth_pair(91101, 900, 0.05); odd.append((t.lower(), q.lower()))
+    t, q = synth_pair(91102, 3000, 0.05); odd.append((t, q[:-1] + b"n"))
+    t, q = synth_pair(91103, 150, 0.1); odd.append((bytes(b ^ 0x15 for b in t), bytes(b ^ 0x15 for b in q)))
+    odd.append((bytes(range(1, 200)), bytes(range(1, 100)) + bytes(range(101, 200))))
+    pairs = pairs + odd
+    for o in (make_opt(), make_opt(flag=1), make_opt(flag=1, o2=4, e2=2), make_opt(flag=1, x=1, o1=0, e1=1, o2=0, e2=1)):
+        go = mw.opt_init(**{k: getattr(o, k) for k in OPT_KEYS})
+        b = eng.upload(PackedBatch(pairs))
+        b.align(go)
+        s, it, nc = b.results()
+        for i, (t, q) in enumerate(pairs):
+            es, eit, ecig = oracle.align(t, q, o)
+            assert (s[i], it[i]) == (es, eit), (mode, i, len(t), len(q), o.flag, o.o2)
+            if ecig is not None:
+                assert b.cigar(i, int(nc[i])).tolist() == ecig, (mode, i)
+        if mode != "bytes":
+            assert eng.stats().n_retries >= len(odd)   # every pair that is not plain ACGT went round once more
+        b.free()
+    if mode == "band3":   # and the balanced kernel is what a wide, plain-ACGT class runs on when asked for
+        wide = [synth_pair(91200 + i, 7000, 0.06) for i in range(6)]
+        b = eng.upload(PackedBatch(wide))
+        b.align(mw.opt_init(flag=1))
+        s, it, nc = b.results()
+        assert eng.stats().packed == 2
+        for i, (t, q) in enumerate(wide):
+            es, eit, ecig = oracle.align(t, q, make_opt(flag=1))
+            assert (s[i], it[i]) == (es, eit) and b.cigar(i, int(nc[i])).tolist() == ecig, i
+        b.free()
+    eng.close()
+
+
 def test_band_kernel_stop_rules_and_shrink(oracle):
     """Long enough for several shrinks (every 256 penalties) plus the max_s / max_iter exits, band kernel forced."""
     eng = mw.Engine(0)
