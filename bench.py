@@ -71,7 +71,7 @@ class _DevPtr:
 
 KERNEL_NAMES = {0: "wfa_batch_kernel (generic: one workgroup per pair, ring in HBM)", 1: "wfa_coop_kernel (one pair across the device)",
                 2: "wfa_band_kernel (one workgroup per pair, E/F in registers, 32-bit H rows in HBM)",
-                3: "wfa_band2_kernel (one workgroup per pair, E/F in registers, 16-bit H rows in HBM, sequences in LDS)"}
+                3: "wfa_band2_kernel (one workgroup per pair, E/F in registers, 16-bit H rows in HBM, sequences in LDS at 2 bits per base)"}
 
 
 def call_latency(mw, synth_pair, reps=40):

@@ -18,7 +18,6 @@
 //     SIXTEEN bases with two ds_read2_b32, two v_alignbit and one xor.
 // H rows stay in HBM/L2 as int16 (one 2-byte load per lane and source: hx, o1-, o1+, o2-, o2+).
 // Results are bit-identical to the other kernels (tests/test_gpu_parity.py).
-#include <type_traits>
 #include "mwf_device.h"
 
 namespace mwf {
@@ -29,9 +28,6 @@ namespace {
 
 extern __shared__ __attribute__((aligned(16))) uint8_t lds3[];
 
-#ifndef MWF_B3_PF
-#define MWF_B3_PF 1 // two chunks per iteration, the next two requested a whole iteration ahead
-#endif
 
 constexpr int32_t kDead16 = -32768;
 
@@ -215,7 +211,7 @@ __device__ PassResult band3_pass(const BatchArgs &A, const PairMem &M, Shared &s
 		// lane-constant parts of the state addresses: E is read at column c-1 and replaced at c, F read at c+1 and replaced at c
 		const int32_t vE1 = sE1 + 2 * lane - 2, vE2 = sE2 + 2 * lane - 2, vF1 = sF1 + 2 * lane, vF2 = sF2 + 2 * lane;
 
-		// One chunk's inputs: requested a whole iteration ahead, so that the round trips to L2 and LDS overlap the chunks before.
+		// One chunk's inputs
 		struct In { int32_t hx, o1m, o1p, o2m, o2p, g1m, g2m, g1p, g2p, g, rg; };
 		auto fetch = [&](In &x, int32_t g, int32_t rg) {
 			const uint32_t co = (uint32_t)((g << 6) + lane) << 1;
@@ -230,24 +226,10 @@ __device__ PassResult band3_pass(const BatchArgs &A, const PairMem &M, Shared &s
 			x.g1p = lds_i16(lane == 63 ? eF1 + 4 * rr : vF1 + so + 2), x.g2p = lds_i16(lane == 63 ? eF2 + 4 * rr : vF2 + so + 2);
 			x.g = g, x.rg = rg;
 		};
-		// U chunks side by side: two independent dependency chains per wave
-#if MWF_B3_TIMING == 2
-		uint32_t ph1 = 0, ph2 = 0, ph3 = 0, ph4 = 0;
-#endif
-		auto process = [&](auto UU, In (&X)[2]) {
-			constexpr int U = decltype(UU)::value;
-#if MWF_B3_TIMING == 2
-			const uint64_t q0 = __builtin_readcyclecounter();
-#endif
-			bool deep[U];
-			bool all_deep = true;
-#pragma unroll
-			for (int u = 0; u < U; ++u) {
-				const int32_t cb = X[u].g << 6;
-				deep[u] = cb >= dlo && cb + 63 <= dhi && !track_good; // uniform
-				all_deep = all_deep && deep[u];
-			}
-			if (!all_deep) {
+		auto process = [&](In &x) {
+			const int32_t g = x.g, cb = g << 6, c = cb + lane;
+			const bool deep = cb >= dlo && cb + 63 <= dhi && !track_good; // uniform
+			if (!deep) {
 				if (!hist) {
 					xlo = uni(sh.rng_lo[jx]), xhi = uni(sh.rng_hi[jx]);
 					alo = uni(sh.rng_lo[j1]), ahi = uni(sh.rng_hi[j1]);
@@ -256,180 +238,106 @@ __device__ PassResult band3_pass(const BatchArgs &A, const PairMem &M, Shared &s
 					vlo = uni(sh.rng_lo[k2]), vhi = uni(sh.rng_hi[k2]);
 					hist = true;
 				}
-#pragma unroll
-				for (int u = 0; u < U; ++u) {
-					if (deep[u]) continue; // uniform
-					In &x = X[u];
-					const int32_t c = (x.g << 6) + lane;
-					// reads outside a source window yield "dead" (what the reference's pads supply, miniwfa.c:96-99)
-					x.hx = (uint32_t)(c - xlo) <= (uint32_t)(xhi - xlo) && xlo <= xhi ? x.hx : kDead16;
-					x.o1m = (uint32_t)(c - 1 - alo) <= (uint32_t)(ahi - alo) && alo <= ahi ? x.o1m : kDead16;
-					x.o1p = (uint32_t)(c + 1 - alo) <= (uint32_t)(ahi - alo) && alo <= ahi ? x.o1p : kDead16;
-					x.o2m = (uint32_t)(c - 1 - blo) <= (uint32_t)(bhi - blo) && blo <= bhi ? x.o2m : kDead16;
-					x.o2p = (uint32_t)(c + 1 - blo) <= (uint32_t)(bhi - blo) && blo <= bhi ? x.o2p : kDead16;
-					x.g1m = (uint32_t)(c - 1 - ulo) <= (uint32_t)(uhi - ulo) && ulo <= uhi ? x.g1m : kDead16;
-					x.g1p = (uint32_t)(c + 1 - ulo) <= (uint32_t)(uhi - ulo) && ulo <= uhi ? x.g1p : kDead16;
-					x.g2m = (uint32_t)(c - 1 - vlo) <= (uint32_t)(vhi - vlo) && vlo <= vhi ? x.g2m : kDead16;
-					x.g2p = (uint32_t)(c + 1 - vlo) <= (uint32_t)(vhi - vlo) && vlo <= vhi ? x.g2p : kDead16;
+				// reads outside a source window yield "dead" (what the reference's pads supply, miniwfa.c:96-99)
+				x.hx = (uint32_t)(c - xlo) <= (uint32_t)(xhi - xlo) && xlo <= xhi ? x.hx : kDead16;
+				x.o1m = (uint32_t)(c - 1 - alo) <= (uint32_t)(ahi - alo) && alo <= ahi ? x.o1m : kDead16;
+				x.o1p = (uint32_t)(c + 1 - alo) <= (uint32_t)(ahi - alo) && alo <= ahi ? x.o1p : kDead16;
+				x.o2m = (uint32_t)(c - 1 - blo) <= (uint32_t)(bhi - blo) && blo <= bhi ? x.o2m : kDead16;
+				x.o2p = (uint32_t)(c + 1 - blo) <= (uint32_t)(bhi - blo) && blo <= bhi ? x.o2p : kDead16;
+				x.g1m = (uint32_t)(c - 1 - ulo) <= (uint32_t)(uhi - ulo) && ulo <= uhi ? x.g1m : kDead16;
+				x.g1p = (uint32_t)(c + 1 - ulo) <= (uint32_t)(uhi - ulo) && ulo <= uhi ? x.g1p : kDead16;
+				x.g2m = (uint32_t)(c - 1 - vlo) <= (uint32_t)(vhi - vlo) && vlo <= vhi ? x.g2m : kDead16;
+				x.g2p = (uint32_t)(c + 1 - vlo) <= (uint32_t)(vhi - vlo) && vlo <= vhi ? x.g2p : kDead16;
+			}
+			const Cell v = wf_cell<TB>(x.hx, x.o1m, x.g1m, x.o2m, x.g2m, x.o1p, x.g1p, x.o2p, x.g2p);
+			int32_t ne1 = v.e1, nf1 = v.f1, ne2 = v.e2, nf2 = v.f2, hq = v.h;
+			uint32_t live = 0, gbit = 0;
+			if (!deep) { // uniform: mask the columns outside the window, note edge liveness and the good bits
+				const uint32_t a = (uint32_t)((c >= lo) & (c <= hi));
+				ne1 = a ? v.e1 : kDead16, nf1 = a ? v.f1 : kDead16, ne2 = a ? v.e2 : kDead16, nf2 = a ? v.f2 : kDead16;
+				hq = a ? v.h : kDead16;
+				if (track_good) { // uniform
+					const int32_t d = c - 1 - tl;
+					gbit = a & (inm_bit(d, v.h, tl, ql) | inm_bit(d, v.e1, tl, ql) | inm_bit(d, v.f1, tl, ql) | inm_bit(d, v.e2, tl, ql) | inm_bit(d, v.f2, tl, ql));
 				}
+				// edge rule (miniwfa.c:325-326): H is the max of the five, so "any live" == "H live"
+				const uint32_t lv = (uint32_t)(v.h >= -1);
+				live = (lv & (uint32_t)(c == lo)) | ((lv & (uint32_t)(c == hi)) << 1);
 			}
-			Cell v[U];
-			int32_t ne1[U], nf1[U], ne2[U], nf2[U], hq[U];
-			uint32_t live[U], gbit[U];
-#pragma unroll
-			for (int u = 0; u < U; ++u) {
-				const In &x = X[u];
-				v[u] = wf_cell<TB>(x.hx, x.o1m, x.g1m, x.o2m, x.g2m, x.o1p, x.g1p, x.o2p, x.g2p);
-				ne1[u] = v[u].e1, nf1[u] = v[u].f1, ne2[u] = v[u].e2, nf2[u] = v[u].f2, hq[u] = v[u].h;
-				live[u] = 0, gbit[u] = 0;
-			}
-			if (!all_deep) {
-#pragma unroll
-				for (int u = 0; u < U; ++u) {
-					if (deep[u]) continue; // uniform: mask the columns outside the window, note edge liveness and the good bits
-					const int32_t c = (X[u].g << 6) + lane;
-					const uint32_t a = (uint32_t)((c >= lo) & (c <= hi));
-					ne1[u] = a ? v[u].e1 : kDead16, nf1[u] = a ? v[u].f1 : kDead16, ne2[u] = a ? v[u].e2 : kDead16, nf2[u] = a ? v[u].f2 : kDead16;
-					hq[u] = a ? v[u].h : kDead16;
-					if (track_good) { // uniform
-						const int32_t d = c - 1 - tl;
-						gbit[u] = a & (inm_bit(d, v[u].h, tl, ql) | inm_bit(d, v[u].e1, tl, ql) | inm_bit(d, v[u].f1, tl, ql) | inm_bit(d, v[u].e2, tl, ql) | inm_bit(d, v[u].f2, tl, ql));
-					}
-					// edge rule (miniwfa.c:325-326): H is the max of the five, so "any live" == "H live"
-					const uint32_t lv = (uint32_t)(v[u].h >= -1);
-					live[u] = (lv & (uint32_t)(c == lo)) | ((lv & (uint32_t)(c == hi)) << 1);
-				}
-			}
-#if MWF_B3_TIMING == 2
-			const uint64_t q1 = __builtin_readcyclecounter();
-#endif
 			// ---- match extension (miniwfa.c:212-226): j = k+1 clamped to the largest j inside the matrix, so that dead and
 			// phantom offsets have no room; the first probe compares sixteen bases
-			int32_t j[U], i[U], room[U], n[U];
-			uint32_t pt[U], pq[U];
-#pragma unroll
-			for (int u = 0; u < U; ++u) {
-				const int32_t c = (X[u].g << 6) + lane;
-				const int32_t rj = min(tl, cmax - c);                                  // min(tl, ql - d)
-				j[u] = (int32_t)min((uint32_t)(hq[u] + 1), (uint32_t)rj);
-				i[u] = j[u] + c - 1 - tl;                                              // query index d + j
-				room[u] = rj - j[u];
-				pt[u] = seq16(0, j[u]), pq[u] = seq16(Y.qbase, i[u]);
-			}
+			const int32_t rj = min(tl, cmax - c);                                  // min(tl, ql - d)
+			const int32_t j = (int32_t)min((uint32_t)(hq + 1), (uint32_t)rj);
+			const int32_t i = j + c - 1 - tl;                                      // query index d + j
+			const int32_t room = rj - j;
+			const uint32_t pt = seq16(0, j), pq = seq16(Y.qbase, i);
 			// the new E/F are final: replace the slices in place, publish the chunk's outer columns for the neighbouring waves
-#pragma unroll
-			for (int u = 0; u < U; ++u) {
-				const int32_t so = X[u].rg << 7;
-				lds_w16(vE1 + so + 2, ne1[u]), lds_w16(vF1 + so, nf1[u]), lds_w16(vE2 + so + 2, ne2[u]), lds_w16(vF2 + so, nf2[u]);
-			}
+			const int32_t so = x.rg << 7;
+			lds_w16(vE1 + so + 2, ne1), lds_w16(vF1 + so, nf1), lds_w16(vE2 + so + 2, ne2), lds_w16(vF2 + so, nf2);
 			if (lane == 0 || lane == 63) {
-#pragma unroll
-				for (int u = 0; u < U; ++u) {
-					const uint32_t pe = (uint32_t)(ne1[u] & 0xffff) | (uint32_t)ne2[u] << 16, pf = (uint32_t)(nf1[u] & 0xffff) | (uint32_t)nf2[u] << 16;
-					lds_w32((lane == 0 ? eFn : eEn) + 4 * X[u].rg, lane == 0 ? pf : pe);
-				}
+				const uint32_t pe = (uint32_t)(ne1 & 0xffff) | (uint32_t)ne2 << 16, pf = (uint32_t)(nf1 & 0xffff) | (uint32_t)nf2 << 16;
+				lds_w32((lane == 0 ? eFn : eEn) + 4 * x.rg, lane == 0 ? pf : pe);
 			}
-#if MWF_B3_TIMING == 2
-			const uint64_t q2 = __builtin_readcyclecounter();
-#endif
-			bool more = false;
-#pragma unroll
-			for (int u = 0; u < U; ++u) {
-				n[u] = min(lead_eq2(pt[u] ^ pq[u]), room[u]);
-				more = more || (n[u] == 16 && room[u] > 16);
-			}
+			int32_t n = min(lead_eq2(pt ^ pq), room);
 			// a run of sixteen matches continues (the cells near the alignment path): each lane walks its own run, four trips at
 			// most; what is still open then the whole wave walks, 1024 bases per trip
-			if (__ballot(more)) {
-#pragma unroll
-				for (int u = 0; u < U; ++u) {
-					uint32_t open = 0;
-					if (n[u] == 16 && room[u] > 16) {
-						for (int trip = 0; n[u] < room[u]; ++trip) {
-							if (trip == 4) { open = 1; break; }
-							const int32_t m = lead_eq2(seq16(0, j[u] + n[u]) ^ seq16(Y.qbase, i[u] + n[u]));
-							n[u] += m;
-							if (m < 16) break;
-						}
-						n[u] = min(n[u], room[u]);
+			if (__ballot(n == 16 && room > 16)) {
+				uint32_t open = 0;
+				if (n == 16 && room > 16) {
+					for (int trip = 0; n < room; ++trip) {
+						if (trip == 4) { open = 1; break; }
+						const int32_t m = lead_eq2(seq16(0, j + n) ^ seq16(Y.qbase, i + n));
+						n += m;
+						if (m < 16) break;
 					}
-					for (unsigned long long owners = __ballot(open != 0); owners; owners &= owners - 1) {
-						const int32_t src = (int32_t)__builtin_ctzll(owners);
-						const int32_t js = __builtin_amdgcn_readlane(j[u], src), is = __builtin_amdgcn_readlane(i[u], src), rs = __builtin_amdgcn_readlane(room[u], src);
-						const int32_t nn = run_wave3(Y.qbase, js, is, rs, 80);
-						n[u] = lane == src ? nn : n[u];
-					}
+					n = min(n, room);
+				}
+				for (unsigned long long owners = __ballot(open != 0); owners; owners &= owners - 1) {
+					const int32_t src = (int32_t)__builtin_ctzll(owners);
+					const int32_t js = __builtin_amdgcn_readlane(j, src), is = __builtin_amdgcn_readlane(i, src), rs = __builtin_amdgcn_readlane(room, src);
+					const int32_t nn = run_wave3(Y.qbase, js, is, rs, 80);
+					n = lane == src ? nn : n;
 				}
 			}
-#if MWF_B3_TIMING == 2
-			const uint64_t q3 = __builtin_readcyclecounter();
-#endif
-#pragma unroll
-			for (int u = 0; u < U; ++u) {
-				const int32_t g = X[u].g, cb = g << 6, c = cb + lane;
-				const int32_t hv = v[u].h + n[u];
-				// ---- termination test of the extension sweep (miniwfa.c:405-409): only column ql+1 can hold the end cell
-				if ((uint32_t)(cfin - cb) < 64u && cfin >= lo && cfin <= hi) { // uniform
-					const uint32_t f = (uint32_t)(c == cfin) & (uint32_t)(hv == tl - 1) & inm_bit(ql - tl, v[u].h, tl, ql);
-					const unsigned long long fm = __ballot(f != 0);
-					if (fm) {
-						const int32_t info = f ? (n[u] == 0 ? (int32_t)(v[u].tb & 7u) : 0) : 0;
-						const uint32_t bits = 4u | (uint32_t)__builtin_amdgcn_readlane(info, (int32_t)__builtin_ctzll(fm)) << 4;
-						if (lane == 0) atomicOr((unsigned int*)&sh.flags[npar][0], bits);
-					}
-				}
-				*(int16_t*)(rown + ((uint32_t)c << 1)) = (int16_t)hv;
-				if (TB && c >= lo && c <= hi) M.tb[tb_used - origin + c] = (uint8_t)v[u].tb;
-				if (track_good) {
-					const unsigned long long m = __ballot(gbit[u] != 0);
-					if (lane == 0) M.good[(int64_t)newH * A.GW + g] = m;
-				}
-				if (!deep[u]) { // uniform
-					const uint32_t bits = (__ballot(live[u] & 1u) ? 1u : 0u) | (__ballot(live[u] & 2u) ? 2u : 0u);
-					if (bits && lane == 0) atomicOr((unsigned int*)&sh.flags[npar][0], bits);
+			const int32_t hv = v.h + n;
+			// ---- termination test of the extension sweep (miniwfa.c:405-409): only column ql+1 can hold the end cell
+			if ((uint32_t)(cfin - cb) < 64u && cfin >= lo && cfin <= hi) { // uniform
+				const uint32_t f = (uint32_t)(c == cfin) & (uint32_t)(hv == tl - 1) & inm_bit(ql - tl, v.h, tl, ql);
+				const unsigned long long fm = __ballot(f != 0);
+				if (fm) {
+					const int32_t info = f ? (n == 0 ? (int32_t)(v.tb & 7u) : 0) : 0;
+					const uint32_t bits = 4u | (uint32_t)__builtin_amdgcn_readlane(info, (int32_t)__builtin_ctzll(fm)) << 4;
+					if (lane == 0) atomicOr((unsigned int*)&sh.flags[npar][0], bits);
 				}
 			}
-#if MWF_B3_TIMING == 2
-			const uint64_t q4 = __builtin_readcyclecounter();
-			ph1 += (uint32_t)(q1 - q0), ph2 += (uint32_t)(q2 - q1), ph3 += (uint32_t)(q3 - q2), ph4 += (uint32_t)(q4 - q3);
-#endif
+			*(int16_t*)(rown + ((uint32_t)c << 1)) = (int16_t)hv;
+			if (TB && c >= lo && c <= hi) M.tb[tb_used - origin + c] = (uint8_t)v.tb;
+			if (track_good) {
+				const unsigned long long m = __ballot(gbit != 0);
+				if (lane == 0) M.good[(int64_t)newH * A.GW + g] = m;
+			}
+			if (!deep) { // uniform
+				const uint32_t bits = (__ballot(live & 1u) ? 1u : 0u) | (__ballot(live & 2u) ? 2u : 0u);
+				if (bits && lane == 0) atomicOr((unsigned int*)&sh.flags[npar][0], bits);
+			}
 		};
 
-		// this wave's chunks: the first at or after ga, then every NW-th; two per iteration, the next two requested before
+		// this wave's chunks: the first at or after ga, then every NW-th.  (Measured and dropped: two chunks per iteration with the
+		// next two requested a whole iteration ahead — 113 VGPRs, no faster: a wave's time goes into issuing its ~16 memory
+		// instructions per chunk)
 #ifdef MWF_B3_TIMING
 		const uint64_t tm1 = __builtin_readcyclecounter();
 #endif
 		const int32_t skip = (NW & (NW - 1)) == 0 ? ((wave - ga) & (NW - 1)) : ((wave - ga) % NW + NW) % NW;
 		int32_t g = ga + skip, rg = ra + skip;
 		if (rg >= nch) rg -= nch;
-#if !MWF_B3_PF
-		for (; g <= gb; g += NW) { // one chunk at a time, nothing requested ahead: the other waves of the SIMD hide the round trips
-			In cu[2];
-			fetch(cu[0], g, rg);
-			process(std::integral_constant<int, 1>{}, cu);
+		for (; g <= gb; g += NW) {
+			In x;
+			fetch(x, g, rg);
+			process(x);
 			rg += NW;
 			if (rg >= nch) rg -= nch;
 		}
-#else
-		In nx[2];
-		int n_nx = 0;
-		for (; n_nx < 2 && g <= gb; ++n_nx) {
-			fetch(nx[n_nx], g, rg);
-			g += NW, rg += NW;
-			if (rg >= nch) rg -= nch;
-		}
-		while (n_nx) {
-			In cu[2] = {nx[0], nx[1]};
-			const int n_cu = n_nx;
-			for (n_nx = 0; n_nx < 2 && g <= gb; ++n_nx) {
-				fetch(nx[n_nx], g, rg);
-				g += NW, rg += NW;
-				if (rg >= nch) rg -= nch;
-			}
-			if (n_cu == 2) process(std::integral_constant<int, 2>{}, cu);
-			else process(std::integral_constant<int, 1>{}, cu);
-		}
-#endif
 
 		// everything this penalty wrote must be complete before another wave may load it
 #ifdef MWF_B3_TIMING
@@ -450,14 +358,9 @@ __device__ PassResult band3_pass(const BatchArgs &A, const PairMem &M, Shared &s
 #ifdef MWF_B3_TIMING
 		if (trace_band && tid == (A.max_s < 0 ? -A.max_s : 0) && s_new - 1 < A.dbg_cap) { // cycles: header+first requests | chunks, drain | barrier+flags
 			const uint64_t tm4 = __builtin_readcyclecounter();
-#if MWF_B3_TIMING == 2 // inside the chunk loop: masks+recurrence | probe requests + state writes | probe results + runs | end test + stores
-			(void)tm3, (void)tm4;
-			M.dbg[2 * (s_new - 1)] = (int32_t)(min(ph1, 65535u) | min(ph2, 65535u) << 16);
-			M.dbg[2 * (s_new - 1) + 1] = (int32_t)(min(ph3, 65535u) | min(ph4, 65535u) << 16);
-#else
 			M.dbg[2 * (s_new - 1)] = (int32_t)(min((uint32_t)(tm1 - tm0), 65535u) | min((uint32_t)(tm2 - tm1), 65535u) << 16);
 			M.dbg[2 * (s_new - 1) + 1] = (int32_t)(min((uint32_t)(tm3 - tm2), 65535u) | min((uint32_t)(tm4 - tm3), 65535u) << 16);
-#endif
+
 		}
 #endif
 		if (fl & 1u) wf_lo = lo;
