@@ -286,6 +286,9 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 		}
 	};
 	remap(gl);
+	int32_t idle[K]; // penalties since the slot last held an active chunk (registers and edge-table entries start dead)
+#pragma unroll
+	for (int k = 0; k < K; ++k) idle[k] = D;
 
 	// rows of one chunk: H at the three lags (four columns = one 8-byte load each) and the two neighbouring columns
 	struct Rows { int2 hx, o1, o2; int32_t v1, v2; };
@@ -299,6 +302,9 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 	};
 
 	for (;;) {
+#ifdef MWF_B2_TIMING
+		const uint64_t tm0 = __builtin_readcyclecounter();
+#endif
 		const int32_t lo = wf_lo > 1 ? wf_lo - 1 : 1;       // miniwfa.c:417-418
 		const int32_t hi = wf_hi < cmax ? wf_hi + 1 : cmax;
 		const int32_t s_new = s + 1;
@@ -330,7 +336,9 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 			sh.rng_lo[newH] = lo, sh.rng_hi[newH] = hi;
 			sh.flags[npar + 1 == 3 ? 0 : npar + 1][0] = 0; // the flag word of the NEXT penalty (its last readers passed the previous barrier)
 			if (TB) M.row_off[s_new - 1] = tb_used, M.row_lo[s_new - 1] = origin;
+#ifndef MWF_B2_TIMING // (the timing build keeps per-phase cycle counts in the trace buffer instead)
 			if (trace_band && s_new - 1 < A.dbg_cap) M.dbg[2 * (s_new - 1)] = lo, M.dbg[2 * (s_new - 1) + 1] = hi;
+#endif
 		}
 
 		bool act[K];
@@ -341,6 +349,9 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 		if (n_act >= 2) __builtin_amdgcn_s_setprio(3);
 		else __builtin_amdgcn_s_setprio(0);
 
+#ifdef MWF_B2_TIMING
+		const uint64_t tm1 = __builtin_readcyclecounter();
+#endif
 		// window history: only a chunk near a window edge needs it
 		int32_t xlo = 1, xhi = 0, alo = 1, ahi = 0, blo = 1, bhi = 0;
 		bool hist = false;
@@ -349,7 +360,10 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 #pragma unroll
 		for (int k = 0; k < K; ++k) {
 			if (!act[k]) {
-				// a chunk outside the window: its columns were not computed at this penalty, i.e. their E/F are dead
+				// a chunk outside the window: its columns were not computed at this penalty, i.e. their E/F are dead — once every
+				// age of the slot's registers and of its edge-table entries is dead (D penalties outside), there is nothing to do
+				if (!TB && idle[k] >= D) continue; // uniform
+				++idle[k];
 #pragma unroll
 				for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -364,6 +378,7 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 				continue;
 			}
 			const int32_t r = wave + NW * k, g = gk[k], cb = g * kChunk, c0 = cb + 4 * lane;
+			idle[k] = 0;
 			load_rows(cur, g, jx, j1, j2);
 
 			const bool deep = (uint32_t)(g - gd) <= (uint32_t)dspan && dspan >= 0 && !track_good; // uniform
@@ -554,13 +569,26 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 		// Everything older than this penalty's last operations must be complete before another wave may load it (vmcnt retires
 		// in issue order).  With every lag >= 3 the rows written now are first loaded two penalties from now: the youngest store
 		// may stay in flight across the barrier.
+#ifdef MWF_B2_TIMING
+		const uint64_t tm2 = __builtin_readcyclecounter();
+#endif
 		if (relaxed_stores && n_stores > 0 && !TB && !track_good) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
 		else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifdef MWF_B2_TIMING
+		const uint64_t tm3 = __builtin_readcyclecounter();
+#endif
 		__builtin_amdgcn_s_barrier();
 		asm volatile("" ::: "memory");
 
 		// ---- bookkeeping, identical on every thread
 		const uint32_t fl = (uint32_t)uni(sh.flags[npar][0]);
+#ifdef MWF_B2_TIMING
+		if (trace_band && tid == (A.max_iter < 0 ? (int32_t)-A.max_iter : 0) && s_new - 1 < A.dbg_cap) { // cycles: header | chunks, drain | barrier+flags; chunks this wave ran in bits 28..
+			const uint64_t tm4 = __builtin_readcyclecounter();
+			M.dbg[2 * (s_new - 1)] = (int32_t)(min((uint32_t)(tm1 - tm0), 65535u) | min((uint32_t)(tm2 - tm1), 65535u) << 16);
+			M.dbg[2 * (s_new - 1) + 1] = (int32_t)(min((uint32_t)(tm3 - tm2), 4095u) | min((uint32_t)(tm4 - tm3), 65535u) << 12 | (uint32_t)n_act << 28);
+		}
+#endif
 		if (fl & 1u) wf_lo = lo;
 		if (fl & 2u) wf_hi = hi;
 		const int32_t done = (int32_t)((fl >> 2) & 1u), payload = (int32_t)((fl >> 4) & 7u);
