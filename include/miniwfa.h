@@ -151,7 +151,10 @@ void mwf_gpu_get_stats(const mwf_gpu_t *g, mwf_gpu_stats_t *st);
 int32_t mwf_gpu_debug_band(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt, int32_t pair, int32_t *lohi, int32_t cap);
 
 /* Tunables (call before align): name in {"block", "slots_per_cu", "coop_min_len", "tb_budget_mb", "force_kind", "coop_tb_cap_mb", "band_pack",
- * "coop_spin_limit", "scalar_generic", "lds_e2", "lowmem_budget_mb"}; "trim" frees the engine's workspace pools (they grow back on demand). */
+ * "coop_spin_limit", "scalar_generic", "lds_e2", "lowmem_budget_mb", "seq2bit" (packed band kernel: 0 = always keep the byte-wise sequence
+ * copy; default 1: pairs of plain A/C/G/T are held at 2 bits per base, any other pair is re-run byte-wise), "band3" (1: the balanced band
+ * kernel of DESIGN.md section 4.5 for the wide class), "band3_block" (512, 768, 1024)}; "trim" frees the engine's workspace pools (they grow
+ * back on demand). */
 int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value);
 
 #ifdef __cplusplus

@@ -888,6 +888,7 @@ mwf_gpu_t *mwf_gpu_create(int device, void *stream)
 	if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete g; return nullptr; }
 	g->n_cu = prop.multiProcessorCount;
 	if (const char *e = getenv("MWF_BAND3_BLOCK")) { const int v = atoi(e); if (v == 512 || v == 768 || v == 1024) g->band3_block = v; } // experiments
+	if (const char *e = getenv("MWF_BAND3")) g->band3 = atoi(e) != 0;                                                                                       // experiments
 	g->total_mem = prop.totalGlobalMem;
 	if (stream) g->stream = (hipStream_t)stream;
 	else {
