@@ -321,7 +321,7 @@ def main():
     }
     # What the kernel itself must move per cell (the floor of ITS traffic): the band kernels keep E1/F1/E2/F2 in registers,
     # so only H crosses HBM (three loads + one store per cell: 16 bytes, 8 with the packed kernel's 16-bit rows), +1 traceback byte;
-    # the generic kernel with E2/F2 in LDS moves 32 of the 48.
+    # the generic kernel with E2/F2 in LDS moves 32 of the 48, 16 with its 16-bit ring rows.
     tr = {}
     try:
         tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
@@ -333,7 +333,7 @@ def main():
     if st.kernel_kind == 2:
         kb = (8 if st.packed else 16) + (1 if args.cigar else 0)
     elif st.kernel_kind == 0:
-        kb = 32 + (1 if args.cigar else 0)
+        kb = (16 if st.packed == 16 else 32) + (1 if args.cigar else 0)   # 16-bit ring rows: H (three loads, one store) + E1/F1 (load + store each) at 2 bytes
     else:
         kb = 16 + (1 if args.cigar else 0)
     rf["kernel_bytes_per_cell"] = kb

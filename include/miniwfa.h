@@ -141,7 +141,7 @@ typedef struct {
 	int32_t kernel_kind;   /* 0: one workgroup per pair (generic); 1: one pair across the whole device; 2: one workgroup per pair (band) */
 	int64_t dev_bytes;     /* device memory the engine holds now: workspace pools + recycled batch allocations (live batches hold their own) */
 	int64_t dev_bytes_peak;/* ... and the most it held since creation or the last mwf_gpu_set(g, "trim", 0) */
-	int32_t packed;        /* band kernel: 1 = the 16-bit variant (mwf_band2.hip), 2 = the balanced kernel with E/F in LDS and 2-bit sequences (mwf_band3.hip) */
+	int32_t packed;        /* band kernel: 1 = the 16-bit variant (mwf_band2.hip), 2 = the balanced kernel with E/F in LDS and 2-bit sequences (mwf_band3.hip); generic kernel: 16 = 16-bit ring rows */
 	int32_t lowmem_two_pass; /* low-memory mode: 1 = the first pass stored no traceback (provenance + snapshots), 0 = checkpoints walked off a full traceback */
 } mwf_gpu_stats_t;
 void mwf_gpu_get_stats(const mwf_gpu_t *g, mwf_gpu_stats_t *st);
@@ -153,7 +153,9 @@ int32_t mwf_gpu_debug_band(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *op
 /* Tunables (call before align): name in {"block", "slots_per_cu", "coop_min_len", "tb_budget_mb", "force_kind", "coop_tb_cap_mb", "band_pack",
  * "coop_spin_limit", "scalar_generic", "lds_e2", "lowmem_budget_mb", "seq2bit" (packed band kernel: 0 = always keep the byte-wise sequence
  * copy; default 1: pairs of plain A/C/G/T are held at 2 bits per base, any other pair is re-run byte-wise), "band3" (1: the balanced band
- * kernel of DESIGN.md section 4.5 for the wide class), "band3_block" (512, 768, 1024)}; "trim" frees the engine's workspace pools (they grow
+ * kernel of DESIGN.md section 4.5 for the wide class), "band3_block" (512, 768, 1024), "ring16" (generic kernel: 0 = always 32-bit ring rows; default 1: 16-bit rows — half the HBM traffic — for batches
+ * of at least as many pairs as CUs while target length + penalty fits 16 bits, a pair that outgrows them is re-run with 32-bit rows; 2: also for
+ * smaller batches), "ring16_block" (0, 512, 768)}; "trim" frees the engine's workspace pools (they grow
  * back on demand). */
 int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value);
 

@@ -68,6 +68,9 @@ struct mwf_gpu_s {
 	int64_t tb_budget_mb = 0;   // 0: automatic
 	int force_kind = -1;
 	int band_pack = -1;        // int16-packed E/F registers in the band kernel: 0 never, otherwise whenever the value ranges allow
+	int ring16 = 1;            // generic kernel with E2/F2 in LDS: 16-bit ring rows in HBM while target length + penalty fits 16 bits (0: never)
+	int ring16_block = 0;      // its threads per workgroup (0: 512 score-only — two workgroups per CU with the 64 KB LDS copy —, 768 with traceback)
+	bool ring16_off_once = false; // set around the re-run of pairs whose offsets outgrew 16 bits
 	int seq2bit = 1;           // packed band kernel: 2-bit sequence copy in LDS for pairs of plain A/C/G/T (0: always bytes)
 	int band3 = 0;             // 1: the balanced band kernel (mwf_band3.hip: E/F in LDS, one column per lane) for the wide class — an experiment, slower than the packed kernel
 	int band3_block = 512;     // its threads per workgroup (512, 768 or 1024)
@@ -382,18 +385,18 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 }
 
 // resident workgroups per CU of a kernel variant (one runtime query per variant and engine)
-int cached_occupancy(mwf_gpu_t *g, const Penalty &P, const Plan &pl, int lds_e2_cols, bool stream_pass)
+int cached_occupancy(mwf_gpu_t *g, const Penalty &P, const Plan &pl, int lds_e2_cols, bool stream_pass, bool ring16 = false)
 {
 	uint64_t key;
 	if (pl.kind == 2)
 		key = 1ull | (uint64_t)pl.band.block << 4 | (uint64_t)(pl.band.packed == 1) << 16 | (uint64_t)(pl.band.lds_bytes > 0) << 17 | (uint64_t)pl.cigar << 18 |
 		      (uint64_t)(pl.band.packed == 2) << 19 | (uint64_t)(pl.band.seq2 != 0) << 3 | (uint64_t)P.e1 << 20 | (uint64_t)P.e2 << 28 |
 		      (uint64_t)(pl.band.packed == 2 ? band3_lds_bytes(P, pl.band.lds_bytes, pl.band.span) : pl.band.lds_bytes) << 36;
-	else key = 2ull | (uint64_t)pl.block << 4 | (uint64_t)stream_pass << 16 | (uint64_t)lds_e2_cols << 20;
+	else key = 2ull | (uint64_t)pl.block << 4 | (uint64_t)stream_pass << 16 | (uint64_t)ring16 << 17 | (uint64_t)lds_e2_cols << 20;
 	auto it = g->occ_cache.find(key);
 	if (it != g->occ_cache.end()) return it->second;
 	const int per = pl.kind == 2 ? (pl.band.packed == 2 ? band3_kernel_occupancy(P, pl.band, pl.cigar) : pl.band.packed ? band2_kernel_occupancy(P, pl.band, pl.cigar) : band_kernel_occupancy(P, pl.band, pl.cigar))
-	                             : batch_kernel_occupancy(pl.block, stream_pass, lds_e2_cols);
+	                             : batch_kernel_occupancy(pl.block, stream_pass, lds_e2_cols, ring16);
 	g->occ_cache[key] = per;
 	return per;
 }
@@ -425,6 +428,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	// `slots` is an upper bound from the caller (retries ask for fewer, larger slots); the chosen kernel's own residency
 	// bounds it as well
 	int per_cu, lds_e2_cols = 0;
+	bool ring16 = false;
 	if (pl.kind == 2) {
 		pl.block = pl.band.block;
 		per_cu = g->slots_per_cu > 0 ? g->slots_per_cu : cached_occupancy(g, P, pl, 0, false);
@@ -432,9 +436,19 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 		// wide windows (the 512-thread choice above), default gap extension: E2/F2 stay in LDS while the window fits 16 k columns
 		if (g->lds_e2 && pl.block == 512 && g->block == 0 && P.e2 == 1 && !g->scalar_generic && !pl.low_mem) {
 			lds_e2_cols = 16384;
-			pl.block = 768; // one workgroup per CU either way (128 KB of LDS): twelve waves fit its 168-VGPR budget, 490 ms against 519 ms with eight
+			// 16-bit ring rows halve the traffic of this HBM-bound kernel.  An offset is a target index (or runs past the matrix by
+			// at most one per penalty), so they hold while target length + penalty < 65530: taken optimistically for pairs whose
+			// penalty would have to exceed an eighth of their length to break that; a pair that does comes back as
+			// ST_BAND_OVERFLOW and is re-run with 32-bit rows.  The LDS copy of E2/F2 is coded the same way: 64 KB instead of 128.
+			// Only where the kernel IS HBM-bound — every CU streaming a pair of its own: with fewer pairs than CUs the coding and
+			// decoding is pure overhead (64 x 50 kb: 88 ms against 73 ms).  ring16 = 2 forces it (tests).
+			ring16 = g->ring16 != 0 && !g->ring16_off_once && max_tl + max_len / 8 < 65500 && (n_items >= g->n_cu || g->ring16 == 2);
+			// 32-bit: one workgroup per CU either way (128 KB of LDS): twelve waves fit its 168-VGPR budget, 490 ms against 519 ms with eight
+			// 16-bit: 512 threads, two workgroups per CU (64 KB of LDS each, 128 VGPRs) — 354 ms on 1250 x 50 kb against 375 ms for
+			// 768 threads and one per CU (479 ms with 32-bit rows); with traceback the 512-thread copy spills too much: 768 (451 against 477 ms)
+			pl.block = ring16 ? (g->ring16_block ? g->ring16_block : (pl.cigar ? 768 : 512)) : 768;
 		}
-		per_cu = g->slots_per_cu > 0 ? g->slots_per_cu : cached_occupancy(g, P, pl, lds_e2_cols, !g->scalar_generic);
+		per_cu = g->slots_per_cu > 0 ? g->slots_per_cu : cached_occupancy(g, P, pl, lds_e2_cols, !g->scalar_generic, ring16);
 	}
 	slots = std::max(1, std::min(slots, g->n_cu * std::max(1, per_cu)));
 	if (getenv("MWF_DEBUG"))
@@ -498,6 +512,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	}
 	a.scalar_generic = g->scalar_generic;
 	a.lds_e2_cols = lds_e2_cols;
+	a.ring16 = ring16 ? 1 : 0;
 	a.pen = P;
 	a.want_cigar = pl.cigar ? 1 : 0;
 	a.step = pl.low_mem ? opt.step : 0;
@@ -535,7 +550,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	}
 	g->stats.n_launches += 1;
 	g->stats.grid = std::max(g->stats.grid, pl.grid), g->stats.block = pl.block, g->stats.kernel_kind = pl.kind;
-	g->stats.packed = pl.kind == 2 ? pl.band.packed : 0;
+	g->stats.packed = pl.kind == 2 ? pl.band.packed : (ring16 ? 16 : 0);
 	g->stats.lowmem_two_pass = pl.low_mem ? 1 : 0;
 	if (ran_kind) *ran_kind = pl.kind;
 	return 0;
@@ -940,6 +955,8 @@ int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value)
 	else if (!strcmp(name, "force_kind")) g->force_kind = (int)value;
 	else if (!strcmp(name, "band3")) g->band3 = (int)value;
 	else if (!strcmp(name, "seq2bit")) g->seq2bit = (int)value;
+	else if (!strcmp(name, "ring16")) g->ring16 = (int)value;
+	else if (!strcmp(name, "ring16_block") && (value == 0 || value == 512 || value == 768)) g->ring16_block = (int)value;
 	else if (!strcmp(name, "band3_block") && (value == 512 || value == 768 || value == 1024)) g->band3_block = (int)value;
 	else if (!strcmp(name, "band_pack")) g->band_pack = (int)value;
 	else if (!strcmp(name, "lds_e2")) g->lds_e2 = value != 0;
@@ -1172,13 +1189,15 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 	const char *fail = nullptr;
 	for (int round = 0; round < 16 && !fail; ++round) {
 		// where every unfinished pair goes next: route = kind (0 generic, 1 whole-device alone, 2 band) and, for the band kernel, the class
-		std::vector<int32_t> to_generic[2], to_band_wide[2], to_band_bytes[2], same_fewer[3][2], coop_alone;
+		std::vector<int32_t> to_generic[2], to_generic32[2], to_band_wide[2], to_band_bytes[2], same_fewer[3][2], coop_alone;
 		bool grow_coop = false;
 		for (size_t i = 0; i < n; ++i) {
 			const int32_t st = b->h_status[i];
 			if (st == ST_OK || st == ST_STOPPED) continue;
 			const int kind = b->h_kind[i], step0 = b->h_flags[i] & 1;
-			if (st == ST_ALPHABET && kind == 2) {
+			if (st == ST_BAND_OVERFLOW && kind == 0) {
+				to_generic32[step0].push_back((int32_t)i); // an offset outgrew the generic kernel's 16-bit ring rows: 32-bit rows
+			} else if (st == ST_ALPHABET && kind == 2) {
 				to_band_bytes[step0].push_back((int32_t)i); // not plain ACGT: the byte-wise band kernel of the same class
 			} else if (st == ST_BAND_OVERFLOW && kind == 2) {
 				if (b->h_class[i] >= 2) b->h_class[i] = 1, to_band_wide[step0].push_back((int32_t)i);
@@ -1212,7 +1231,7 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 			}
 		}
 		size_t n_redo = coop_alone.size();
-		for (int z = 0; z < 2; ++z) n_redo += to_generic[z].size() + to_band_wide[z].size() + to_band_bytes[z].size() + same_fewer[0][z].size() + same_fewer[2][z].size();
+		for (int z = 0; z < 2; ++z) n_redo += to_generic[z].size() + to_generic32[z].size() + to_band_wide[z].size() + to_band_bytes[z].size() + same_fewer[0][z].size() + same_fewer[2][z].size();
 		if (n_redo == 0) break;
 		g->stats.n_retries += (int32_t)n_redo;
 		if (grow_coop) g->coop_tb_mult *= 2;
@@ -1247,6 +1266,10 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 		const int wide = 1 << 30;
 		for (int z = 0; z < 2; ++z) {
 			if (rerun(to_generic[z], z, 0, std::max(1, g->stats.grid))) return -1;
+			g->ring16_off_once = true;
+			const int rc32 = rerun(to_generic32[z], z, 0, std::max(1, g->stats.grid));
+			g->ring16_off_once = false;
+			if (rc32) return -1;
 			if (rerun(to_band_wide[z], z, 2, wide)) return -1;
 			g->acgt_off_once = true;
 			const int rc_bytes = rerun(to_band_bytes[z], z, 2, wide);

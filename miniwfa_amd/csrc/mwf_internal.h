@@ -88,6 +88,7 @@ struct BatchArgs {
 	// ---- whole-device (cooperative) kernel only: cross-workgroup state, all accessed at agent scope
 	int32_t coop_pair;         // the one pair this launch aligns
 	int32_t lds_e2_cols;       // generic kernel, 512 threads, e2 == 1: columns of E2/F2 kept in LDS (power of two; 0 = all in HBM)
+	int32_t ring16;            // generic kernel with E2/F2 in LDS: the ring rows in HBM hold 16-bit codes (half the traffic; offsets up to 65532)
 	int32_t scalar_generic;    // generic kernel: 1 = one column per lane (forward_pass) also where the four-columns-per-lane pass applies
 	int32_t band_lds_seq;      // band kernel with the sequences in LDS: bytes of the sequence copy (bookkeeping words and edge table sit behind it)
 	int32_t band3_cap;         // balanced band kernel: columns of E/F state its LDS ring holds (a multiple of 64)
@@ -107,7 +108,7 @@ struct BatchArgs {
 // launch wrappers implemented in mwf_kernels.hip (generic kernel: any penalties, any band, low-memory mode)
 int launch_reset(int32_t *status, int32_t *s, int32_t n, unsigned long long *cig_head, int32_t *queue, int32_t n_queue, void *stream);
 int launch_batch(const BatchArgs &a, int grid, int block, void *stream);
-int  batch_kernel_occupancy(int block, bool stream_pass, int lds_e2_cols);   // resident workgroups per CU for that block size
+int  batch_kernel_occupancy(int block, bool stream_pass, int lds_e2_cols, bool ring16);   // resident workgroups per CU for that block size
 
 // launch wrappers implemented in mwf_band.hip (band kernel: E/F wavefronts live in registers)
 struct BandGeom {

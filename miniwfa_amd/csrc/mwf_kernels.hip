@@ -393,16 +393,47 @@ extern __shared__ __attribute__((aligned(16))) int32_t lds_e2f2[];
 
 // SEG: the low-memory first pass (shadow ring + snapshots, no traceback bytes, no stop rules, miniwfa.c:569-589) in the same
 // four-columns-per-lane form: every shadow array-slice is one 16-byte load or store per lane as well.
-template <int T, bool TB, bool LDS2, bool SEG = false>
+// H16: the ring rows hold 16-bit codes instead of 32-bit offsets (half the HBM traffic of this HBM-bound kernel): a live offset
+// k >= -1 is stored as k + 3, every dead one (k < -1: NEG_INF plus whatever drift) as 0, which reads back as -3 — dead, and still
+// dead after the one or two increments a penalty can add before the value is stored (and collapsed) again.  Dead values only ever
+// meet comparisons whose outcome does not depend on how dead they are (and traceback bytes of dead cells are never visited), so
+// s, n_iter and the CIGAR are unchanged.  Offsets up to 65532 fit: the pass gives up (ST_BAND_OVERFLOW, re-run with 32-bit rows)
+// when target length + penalty could exceed that.
+__device__ __forceinline__ int32_t dec16(uint32_t u) { return (int32_t)u - 3; }
+__device__ __forceinline__ uint32_t enc16(int32_t k) { return k < -1 ? 0u : (uint32_t)(k + 3); }
+
+template <int T, bool TB, bool LDS2, bool SEG = false, bool H16 = false>
 __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &sh, int32_t n_seg, bool trace_band)
 {
 	static_assert(!(SEG && (TB || LDS2)), "the low-memory first pass stores no traceback and keeps every array in HBM");
+	static_assert(!(SEG && H16), "16-bit ring rows: not in the low-memory first pass");
+	using Raw4 = std::conditional_t<H16, uint2, int4>; // four columns of a ring row as they lie in memory
+	constexpr int ESH = H16 ? 1 : 2;                    // log2(bytes per element)
+	auto rowp = [&](const int32_t *base, int32_t r) -> char* { return (char*)base + (((int64_t)r * A.W) << ESH); };
+	auto ld4 = [&](const char *row, int32_t c) -> Raw4 { return *(const Raw4*)(row + ((int64_t)c << ESH)); };
+	auto ld1 = [&](const char *row, int32_t c) -> int32_t {
+		if constexpr (H16) return dec16(*(const uint16_t*)(row + ((int64_t)c << 1)));
+		else return *(const int32_t*)(row + ((int64_t)c << 2));
+	};
+	auto unpack4 = [&](const Raw4 &v, int32_t *o) {
+		if constexpr (H16) o[0] = dec16(v.x & 0xffffu), o[1] = dec16(v.x >> 16), o[2] = dec16(v.y & 0xffffu), o[3] = dec16(v.y >> 16);
+		else o[0] = v.x, o[1] = v.y, o[2] = v.z, o[3] = v.w;
+	};
+	auto st4 = [&](char *row, int32_t c, const int32_t *v) {
+		if constexpr (H16) *(uint2*)(row + ((int64_t)c << 1)) = make_uint2(enc16(v[0]) | enc16(v[1]) << 16, enc16(v[2]) | enc16(v[3]) << 16);
+		else *(int4*)(row + ((int64_t)c << 2)) = make_int4(v[0], v[1], v[2], v[3]);
+	};
+	auto st1 = [&](char *row, int32_t c, int32_t v) {
+		if constexpr (H16) *(uint16_t*)(row + ((int64_t)c << 1)) = (uint16_t)enc16(v);
+		else *(int32_t*)(row + ((int64_t)c << 2)) = v;
+	};
+	const int32_t cap = LDS2 ? A.lds_e2_cols : 0, cap_mask = cap - 1;
+	char *const lE2 = (char*)lds_e2f2, *const lF2 = (char*)lds_e2f2 + ((int64_t)cap << ESH);
+
 	constexpr bool WTB = TB || SEG;
 	constexpr int NW = T / 64;
 	constexpr int32_t kChunk = 256;
 	__shared__ int32_t e2_edge[2][64][2]; // [penalty parity][chunk mod 64]{first column's F2, last column's E2}
-	const int32_t cap = LDS2 ? A.lds_e2_cols : 0, cap_mask = cap - 1;
-	int32_t *const lE2 = lds_e2f2, *const lF2 = lds_e2f2 + cap;
 	bool prev_in_lds = false; // where the previous penalty left its E2/F2
 	const Penalty &P = A.pen;
 	const int32_t tl = M.tl, ql = M.ql, cmax = tl + ql + 1;
@@ -417,8 +448,8 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 		for (int32_t j = 0; j < 12; ++j) (&sh.flags[0][0])[j] = 0;
 		const int32_t c0 = tl + 1;
 		const int32_t k0 = extend_run(M.ts, M.qs, tl, ql, -1, 0);
-		M.H[c0] = k0;
-		M.E1[c0] = M.F1[c0] = M.E2[c0] = M.F2[c0] = kNegInf;
+		st1(rowp(M.H, 0), c0, k0);
+		st1(rowp(M.E1, 0), c0, kNegInf), st1(rowp(M.F1, 0), c0, kNegInf), st1(rowp(M.E2, 0), c0, kNegInf), st1(rowp(M.F2, 0), c0, kNegInf);
 		if (SEG) {
 			M.sH[c0] = -1;
 			M.sE1[c0] = M.sF1[c0] = M.sE2[c0] = M.sF2[c0] = kNegInf;
@@ -467,6 +498,7 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 			if (s_new - 1 >= A.rows_slot) { R.status = ST_ROWS_OVERFLOW; break; }
 			if (tb_used + row_bytes > A.tb_slot_bytes) { R.status = ST_TB_OVERFLOW; break; }
 		}
+		if (H16 && tl + s_new + 3 > 65532) { R.status = ST_BAND_OVERFLOW; break; } // an offset (a target index, or past the matrix by at most one per penalty) may no longer fit
 		// source slices (reference wf_next_prep, miniwfa.c:243-259) and their windows
 		int32_t jx = newH - P.x;    if (jx < 0) jx += P.nH;
 		int32_t j1 = newH - P.oe1;  if (j1 < 0) j1 += P.nH;
@@ -482,9 +514,9 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 		const int32_t p2lo = uni(sh.rng_lo[jg2]), p2hi = uni(sh.rng_hi[jg2]);
 		const int32_t ilo = max(max(lo, xlo), max(max(alo, blo), max(p1lo, p2lo)) + 1);
 		const int32_t ihi = min(min(hi, xhi), min(min(ahi, bhi), min(p1hi, p2hi)) - 1);
-		const int32_t *sHx = M.H + jx * W, *sHa = M.H + j1 * W, *sHb = M.H + j2 * W;
-		const int32_t *sE1 = M.E1 + r1 * W, *sF1 = M.F1 + r1 * W, *sE2 = M.E2 + r2 * W, *sF2 = M.F2 + r2 * W;
-		int32_t *dH = M.H + newH * W, *dE1 = M.E1 + new1 * W, *dF1 = M.F1 + new1 * W, *dE2 = M.E2 + new2 * W, *dF2 = M.F2 + new2 * W;
+		const char *sHx = rowp(M.H, jx), *sHa = rowp(M.H, j1), *sHb = rowp(M.H, j2);
+		const char *sE1 = rowp(M.E1, r1), *sF1 = rowp(M.F1, r1), *sE2 = rowp(M.E2, r2), *sF2 = rowp(M.F2, r2);
+		char *dH = rowp(M.H, newH), *dE1 = rowp(M.E1, new1), *dF1 = rowp(M.F1, new1), *dE2 = rowp(M.E2, new2), *dF2 = rowp(M.F2, new2);
 		// SEG: the shadow ring, same rows
 		const int32_t *tHx = 0, *tHa = 0, *tHb = 0, *tE1 = 0, *tF1 = 0, *tE2 = 0, *tF2 = 0;
 		int32_t *uH = 0, *uE1 = 0, *uF1 = 0, *uE2 = 0, *uF2 = 0;
@@ -509,14 +541,14 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 		const int32_t g_first = lo >> 8, g_last = hi >> 8;
 		int32_t g = g_first + (wave - g_first % NW + NW) % NW; // this wave's first chunk of the window
 		// what a chunk reads from HBM; the next chunk's loads are issued before the current chunk's arithmetic
-		struct ChunkIn { int4 hx4, a4, b4, e14, f14; int32_t va, vb, vg1; };
+		struct ChunkIn { Raw4 hx4, a4, b4, e14, f14; int32_t va, vb, vg1; };
 		auto issue = [&](int32_t gq, ChunkIn &x) {
 			const int32_t c0q = gq * kChunk + 4 * lane;
-			x.hx4 = *(const int4*)(sHx + c0q), x.a4 = *(const int4*)(sHa + c0q), x.b4 = *(const int4*)(sHb + c0q);
-			x.e14 = *(const int4*)(sE1 + c0q), x.f14 = *(const int4*)(sF1 + c0q);
+			x.hx4 = ld4(sHx, c0q), x.a4 = ld4(sHa, c0q), x.b4 = ld4(sHb, c0q);
+			x.e14 = ld4(sE1, c0q), x.f14 = ld4(sF1, c0q);
 			// the neighbouring chunks' outer columns: lane 0 the column to the left (H for the o-lags, E), lane 63 the one to the right (H, F)
 			const int32_t ceq = lane == 0 ? max(c0q - 1, 0) : c0q + 4; // column 0 is a pad
-			x.va = sHa[ceq], x.vb = sHb[ceq], x.vg1 = (lane == 0 ? sE1 : sF1)[ceq];
+			x.va = ld1(sHa, ceq), x.vb = ld1(sHb, ceq), x.vg1 = ld1(lane == 0 ? sE1 : sF1, ceq);
 		};
 		ChunkIn in_cur, in_next;
 		if (g <= g_last) issue(g, in_cur);
@@ -524,18 +556,15 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 			if (g + NW <= g_last) issue(g + NW, in_next);
 			const int32_t cb = g * kChunk, c0 = cb + 4 * lane;
 			const bool inner = cb >= ilo && cb + kChunk - 1 <= ihi; // uniform: no window test needed anywhere
-			const int4 hx4 = in_cur.hx4, a4 = in_cur.a4, b4 = in_cur.b4, e14 = in_cur.e14, f14 = in_cur.f14;
-			int4 e24, f24;
-			if (LDS2 && prev_in_lds) e24 = *(const int4*)(lE2 + (c0 & cap_mask)), f24 = *(const int4*)(lF2 + (c0 & cap_mask));
-			else e24 = *(const int4*)(sE2 + c0), f24 = *(const int4*)(sF2 + c0);
+			int32_t hx[4], o1[6], o2[6], e1s[4], f1s[4], e2s[4], f2s[4];
+			o1[0] = o1[5] = o2[0] = o2[5] = 0;
+			unpack4(in_cur.hx4, hx), unpack4(in_cur.a4, o1 + 1), unpack4(in_cur.b4, o2 + 1), unpack4(in_cur.e14, e1s), unpack4(in_cur.f14, f1s);
+			if (LDS2 && prev_in_lds) unpack4(ld4(lE2, c0 & cap_mask), e2s), unpack4(ld4(lF2, c0 & cap_mask), f2s); // (the LDS copy of E2/F2 is coded like the rows)
+			else unpack4(ld4(sE2, c0), e2s), unpack4(ld4(sF2, c0), f2s);
 			const int32_t ce = lane == 0 ? max(c0 - 1, 0) : c0 + 4;
 			int32_t va = in_cur.va, vb = in_cur.vb, vg1 = in_cur.vg1, vg2;
 			if (LDS2 && prev_in_lds) vg2 = lane == 0 ? e2_edge[epar ^ 1][(g - 1) & 63][1] : e2_edge[epar ^ 1][(g + 1) & 63][0];
-			else vg2 = (lane == 0 ? sE2 : sF2)[ce];
-			int32_t hx[4] = {hx4.x, hx4.y, hx4.z, hx4.w};
-			int32_t o1[6] = {0, a4.x, a4.y, a4.z, a4.w, 0}, o2[6] = {0, b4.x, b4.y, b4.z, b4.w, 0};
-			int32_t e1s[4] = {e14.x, e14.y, e14.z, e14.w}, f1s[4] = {f14.x, f14.y, f14.z, f14.w};
-			int32_t e2s[4] = {e24.x, e24.y, e24.z, e24.w}, f2s[4] = {f24.x, f24.y, f24.z, f24.w};
+			else vg2 = ld1(lane == 0 ? sE2 : sF2, ce);
 			if (!inner) { // reads outside a source window yield NEG_INF (what the reference's pads supply, miniwfa.c:96-99)
 #pragma unroll
 				for (int i = 0; i < 4; ++i) {
@@ -632,8 +661,8 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 			if (inner) columns(std::true_type{});
 			else columns(std::false_type{});
 			// E/F of this penalty: final, store now
-			*(int4*)(dE1 + c0) = make_int4(ne1[0], ne1[1], ne1[2], ne1[3]);
-			*(int4*)(dF1 + c0) = make_int4(nf1[0], nf1[1], nf1[2], nf1[3]);
+			st4(dE1, c0, ne1);
+			st4(dF1, c0, nf1);
 			if (SEG) { // (whole chunks are stored: columns outside the window are never read back as anything but NEG_INF)
 				*(int4*)(uH + c0) = make_int4(uh[0], uh[1], uh[2], uh[3]);
 				*(int4*)(uE1 + c0) = make_int4(ue1[0], ue1[1], ue1[2], ue1[3]);
@@ -642,13 +671,15 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 				*(int4*)(uF2 + c0) = make_int4(uf2[0], uf2[1], uf2[2], uf2[3]);
 			}
 			if (LDS2 && cur_in_lds) {
-				*(int4*)(lE2 + (c0 & cap_mask)) = make_int4(ne2[0], ne2[1], ne2[2], ne2[3]);
-				*(int4*)(lF2 + (c0 & cap_mask)) = make_int4(nf2[0], nf2[1], nf2[2], nf2[3]);
-				if (lane == 0) e2_edge[epar][g & 63][0] = nf2[0];
-				if (lane == 63) e2_edge[epar][g & 63][1] = ne2[3];
+				st4(lE2, c0 & cap_mask, ne2);
+				st4(lF2, c0 & cap_mask, nf2);
+				// (H16: whatever outlives the penalty must be collapsed like the coded rows — a dead -3 that picked up its +1 is -2, and
+				// one more +1 next penalty would make it "live")
+				if (lane == 0) e2_edge[epar][g & 63][0] = H16 ? dec16(enc16(nf2[0])) : nf2[0];
+				if (lane == 63) e2_edge[epar][g & 63][1] = H16 ? dec16(enc16(ne2[3])) : ne2[3];
 			} else {
-				*(int4*)(dE2 + c0) = make_int4(ne2[0], ne2[1], ne2[2], ne2[3]);
-				*(int4*)(dF2 + c0) = make_int4(nf2[0], nf2[1], nf2[2], nf2[3]);
+				st4(dE2, c0, ne2);
+				st4(dF2, c0, nf2);
 			}
 			if ((uint32_t)(lo - cb) < (uint32_t)kChunk || (uint32_t)(hi - cb) < (uint32_t)kChunk) // this chunk holds an edge column
 #pragma unroll
@@ -700,7 +731,7 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 					done_info = f ? (SEG ? uh[i] : (nmat[i] == 0 ? (int32_t)((tbw >> (8 * i)) & 7u) : 0)) : done_info;
 				}
 			}
-			*(int4*)(dH + c0) = make_int4(hv[0], hv[1], hv[2], hv[3]);
+			st4(dH, c0, hv);
 			if (TB && c0 >= origin && c0 <= hi) *(uint32_t*)(M.tb + tb_used - origin + c0) = tbw;
 			if (track_good) {
 				unsigned long long *gword = M.good + (int64_t)newH * A.GW + (int64_t)g * 4;
@@ -762,7 +793,7 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 }
 
 // STREAM: the four-columns-per-lane passes (two kernels rather than one, so that neither pays for the other's registers)
-template <int T, bool STREAM, bool LDS2>
+template <int T, bool STREAM, bool LDS2, bool H16>
 __device__ void align_pair(const BatchArgs &A, Shared &sh, int32_t slot, int32_t pair)
 {
 	PairMem M;
@@ -787,7 +818,8 @@ __device__ void align_pair(const BatchArgs &A, Shared &sh, int32_t slot, int32_t
 		__syncthreads();
 	}
 	if (status == ST_OK) {
-		if (STREAM) R = A.want_cigar ? stream_pass<T, true, LDS2>(A, M, sh, n_seg, trace) : stream_pass<T, false, LDS2>(A, M, sh, 0, trace);
+		if (STREAM && LDS2 && H16) R = A.want_cigar ? stream_pass<T, true, LDS2, false, LDS2 && H16>(A, M, sh, n_seg, trace) : stream_pass<T, false, LDS2, false, LDS2 && H16>(A, M, sh, 0, trace);
+		else if (STREAM) R = A.want_cigar ? stream_pass<T, true, LDS2>(A, M, sh, n_seg, trace) : stream_pass<T, false, LDS2>(A, M, sh, 0, trace);
 		else R = A.want_cigar ? forward_pass<T, true, false>(A, M, sh, n_seg, trace) : forward_pass<T, false, false>(A, M, sh, 0, trace);
 		status = R.status;
 	}
@@ -795,8 +827,9 @@ __device__ void align_pair(const BatchArgs &A, Shared &sh, int32_t slot, int32_t
 }
 
 // Persistent workgroups: each pulls pairs from a shared counter until the batch is drained.
-template <int T, bool STREAM, bool LDS2 = false>
-__global__ __launch_bounds__(T) void wfa_batch_kernel(const BatchArgs A)
+// (H16: the kernel with 16-bit ring rows and a 64 KB LDS copy of E2/F2 — two 512-thread workgroups per CU, i.e. 128 VGPRs)
+template <int T, bool STREAM, bool LDS2 = false, bool H16 = false>
+__global__ __launch_bounds__(T, (H16 && T == 512) ? 4 : 1) void wfa_batch_kernel(const BatchArgs A)
 {
 	__shared__ Shared sh;
 	for (;;) {
@@ -806,7 +839,7 @@ __global__ __launch_bounds__(T) void wfa_batch_kernel(const BatchArgs A)
 		__syncthreads();
 		if (item >= A.n_pairs) break;
 		const int32_t pair = A.order ? A.order[item] : item;
-		align_pair<T, STREAM, LDS2>(A, sh, (int32_t)blockIdx.x, pair);
+		align_pair<T, STREAM, LDS2, H16>(A, sh, (int32_t)blockIdx.x, pair);
 	}
 }
 
@@ -851,22 +884,17 @@ static bool wants_lds2(const BatchArgs &a, int block) { return wants_stream(a) &
 int launch_batch(const BatchArgs &a, int grid, int block, void *stream)
 {
 	if (wants_lds2(a, block)) {
-		const int lds = a.lds_e2_cols * 2 * 4;
-		static bool attr_set = false;
-		if (!attr_set) {
-			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wfa_batch_kernel<512, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+		const int lds = a.lds_e2_cols * 2 * (a.ring16 ? 2 : 4); // E2 and F2, as 16-bit codes with the 16-bit ring rows
+		const int lds_max = a.lds_e2_cols * 2 * 4;
+		auto go = [&](auto kernel, int threads) {
+			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
 			(void)hipGetLastError();
-			attr_set = true;
-		}
-		if (block == 768) {
-			static bool attr768 = false;
-			if (!attr768) {
-				(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wfa_batch_kernel<768, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-				(void)hipGetLastError();
-				attr768 = true;
-			}
-			hipLaunchKernelGGL((wfa_batch_kernel<768, true, true>), dim3(grid), dim3(768), lds, (hipStream_t)stream, a);
-		} else hipLaunchKernelGGL((wfa_batch_kernel<512, true, true>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+			hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, (hipStream_t)stream, a);
+		};
+		if (a.ring16 && block == 768) go(&wfa_batch_kernel<768, true, true, true>, 768);
+		else if (a.ring16) go(&wfa_batch_kernel<512, true, true, true>, 512);
+		else if (block == 768) go(&wfa_batch_kernel<768, true, true>, 768);
+		else go(&wfa_batch_kernel<512, true, true>, 512);
 		return hipGetLastError() == hipSuccess ? 0 : -2;
 	}
 	return wants_stream(a) ? launch_batch_as<true>(a, grid, block, (hipStream_t)stream) : launch_batch_as<false>(a, grid, block, (hipStream_t)stream);
@@ -888,12 +916,16 @@ static int occupancy_as(int block)
 	return e == hipSuccess ? n : 0;
 }
 
-int batch_kernel_occupancy(int block, bool stream_pass, int lds_e2_cols)
+int batch_kernel_occupancy(int block, bool stream_pass, int lds_e2_cols, bool ring16)
 {
 	if (stream_pass && lds_e2_cols > 0 && (block == 512 || block == 768)) {
 		int n = 0;
-		hipError_t e = block == 768 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<768, true, true>, 768, (size_t)lds_e2_cols * 8)
-		                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<512, true, true>, 512, (size_t)lds_e2_cols * 8);
+		const size_t lds = (size_t)lds_e2_cols * (ring16 ? 4 : 8);
+		hipError_t e;
+		if (ring16) e = block == 768 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<768, true, true, true>, 768, lds)
+		                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<512, true, true, true>, 512, lds);
+		else e = block == 768 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<768, true, true>, 768, lds)
+		                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<512, true, true>, 512, lds);
 		return e == hipSuccess ? n : 0;
 	}
 	return stream_pass ? occupancy_as<true>(block) : occupancy_as<false>(block);

@@ -153,6 +153,46 @@ def test_generic_kernel_wide_windows(oracle):
         eng.close()
 
 
+def test_generic_kernel_16_bit_ring_rows(oracle):
+    """The generic kernel's 16-bit ring rows (ring16; forced here with 2 — by default only batches of at least as many pairs as
+    CUs take them): same s, n_iter and CIGAR as with 32-bit rows on ragged 13-33 kb pairs (tl = 21000 puts a window edge on a
+    chunk boundary: what outlives a penalty in LDS must be collapsed like the coded rows), the oracle's answers on the shortest
+    ones, and a pair whose offsets outgrow 16 bits (target + penalty > 65532) comes back through the 32-bit rows."""
+    pairs = [synth_pair(7100 + i, 13000 + 4000 * (i % 6), 0.02 + 0.01 * (i % 5)) for i in range(18)]
+    out = {}
+    for r16 in (0, 2):
+        eng = mw.Engine(0)
+        eng.set("ring16", r16)
+        eng.set("force_kind", 0)
+        b = eng.upload(PackedBatch(pairs))
+        for flag in (0, 1):
+            b.align(mw.opt_init(flag=flag))
+            s, it, nc = b.results()
+            out[(r16, flag)] = (np.array(s), np.array(it), [b.cigar(i, int(nc[i])).tolist() for i in range(len(pairs))] if flag else None)
+            assert eng.stats().kernel_kind == 0 and eng.stats().n_retries == 0
+        b.free()
+        eng.close()
+    for flag in (0, 1):
+        a, c = out[(0, flag)], out[(2, flag)]
+        assert (a[0] == c[0]).all() and (a[1] == c[1]).all() and a[2] == c[2], flag
+    for i in (0, 6, 12):   # the 13 kb pairs against the oracle
+        es, eit, ecig = oracle.align(pairs[i][0], pairs[i][1], make_opt(flag=1))
+        assert (int(out[(2, 1)][0][i]), int(out[(2, 1)][1][i])) == (es, eit) and out[(2, 1)][2][i] == ecig, i
+    big = [synth_pair(7200, 52000, 0.10)]
+    res = []
+    for r16 in (0, 2):
+        eng = mw.Engine(0)
+        eng.set("ring16", r16)
+        eng.set("force_kind", 0)
+        b = eng.upload(PackedBatch(big))
+        b.align(mw.opt_init())
+        s, it, nc = b.results()
+        res.append((int(s[0]), int(it[0]), eng.stats().n_retries))
+        b.free()
+        eng.close()
+    assert res[0][:2] == res[1][:2] and res[0][2] == 0 and res[1][2] == 1 and res[0][0] + 52000 > 65532, res
+
+
 def test_mixed_batch_runs_in_size_classes(oracle):
     """One batch with three very different pair sizes (what mwf_wfa_chain's gap fills look like): every size class goes
     to its own kernel in its own launch, results identical to the oracle, in the caller's order."""
