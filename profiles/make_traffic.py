@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = {  # key in traffic.json -> summary file, kernel the numbers are taken from
     "1024x10000@0.05s": ("profiles/r02/rocprof_band2_kernel_1024x10kb_score.txt", "wfa_band2_kernel<512, 3, 2, 1, false, true>"),
     "1024x10000@0.05c": ("profiles/r02/rocprof_band2_kernel_1024x10kb_cigar.txt", "wfa_band2_kernel<512, 3, 2, 1, true, true>"),
-    "1250x50000@0.03s": ("profiles/r02/rocprof_generic_stream_kernel_1250x50kb.txt", "wfa_batch_kernel<768, true, true>"),
+    "1250x50000@0.03s": ("profiles/r02/rocprof_generic_stream16_kernel_1250x50kb.txt", "wfa_batch_kernel<512, true, true, true>"),
 }
 out = {}
 for key, (path, kern) in SRC.items():
