@@ -390,9 +390,19 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 			bool inner = true;
 			if (!deep) {
 				if (!hist) {
+					if (!TB) { // (with traceback the extra live registers cost more than the round trips: 34.2 against 33.8 ms)
+					// the six window words in ONE LDS round trip (lane L < 6 reads word L) instead of three dependent ones: this is
+					// the window-edge chunk, i.e. the wave the whole workgroup is waiting for
+					const int32_t sel = lane < 6 ? lane : 0, jj = sel < 2 ? jx : sel < 4 ? j1 : j2;
+					const int32_t wv = (sel & 1) ? sh.rng_hi[jj] : sh.rng_lo[jj];
+					xlo = __builtin_amdgcn_readlane(wv, 0), xhi = __builtin_amdgcn_readlane(wv, 1);
+					alo = __builtin_amdgcn_readlane(wv, 2), ahi = __builtin_amdgcn_readlane(wv, 3);
+					blo = __builtin_amdgcn_readlane(wv, 4), bhi = __builtin_amdgcn_readlane(wv, 5);
+					} else {
 					xlo = uni(sh.rng_lo[jx]), xhi = uni(sh.rng_hi[jx]);
 					alo = uni(sh.rng_lo[j1]), ahi = uni(sh.rng_hi[j1]);
 					blo = uni(sh.rng_lo[j2]), bhi = uni(sh.rng_hi[j2]);
+					}
 					hist = true;
 				}
 				// columns whose every H read (c and c+-1) falls inside its source window and that are inside [lo,hi]
