@@ -193,6 +193,26 @@ def test_generic_kernel_16_bit_ring_rows(oracle):
     assert res[0][:2] == res[1][:2] and res[0][2] == 0 and res[1][2] == 1 and res[0][0] + 52000 > 65532, res
 
 
+def test_generic_kernel_takes_16_bit_rows_for_big_batches():
+    """Default admission of the 16-bit ring rows: a batch of at least as many long pairs as CUs takes them (stats.packed == 16),
+    a small one does not, and both give what 32-bit rows give."""
+    pairs = [synth_pair(7400 + i, 12600 + 40 * (i % 11), 0.02) for i in range(300)]
+    res = {}
+    for r16, n in ((0, 300), (1, 300), (1, 40)):
+        eng = mw.Engine(0)
+        eng.set("ring16", r16)
+        b = eng.upload(PackedBatch(pairs[:n]))
+        b.align(mw.opt_init())
+        s, it, nc = b.results()
+        res[(r16, n)] = (np.array(s), np.array(it), eng.stats().packed, eng.stats().kernel_kind)
+        b.free()
+        eng.close()
+    assert res[(0, 300)][3] == 0 and res[(0, 300)][2] == 0
+    assert res[(1, 300)][2] == 16 and res[(1, 40)][2] == 0
+    assert (res[(0, 300)][0] == res[(1, 300)][0]).all() and (res[(0, 300)][1] == res[(1, 300)][1]).all()
+    assert (res[(0, 300)][0][:40] == res[(1, 40)][0]).all() and (res[(0, 300)][1][:40] == res[(1, 40)][1]).all()
+
+
 def test_mixed_batch_runs_in_size_classes(oracle):
     """One batch with three very different pair sizes (what mwf_wfa_chain's gap fills look like): every size class goes
     to its own kernel in its own launch, results identical to the oracle, in the caller's order."""
