@@ -586,6 +586,11 @@ template <int T, int K, int E1, int E2, bool PACK>
 int launch_one(const BatchArgs &a, int grid, int lds, hipStream_t st)
 {
 	const bool tb = a.want_cigar != 0;
+	if (lds > 48 * 1024) { // per device, possibly from several host threads: on every launch that needs it
+		if (tb) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wfa_band_kernel<T, K, E1, E2, true, true, PACK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+		else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wfa_band_kernel<T, K, E1, E2, false, true, PACK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+		(void)hipGetLastError();
+	}
 	if (lds > 0 && tb) hipLaunchKernelGGL((wfa_band_kernel<T, K, E1, E2, true, true, PACK>), dim3(grid), dim3(T), lds, st, a);
 	else if (lds > 0) hipLaunchKernelGGL((wfa_band_kernel<T, K, E1, E2, false, true, PACK>), dim3(grid), dim3(T), lds, st, a);
 	else if (tb) hipLaunchKernelGGL((wfa_band_kernel<T, K, E1, E2, true, false, PACK>), dim3(grid), dim3(T), 0, st, a);

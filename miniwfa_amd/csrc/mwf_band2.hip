@@ -643,7 +643,7 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 // Workgroups share a CU: 2 x 512, 4 x 256, 8 x 128 or 16 x 64 threads = 4 waves per SIMD, i.e. at most 128 VGPRs; with traceback
 // the smaller ones get 168 (3 per SIMD).  768 threads: one workgroup per CU.
 template <int T, int K, int E1, int E2, bool TB, bool S2>
-__global__ __launch_bounds__(T, T <= 512 ? ((TB && T < 512) ? 3 : 4) : T == 640 ? 5 : 1) void wfa_band2_kernel(const BatchArgs A)
+__global__ __launch_bounds__(T, T <= 512 ? ((TB && T < 512) ? 3 : 4) : 1) void wfa_band2_kernel(const BatchArgs A)
 {
 	constexpr int NWK = (T / 64) * K, D = (E1 > E2 ? E1 : E2) + 1;
 	// the sequence copy starts at LDS offset 0; the bookkeeping words and the edge table sit behind it
@@ -684,8 +684,11 @@ constexpr int lds_tail() { return (int)sizeof(Band2Lds<(E1 > E2 ? E1 : E2) + 1, 
 template <int T, int K, int E1, int E2, bool TB, bool S2>
 void launch_variant(const BatchArgs &a, int grid, int lds, hipStream_t st)
 {
-	static int max_set = 0;
-	if (lds > 48 * 1024 && lds > max_set) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wfa_band2_kernel<T, K, E1, E2, TB, S2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds), max_set = lds;
+	// the attribute is per device and this may run on several host threads (mwf_wfa_batch_multi): set it on every launch that needs it
+	if (lds > 48 * 1024) {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wfa_band2_kernel<T, K, E1, E2, TB, S2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+		(void)hipGetLastError();
+	}
 	hipLaunchKernelGGL((wfa_band2_kernel<T, K, E1, E2, TB, S2>), dim3(grid), dim3(T), lds, st, a);
 }
 
@@ -748,7 +751,6 @@ bool band2_supported(const Penalty &p)
 	do {                                                                            \
 		if (g.block == 512) MWF_BAND2_PEN(FN, 512, 3, __VA_ARGS__)                  \
 		if (g.block == 768) MWF_BAND2_PEN(FN, 768, 2, __VA_ARGS__)                  \
-		if (g.block == 640) MWF_BAND2_PEN(FN, 640, 2, __VA_ARGS__)                  \
 		MWF_BAND2_REST(FN, __VA_ARGS__)                                             \
 	} while (0)
 

@@ -22,6 +22,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <shared_mutex>
 #include <numeric>
 #include <string>
 #include <thread>
@@ -72,8 +73,6 @@ struct mwf_gpu_s {
 	int ring16_block = 0;      // its threads per workgroup (0: 512 score-only — two workgroups per CU with the 64 KB LDS copy —, 768 with traceback)
 	bool ring16_off_once = false; // set around the re-run of pairs whose offsets outgrew 16 bits
 	int seq2bit = 1;           // packed band kernel: 2-bit sequence copy in LDS for pairs of plain A/C/G/T (0: always bytes)
-	int band3 = 0;             // 1: the balanced band kernel (mwf_band3.hip: E/F in LDS, one column per lane) for the wide class — an experiment, slower than the packed kernel
-	int band3_block = 512;     // its threads per workgroup (512, 768 or 1024)
 	bool acgt_off_once = false; // set around the re-run of pairs that are not plain ACGT
 	int lds_e2 = 1;            // generic kernel: keep E2/F2 in LDS where that applies (0: never)
 	int scalar_generic = 0;    // 1: the generic kernel's original one-column-per-lane pass everywhere (comparison / fallback)
@@ -113,6 +112,9 @@ struct mwf_gpu_batch_s {
 	std::vector<int32_t> h_order;   // what d_order holds: pair ids, grouped by size class, longest first inside a class
 	std::vector<int8_t> h_class;    // size class of every pair (0 generic, then band kernels: 1 wide, 2 small, 3 tiny, 4 micro)
 	std::vector<int8_t> h_kind;     // kernel that ran the pair last (0 generic, 1 whole-device, 2 band)
+	std::vector<int8_t> h_acgt;     // from the host's look at the bytes while a batch is built from host memory: 1 both sequences are plain
+	                                // A/C/G/T, 0 not (such a pair goes to the byte-wise sequence copy at once); empty: unknown (wrapped device
+	                                // buffers — the 2-bit copy finds out on the device and the pair comes back as ST_ALPHABET)
 	std::vector<int8_t> h_flags;    // bit 0: runs as high-memory although opt.step > 0 (its penalty bound is below step);
 	                                // bit 1: shared the whole-device kernel with other pairs; bit 2: walk variant of the low-memory mode
 	// results: one region of the block, fetched by one copy
@@ -131,6 +133,9 @@ struct mwf_gpu_batch_s {
 	int64_t cig_used = 0;           // words of the pool in use (known after finalize)
 	std::vector<uint32_t> h_cig;    // host copy of the used part of the pool (fetch_cigars)
 	bool h_cig_valid = false;
+	// geometry and counters of the last align of THIS batch (finalize() must not read the engine's: another batch may have
+	// been aligned on the same engine in between)
+	int32_t last_grid = 0, n_retries = 0;
 	// debug band trace (tests)
 	int32_t debug_pair = -1;
 };
@@ -350,11 +355,11 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 	if ((g->block == 64 || g->block == 128) && range_ok) bg.block = g->block, bg.packed = 1;
 	if (g->block == 256) bg.block = 256, bg.packed = range_ok && g->band_pack == 1;
 	if (g->block == 768) bg.block = 768, bg.packed = range_ok && (cigar || g->band_pack == 1);
-	if ((g->block == 512 || g->block == 640) && range_ok) bg.block = g->block, bg.packed = 1;
+	if (g->block == 512 && range_ok) bg.block = 512, bg.packed = 1;
 	// geometry picked by the caller for a size class (pairs short enough that their window should stay inside a small span)
 	if (g->block == 0 && (geom_block == 64 || geom_block == 128) && range_ok) bg.block = geom_block, bg.packed = 1;
 	if (g->block == 0 && geom_block == 256) bg.block = 256, bg.packed = range_ok;
-	bg.span = bg.block / 64 * (bg.packed && bg.block != 768 && bg.block != 640 ? 3 : 2) * 256;
+	bg.span = bg.block / 64 * (bg.packed && bg.block != 768 ? 3 : 2) * 256;
 	if (want_kind != 2 && max_len + 1 > 4 * (int64_t)bg.span) return; // windows will mostly outgrow the span: go generic at once
 	const int64_t lds_cap = bg.block >= 768 ? 140 * 1024 : bg.block >= 512 ? 70 * 1024 : bg.block == 256 ? 36 * 1024 : bg.block == 128 ? 18 * 1024 : 9 * 1024;
 	// the packed kernel's sequence copy holds 2 bits per base unless that is switched off (or this is the re-run of pairs that
@@ -369,18 +374,6 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 		bg.packed = 0, bg.block = max_window <= 8 * 256 - 256 - 64 ? 256 : 768, bg.span = bg.block / 64 * 2 * 256;
 	}
 	if (!bg.packed && !can_plain) return;
-	// Wide class: the balanced kernel (mwf_band3.hip) keeps E/F in LDS (12 bytes per column with the default penalties) next to a
-	// 2-bit copy of the sequences; two workgroups share a CU, so each may use half of its 160 KB.  The state ring is sized for
-	// the widest window the pairs can reach when that fits, else for what fits (a pair that outgrows it goes to the generic
-	// kernel, as with the other band kernels).  A pair with bases other than A/C/G/T comes back as ST_ALPHABET and is re-run
-	// on the byte-wise packed kernel.
-	if (bg.packed == 1 && bg.block == 512 && band3_supported(P) && !g->acgt_off_once && g->band3 == 1) {
-		const int lds_seq = (int)((((max_len >> 4) + 4) * 4 + 15) / 16 * 16);
-		const int budget = 80 * 1024;
-		int nch = (int)std::min<int64_t>((max_window + 2) / 64 + 3, 4096);
-		while (nch > 8 && band3_lds_bytes(P, lds_seq, nch * 64) > budget) --nch;
-		if (band3_lds_bytes(P, lds_seq, nch * 64) <= budget && nch * 64 >= 1024) bg.packed = 2, bg.span = nch * 64, bg.lds_bytes = lds_seq, bg.block = g->band3_block, bg.seq2 = 1;
-	}
 	pl.kind = 2, pl.band = bg;
 }
 
@@ -390,12 +383,11 @@ int cached_occupancy(mwf_gpu_t *g, const Penalty &P, const Plan &pl, int lds_e2_
 	uint64_t key;
 	if (pl.kind == 2)
 		key = 1ull | (uint64_t)pl.band.block << 4 | (uint64_t)(pl.band.packed == 1) << 16 | (uint64_t)(pl.band.lds_bytes > 0) << 17 | (uint64_t)pl.cigar << 18 |
-		      (uint64_t)(pl.band.packed == 2) << 19 | (uint64_t)(pl.band.seq2 != 0) << 3 | (uint64_t)P.e1 << 20 | (uint64_t)P.e2 << 28 |
-		      (uint64_t)(pl.band.packed == 2 ? band3_lds_bytes(P, pl.band.lds_bytes, pl.band.span) : pl.band.lds_bytes) << 36;
+		      (uint64_t)(pl.band.seq2 != 0) << 3 | (uint64_t)P.e1 << 20 | (uint64_t)P.e2 << 28 | (uint64_t)pl.band.lds_bytes << 36;
 	else key = 2ull | (uint64_t)pl.block << 4 | (uint64_t)stream_pass << 16 | (uint64_t)ring16 << 17 | (uint64_t)lds_e2_cols << 20;
 	auto it = g->occ_cache.find(key);
 	if (it != g->occ_cache.end()) return it->second;
-	const int per = pl.kind == 2 ? (pl.band.packed == 2 ? band3_kernel_occupancy(P, pl.band, pl.cigar) : pl.band.packed ? band2_kernel_occupancy(P, pl.band, pl.cigar) : band_kernel_occupancy(P, pl.band, pl.cigar))
+	const int per = pl.kind == 2 ? (pl.band.packed ? band2_kernel_occupancy(P, pl.band, pl.cigar) : band_kernel_occupancy(P, pl.band, pl.cigar))
 	                             : batch_kernel_occupancy(pl.block, stream_pass, lds_e2_cols, ring16);
 	g->occ_cache[key] = per;
 	return per;
@@ -411,6 +403,11 @@ int64_t tb_budget_bytes(mwf_gpu_t *g)
 	int64_t b = (int64_t)(fr / 5 * 4) + (int64_t)g->tb.bytes;
 	return std::min<int64_t>(b, std::min<int64_t>((int64_t)64 << 30, (int64_t)(tot / 4)));
 }
+
+// Per device: one-workgroup-per-pair launches take it shared (just around the launch), the whole-device kernel takes it
+// exclusively for its whole run and first waits for everything already running on the device (any engine's stream), so that
+// no other kernel of this process holds CUs while its workgroups wait for one another.
+std::shared_mutex g_dev_gate[kMaxDevices];
 
 // Run the one-workgroup-per-pair kernel over `n_items` pairs given by d_order (device) on at most `slots` workgroups.
 // tb_total_budget < 0: the traceback budget is looked up here, and only when the arena has to grow.
@@ -538,12 +535,15 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 
 	// HIP events bracket the kernel only: every workspace allocation above is already done
 	if (timed) HIP_TRY(g, hipEventRecord(g->ev0, g->stream));
-	const int lrc = pl.kind == 2 ? (pl.band.packed == 2 ? launch_band3(a, pl.grid, pl.band, g->stream) : pl.band.packed ? launch_band2(a, pl.grid, pl.band, g->stream) : launch_band(a, pl.grid, pl.band, g->stream))
+	std::shared_lock<std::shared_mutex> gate(g_dev_gate[g->device % kMaxDevices]); // not while a whole-device kernel runs
+	const int lrc = pl.kind == 2 ? (pl.band.packed ? launch_band2(a, pl.grid, pl.band, g->stream) : launch_band(a, pl.grid, pl.band, g->stream))
 	                             : launch_batch(a, pl.grid, pl.block, g->stream);
+	gate.unlock();
 	if (lrc != 0) {
 		g->err = "kernel launch failed";
 		return -1;
 	}
+	b->last_grid = std::max(b->last_grid, pl.grid);
 	if (timed_end < 0 ? timed : timed_end != 0) { // the events bracket all launches of an align call, not the retries
 		HIP_TRY(g, hipEventRecord(g->ev1, g->stream));
 		g->ev_pending = true;
@@ -561,7 +561,6 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 // Its workgroups wait for one another, so all of them must be resident: launches on one device are serialised process-wide
 // (two host threads' engines would otherwise starve each other until the spin limit), and the call returns after the kernels
 // completed.  Other processes' kernels can still hold CUs; that is what the bounded waits and the fallback are for.
-std::mutex g_coop_mutex[kMaxDevices];
 
 int coop_grid_limit(mwf_gpu_t *g)
 {
@@ -715,7 +714,8 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 		HIP_TRY(g, hipMemsetAsync(g->coop_edge.p, 0xff, NG * gran_bytes, g->stream));
 		return 0;
 	};
-	std::lock_guard<std::mutex> lock(g_coop_mutex[g->device % kMaxDevices]);
+	std::unique_lock<std::shared_mutex> lock(g_dev_gate[g->device % kMaxDevices]);
+	HIP_TRY(g, hipDeviceSynchronize()); // kernels of other engines (other host threads) on this device: let them drain first
 	if (reset_sync(true)) return -1;
 	if (first) HIP_TRY(g, hipEventRecord(g->ev0, g->stream));
 	a.coop_pass = two_pass ? 3 : low_mem ? 1 : 0;
@@ -737,6 +737,7 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 		g->ev_pending = true;
 	}
 	g->stats.grid = Gs * n_groups, g->stats.block = 512, g->stats.kernel_kind = 1;
+	b->last_grid = std::max(b->last_grid, Gs * n_groups);
 	for (int32_t pair : pairs) b->h_kind[pair] = 1, b->h_flags[pair] = (int8_t)((b->h_flags[pair] & ~2) | (n_groups > 1 ? 2 : 0));
 	HIP_TRY(g, hipStreamSynchronize(g->stream)); // the device stays ours until the kernels are through
 	return 0;
@@ -831,6 +832,26 @@ mwf_gpu_batch_t *batch_common(mwf_gpu_t *g, int32_t n, const int32_t *h_tl, cons
 	return b;
 }
 
+// Every byte one of A, C, G, T (what the packed band kernel's 2-bit sequence copy can hold)?  Eight bytes per step: the code
+// the kernel would store, (byte >> 1) & 3, stands for exactly one letter; the byte must be that letter.
+bool plain_acgt(const uint8_t *p, size_t n)
+{
+	uint64_t bad = 0;
+	size_t i = 0;
+	for (; i + 8 <= n; i += 8) {
+		uint64_t x;
+		memcpy(&x, p + i, 8);
+		const uint64_t code = (x >> 1) & 0x0303030303030303ull, lo1 = code & 0x0101010101010101ull, hi1 = (code >> 1) & 0x0101010101010101ull;
+		const uint64_t expect = 0x4141414141414141ull + (lo1 & ~hi1) * 0x02u + (hi1 & ~lo1) * 0x13u + (hi1 & lo1) * 0x06u; // A 0x41, C 0x43, T 0x54, G 0x47
+		bad |= x ^ expect;
+	}
+	for (; i < n; ++i) {
+		const uint32_t x = p[i], code = (x >> 1) & 3u;
+		bad |= x ^ ((0x47544341u >> (8 * code)) & 0xffu);
+	}
+	return bad == 0;
+}
+
 // A batch from host memory: pair i is (ts[i], tl[i]) / (qs[i], ql[i]) when `ts` is given, else it lies in `packed` at
 // t_off[i] / q_off[i].  Everything goes up in one stream of copies through the pinned buffer.
 mwf_gpu_batch_t *batch_from_host(mwf_gpu_t *g, int32_t n, const int32_t *tl, const char *const *ts, const int32_t *ql, const char *const *qs,
@@ -852,6 +873,14 @@ mwf_gpu_batch_t *batch_from_host(mwf_gpu_t *g, int32_t n, const int32_t *tl, con
 	mwf_gpu_batch_t *b = batch_common(g, n, tl, ql, (size_t)seq_bytes, true, L);
 	if (!b) return nullptr;
 	b->seq_bytes = seq_bytes;
+	// the host touches every byte anyway: note which pairs the 2-bit sequence copy cannot hold, so that they never take the
+	// device round trip through ST_ALPHABET
+	b->h_acgt.resize((size_t)n);
+	for (int32_t i = 0; i < n; ++i) {
+		const uint8_t *pt = ts ? (const uint8_t*)ts[i] : (const uint8_t*)packed + p_t_off[i];
+		const uint8_t *pq = ts ? (const uint8_t*)qs[i] : (const uint8_t*)packed + p_q_off[i];
+		b->h_acgt[i] = plain_acgt(pt, (size_t)tl[i]) && plain_acgt(pq, (size_t)ql[i]) ? 1 : 0;
+	}
 	char *base = (char*)b->block.p;
 	b->d_t_off = (const int64_t*)(base + L.t_off), b->d_q_off = (const int64_t*)(base + L.q_off);
 	b->d_tl = (const int32_t*)(base + L.tl), b->d_ql = (const int32_t*)(base + L.ql);
@@ -902,8 +931,6 @@ mwf_gpu_t *mwf_gpu_create(int device, void *stream)
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete g; return nullptr; }
 	g->n_cu = prop.multiProcessorCount;
-	if (const char *e = getenv("MWF_BAND3_BLOCK")) { const int v = atoi(e); if (v == 512 || v == 768 || v == 1024) g->band3_block = v; } // experiments
-	if (const char *e = getenv("MWF_BAND3")) g->band3 = atoi(e) != 0;                                                                                       // experiments
 	g->total_mem = prop.totalGlobalMem;
 	if (stream) g->stream = (hipStream_t)stream;
 	else {
@@ -947,17 +974,15 @@ int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value)
 {
 	if (!g || !name) return -1;
 	if (!strcmp(name, "block")) {
-		if (value != 0 && value != 64 && value != 128 && value != 256 && value != 384 && value != 512 && value != 640 && value != 768 && value != 1024) return -1;
+		if (value != 0 && value != 64 && value != 128 && value != 256 && value != 512 && value != 768 && value != 1024) return -1;
 		g->block = (int)value;
 	} else if (!strcmp(name, "slots_per_cu")) g->slots_per_cu = (int)value;
 	else if (!strcmp(name, "coop_min_len")) g->coop_min_len = value;
 	else if (!strcmp(name, "tb_budget_mb")) g->tb_budget_mb = value;
 	else if (!strcmp(name, "force_kind")) g->force_kind = (int)value;
-	else if (!strcmp(name, "band3")) g->band3 = (int)value;
 	else if (!strcmp(name, "seq2bit")) g->seq2bit = (int)value;
 	else if (!strcmp(name, "ring16")) g->ring16 = (int)value;
 	else if (!strcmp(name, "ring16_block") && (value == 0 || value == 512 || value == 768)) g->ring16_block = (int)value;
-	else if (!strcmp(name, "band3_block") && (value == 512 || value == 768 || value == 1024)) g->band3_block = (int)value;
 	else if (!strcmp(name, "band_pack")) g->band_pack = (int)value;
 	else if (!strcmp(name, "lds_e2")) g->lds_e2 = value != 0;
 	else if (!strcmp(name, "scalar_generic")) g->scalar_generic = value != 0;
@@ -1028,6 +1053,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	(void)hipSetDevice(g->device);
 	b->opt = *opt;
 	b->aligned = false, b->finalized = false, b->h_cig_valid = false;
+	b->last_grid = 0, b->n_retries = 0;
 	g->stats = mwf_gpu_stats_t{};
 	if (b->n == 0) { b->aligned = b->finalized = true; return 0; }
 	const bool cigar = (opt->flag & MWF_F_CIGAR) != 0;
@@ -1093,7 +1119,10 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	// genuinely long pairs go through the two-pass kernel (group 5).
 	const bool low_mem = cigar && opt->step > 0;
 	const bool classes = g->force_kind < 0 && g->block == 0 && (band_supported(P0) || (band2_supported(P0) && g->band_pack != 0));
-	struct Group { std::vector<int32_t> ids; int64_t max_len = 0, max_bound = 0, max_bound1 = 0, max_tl = 0, max_seq_lds = 0; } grp[6];
+	// groups 0-4: the size classes, 5: two-pass low-memory pairs, 6-9: classes 1-4 again for the pairs the host knows not to be
+	// plain A/C/G/T (byte-wise sequence copy from the start)
+	struct Group { std::vector<int32_t> ids; int64_t max_len = 0, max_bound = 0, max_bound1 = 0, max_tl = 0, max_seq_lds = 0; } grp[10];
+	const bool know_acgt = !b->h_acgt.empty() && g->seq2bit != 0;
 	for (int32_t i = 0; i < b->n; ++i) {
 		const int64_t len = (int64_t)b->h_tl[i] + b->h_ql[i], bound = penalty_bound(*opt, b->h_tl[i], b->h_ql[i], true);
 		const int64_t bound1 = penalty_bound(*opt, b->h_tl[i], b->h_ql[i], false);
@@ -1113,6 +1142,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		}
 		b->h_class[i] = (int8_t)(c == 5 ? 0 : c);
 		b->h_flags[i] = (int8_t)(step0 ? 1 : 0);
+		if (c >= 1 && c <= 4 && know_acgt && !b->h_acgt[i] && (int64_t)b->h_tl[i] + bound < 32767 && g->band_pack != 0 && band2_supported(P0)) c += 5;
 		Group &G = grp[c];
 		G.ids.push_back(i);
 		G.max_len = std::max(G.max_len, len), G.max_bound = std::max(G.max_bound, bound);
@@ -1120,7 +1150,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		G.max_tl = std::max<int64_t>(G.max_tl, b->h_tl[i]);
 		G.max_seq_lds = std::max<int64_t>(G.max_seq_lds, (((int64_t)b->h_tl[i] + 3) & ~3LL) + 8 + (((int64_t)b->h_ql[i] + 3) & ~3LL) + 16);
 	}
-	static const int run_order[6] = {5, 0, 1, 2, 3, 4}; // largest workspace first
+	static const int run_order[10] = {5, 0, 1, 6, 2, 7, 3, 8, 4, 9}; // largest workspace first
 	std::vector<int32_t> order;
 	order.reserve((size_t)b->n);
 	for (int c : run_order) {
@@ -1144,9 +1174,13 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		if (G.ids.empty()) continue;
 		++done_groups;
 		int ran = 0;
-		if (run_batch_kernel(g, b, c == 5 ? *opt : opt_hi, b->d_order + at, (int32_t)G.ids.size(), slots, G.max_len, G.max_bound, G.max_bound1,
-		                     done_groups == 1, classes ? (c == 0 || c == 5 ? 0 : 2) : -1, G.max_tl, G.max_seq_lds, done_groups == n_groups,
-		                     c == 4 ? 64 : c == 3 ? 128 : c == 2 ? 256 : 0, &ran)) return -1;
+		const int cc = c > 5 ? c - 5 : c;
+		g->acgt_off_once = c > 5;
+		const int rc = run_batch_kernel(g, b, c == 5 ? *opt : opt_hi, b->d_order + at, (int32_t)G.ids.size(), slots, G.max_len, G.max_bound, G.max_bound1,
+		                                done_groups == 1, classes ? (c == 0 || c == 5 ? 0 : 2) : -1, G.max_tl, G.max_seq_lds, done_groups == n_groups,
+		                                cc == 4 ? 64 : cc == 3 ? 128 : cc == 2 ? 256 : 0, &ran);
+		g->acgt_off_once = false;
+		if (rc) return -1;
 		for (int32_t i : G.ids) b->h_kind[i] = (int8_t)ran;
 		at += G.ids.size();
 	}
@@ -1184,7 +1218,8 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 	b->busy = false;
 	mwf_opt_t opt_hi = b->opt;
 	opt_hi.step = 0;
-	int tb_slots = std::max(1, g->stats.grid);
+	int tb_slots = std::max(1, b->last_grid);
+	const int grid0 = std::max(1, b->last_grid);
 	bool coop_warned = false;
 	const char *fail = nullptr;
 	for (int round = 0; round < 16 && !fail; ++round) {
@@ -1233,7 +1268,7 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 		size_t n_redo = coop_alone.size();
 		for (int z = 0; z < 2; ++z) n_redo += to_generic[z].size() + to_generic32[z].size() + to_band_wide[z].size() + to_band_bytes[z].size() + same_fewer[0][z].size() + same_fewer[2][z].size();
 		if (n_redo == 0) break;
-		g->stats.n_retries += (int32_t)n_redo;
+		b->n_retries += (int32_t)n_redo;
 		if (grow_coop) g->coop_tb_mult *= 2;
 		for (int32_t i : coop_alone)
 			if (run_coop_pair(g, b, b->opt, i, false, false)) return -1;
@@ -1265,9 +1300,9 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 		};
 		const int wide = 1 << 30;
 		for (int z = 0; z < 2; ++z) {
-			if (rerun(to_generic[z], z, 0, std::max(1, g->stats.grid))) return -1;
+			if (rerun(to_generic[z], z, 0, grid0)) return -1;
 			g->ring16_off_once = true;
-			const int rc32 = rerun(to_generic32[z], z, 0, std::max(1, g->stats.grid));
+			const int rc32 = rerun(to_generic32[z], z, 0, grid0);
 			g->ring16_off_once = false;
 			if (rc32) return -1;
 			if (rerun(to_band_wide[z], z, 2, wide)) return -1;
@@ -1286,7 +1321,7 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 			g->err = "pair " + std::to_string(i) + " is still unfinished after every retry (status " + std::to_string(b->h_status[i]) + ")";
 			return -3;
 		}
-	g->stats.cells = 0, g->stats.cells_pass1 = 0;
+	g->stats.cells = 0, g->stats.cells_pass1 = 0, g->stats.n_retries = b->n_retries;
 	for (size_t i = 0; i < n; ++i) g->stats.cells += b->h_iter[i], g->stats.cells_pass1 += b->h_cells1[i];
 	b->finalized = true;
 	return 0;
@@ -1384,10 +1419,15 @@ EnginePool &engine_pool() { static EnginePool *p = new EnginePool(); return *p; 
 
 mwf_gpu_t *acquire_engine(int dev)
 {
+	if (dev < 0 || dev >= kMaxDevices || dev >= mwf_gpu_device_count()) {
+		char what[192];
+		snprintf(what, sizeof(what), "device ordinal %d (MWF_DEVICE / devices[]) is not one of the %d visible gfx950 devices; this library has no CPU path", dev, mwf_gpu_device_count());
+		fatal(what, nullptr);
+	}
 	EnginePool &P = engine_pool();
 	{
 		std::lock_guard<std::mutex> lock(P.mu);
-		std::vector<mwf_gpu_t*> &v = P.idle[dev % kMaxDevices];
+		std::vector<mwf_gpu_t*> &v = P.idle[dev];
 		if (!v.empty()) {
 			mwf_gpu_t *g = v.back();
 			v.pop_back();
@@ -1406,10 +1446,22 @@ void release_engine(mwf_gpu_t *g)
 	P.idle[g->device % kMaxDevices].push_back(g);
 }
 
+// a whole non-negative decimal number, or -1
+int parse_ordinal(const char *e)
+{
+	if (!e || !*e) return -1;
+	char *end = nullptr;
+	const long v = strtol(e, &end, 10);
+	return (*end == 0 && v >= 0 && v < 1 << 20) ? (int)v : -1;
+}
+
 int default_device()
 {
 	const char *e = getenv("MWF_DEVICE");
-	return e ? atoi(e) : 0;
+	if (!e) return 0;
+	const int v = parse_ordinal(e);
+	if (v < 0) fatal("MWF_DEVICE must be a device ordinal (a non-negative number)", e);
+	return v;
 }
 
 // What one device produced for its share of a call, in host memory; the caller's thread turns it into mwf_rst_t's (kalloc
@@ -1521,7 +1573,8 @@ void mwf_wfa_batch(void *km, const mwf_opt_t *opt, int32_t n, const int32_t *tl,
 	// MWF_DEVICES = "all" or a count: deal the batch over that many devices; otherwise the one device MWF_DEVICE names
 	const char *e = getenv("MWF_DEVICES");
 	if (e && n > 1) {
-		const int32_t k = !strcmp(e, "all") ? 0 : atoi(e);
+		const int32_t k = !strcmp(e, "all") ? 0 : parse_ordinal(e);
+		if (k < 0 || (k == 0 && strcmp(e, "all"))) fatal("MWF_DEVICES must be \"all\" or a positive device count", e);
 		if (k != 1) { mwf_wfa_batch_multi(km, opt, n, tl, ts, ql, qs, r, k, nullptr); return; }
 	}
 	const int32_t dev = default_device();

@@ -91,7 +91,6 @@ struct BatchArgs {
 	int32_t ring16;            // generic kernel with E2/F2 in LDS: the ring rows in HBM hold 16-bit codes (half the traffic; offsets up to 65532)
 	int32_t scalar_generic;    // generic kernel: 1 = one column per lane (forward_pass) also where the four-columns-per-lane pass applies
 	int32_t band_lds_seq;      // band kernel with the sequences in LDS: bytes of the sequence copy (bookkeeping words and edge table sit behind it)
-	int32_t band3_cap;         // balanced band kernel: columns of E/F state its LDS ring holds (a multiple of 64)
 	int32_t coop_groups, coop_group_size; // pairs side by side on the whole-device kernel and workgroups per pair (grid = product)
 	int64_t coop_edge_stride;  // ints between two groups' granule arrays
 	int64_t coop_sedge_off;    // ints from a group's granule array to its array of provenance granules (true low-memory first pass)
@@ -113,7 +112,7 @@ int  batch_kernel_occupancy(int block, bool stream_pass, int lds_e2_cols, bool r
 // launch wrappers implemented in mwf_band.hip (band kernel: E/F wavefronts live in registers)
 struct BandGeom {
 	int block;        // threads per workgroup: 256 (x2 chunks), 768 (x2 chunks) or 512 (x3 chunks, packed state)
-	int packed;       // 1: E/F register state held as int16 pairs (mwf_band2.hip); 2: the balanced kernel, E/F in LDS (mwf_band3.hip)
+	int packed;       // 1: E/F register state held as int16 pairs (mwf_band2.hip)
 	int span;         // columns the workgroup can hold: waves * chunks * 256 (balanced kernel: columns of its LDS state ring)
 	int lds_bytes;    // dynamic LDS for the sequence copy (0: read sequences from global memory)
 	int seq2;         // packed kernel: the sequence copy holds 2 bits per base (pairs of plain A/C/G/T; others come back as ST_ALPHABET)
@@ -132,11 +131,6 @@ bool band_supported(const Penalty &p);                       // (e1,e2) instanti
 bool band2_supported(const Penalty &p);
 int  launch_band2(const BatchArgs &a, int grid, const BandGeom &g, void *stream);
 int  band2_kernel_occupancy(const Penalty &p, const BandGeom &g, bool cigar);
-// launch wrappers implemented in mwf_band3.hip (balanced band kernel: one column per lane, E/F in LDS, 2-bit sequences; BandGeom::packed == 2)
-bool band3_supported(const Penalty &p);
-int  band3_lds_bytes(const Penalty &p, int lds_seq, int cap);
-int  launch_band3(const BatchArgs &a, int grid, const BandGeom &g, void *stream);
-int  band3_kernel_occupancy(const Penalty &p, const BandGeom &g, bool cigar);
 int  launch_band(const BatchArgs &a, int grid, const BandGeom &g, void *stream);
 int  band_kernel_occupancy(const Penalty &p, const BandGeom &g, bool cigar);
 
