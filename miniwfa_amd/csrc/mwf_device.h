@@ -131,7 +131,21 @@ struct PairMem {
 	int32_t *row_lo;
 	int32_t *snap, *snap_meta, *seg;
 	int32_t *dbg;
+	// traceback bytes laid out per epoch of 256 penalties and chunk slot (mwf_sys.hip); null: rows back to back (row_off / row_lo)
+	const int64_t *ep;
+	int32_t ep_ow, ep_p;
 };
+
+// the traceback byte of (penalty row + 1, column col)
+__device__ __forceinline__ uint32_t tb_byte(const PairMem &M, int32_t row, int32_t col)
+{
+	if (M.ep) {
+		const int64_t base = M.ep[2 * (row >> 8)], gn = M.ep[2 * (row >> 8) + 1];
+		const int32_t g = col / M.ep_ow;
+		return M.tb[base + ((int64_t)(row & 255) * (int32_t)(gn >> 32) + (g - (int32_t)(gn & 0xffffffff))) * 256 + (col - (g * M.ep_ow - M.ep_p))];
+	}
+	return M.tb[M.row_off[row] + (col - M.row_lo[row])];
+}
 
 // Traceback on one wave (reference wf_traceback, miniwfa.c:329-377).  Ops are emitted from the end of
 // the alignment to its start, so writing them backwards from the end of the scratch buffer leaves the
@@ -171,7 +185,7 @@ static __device__ int32_t traceback_wave(const BatchArgs &A, const PairMem &M, u
 		}
 		if (row < 0) { overflow = true; break; }
 		const int32_t col = i - k + M.tl + 1;
-		const uint32_t x = M.tb[M.row_off[row] + (col - M.row_lo[row])];
+		const uint32_t x = tb_byte(M, row, col);
 		const int32_t state = last == 0 ? (int32_t)(x & 7u) : last;           // :346
 		const int32_t ext = state > 0 ? (int32_t)(x >> (state + 2)) & 1 : 0;  // :347
 		if (state == 0) { push(8, 1); --i, --k; row -= P.x; }
@@ -212,6 +226,7 @@ __device__ __forceinline__ void pair_mem(const BatchArgs &A, int32_t slot, int32
 	M.snap_meta = A.snap_meta ? A.snap_meta + (int64_t)slot * A.snap_meta_slot : 0;
 	M.seg = A.seg ? A.seg + (int64_t)slot * 2 * A.seg_slot : 0;
 	M.dbg = A.dbg;
+	M.ep = 0, M.ep_ow = 0, M.ep_p = 0;
 }
 
 // After the forward pass(es): traceback on the first wave, CIGAR into the pool, per-pair outputs.

@@ -80,8 +80,11 @@ struct mwf_gpu_s {
 	int64_t coop_tb_cap = (int64_t)96 << 30; // whole-device traceback arena: first allocation never above this ...
 	int64_t coop_tb_mult = 1;                // ... times this; doubled after an overflow while memory lasts
 	int64_t lowmem_budget_mb = 0; // whole-device low-memory mode: first-pass traceback above this many MB -> true two-pass (0: automatic)
+	int sys = 1;               // whole-device passes on the systolic kernel (mwf_sys.hip); 0: every pass on mwf_coop.hip (comparison)
+	int sys_p = 8;             // its penalties per hand-off block (4, 8 or 16)
 	// workspace (per-stream pool)
 	DevBuf ring, sring, good, tb, row_off, row_lo, cig_scratch, snap, snap_meta, seg, queue, dbg, coop_edge, coop_misc;
+	DevBuf sys_box, sys_prog, sys_log, sys_ep, sys_park, sys_ring, sys_good;
 	DevBuf spare_block, spare_cig; // allocations of freed batches, waiting for the next batch
 	int queue_next = 0;            // next unused work counter of the current align call
 	// pinned staging
@@ -573,10 +576,11 @@ int coop_grid_limit(mwf_gpu_t *g)
 // a third of tl+ql needs (windows stay near a quarter at 3-5 % divergence) — a pair that does outgrow its group is re-run
 // alone by finalize().  The per-penalty latency does not depend on the group size (C4-like 150 kb pair: 151 ms on 256
 // workgroups, 141 ms on 64), so pairs side by side multiply the throughput.
-int coop_group_size(int n_cu, int64_t len, bool alone)
+int coop_group_size(int n_cu, int64_t len, bool alone, int ow = 256)
 {
 	int G = n_cu;
-	const int64_t chunks = alone ? (len >> 8) + 3 : (len >> 8) / 3 + 8;
+	// (the systolic kernel's slots own `ow` = 240 of their 256 columns, and a few chunks beyond the window take part)
+	const int64_t chunks = alone ? len / ow + (ow == 256 ? 3 : 8) : len / ow / 3 + (ow == 256 ? 8 : 12);
 	while (G > (alone ? 64 : 16) && chunks <= coop_chunk_slots(G / 2)) G /= 2;
 	return G;
 }
@@ -601,6 +605,9 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 	const int32_t W = (int32_t)((len + 3 + 255) / 256 * 256 + 512), GW = W / 64 + 2;
 	const int64_t TC = coop_chunk_slots(Gs);
 	const size_t NG = (size_t)n_groups;
+	// the systolic kernel (mwf_sys.hip) runs every pass but the provenance pass of the two-pass low-memory mode
+	const bool use_sys = g->sys != 0;
+	const int sysP = g->sys_p;
 	if (ensure(g, g->ring, NG * (size_t)P.nH * W * 4 + 4096)) return -1;
 	if (ensure(g, g->good, NG * (size_t)P.nH * GW * 8)) return -1;
 	// Low-memory mode (opt.step > 0), two ways to the checkpoints:
@@ -611,8 +618,10 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 	// Chosen by what the walk variant's arena would be against the budget ("lowmem_budget_mb", default 8 GB).
 	bool two_pass = false;
 	if (low_mem) {
-		const int64_t budget = (g->lowmem_budget_mb > 0 ? g->lowmem_budget_mb : 8192) << 20;
-		two_pass = std::max<int64_t>((int64_t)1 << 30, 6000 * len) * (int64_t)NG * g->coop_tb_mult > budget;
+		// automatic: a quarter of the device (the 5 Mb pair's first-pass traceback, ~60 GB, fits a 288 GB device and the walk
+		// variant is several times faster than carrying provenance through the first pass)
+		const int64_t budget = g->lowmem_budget_mb > 0 ? g->lowmem_budget_mb << 20 : (int64_t)(g->total_mem / 4);
+		two_pass = std::max<int64_t>((int64_t)1 << 30, 6000 * len) * (int64_t)NG * g->coop_tb_mult * (use_sys ? 9 : 8) / 8 > budget;
 	}
 	// granules crossing waves: [nH][TC][2 sides][4] x 8 bytes (twice for the two-pass mode: values and their provenance);
 	// misc: flags, barrier words, pass state, then the flag ring
@@ -635,7 +644,9 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 		// two-pass: only the second pass stores traceback, and its rows are at most about 2*(step+nH) wide (the band collapses
 		// to one diagonal at every checkpoint, miniwfa.c:413-416); s is guessed as 3 % of tl+ql
 		if (two_pass) guess = std::min<int64_t>(guess, std::max<int64_t>((int64_t)64 << 20, (len * 3 / 100 + 1024) * std::min<int64_t>(len + 1, 2 * (int64_t)(opt.step + 2 * P.nH) + 8)) * (int64_t)NG);
-		int64_t want = std::min(worst, g->tb_budget_mb > 0 ? (g->tb_budget_mb << 20) : guess * g->coop_tb_mult);
+		// (the systolic kernel stores 256 bytes per penalty and chunk slot that takes part, a few slots beyond the window included)
+		if (use_sys) guess = std::min<int64_t>(g->coop_tb_cap, guess / 8 * 9 + (rows_slot / 256 + 2) * 8 * 65536 * (int64_t)NG);
+		int64_t want = std::min(use_sys ? worst / 8 * 9 + (rows_slot / 256 + 2) * 8 * 65536 * (int64_t)NG : worst, g->tb_budget_mb > 0 ? (g->tb_budget_mb << 20) : guess * g->coop_tb_mult);
 		if ((int64_t)g->tb.bytes >= want) want = (int64_t)g->tb.bytes;
 		else {
 			size_t fr = 0, tot = 0;
@@ -669,6 +680,17 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 		HIP_TRY(g, hipMemsetAsync(g->dbg.p, 0, g->dbg.bytes, g->stream));
 	}
 
+	const int64_t sys_rows = std::max(bound, bound1) + 2, sys_log_ints = 2 * (sys_rows + 256 + 8), sys_ep_words = 2 * (sys_rows / 256 + 3);
+	const int64_t sys_box_group = TC * 2 * sys_box_ints(sysP), sys_park_group = TC * 8 * 64 * 4;
+	if (use_sys) {
+		if (ensure(g, g->sys_ring, NG * (size_t)TC * P.nH * 256 * 4)) return -1;
+		if (ensure(g, g->sys_good, NG * (size_t)P.nH * TC * 4 * 8)) return -1;
+		if (ensure(g, g->sys_box, NG * (size_t)sys_box_group * 4)) return -1;
+		if (ensure(g, g->sys_prog, NG * (size_t)TC * 64)) return -1;
+		if (ensure(g, g->sys_log, NG * (size_t)sys_log_ints * 4)) return -1;
+		if (ensure(g, g->sys_ep, NG * (size_t)sys_ep_words * 8)) return -1;
+		if (ensure(g, g->sys_park, NG * (size_t)sys_park_group * 4)) return -1;
+	}
 	BatchArgs a;
 	memset(&a, 0, sizeof(a));
 	a.seqs = b->d_seqs, a.t_off = b->d_t_off, a.q_off = b->d_q_off, a.tl = b->d_tl, a.ql = b->d_ql;
@@ -714,23 +736,46 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 		HIP_TRY(g, hipMemsetAsync(g->coop_edge.p, 0xff, NG * gran_bytes, g->stream));
 		return 0;
 	};
+	// the same launch on the systolic kernel: a private H ring per chunk slot, its own good-bit rows, hand-off boxes, edge log
+	BatchArgs as = a;
+	if (use_sys) {
+		as.ring = (int32_t*)g->sys_ring.p, as.ring_slot_ints = TC * P.nH * 256;
+		as.good = (unsigned long long*)g->sys_good.p, as.GW = (int32_t)(TC * 4);
+		as.rows_slot = sys_rows;
+		as.sys_p = sysP;
+		as.sys_box = (int32_t*)g->sys_box.p, as.sys_box_stride = sys_box_group;
+		as.sys_prog = (unsigned long long*)g->sys_prog.p, as.sys_prog_stride = TC * 8;
+		as.sys_log = (int32_t*)g->sys_log.p, as.sys_log_stride = sys_log_ints;
+		as.sys_ep = cigar ? (int64_t*)g->sys_ep.p : nullptr, as.sys_ep_stride = sys_ep_words;
+		as.sys_park = (int32_t*)g->sys_park.p, as.sys_park_stride = sys_park_group;
+	}
+	auto reset_sys = [&](bool all) -> int { // counters at zero, nothing published
+		for (size_t q = 0; q < NG; ++q) {
+			char *m = (char*)g->coop_misc.p + q * misc_bytes;
+			if (all) { HIP_TRY(g, hipMemsetAsync(m, 0, 4096, g->stream)); }
+			else HIP_TRY(g, hipMemsetAsync(m + 1024, 0, 1024, g->stream));
+		}
+		HIP_TRY(g, hipMemsetAsync(g->sys_prog.p, 0, NG * (size_t)TC * 64, g->stream));
+		return 0;
+	};
 	std::unique_lock<std::shared_mutex> lock(g_dev_gate[g->device % kMaxDevices]);
 	HIP_TRY(g, hipDeviceSynchronize()); // kernels of other engines (other host threads) on this device: let them drain first
-	if (reset_sync(true)) return -1;
+	const bool sys_first = use_sys && !two_pass; // the provenance pass of the two-pass mode stays on mwf_coop.hip
+	if (sys_first ? reset_sys(true) : reset_sync(true)) return -1;
 	if (first) HIP_TRY(g, hipEventRecord(g->ev0, g->stream));
-	a.coop_pass = two_pass ? 3 : low_mem ? 1 : 0;
+	a.coop_pass = as.coop_pass = two_pass ? 3 : low_mem ? 1 : 0;
 	g->stats.lowmem_two_pass = two_pass ? 1 : 0;
-	if (launch_coop_pass(a, Gs * n_groups, g->stream)) { g->err = "kernel launch failed (whole-device pass)"; return -1; }
+	if (sys_first ? launch_sys_pass(as, Gs * n_groups, g->stream) : launch_coop_pass(a, Gs * n_groups, g->stream)) { g->err = "kernel launch failed (whole-device pass)"; return -1; }
 	g->stats.n_launches += 1;
 	if (low_mem) {
-		if (two_pass ? launch_coop_trace(a, g->stream) : launch_coop_walk(a, g->stream)) { g->err = "kernel launch failed (checkpoints)"; return -1; }
-		if (reset_sync(false)) return -1; // barrier counters, flag ring and granules of the second pass
-		a.coop_pass = 2;
+		if (two_pass ? launch_coop_trace(a, g->stream) : sys_first ? launch_sys_walk(as, g->stream) : launch_coop_walk(a, g->stream)) { g->err = "kernel launch failed (checkpoints)"; return -1; }
+		if (use_sys ? reset_sys(false) : reset_sync(false)) return -1; // barrier counters (and the old kernel's flag ring and granules) of the second pass
+		a.coop_pass = as.coop_pass = 2;
 		// the second pass is not traced: the band trace of a low-memory run is that of its second pass, traced below
-		if (launch_coop_pass(a, Gs * n_groups, g->stream)) { g->err = "kernel launch failed (second pass)"; return -1; }
+		if (use_sys ? launch_sys_pass(as, Gs * n_groups, g->stream) : launch_coop_pass(a, Gs * n_groups, g->stream)) { g->err = "kernel launch failed (second pass)"; return -1; }
 		g->stats.n_launches += 2;
 	}
-	if (launch_coop_finish(a, g->stream)) { g->err = "kernel launch failed (traceback)"; return -1; }
+	if (use_sys ? launch_sys_finish(as, g->stream) : launch_coop_finish(a, g->stream)) { g->err = "kernel launch failed (traceback)"; return -1; }
 	g->stats.n_launches += 1;
 	if (last) {
 		HIP_TRY(g, hipEventRecord(g->ev1, g->stream));
@@ -746,7 +791,7 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 // one pair with the device to itself
 int run_coop_pair(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, int32_t pair, bool first, bool last)
 {
-	const int G = coop_group_size(coop_grid_limit(g), (int64_t)b->h_tl[pair] + b->h_ql[pair], true);
+	const int G = coop_group_size(coop_grid_limit(g), (int64_t)b->h_tl[pair] + b->h_ql[pair], true, g->sys ? sys_owned_cols(g->sys_p) : 256);
 	return run_coop_group(g, b, opt, std::vector<int32_t>{pair}, G, first, last);
 }
 
@@ -950,7 +995,8 @@ static void trim(mwf_gpu_t *g)
 {
 	(void)hipStreamSynchronize(g->stream);
 	for (DevBuf *b : {&g->ring, &g->sring, &g->good, &g->tb, &g->row_off, &g->row_lo, &g->cig_scratch, &g->snap, &g->snap_meta, &g->seg, &g->dbg,
-	                  &g->coop_edge, &g->coop_misc, &g->spare_block, &g->spare_cig})
+	                  &g->coop_edge, &g->coop_misc, &g->sys_box, &g->sys_prog, &g->sys_log, &g->sys_ep, &g->sys_park, &g->sys_ring, &g->sys_good,
+	                  &g->spare_block, &g->spare_cig})
 		release(g, *b);
 	g->dev_bytes_peak = g->dev_bytes;
 }
@@ -989,6 +1035,8 @@ int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value)
 	else if (!strcmp(name, "coop_spin_limit")) g->coop_spin_limit = std::max<int64_t>(0, std::min<int64_t>(value, 0x7fffffff));
 	else if (!strcmp(name, "coop_tb_cap_mb")) g->coop_tb_cap = std::max<int64_t>(1, value) << 20;
 	else if (!strcmp(name, "lowmem_budget_mb")) g->lowmem_budget_mb = std::max<int64_t>(0, value);
+	else if (!strcmp(name, "sys")) g->sys = value != 0;
+	else if (!strcmp(name, "sys_p") && (value == 4 || value == 8 || value == 16)) g->sys_p = (int)value;
 	else if (!strcmp(name, "trim")) { (void)hipSetDevice(g->device); trim(g); }
 	else return -1;
 	return 0;
@@ -1084,7 +1132,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	int n_cu_coop = 0;
 	if (coop || (g->force_kind < 0 && max_len >= coop_len && coop_supported(P0))) {
 		n_cu_coop = coop_grid_limit(g);
-		const int coop_side_by_side = n_cu_coop > 0 ? std::max(1, n_cu_coop / coop_group_size(n_cu_coop, max_len, false)) : 1;
+		const int coop_side_by_side = n_cu_coop > 0 ? std::max(1, n_cu_coop / coop_group_size(n_cu_coop, max_len, false, g->sys ? sys_owned_cols(g->sys_p) : 256)) : 1;
 		const int64_t coop_max_pairs = std::max<int64_t>(1, std::min<int64_t>(256, max_len / 70000 * coop_side_by_side));
 		coop = coop || b->n <= coop_max_pairs;
 	}
@@ -1095,7 +1143,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		std::stable_sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) { return (int64_t)b->h_tl[x] + b->h_ql[x] > (int64_t)b->h_tl[y] + b->h_ql[y]; }); // longest first
 		for (size_t at = 0; at < idx.size();) {
 			const int64_t len0 = (int64_t)b->h_tl[idx[at]] + b->h_ql[idx[at]];
-			const int Gs = coop_group_size(n_cu_coop, len0, false);
+			const int Gs = coop_group_size(n_cu_coop, len0, false, g->sys ? sys_owned_cols(g->sys_p) : 256);
 			const size_t n_side = std::min<size_t>(idx.size() - at, (size_t)std::max(1, n_cu_coop / Gs));
 			const bool last = at + n_side == idx.size();
 			if (n_side <= 1 || b->debug_pair >= 0) { // alone (also: band traces are single-pair diagnostics)

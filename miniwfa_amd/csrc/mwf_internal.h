@@ -102,6 +102,19 @@ struct BatchArgs {
 	int32_t *coop_flags;       // [12..14] origin offset and shrink reduction; [1024 + 4*(penalty mod 64) ..] edge-live / end-cell flag ring
 	unsigned int *coop_sync;   // [0..1]: arrivals of the full barrier, [16+8g]: per-group arrivals, [96+8g]: per-group generation, [200..201]: workgroup-penalties finished
 	int32_t *coop_state;       // results of a pass handed to the next launch: [0]=status [1]=s [2]=info [3]=n_seg [4..5]=cells
+	// ---- systolic whole-device kernel (mwf_sys.hip): every chunk slot has a private H ring (`ring`: [group][slot][nH][256]) and
+	// hands its outer columns to its two neighbours once per block of `sys_p` penalties
+	int32_t sys_p;             // penalties per hand-off block (4, 8 or 16); a slot owns 256 - 2*sys_p columns, the rest is halo
+	int32_t *sys_box;          // [group][slot][2 parities][box ints]: outer columns' H rows of the block, E/F state at its end, window views
+	int64_t sys_box_stride;    // ints between two groups' boxes
+	unsigned long long *sys_prog; // [group][slot] x 64 bytes: blocks published
+	int64_t sys_prog_stride;   // 8-byte words between two groups' progress words
+	int32_t *sys_log;          // [group][2][rows_slot + 1]: wf_lo / wf_hi after every penalty, written by the owner of the edge column
+	int64_t sys_log_stride;    // ints between two groups' logs
+	int32_t *sys_park;         // [group][slot][E/F arrays][64 lanes][4]: registers of a wave's slot that is not the one it works on
+	int64_t sys_park_stride;   // ints between two groups' parking areas
+	int64_t *sys_ep;           // [group][epochs][2]: traceback layout per epoch of 256 penalties: base offset, first chunk | chunks << 32
+	int64_t sys_ep_stride;     // int64 words between two groups' tables
 };
 
 // launch wrappers implemented in mwf_kernels.hip (generic kernel: any penalties, any band, low-memory mode)
@@ -125,6 +138,15 @@ int  launch_coop_pass(const BatchArgs &a, int grid, void *stream);       // forw
 int  launch_coop_walk(const BatchArgs &a, void *stream);                 // checkpoints from the traceback matrix
 int  launch_coop_trace(const BatchArgs &a, void *stream);                // checkpoints from the snapshots of a provenance pass
 int  launch_coop_finish(const BatchArgs &a, void *stream);               // traceback + per-pair outputs
+// launch wrappers implemented in mwf_sys.hip (the systolic whole-device kernel: same penalties as mwf_coop.hip, every pass but
+// the provenance pass of the two-pass low-memory mode)
+int64_t sys_chunk_slots(int grid);                   // chunk slots a launch of `grid` workgroups holds
+int  sys_owned_cols(int p);                          // columns a chunk slot owns: 256 - 2p
+int64_t sys_box_ints(int p);                         // ints of one hand-off box
+int  sys_max_grid();                                 // co-resident workgroups the kernel may be launched with (one per CU)
+int  launch_sys_pass(const BatchArgs &a, int grid, void *stream);        // forward pass (score / traceback bytes / second pass with band resets)
+int  launch_sys_walk(const BatchArgs &a, void *stream);                  // checkpoints from the traceback matrix of a first pass
+int  launch_sys_finish(const BatchArgs &a, void *stream);                // traceback + per-pair outputs
 
 bool band_supported(const Penalty &p);                       // (e1,e2) instantiated and every H lag >= 2
 // launch wrappers implemented in mwf_band2.hip (packed band kernel: 16-bit offsets, sequences in LDS; BandGeom::packed)

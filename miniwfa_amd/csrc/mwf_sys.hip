@@ -1,0 +1,889 @@
+// mwf_sys.hip — one sequence pair across the whole device, systolic form (BASELINE configs 2 and 4: a 150 kb pair, a 5 Mb pair).
+//
+// A single pair is a strictly sequential chain of penalties (reference miniwfa.c:397-426); the only parallelism is across the
+// diagonals of one wavefront, and the only dependence of lag 1 is E2/F2 of the neighbouring diagonal.  mwf_coop.hip exchanged
+// the outer columns of every 256-column chunk between neighbouring waves at EVERY penalty and polled the fate of the two edge
+// columns at every penalty: 5-6 us per penalty, whatever the window, because a penalty costs two dependent cross-CU round trips.
+// Here the exchange happens once per block of P penalties (P = 8):
+//   * a chunk slot computes 256 columns but owns only the inner 256 - 2P; the P columns on either side are a halo that
+//     duplicates the neighbours' outer columns.  After the hand-off every column of the slot is exact; each penalty computed
+//     without one loses one column per side (a cell reads columns c-1, c, c+1 of older wavefronts), so after P penalties exactly
+//     the owned columns are still exact — nothing is masked, the garbage in the halo simply never reaches an owned column;
+//   * every slot has a PRIVATE ring of H rows ([nH][256], halo included) and keeps E/F in registers: between hand-offs a wave
+//     talks to nobody — no granule waits, no flag polls, no workgroup barrier; waves of one workgroup drift freely;
+//   * at the end of a block a slot publishes what its two neighbours' halos must become — H of its outer P owned columns for
+//     the block's P penalties (stored as it goes), their E/F registers, and its view of the window edges — with write-through
+//     stores, then a progress word; it then waits for both neighbours' progress words and refreshes its own halo;
+//   * the window (reference wf_lo/wf_hi, grown by the liveness of the edge cells, miniwfa.c:417-418, :325-326) is tracked by
+//     every slot for itself: the slot that OWNS an edge column computes its liveness exactly and logs the new edge; a slot whose
+//     valid columns do not contain the edge cannot be affected by it within the block; at the hand-off the exact chain of the
+//     block's edges is re-derived from the owners' published values (see refresh());
+//   * everything global happens once per EPOCH of 256 penalties, where the reference shrinks the band (miniwfa.c:144-171) and a
+//     device-wide barrier is needed anyway: which slots take part in the next epoch (the window can grow by at most one column
+//     per penalty and side), the end cell / stop rules (acted upon at the epoch's end: at most 255 surplus penalties), n_iter
+//     (from the edge log), the traceback layout.
+// Traceback bytes are laid out per epoch and slot (256 bytes per slot and penalty, dev::tb_byte); the second pass of the
+// low-memory mode collapses the window at its checkpoints exactly as the reference does (miniwfa.c:413-416) — every slot
+// knows the checkpoints in advance.  The provenance pass of the two-pass low-memory mode stays in mwf_coop.hip.
+// Results are bit-identical to the other kernels (tests/test_gpu_parity.py, tests/test_long_pairs.py).
+#include "mwf_device.h"
+
+namespace mwf {
+
+using namespace dev;
+
+namespace {
+
+constexpr int kT = 512;          // threads per workgroup: 8 waves, up to 256 VGPRs each
+constexpr int kNW = kT / 64;
+constexpr int kK = 2;            // chunk slots per wave
+constexpr int kW = 256;          // columns a slot computes: 64 lanes x 4
+constexpr int kEpoch = 256;      // penalties between two band shrinks (reference miniwfa.c:429)
+constexpr int kMaxP = 16;
+
+__device__ __forceinline__ int32_t from_left(int32_t v, int32_t fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int32_t from_right(int32_t v, int32_t fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false); }
+
+__device__ __forceinline__ int32_t ld_ag(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_ag(int32_t *p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// hand-off payload: naturally aligned 8-byte words, write-through stores and L2-served loads (sc1) on both sides
+typedef unsigned long long u64;
+__device__ __forceinline__ u64 ld2_ag(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st2_ag(u64 *p, int32_t a, int32_t b) { __hip_atomic_store(p, (u64)(uint32_t)a | (u64)(uint32_t)b << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int32_t lo32(u64 v) { return (int32_t)(uint32_t)v; }
+__device__ __forceinline__ int32_t hi32(u64 v) { return (int32_t)(uint32_t)(v >> 32); }
+
+__device__ __forceinline__ uint32_t probe4g(const PairMem &M, int32_t j, int32_t i)
+{
+	uint32_t a, b;
+	__builtin_memcpy(&a, M.ts + j, 4);
+	__builtin_memcpy(&b, M.qs + i, 4);
+	return a ^ b;
+}
+
+__device__ __forceinline__ uint32_t inm_bit(int32_t d, int32_t k, int32_t tl, int32_t ql)
+{
+	return (uint32_t)((uint32_t)(k + 1) < (uint32_t)(tl + 1)) & (uint32_t)((uint32_t)(d + k + 1) < (uint32_t)(ql + 1));
+}
+
+__device__ __forceinline__ int32_t pick4(int32_t i, int32_t a0, int32_t a1, int32_t a2, int32_t a3)
+{
+	return i == 0 ? a0 : i == 1 ? a1 : i == 2 ? a2 : a3;
+}
+
+// The whole wave walks one diagonal: t[j+n..] vs q[i+n..], up to `room` bytes, starting after n0 matched bytes.
+// Every argument is wave-uniform; returns the total number of matching bytes (<= room).
+__device__ __forceinline__ int32_t lcp_wave(const PairMem &M, int32_t j, int32_t i, int32_t room, int32_t n0)
+{
+	const int32_t lane = threadIdx.x & 63;
+	int32_t n = n0;
+	while (n < room) {
+		const int32_t off = n + 4 * lane;
+		int32_t m = 0;
+		if (off < room) {
+			const uint32_t x = probe4g(M, j + off, i + off);
+			m = min(x ? (int32_t)(__builtin_ctz(x) >> 3) : 4, room - off);
+		}
+		const unsigned long long stop = __ballot(m < 4); // lanes beyond `room` have m == 0 and stop the scan too
+		if (stop == 0) { n += 256; continue; }
+		const int32_t first = (int32_t)__builtin_ctzll(stop);
+		n += 4 * first + __builtin_amdgcn_readlane(m, first);
+		break;
+	}
+	return min(n, room);
+}
+
+// per slot, in LDS (a wave works on one slot at a time; the other one's registers are parked in HBM, see make_resident)
+struct SlotVars {
+	int32_t g;          // chunk the slot holds in this epoch
+	int32_t part;       // takes part in this epoch
+	int32_t fresh;      // has just joined: nothing live, registers start dead
+	int32_t wl, wh;     // the slot's view of wf_lo / wf_hi
+	int32_t fin_seen;
+	int32_t pad[2];
+};
+
+struct SysLds {
+	int32_t word[8];
+	int32_t red[2];
+	SlotVars sv[kNW * kK];
+	int2 hist[kNW * kK][kMaxRing];     // per slot and H ring row: the slot's view {lo, hi} of that slice's window, clamped to its columns
+	int32_t mywl[kNW * kK][kMaxP], mywh[kNW * kK][kMaxP]; // per slot: its view of wf_lo / wf_hi after every penalty of the current block
+};
+
+// Device-wide barrier of this pair's group of workgroups, with a release/acquire pair for data written with ordinary
+// stores (counters on two levels: workgroups with the same index mod 8 share a word; see mwf_coop.hip grid_sync).
+__device__ __forceinline__ bool sys_grid_sync(uint32_t spin_limit, unsigned *sync, int32_t *abort_flag, unsigned lb, SysLds &L, unsigned &epoch, unsigned n_wg)
+{
+	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+	__syncthreads();
+	++epoch;
+	if (threadIdx.x == 0) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		unsigned long long *const top = (unsigned long long*)sync;                        // [0]
+		unsigned *const grp_cnt = sync + 16;                                               // [16 + 8*g]
+		unsigned long long *const grp_gen = (unsigned long long*)(sync + 96);              // [96 + 8*g] (8-byte aligned)
+		const unsigned grp = lb & 7u, n_grp = n_wg < 8u ? n_wg : 8u;
+		const unsigned gsize = (n_wg - grp + 7u) / 8u;
+		unsigned spins = 0;
+		int32_t ok = 1;
+		unsigned long long seen = 0;
+		const unsigned old = __hip_atomic_fetch_add(&grp_cnt[8 * grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (old + 1 == gsize * epoch) {
+			(void)__hip_atomic_fetch_add(top, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			for (;;) {
+				seen = __hip_atomic_load(top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if ((unsigned)(seen & 0xffffffffu) >= n_grp * epoch) break;
+				__builtin_amdgcn_s_sleep(1);
+				if (++spins > spin_limit || ((spins & 255u) == 0 && ld_ag(abort_flag))) { ok = 0; break; }
+			}
+			__hip_atomic_store(&grp_gen[4 * grp], (unsigned long long)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		} else {
+			for (;;) {
+				seen = __hip_atomic_load(&grp_gen[4 * grp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if ((unsigned)(seen & 0xffffffffu) >= epoch) break;
+				__builtin_amdgcn_s_sleep(1);
+				if (++spins > spin_limit || ((spins & 255u) == 0 && ld_ag(abort_flag))) { ok = 0; break; }
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+		if (!ok) st_ag(abort_flag, 1); // whoever gives up first releases everybody else at once
+		L.word[3] = ok;
+	}
+	__syncthreads();
+	return uni(L.word[3]) != 0;
+}
+
+// Checkpoints the second pass really applies: the reference looks at ONE checkpoint per penalty, `seg[sid].s == s` (miniwfa.c:413),
+// so a checkpoint whose penalty is not above its predecessor's (tiny steps: several snapshots can map to one cell) is never
+// reached and blocks every later one — the applied ones are the strictly increasing prefix.
+__device__ __forceinline__ int32_t seg_effective(const int32_t *seg, int32_t n_seg)
+{
+	if (n_seg < 2) return n_seg;
+	int32_t j = 1;
+	while (j < n_seg && seg[2 * j] > seg[2 * (j - 1)]) ++j;
+	return uni(j);
+}
+
+__device__ __forceinline__ int32_t floordiv(int32_t a, int32_t b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+
+// grp / lb / G: this pair's group of workgroups, this workgroup's index in it, the group's size
+template <int E1, int E2, bool TB, int P>
+__device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, int32_t n_seg, int32_t grp, int32_t lb, int32_t G)
+{
+	constexpr int PL = P / 4;                 // halo lanes per side
+	constexpr int OW = kW - 2 * P;            // columns a slot owns
+	constexpr int NEF = 2 * E1 + 2 * E2;      // E/F register arrays per column
+	constexpr int LANE_D2 = (P + NEF) * 2;    // 8-byte words one outer lane publishes per block
+	constexpr int WIN_OFF = 2 * PL * LANE_D2 * 2; // ints in front of a box's window views
+	constexpr int BOX_INTS = (WIN_OFF + 2 * P + 31) / 32 * 32;
+	constexpr int NBLK = kEpoch / P;
+	static_assert(P == 4 || P == 8 || P == 16, "block length");
+	const int32_t NWt = G * kNW, TC = NWt * kK;
+	const int32_t tl = M.tl, ql = M.ql, cmax = tl + ql + 1;
+	const int32_t tid = threadIdx.x, lane = tid & 63, wv = uni(tid >> 6), gw = uni(lb * kNW + wv);
+	const bool lead = lb == 0 && tid == 0;
+	char *const misc = (char*)A.coop_flags + (int64_t)grp * A.coop_misc_stride; // this group's flags | barrier words | pass state
+	unsigned *const sync = (unsigned*)(misc + 1024);
+	int32_t *const gflags = (int32_t*)misc;   // [12]: origin offset; [13..14] and [17..18]: shrink reduction (two parities); [15]: abort; [20..21]: end cell (penalty, last state)
+	const int32_t nH = A.pen.nH, lagx = A.pen.x, lag1 = A.pen.oe1, lag2 = A.pen.oe2;
+	const uint32_t spin_limit = A.coop_spin_limit;
+	const bool lag_one = min(lagx, min(lag1, lag2)) < 2; // a row this penalty writes is read at the next one: no loads ahead of the store
+	int32_t *const ring = M.H;                                   // [slot][nH][256]
+	int32_t *const box = A.sys_box + (int64_t)grp * A.sys_box_stride;
+	u64 *const prog = A.sys_prog + (int64_t)grp * A.sys_prog_stride;
+	int32_t *const logL = A.sys_log + (int64_t)grp * A.sys_log_stride, *const logH = logL + A.sys_log_stride / 2;
+	int32_t *const park = A.sys_park + (int64_t)grp * A.sys_park_stride;    // [slot][NEF][64 lanes][4]
+	PassResult R;
+	R.status = ST_OK, R.s = 0, R.info = 0, R.n_snap = 0, R.cells = 0;
+	unsigned epoch = 0; // the host zeroes the barrier words before every pass
+
+	// E/F wavefronts of the RESIDENT slot (four columns per lane; age 0 is the previous penalty) and its prefetched H rows
+	int32_t e1h[E1][4], f1h[E1][4], e2h[E2][4], f2h[E2][4];
+	int4 phx, po1, po2;
+	int32_t res = -1; // slot of this wave whose E/F are in the registers
+	auto set_dead = [&]() {
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+#pragma unroll
+			for (int a = 0; a < E1; ++a) e1h[a][i] = f1h[a][i] = kNegInf;
+#pragma unroll
+			for (int a = 0; a < E2; ++a) e2h[a][i] = f2h[a][i] = kNegInf;
+		}
+	};
+	set_dead();
+	// A wave holds up to kK slots but works on one at a time, a whole block of penalties each: the other slot's registers rest
+	// in HBM (six 16-byte words per lane; only waves whose two slots are both inside the window ever swap)
+	auto park_ptr = [&](int32_t r, int32_t a) -> int4* { return (int4*)(park + (((int64_t)r * NEF + a) * 64 + lane) * 4); };
+	auto make_resident = [&](int32_t k) {
+		if (res == k) return;
+		if (res >= 0 && uni(L.sv[wv * kK + res].part)) {
+			const int32_t r = gw + NWt * res;
+			int a = 0;
+#pragma unroll
+			for (int q = 0; q < E1; ++q, ++a) *park_ptr(r, a) = make_int4(e1h[q][0], e1h[q][1], e1h[q][2], e1h[q][3]);
+#pragma unroll
+			for (int q = 0; q < E1; ++q, ++a) *park_ptr(r, a) = make_int4(f1h[q][0], f1h[q][1], f1h[q][2], f1h[q][3]);
+#pragma unroll
+			for (int q = 0; q < E2; ++q, ++a) *park_ptr(r, a) = make_int4(e2h[q][0], e2h[q][1], e2h[q][2], e2h[q][3]);
+#pragma unroll
+			for (int q = 0; q < E2; ++q, ++a) *park_ptr(r, a) = make_int4(f2h[q][0], f2h[q][1], f2h[q][2], f2h[q][3]);
+		}
+		res = k;
+		if (uni(L.sv[wv * kK + k].fresh)) {
+			set_dead();
+			if (lane == 0) L.sv[wv * kK + k].fresh = 0;
+			return;
+		}
+		const int32_t r = gw + NWt * k;
+		int a = 0;
+		int4 v;
+#pragma unroll
+		for (int q = 0; q < E1; ++q, ++a) v = *park_ptr(r, a), e1h[q][0] = v.x, e1h[q][1] = v.y, e1h[q][2] = v.z, e1h[q][3] = v.w;
+#pragma unroll
+		for (int q = 0; q < E1; ++q, ++a) v = *park_ptr(r, a), f1h[q][0] = v.x, f1h[q][1] = v.y, f1h[q][2] = v.z, f1h[q][3] = v.w;
+#pragma unroll
+		for (int q = 0; q < E2; ++q, ++a) v = *park_ptr(r, a), e2h[q][0] = v.x, e2h[q][1] = v.y, e2h[q][2] = v.z, e2h[q][3] = v.w;
+#pragma unroll
+		for (int q = 0; q < E2; ++q, ++a) v = *park_ptr(r, a), f2h[q][0] = v.x, f2h[q][1] = v.y, f2h[q][2] = v.z, f2h[q][3] = v.w;
+	};
+
+	// ---- penalty 0: origin and its extension (the first wave of workgroup 0 walks it cooperatively)
+	if (lb == 0 && tid < 64) {
+		const int32_t k0 = lcp_wave(M, 0, 0, min(tl, ql), 0) - 1;
+		if (tid == 0) st_ag(&gflags[12], k0), st_ag(&logL[0], tl + 1), st_ag(&logH[0], tl + 1);
+	}
+	if (lead) st_ag(&gflags[13], 0x7fffffff), st_ag(&gflags[14], -1), st_ag(&gflags[17], 0x7fffffff), st_ag(&gflags[18], -1), st_ag(&gflags[20], 0x7fffffff);
+	if (lane < kK) {
+		SlotVars z;
+		z.g = -1, z.part = 0, z.fresh = 1, z.wl = z.wh = 0, z.fin_seen = 0, z.pad[0] = z.pad[1] = 0;
+		L.sv[wv * kK + lane] = z;
+	}
+	if (!sys_grid_sync(spin_limit, sync, &gflags[15], (unsigned)lb, L, epoch, G)) { R.status = ST_INTERNAL; return R; }
+	const int32_t k0 = uni(ld_ag(&gflags[12]));
+	if (k0 == tl - 1 && k0 == ql - 1) return R;
+
+	int32_t s = 0, wf_lo = tl + 1, wf_hi = tl + 1;
+	if (TB) n_seg = seg_effective(M.seg, n_seg);
+	int32_t sid = 0, sid_blk = 0;
+	int32_t seg_s = TB && n_seg > 0 ? uni(M.seg[0]) : -1, seg_c = TB && n_seg > 0 ? uni(M.seg[1]) : 0; // the next checkpoint
+	int64_t cells = 0, tb_used = 0;
+	int32_t pgA = 1, pgB = 0; // chunks that took part in the previous epoch
+	const int32_t cfin = ql + 1; // the end cell (tl-1, ql-1) lies on diagonal ql-tl, i.e. in this column
+	const int32_t gmax = cmax / OW;
+
+	auto row_ptr = [&](int32_t r, int32_t j) -> int32_t* { return ring + (((int64_t)r * nH + j) * kW + 4 * lane); };
+	auto prefetch = [&](int32_t r, int32_t slotH) { // the three H rows the penalty that writes ring row slotH reads
+		int32_t jx = slotH - lagx; if (jx < 0) jx += nH;
+		int32_t j1 = slotH - lag1; if (j1 < 0) j1 += nH;
+		int32_t j2 = slotH - lag2; if (j2 < 0) j2 += nH;
+		phx = *(const int4*)row_ptr(r, jx);
+		po1 = *(const int4*)row_ptr(r, j1);
+		po2 = *(const int4*)row_ptr(r, j2);
+	};
+
+	for (;;) { // ---- one epoch: penalties s+1 .. s+256
+		const int32_t ep = s >> 8;
+		// chunks that take part: their owned columns meet [wf_lo - 257 - P, wf_hi + 257 + P]; then the chunk beyond the outermost
+		// one — which does not take part — holds no column the window can reach before the next shrink, and neither do the
+		// outermost chunk's own outer P columns (that chunk's halo): a chunk that joins later starts from nothing
+		const int32_t gA = max(0, floordiv(wf_lo - (kEpoch + 1 + P), OW)), gB = min(gmax, (wf_hi + kEpoch + 1 + P) / OW);
+		const int32_t n_ep = gB - gA + 1;
+		if (n_ep > TC - 1) { R.status = ST_BAND_OVERFLOW; break; }
+		if (s + 1 > A.rows_slot) { R.status = ST_ROWS_OVERFLOW; break; } // (the log and the epoch table hold rows_slot + 256 penalties)
+		const int64_t ep_base = tb_used;
+		if (TB) {
+			if (tb_used + (int64_t)kEpoch * n_ep * kW > A.tb_slot_bytes) { R.status = ST_TB_OVERFLOW; break; }
+			if (lead) {
+				int64_t *const ept = A.sys_ep + (int64_t)grp * A.sys_ep_stride;
+				ept[2 * ep] = ep_base, ept[2 * ep + 1] = (int64_t)(uint32_t)gA | (int64_t)n_ep << 32;
+			}
+			tb_used += (int64_t)kEpoch * n_ep * kW;
+		}
+		const int32_t gbase = gA - gA % TC;
+		int32_t n_mine = 0;
+#pragma unroll 1
+		for (int32_t k = 0; k < kK; ++k) {
+			const int32_t r = gw + NWt * k, sl = wv * kK + k;
+			int32_t g = gbase + r;
+			if (g < gA) g += TC;
+			const bool now = g <= gB;
+			const bool kept = now && uni(L.sv[sl].part) && uni(L.sv[sl].g) == g;
+			n_mine += now ? 1 : 0;
+			if (now && !kept) { // joins: no live history
+				if (res == k) res = -1; // (whatever the registers hold is some other chunk's)
+				const int32_t cb = g * OW - P;
+				for (int32_t j = lane; j < nH; j += 64) L.hist[sl][j] = make_int2(cb + kW, cb - 1);
+				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+				if (s == 0) { // the origin (reference wf_stripe_init, miniwfa.c:103-121)
+					const int32_t c0 = tl + 1;
+					if (lane == 0) L.hist[sl][0] = make_int2(min(max(c0, cb), cb + kW), max(min(c0, cb + kW - 1), cb - 1));
+					if ((uint32_t)(c0 - cb) < (uint32_t)kW && lane == ((c0 - cb) >> 2)) ring[((int64_t)r * nH + 0) * kW + (c0 - cb)] = k0;
+				}
+			}
+			if (!now && res == k) res = -1;
+			if (lane == 0) {
+				SlotVars z;
+				z.g = g, z.part = now ? 1 : 0, z.fresh = (now && !kept) ? 1 : (kept ? L.sv[sl].fresh : 1), z.wl = wf_lo, z.wh = wf_hi, z.fin_seen = 0, z.pad[0] = z.pad[1] = 0;
+				L.sv[sl] = z;
+			}
+		}
+		asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+		int32_t curH = s % nH;
+		if (n_mine == 0) { // nothing of this wave is near the window: straight to the epoch's end
+			s += kEpoch;
+			if (TB) while (seg_s >= 0 && seg_s < s) { ++sid; seg_s = sid < n_seg ? uni(M.seg[2 * sid]) : -1, seg_c = sid < n_seg ? uni(M.seg[2 * sid + 1]) : 0; }
+		} else
+		for (int blk = 0; blk < NBLK; ++blk) {
+			const int32_t s0 = s;                        // penalties s0+1 .. s0+P
+			const int64_t B = (int64_t)(s0 / P);         // block number since the start of the pass
+			const int32_t sid0 = sid, seg_s0 = seg_s, seg_c0 = seg_c;
+			// Slots are visited in the order that needs no swap at the start: the resident one first.
+			const int32_t kfirst = res >= 0 ? res : 0;
+#pragma unroll 1
+			for (int32_t kk = 0; kk < kK; ++kk) {
+				const int32_t k = kK == 1 ? 0 : (kk == 0 ? kfirst : (kfirst + kk) % kK);
+				const int32_t sl = wv * kK + k;
+				if (!uni(L.sv[sl].part)) continue;
+				const int32_t r = gw + NWt * k, g = uni(L.sv[sl].g), cb = g * OW - P, c0 = cb + 4 * lane;
+				const int32_t oL = cb + P, oR = cb + kW - 1 - P;
+				const bool nbl = g - 1 >= gA, nbr = g + 1 <= gB;
+				make_resident(k);
+				int32_t wl = uni(L.sv[sl].wl), wh = uni(L.sv[sl].wh);
+				// ---- hand-off: the halo becomes what the neighbours computed (nothing to fetch before the first block)
+				if (s0 > 0) {
+					const int32_t rl = r == 0 ? TC - 1 : r - 1, rr = r + 1 == TC ? 0 : r + 1;
+					// a neighbour has something to say if it took part in the block before: within an epoch, if it takes part in this
+					// epoch; at an epoch's first block, if it took part in the previous epoch — whether or not it still does (what it
+					// left in its outer columns is history this slot may still read); a neighbour that has only just joined has nothing
+					const bool hl = blk > 0 ? nbl : (g - 1 >= pgA && g - 1 <= pgB);
+					const bool hr = blk > 0 ? nbr : (g + 1 >= pgA && g + 1 <= pgB);
+					const bool me = blk > 0 || (g >= pgA && g <= pgB);
+					for (unsigned spins = 0;; ++spins) { // wait for the neighbours' block B-1
+						bool late = false;
+						if (lane == 0 && hl) late = ld2_ag(prog + (int64_t)rl * 8) < (u64)B;
+						if (lane == 1 && hr) late = ld2_ag(prog + (int64_t)rr * 8) < (u64)B;
+						if (!__ballot(late)) break;
+						if (spins > spin_limit || ((spins & 255u) == 255u && uni(ld_ag(&gflags[15])))) {
+							if (lane == 0) L.red[0] = 1, st_ag(&gflags[15], 1);
+							break;
+						}
+						__builtin_amdgcn_s_sleep(1);
+					}
+					const int32_t par = (int32_t)((B - 1) & 1);
+					const int32_t *const bl = box + ((int64_t)rl * 2 + par) * BOX_INTS, *const br = box + ((int64_t)rr * 2 + par) * BOX_INTS;
+					// halo lanes: H rows of the last P penalties and the E/F registers from the neighbour's outer lanes
+					const bool hal = lane < PL, har = lane >= 64 - PL;
+					if ((hal && hl) || (har && hr)) {
+						// left halo lane l <- left neighbour's right outer lane l (side 1); right halo lane 64-PL+l <- right neighbour's left outer lane l (side 0)
+						const int32_t l = hal ? lane : lane - (64 - PL);
+						const u64 *src = (const u64*)(hal ? bl : br) + ((hal ? PL : 0) + l) * LANE_D2;
+						{
+							u64 v[2 * P];
+#pragma unroll
+							for (int q = 0; q < 2 * P; ++q) v[q] = ld2_ag(src + q);
+							int32_t j = (s0 - P + 1) % nH;
+#pragma unroll
+							for (int t = 0; t < P; ++t) {
+								*(int4*)row_ptr(r, j) = make_int4(lo32(v[2 * t]), hi32(v[2 * t]), lo32(v[2 * t + 1]), hi32(v[2 * t + 1]));
+								j = j + 1 == nH ? 0 : j + 1;
+							}
+						}
+						u64 v[2 * NEF];
+#pragma unroll
+						for (int q = 0; q < 2 * NEF; ++q) v[q] = ld2_ag(src + 2 * P + q);
+						int q = 0;
+#pragma unroll
+						for (int a = 0; a < E1; ++a, q += 2) e1h[a][0] = lo32(v[q]), e1h[a][1] = hi32(v[q]), e1h[a][2] = lo32(v[q + 1]), e1h[a][3] = hi32(v[q + 1]);
+#pragma unroll
+						for (int a = 0; a < E1; ++a, q += 2) f1h[a][0] = lo32(v[q]), f1h[a][1] = hi32(v[q]), f1h[a][2] = lo32(v[q + 1]), f1h[a][3] = hi32(v[q + 1]);
+#pragma unroll
+						for (int a = 0; a < E2; ++a, q += 2) e2h[a][0] = lo32(v[q]), e2h[a][1] = hi32(v[q]), e2h[a][2] = lo32(v[q + 1]), e2h[a][3] = hi32(v[q + 1]);
+#pragma unroll
+						for (int a = 0; a < E2; ++a, q += 2) f2h[a][0] = lo32(v[q]), f2h[a][1] = hi32(v[q]), f2h[a][2] = lo32(v[q + 1]), f2h[a][3] = hi32(v[q + 1]);
+					} else if ((hal || har) && me) {
+						// no neighbour on that side (it does not take part, or has just joined): nothing there was ever inside the window
+						// (its H rows are masked by the window views below: the window never reached those columns)
+						set_dead();
+					}
+					// The window edges of the last block, exactly.  wf_lo after a penalty is decided by the liveness of the cell in the
+					// edge column lo (miniwfa.c:325-326), which the slot that OWNS that column computed exactly; so: start from this
+					// slot's view at the start of that block (exact wherever it matters to this slot, by induction), and for every
+					// penalty take the new wf_lo from whoever owned the edge column — this slot, or the neighbour on that side.
+					if (me) {
+						// lanes 0..P-1: own wl of penalty i, P..2P-1: own wh; the neighbours' from their boxes
+						int32_t mine = 0, left = 0, right = 0;
+						if (lane < P) mine = L.mywl[sl][lane];
+						else if (lane < 2 * P) mine = L.mywh[sl][lane - P];
+						if (lane < 2 * P) {
+							if (hl) left = ld_ag(bl + WIN_OFF + lane);
+							if (hr) right = ld_ag(br + WIN_OFF + lane);
+						}
+						int32_t j = (s0 - P + 1) % nH;
+						const int2 h0 = L.hist[sl][j];
+						int32_t lo_i = uni(h0.x), hi_i = uni(h0.y);
+						int32_t cwl = 0, cwh = 0;
+						// second pass: checkpoints not yet consumed when the last block began (the one that collapsed the window before
+						// that block's first penalty is in hist already)
+						int32_t cs = sid_blk;
+						if (TB && cs < n_seg && uni(M.seg[2 * cs]) == s0 - P) ++cs;
+#pragma unroll
+						for (int i = 0; i < P; ++i) {
+							// the penalty s0-P+1+i had window [lo_i, hi_i] (this slot's view; exact if inside its columns)
+							if (lane == 0) L.hist[sl][j] = make_int2(min(max(lo_i, cb), cb + kW), max(min(hi_i, cb + kW - 1), cb - 1));
+							j = j + 1 == nH ? 0 : j + 1;
+							const int32_t mwl = __builtin_amdgcn_readlane(mine, i), mwh = __builtin_amdgcn_readlane(mine, P + i);
+							const int32_t lwl = __builtin_amdgcn_readlane(left, i), lwh = __builtin_amdgcn_readlane(left, P + i);
+							const int32_t rwl = __builtin_amdgcn_readlane(right, i), rwh = __builtin_amdgcn_readlane(right, P + i);
+							// the owner's wf_lo is taken verbatim, so the floor (lo == 1 for wf_lo == 1 and 2) never has to be inverted
+							if (lo_i >= oL && lo_i <= oR) cwl = mwl;
+							else if (lo_i < oL) cwl = hl ? lwl : lo_i + 1;     // (no neighbour: the edge cell there is dead, wf_lo stays)
+							else cwl = hr ? rwl : lo_i + 1;
+							if (hi_i >= oL && hi_i <= oR) cwh = mwh;
+							else if (hi_i > oR) cwh = hr ? rwh : hi_i - 1;
+							else cwh = hl ? lwh : hi_i - 1;
+							if (TB && cs < n_seg && uni(M.seg[2 * cs]) == s0 - P + 1 + i) cwl = cwh = uni(M.seg[2 * cs + 1]), ++cs; // miniwfa.c:413-416
+							lo_i = cwl > 1 ? cwl - 1 : 1, hi_i = cwh < cmax ? cwh + 1 : cmax;
+						}
+						if (blk > 0) wl = cwl, wh = cwh; // (an epoch's first block starts from the shrunk band, known to everybody)
+					}
+					asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+				}
+
+				// ---- P penalties without talking to anybody
+				int32_t curHk = curH;
+				sid = sid0, seg_s = seg_s0, seg_c = seg_c0; // (every slot of the wave walks the same penalties)
+				if (!lag_one) prefetch(r, curHk + 1 == nH ? 0 : curHk + 1);
+				const int32_t par = (int32_t)(B & 1);
+				const bool own_fin = (uint32_t)(cfin - (cb + P)) < (uint32_t)OW; // this slot owns the end diagonal
+				bool fin_seen = uni(L.sv[sl].fin_seen) != 0;
+				const unsigned long long owned_lanes = (~0ull >> PL) & (~0ull << PL);
+#pragma unroll 1
+				for (int t = 0; t < P; ++t) {
+					const int32_t sc = s0 + t; // penalties done so far
+					if (TB && seg_s == sc) { // checkpoint reset of the second pass (miniwfa.c:413-416): every slot knows the checkpoints
+						wl = wh = seg_c;
+						++sid;
+						seg_s = sid < n_seg ? uni(M.seg[2 * sid]) : -1, seg_c = sid < n_seg ? uni(M.seg[2 * sid + 1]) : 0;
+					}
+					const int32_t s_new = sc + 1;
+					const int32_t newH = curHk + 1 == nH ? 0 : curHk + 1;
+					const int32_t nextH = newH + 1 == nH ? 0 : newH + 1;
+					int32_t jx = newH - lagx; if (jx < 0) jx += nH;
+					int32_t j1 = newH - lag1; if (j1 < 0) j1 += nH;
+					int32_t j2 = newH - lag2; if (j2 < 0) j2 += nH;
+					const bool track_good = (((256 - (s_new & 255)) & 255) < nH);
+					const int32_t lo = wl > 1 ? wl - 1 : 1;       // miniwfa.c:417-418, on this slot's view
+					const int32_t hi = wh < cmax ? wh + 1 : cmax;
+					if (lag_one) prefetch(r, newH);
+					const int2 wx = L.hist[sl][jx], w1 = L.hist[sl][j1], w2 = L.hist[sl][j2];
+					if (lane == 0) L.hist[sl][newH] = make_int2(min(max(lo, cb), cb + kW), max(min(hi, cb + kW - 1), cb - 1));
+					const int32_t xlo = uni(wx.x), xhi = uni(wx.y), alo = uni(w1.x), ahi = uni(w1.y), blo = uni(w2.x), bhi = uni(w2.y);
+					// every column of the slot inside the window and inside every source window: no masks
+					const bool inner = max(max(lo, xlo), max(alo, blo)) <= cb && min(min(hi, xhi), min(ahi, bhi)) >= cb + kW - 1;
+					int32_t hx[4] = {phx.x, phx.y, phx.z, phx.w};
+					int32_t o1[6], o2[6];
+					o1[1] = po1.x, o1[2] = po1.y, o1[3] = po1.z, o1[4] = po1.w;
+					o2[1] = po2.x, o2[2] = po2.y, o2[3] = po2.z, o2[4] = po2.w;
+					if (!inner) { // reads outside a source window yield "dead" (what the reference's pads supply, miniwfa.c:96-99)
+#pragma unroll
+						for (int i = 0; i < 4; ++i) {
+							const int32_t c = c0 + i;
+							hx[i] = ((c >= xlo) & (c <= xhi)) ? hx[i] : kNegInf;
+							o1[i + 1] = ((c >= alo) & (c <= ahi)) ? o1[i + 1] : kNegInf;
+							o2[i + 1] = ((c >= blo) & (c <= bhi)) ? o2[i + 1] : kNegInf;
+						}
+					}
+					// the columns next to the slot's 256 are nobody's business: its outermost columns are never exact anyway
+					o1[0] = from_left(o1[4], kNegInf), o1[5] = from_right(o1[1], kNegInf);
+					o2[0] = from_left(o2[4], kNegInf), o2[5] = from_right(o2[1], kNegInf);
+					int32_t g1m[4], g1p[4], g2m[4], g2p[4];
+					g1m[0] = from_left(e1h[E1 - 1][3], kNegInf);
+					g2m[0] = from_left(e2h[E2 - 1][3], kNegInf);
+					g1p[3] = from_right(f1h[E1 - 1][0], kNegInf);
+					g2p[3] = from_right(f2h[E2 - 1][0], kNegInf);
+#pragma unroll
+					for (int i = 1; i < 4; ++i) g1m[i] = e1h[E1 - 1][i - 1], g2m[i] = e2h[E2 - 1][i - 1];
+#pragma unroll
+					for (int i = 0; i < 3; ++i) g1p[i] = f1h[E1 - 1][i + 1], g2p[i] = f2h[E2 - 1][i + 1];
+
+					int32_t hv[4], room[4], nmat[4], ne1[4], nf1[4], ne2[4], nf2[4];
+					uint32_t tbw = 0, pend = 0, live = 0, fin = 0, gbits = 0;
+#pragma unroll
+					for (int i = 0; i < 4; ++i) {
+						const int32_t c = c0 + i, d = c - 1 - tl;
+						const uint32_t act = inner ? 1u : (uint32_t)((c >= lo) & (c <= hi));
+						const Cell v = wf_cell<TB>(hx[i], o1[i], g1m[i], o2[i], g2m[i], o1[i + 2], g1p[i], o2[i + 2], g2p[i]);
+						ne1[i] = act ? v.e1 : kNegInf, nf1[i] = act ? v.f1 : kNegInf;
+						ne2[i] = act ? v.e2 : kNegInf, nf2[i] = act ? v.f2 : kNegInf;
+						const uint32_t inm = act & inm_bit(d, v.h, tl, ql);
+						if (track_good)
+							gbits |= (act & (inm | inm_bit(d, v.e1, tl, ql) | inm_bit(d, v.f1, tl, ql) | inm_bit(d, v.e2, tl, ql) | inm_bit(d, v.f2, tl, ql))) << i;
+						// edge rule (miniwfa.c:325-326): H is the max of the five, so "any live" == "H live"
+						const uint32_t lv = act & (uint32_t)(v.h >= -1);
+						live |= (lv & (uint32_t)(c == lo)) | ((lv & (uint32_t)(c == hi)) << 1);
+						const int32_t j = inm ? v.h + 1 : 0, q = inm ? d + v.h + 1 : 0;
+						room[i] = inm ? min(tl - j, ql - q) : 0;
+						const uint32_t x = probe4g(M, j, q);
+						nmat[i] = min(x ? (int32_t)(__builtin_ctz(x) >> 3) : 4, room[i]);
+						pend |= ((uint32_t)(x == 0) & (uint32_t)(room[i] > 4)) << i;
+						hv[i] = act ? v.h : kNegInf;
+						tbw |= v.tb << (8 * i);
+					}
+					// the next penalty's rows: requested now, so that they travel while the runs are walked
+					if (!lag_one && t + 1 < P) prefetch(r, nextH);
+					// a run of >= 4 matches continues: the wave walks it together, one owning lane and column at a time
+					unsigned long long owners = __ballot(pend != 0);
+					while (owners) {
+						const int32_t src = (int32_t)__builtin_ctzll(owners);
+						owners &= owners - 1;
+						uint32_t bits = (uint32_t)__builtin_amdgcn_readlane((int32_t)pend, src);
+						const int32_t c0s = cb + 4 * src;
+						while (bits) {
+							const int32_t ii = (int32_t)__builtin_ctz(bits);
+							bits &= bits - 1;
+							const int32_t hh = __builtin_amdgcn_readlane(pick4(ii, hv[0], hv[1], hv[2], hv[3]), src);
+							const int32_t rm = __builtin_amdgcn_readlane(pick4(ii, room[0], room[1], room[2], room[3]), src);
+							const int32_t j = hh + 1, q = c0s + ii - 1 - tl + j;
+							const int32_t n = lcp_wave(M, j, q, rm, 4);
+#pragma unroll
+							for (int i = 0; i < 4; ++i) nmat[i] = (ii == i && lane == src) ? n : nmat[i];
+						}
+					}
+					int32_t done_info = 0;
+#pragma unroll
+					for (int i = 0; i < 4; ++i) {
+						const int32_t d = c0 + i - 1 - tl;
+						const uint32_t in = inm_bit(d, hv[i], tl, ql); // (cells outside the window hold NEG_INF)
+						const int32_t kk2 = hv[i] + nmat[i];
+						if (own_fin) {
+							const uint32_t f = in & (uint32_t)(c0 + i == cfin) & (uint32_t)(kk2 == tl - 1) & (uint32_t)(d + kk2 == ql - 1);
+							fin |= f;
+							done_info = f ? (nmat[i] == 0 ? (int32_t)((tbw >> (8 * i)) & 7u) : 0) : done_info;
+						}
+						hv[i] = kk2;
+					}
+					*(int4*)row_ptr(r, newH) = make_int4(hv[0], hv[1], hv[2], hv[3]);
+					// the outer owned columns, for the neighbours' halos
+					{
+						const bool ol = lane >= PL && lane < 2 * PL, orr = lane >= 64 - 2 * PL && lane < 64 - PL;
+						if (ol || orr) {
+							u64 *dst = (u64*)(box + ((int64_t)r * 2 + par) * BOX_INTS) + ((orr ? PL : 0) + (ol ? lane - PL : lane - (64 - 2 * PL))) * LANE_D2 + 2 * t;
+							st2_ag(dst, hv[0], hv[1]), st2_ag(dst + 1, hv[2], hv[3]);
+						}
+					}
+					if (TB) *(uint32_t*)(M.tb + ep_base + ((int64_t)(s_new - 1 - (ep << 8)) * n_ep + (g - gA)) * kW + 4 * lane) = tbw;
+					if (track_good) {
+						unsigned long long *gword = M.good + ((int64_t)newH * TC + r) * 4;
+#pragma unroll
+						for (int i = 0; i < 4; ++i) {
+							const unsigned long long m = __ballot((gbits >> i) & 1u) & owned_lanes;
+							if (lane == 0) gword[i] = m;
+						}
+					}
+					if (own_fin && !fin_seen) {
+						const unsigned long long fm = __ballot(fin);
+						if (fm) {
+							fin_seen = true;
+							const int32_t info = __builtin_amdgcn_readlane(done_info, (int32_t)__builtin_ctzll(fm));
+							if (lane == 0) st_ag(&gflags[21], info), st_ag(&gflags[20], s_new), L.sv[sl].fin_seen = 1; // read after the epoch's barrier
+						}
+					}
+					// the slot's view of the window after this penalty: liveness of an edge cell counts where the cell is exact
+					{
+						const int32_t vl = cb + 1 + t, vr = cb + kW - 2 - t;
+						if (lo >= vl && lo <= vr && __ballot(live & 1u)) wl = lo;
+						if (hi >= vl && hi <= vr && __ballot(live & 2u)) wh = hi;
+						if (lane == 0) {
+							L.mywl[sl][t] = wl, L.mywh[sl][t] = wh;
+							if ((uint32_t)(lo - (cb + P)) < (uint32_t)OW) st_ag(&logL[s_new], wl);   // the owner of the edge column keeps the log
+							if ((uint32_t)(hi - (cb + P)) < (uint32_t)OW) st_ag(&logH[s_new], wh);
+						}
+					}
+#pragma unroll
+					for (int i = 0; i < 4; ++i) {
+#pragma unroll
+						for (int a = E1 - 1; a > 0; --a) e1h[a][i] = e1h[a - 1][i], f1h[a][i] = f1h[a - 1][i];
+#pragma unroll
+						for (int a = E2 - 1; a > 0; --a) e2h[a][i] = e2h[a - 1][i], f2h[a][i] = f2h[a - 1][i];
+						e1h[0][i] = ne1[i], f1h[0][i] = nf1[i], e2h[0][i] = ne2[i], f2h[0][i] = nf2[i];
+					}
+					if (lag_one) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+					curHk = newH;
+				}
+
+				// ---- publish: E/F of the outer owned columns, the window views of the block, then the progress word
+				{
+					int32_t *const bx = box + ((int64_t)r * 2 + par) * BOX_INTS;
+					const bool ol = lane >= PL && lane < 2 * PL, orr = lane >= 64 - 2 * PL && lane < 64 - PL;
+					if (ol || orr) {
+						u64 *dst = (u64*)bx + ((orr ? PL : 0) + (ol ? lane - PL : lane - (64 - 2 * PL))) * LANE_D2 + 2 * P;
+#pragma unroll
+						for (int a = 0; a < E1; ++a, dst += 2) st2_ag(dst, e1h[a][0], e1h[a][1]), st2_ag(dst + 1, e1h[a][2], e1h[a][3]);
+#pragma unroll
+						for (int a = 0; a < E1; ++a, dst += 2) st2_ag(dst, f1h[a][0], f1h[a][1]), st2_ag(dst + 1, f1h[a][2], f1h[a][3]);
+#pragma unroll
+						for (int a = 0; a < E2; ++a, dst += 2) st2_ag(dst, e2h[a][0], e2h[a][1]), st2_ag(dst + 1, e2h[a][2], e2h[a][3]);
+#pragma unroll
+						for (int a = 0; a < E2; ++a, dst += 2) st2_ag(dst, f2h[a][0], f2h[a][1]), st2_ag(dst + 1, f2h[a][2], f2h[a][3]);
+					}
+					if (lane < 2 * P) st_ag(bx + WIN_OFF + lane, lane < P ? L.mywl[sl][lane] : L.mywh[sl][lane - P]);
+					if (lane == 0) L.sv[sl].wl = wl, L.sv[sl].wh = wh;
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the payload has left before the progress word does
+					if (lane == 0) __hip_atomic_store(prog + (int64_t)r * 8, (u64)(B + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+			}
+			// (a wave with two slots inside the window: the second one's hand-off waits for neighbours that may be this wave's
+			// other slot's neighbours' neighbours — every slot publishes before any slot of the NEXT block waits, so nothing cycles)
+			s = s0 + P;
+			for (int t = 0; t < P; ++t) curH = curH + 1 == nH ? 0 : curH + 1;
+			sid_blk = sid0;
+		}
+		pgA = gA, pgB = gB;
+
+		// ---- end of the epoch: everybody meets; edges from the log, n_iter, stop rules, end cell, shrink
+		if (!sys_grid_sync(spin_limit, sync, &gflags[15], (unsigned)lb, L, epoch, G) || uni(L.red[0]) != 0) { R.status = ST_INTERNAL; break; }
+		{
+			// widths of the epoch's 256 slices from the log: lane l looks at penalties s-255+4l .. s-252+4l
+			const int32_t sb = s - kEpoch; // penalties sb+1 .. s
+			int32_t w4[4];
+			int64_t sum = 0;
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				const int32_t sp = sb + 4 * lane + i; // the slice sp+1 grows from the edges after penalty sp
+				int32_t a = logL[sp], b = logH[sp];
+				if (TB && n_seg > 0) // a checkpoint at penalty sp collapses the window before slice sp+1 (checkpoints are few)
+					for (int32_t j = 0; j < n_seg; ++j)
+						if (M.seg[2 * j] == sp) a = b = M.seg[2 * j + 1];
+				const int32_t lo = a > 1 ? a - 1 : 1, hi = b < cmax ? b + 1 : cmax;
+				w4[i] = hi - lo + 1;
+				sum += w4[i];
+			}
+			// inclusive prefix over the lanes
+			int64_t pre = sum;
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1) {
+				const int64_t o = __shfl_up(pre, d, 64);
+				if (lane >= d) pre += o;
+			}
+			const int64_t before = cells + pre - sum; // cells up to and including penalty sb+4*lane
+			const bool rules = A.coop_pass != 1 && A.coop_pass != 3; // the low-memory first pass has no stop rules (miniwfa.c:569-589)
+			const int64_t max_iter = A.max_iter;
+			const int32_t max_s = A.max_s;
+			int32_t first_stop = 0x7fffffff;
+			int64_t stop_cells = 0, run = before;
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				run += w4[i];
+				const int32_t sp1 = sb + 4 * lane + i + 1;
+				if (rules && first_stop == 0x7fffffff && ((max_iter > 0 && run > max_iter) || (max_s > 0 && sp1 > max_s))) first_stop = sp1, stop_cells = run; // miniwfa.c:422-425
+			}
+			const int32_t s_done = uni(ld_ag(&gflags[20])), done_info = uni(ld_ag(&gflags[21]));
+			const unsigned long long sm = __ballot(first_stop != 0x7fffffff);
+			if (sm) {
+				const int32_t sl0 = (int32_t)__builtin_ctzll(sm);
+				const int32_t fs = __builtin_amdgcn_readlane(first_stop, sl0);
+				if (fs <= s_done) { // the rules are looked at before the end cell of the same slice
+					R.status = ST_STOPPED, s = fs;
+					cells = ((int64_t)__builtin_amdgcn_readlane((int32_t)(stop_cells >> 32), sl0) << 32) | (uint32_t)__builtin_amdgcn_readlane((int32_t)(stop_cells & 0xffffffff), sl0);
+					break;
+				}
+			}
+			if (s_done <= s) {
+				// cells up to and including penalty s_done
+				const int32_t at = s_done - sb - 1, ln = at >> 2, ii = at & 3;
+				int64_t c = before;
+#pragma unroll
+				for (int i = 0; i < 4; ++i) c += i <= ii ? w4[i] : 0;
+				cells = ((int64_t)__builtin_amdgcn_readlane((int32_t)(c >> 32), ln) << 32) | (uint32_t)__builtin_amdgcn_readlane((int32_t)(c & 0xffffffff), ln);
+				s = s_done, R.info = done_info;
+				break;
+			}
+			const int64_t tot = before + sum;
+			cells = ((int64_t)__builtin_amdgcn_readlane((int32_t)(tot >> 32), 63) << 32) | (uint32_t)__builtin_amdgcn_readlane((int32_t)(tot & 0xffffffff), 63);
+		}
+		wf_lo = uni(logL[s]), wf_hi = uni(logH[s]);
+		{ // shrink (reference wf_stripe_shrink, miniwfa.c:144-171) on the good bits of the last nH slices
+			const int32_t rd = (ep & 1) ? 17 : 13;            // this epoch's reduction words; the other pair is reset for the next one
+			if (lead) st_ag(&gflags[(ep & 1) ? 13 : 17], 0x7fffffff), st_ag(&gflags[(ep & 1) ? 14 : 18], -1);
+			const int32_t gfirst = max(gA, wf_lo / OW), glast = min(gB, wf_hi / OW), n_words = (glast - gfirst + 1) * 4;
+			int32_t mylo = 0x7fffffff, myhi = -1;
+			for (int32_t q = lb * kT + tid; q < n_words; q += G * kT) {
+				const int32_t gg = gfirst + (q >> 2), kq = q & 3, base = gg * OW - P, rr = gg % TC;
+				unsigned long long m = 0;
+				for (int32_t j = 0; j < nH; ++j) m |= M.good[((int64_t)j * TC + rr) * 4 + kq];
+				// bit l of word kq is column base + 4 l + kq
+				for (; m; m &= m - 1) {
+					const int32_t c = base + 4 * (int32_t)__builtin_ctzll(m) + kq;
+					if (c >= wf_lo && c <= wf_hi) { mylo = min(mylo, c); break; }
+				}
+				for (; m; ) {
+					const int32_t hb = 63 - (int32_t)__builtin_clzll(m);
+					const int32_t c = base + 4 * hb + kq;
+					if (c >= wf_lo && c <= wf_hi) { myhi = max(myhi, c); break; }
+					m &= ~(1ull << hb);
+				}
+			}
+			if (mylo != 0x7fffffff) __hip_atomic_fetch_min(&gflags[rd], mylo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (myhi >= 0) __hip_atomic_fetch_max(&gflags[rd + 1], myhi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (!sys_grid_sync(spin_limit, sync, &gflags[15], (unsigned)lb, L, epoch, G)) { R.status = ST_INTERNAL; break; }
+			const int32_t glo = uni(ld_ag(&gflags[rd])), ghi = uni(ld_ag(&gflags[rd + 1]));
+			if (ghi < 0 || glo == 0x7fffffff) { R.status = ST_INTERNAL; break; }
+			wf_lo = glo, wf_hi = ghi;
+			if (lead) st_ag(&logL[s], glo), st_ag(&logH[s], ghi); // what the next slice grows from
+		}
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	R.s = s, R.cells = cells;
+	return R;
+}
+
+// which pair a group of workgroups works on, and where its pass state lives
+__device__ __forceinline__ int32_t group_pair(const BatchArgs &A, int32_t grp) { return A.coop_pair_ids ? A.coop_pair_ids[grp] : A.coop_pair; }
+__device__ __forceinline__ int32_t *group_state(const BatchArgs &A, int32_t grp) { return (int32_t*)((char*)A.coop_flags + (int64_t)grp * A.coop_misc_stride + 2048); }
+
+__device__ __forceinline__ void sys_pair_mem(const BatchArgs &A, int32_t grp, int32_t pair, PairMem &M)
+{
+	pair_mem(A, grp, pair, M); // ring / good / tb slots are per group
+	M.good = A.good + (int64_t)grp * A.pen.nH * A.GW;
+	if (A.sys_ep) M.ep = A.sys_ep + (int64_t)grp * A.sys_ep_stride, M.ep_ow = kW - 2 * A.sys_p, M.ep_p = A.sys_p;
+}
+
+template <int E1, int E2, int P>
+__global__ __launch_bounds__(kT) void wfa_sys_kernel(const BatchArgs A)
+{
+	__shared__ SysLds L;
+	const int32_t G = A.coop_group_size, grp = (int32_t)blockIdx.x / G, lb = (int32_t)blockIdx.x % G;
+	const int32_t pair = group_pair(A, grp);
+	int32_t *const state = group_state(A, grp);
+	PairMem M;
+	sys_pair_mem(A, grp, pair, M);
+	if (threadIdx.x == 0) L.red[0] = 0;
+	__syncthreads();
+	int32_t n_seg = 0;
+	if (A.coop_pass == 2) { // second pass of the low-memory mode: checkpoints left by the walk / the provenance trace
+		if (state[0] != ST_OK) return; // first pass failed: nothing to do, the finish kernel reports it
+		n_seg = state[3];
+	}
+	PassResult R;
+	if (A.want_cigar) R = sys_pass<E1, E2, true, P>(A, M, L, n_seg, grp, lb, G);
+	else R = sys_pass<E1, E2, false, P>(A, M, L, 0, grp, lb, G);
+	if (lb == 0 && threadIdx.x == 0) {
+		int32_t *st = state + (A.coop_pass == 2 ? 8 : 0);
+		st[0] = R.status, st[1] = R.s, st[2] = R.info;
+		st[4] = (int32_t)(R.cells & 0xffffffff), st[5] = (int32_t)(R.cells >> 32);
+		st[6] = 0;
+	}
+}
+
+// Checkpoints of the low-memory mode from the full traceback matrix of a first pass (see mwf_coop.hip coop_walk_kernel;
+// reference miniwfa.c:495-549): the same walk over this kernel's traceback layout.
+__global__ void sys_walk_kernel(const BatchArgs A)
+{
+	if (threadIdx.x != 0) return;
+	const int32_t grp = (int32_t)blockIdx.x; // one block per pair
+	int32_t *st = group_state(A, grp);
+	st[3] = 0;
+	if (st[0] != ST_OK) return;
+	const Penalty &P = A.pen;
+	PairMem M;
+	sys_pair_mem(A, grp, group_pair(A, grp), M);
+	const int32_t s_final = st[1], step = A.step;
+	const int32_t n_seg = s_final / step;
+	if (n_seg > A.seg_slot) { st[0] = ST_SNAP_OVERFLOW; return; }
+	int32_t arr = 0, s = s_final, col = M.ql + 1; // array 0=H 1=E1 2=F1 3=E2 4=F2; the end cell is on diagonal ql-tl
+	int32_t j = n_seg - 1;
+	while (j >= 0) {
+		const int32_t Sj = (j + 1) * step - 1;
+		if (s <= Sj) { // first cell of the chain that already existed at snapshot j
+			M.seg[2 * j] = s, M.seg[2 * j + 1] = col;
+			--j;
+			continue;
+		}
+		if (s <= 0) { st[0] = ST_INTERNAL; return; }
+		const uint32_t x = tb_byte(M, s - 1, col);
+		if (arr == 0) {
+			const uint32_t z = x & 7u;
+			if (z == 0) s -= P.x;
+			else arr = (int32_t)z == 1 ? 1 : (int32_t)z == 2 ? 2 : (int32_t)z == 3 ? 3 : 4;
+		} else if (arr == 1) { if (x & 0x08u) s -= P.e1; else s -= P.oe1, arr = 0; col -= 1; }
+		else if (arr == 2) { if (x & 0x10u) s -= P.e1; else s -= P.oe1, arr = 0; col += 1; }
+		else if (arr == 3) { if (x & 0x20u) s -= P.e2; else s -= P.oe2, arr = 0; col -= 1; }
+		else { if (x & 0x40u) s -= P.e2; else s -= P.oe2, arr = 0; col += 1; }
+	}
+	st[3] = n_seg;
+}
+
+__global__ __launch_bounds__(64) void sys_finish_kernel(const BatchArgs A)
+{
+	const int32_t grp = (int32_t)blockIdx.x; // one block per pair
+	const int32_t pair = group_pair(A, grp);
+	PairMem M;
+	sys_pair_mem(A, grp, pair, M);
+	const int32_t *st1 = group_state(A, grp), *st = A.step > 0 && A.want_cigar ? st1 + 8 : st1;
+	PassResult R;
+	int32_t status = st1[0] != ST_OK ? st1[0] : st[0];
+	R.status = status, R.s = st[1], R.info = st[2], R.n_snap = 0;
+	R.cells = (int64_t)(uint32_t)st[4] | (int64_t)st[5] << 32;
+	const int64_t cells1 = A.step > 0 && A.want_cigar ? ((int64_t)(uint32_t)st1[4] | (int64_t)st1[5] << 32) : 0;
+	if (A.dbg && (status == ST_OK || status == ST_STOPPED)) { // band trace (diagnostics): lo,hi of every slice, from the edge log
+		const int32_t *logL = A.sys_log + (int64_t)grp * A.sys_log_stride, *logH = logL + A.sys_log_stride / 2;
+		const int32_t cmax = M.tl + M.ql + 1, n_seg = A.step > 0 && A.want_cigar ? seg_effective(M.seg, st1[3]) : 0;
+		for (int32_t sp = threadIdx.x; sp < R.s && sp < A.dbg_cap; sp += 64) {
+			int32_t a = logL[sp], b = logH[sp];
+			for (int32_t j = 0; j < n_seg; ++j)
+				if (M.seg[2 * j] == sp) a = b = M.seg[2 * j + 1];
+			M.dbg[2 * sp] = a > 1 ? a - 1 : 1, M.dbg[2 * sp + 1] = b < cmax ? b + 1 : cmax;
+		}
+	}
+	finish_pair(A, M, grp, pair, R, status, cells1);
+}
+
+template <int E1, int E2>
+int launch_pass_p(const BatchArgs &a, int grid, hipStream_t st)
+{
+	switch (a.sys_p) {
+	case 4:  hipLaunchKernelGGL((wfa_sys_kernel<E1, E2, 4>), dim3(grid), dim3(kT), 0, st, a); break;
+	case 16: hipLaunchKernelGGL((wfa_sys_kernel<E1, E2, 16>), dim3(grid), dim3(kT), 0, st, a); break;
+	default: hipLaunchKernelGGL((wfa_sys_kernel<E1, E2, 8>), dim3(grid), dim3(kT), 0, st, a); break;
+	}
+	return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+} // namespace
+
+int64_t sys_chunk_slots(int grid) { return (int64_t)grid * kNW * kK; }
+int sys_owned_cols(int p) { return kW - 2 * p; }
+int64_t sys_box_ints(int p) { return (2 * (p / 4) * (p + 8) * 2 * 2 + 2 * p + 31) / 32 * 32; }
+
+int sys_max_grid()
+{
+	int dev = 0, n_cu = 0, per = 0;
+	if (hipGetDevice(&dev) != hipSuccess) return 0;
+	if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, wfa_sys_kernel<2, 1, 8>, kT, 0) != hipSuccess || per < 1) return 0;
+	return n_cu; // one workgroup per CU: every one of them is resident, which the waits between them rely on
+}
+
+int launch_sys_pass(const BatchArgs &a, int grid, void *stream)
+{
+	if (a.pen.e1 == 2 && a.pen.e2 == 1) return launch_pass_p<2, 1>(a, grid, (hipStream_t)stream);
+	if (a.pen.e1 == 2 && a.pen.e2 == 2) return launch_pass_p<2, 2>(a, grid, (hipStream_t)stream);
+	if (a.pen.e1 == 1 && a.pen.e2 == 1) return launch_pass_p<1, 1>(a, grid, (hipStream_t)stream);
+	return -1;
+}
+
+int launch_sys_walk(const BatchArgs &a, void *stream)
+{
+	hipLaunchKernelGGL(sys_walk_kernel, dim3(a.coop_groups > 0 ? a.coop_groups : 1), dim3(64), 0, (hipStream_t)stream, a);
+	return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_sys_finish(const BatchArgs &a, void *stream)
+{
+	hipLaunchKernelGGL(sys_finish_kernel, dim3(a.coop_groups > 0 ? a.coop_groups : 1), dim3(64), 0, (hipStream_t)stream, a);
+	return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+} // namespace mwf
