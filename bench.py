@@ -36,6 +36,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+TRAFFIC = {}
+try:
+    TRAFFIC = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+except Exception:
+    pass
+
 ALGO_BYTES_PER_CELL = 48          # score-only; 49 with traceback, 97 in the low-memory first pass
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # VALU issue peak: 256 CUs x 4 SIMD-32 per CU x 2.4 GHz, a wave64 VALU instruction occupies its SIMD for 2 cycles
@@ -69,7 +75,7 @@ class _DevPtr:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
-KERNEL_NAMES = {0: "wfa_batch_kernel (generic: one workgroup per pair, ring in HBM)", 1: "wfa_coop_kernel (one pair across the device)",
+KERNEL_NAMES = {0: "wfa_batch_kernel (generic: one workgroup per pair, ring in HBM)", 1: "wfa_sys_kernel (one pair across the device, systolic hand-offs)",
                 2: "wfa_band_kernel (one workgroup per pair, E/F in registers, 32-bit H rows in HBM)",
                 3: "wfa_band2_kernel (one workgroup per pair, E/F in registers, 16-bit H rows in HBM, sequences in LDS at 2 bits per base)"}
 
@@ -142,6 +148,20 @@ def long_pairs(mw, synth_pair, PackedBatch, cpu: bool):
             st_ = eng.stats()
             rec = {"s": int(s_[0]), "n_iter": int(it_[0]), "kernel_s": st_.kernel_ms * 1e-3, "wall_s": wall, "cells_pass1": int(st_.cells_pass1),
                    "gbp_s": (len(t_) + len(q_)) / wall / 1e9, "peak_device_bytes": int(st_.dev_bytes_peak), "n_retries": int(st_.n_retries)}
+            # SURVEY 8(d) bytes: 48 per cell score-only, 49 with traceback, 97 in the low-memory first pass (+ 49 per cell of the second)
+            if kw.get("step"):
+                nominal = 97 * int(st_.cells_pass1) + 49 * int(it_[0])
+                own = (16 + 1) * (int(st_.cells_pass1) + int(it_[0]))       # what the kernel itself moves: 32-bit H (three loads, one store) + the traceback byte, both passes
+            else:
+                nominal = (49 if kw.get("flag") else 48) * int(it_[0])
+                own = (16 + (1 if kw.get("flag") else 0)) * int(it_[0])
+            ks = max(st_.kernel_ms * 1e-3, 1e-9)
+            prof = TRAFFIC.get(f"{name}:{label}", {})
+            rec["roofline"] = {"bound": "hbm", "achieved": nominal / ks / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nominal / ks / 1e9 / HBM_PEAK_GBS,
+                               "nominal_bytes": nominal, "kernel_own_bytes": own, "kernel_own_frac": own / ks / 1e9 / HBM_PEAK_GBS,
+                               "traffic": prof.get("hbm_bytes_per_launch"), "traffic_source": prof.get("source"),
+                               "us_per_penalty": ks / max(1, int(s_[0])) * 1e6 / (2 if kw.get("step") else 1),
+                               "binding": "per-penalty latency of ONE sequential chain of penalties (hand-off once per 8 penalties + single-wave issue), not bytes"}
             if kw.get("flag"):
                 cg = bb.cigar(0, int(nc_[0])).tolist()
                 rec["cigar_rescored_ok"] = mw.cigar2score(mw.opt_init(), cg) == (int(s_[0]), len(t_), len(q_))
@@ -307,7 +327,8 @@ def main():
             "workload": workload,
             "pairs_this_gpu": pk.n, "pairs_total": n_total, "target_len": args.tl, "divergence": args.div,
             "bases_this_gpu": pk.bases, "cells_this_gpu": cells, "mean_s": float(s.mean()),
-            "step": "alignment kernels on HBM-resident sequences + (s, n_iter) records to the host" + (" + RCCL all_gather of the records" if world > 1 else ""),
+            "step": "alignment kernels on sequences already resident in HBM when the timed region starts (the measurement contract's `value`; the host-buffers-in "
+                    "to host-results-out rate of the same batch is `end_to_end_gbps`) + (s, n_iter) records to the host" + (" + RCCL all_gather of the records" if world > 1 else ""),
             "kernel": KERNEL_NAMES.get(3 if (st.kernel_kind == 2 and st.packed) else st.kernel_kind, "?"), "grid": st.grid, "block": st.block,
             "parallelism": f"pairs dealt over {world} GPU(s), no data-path collective, one RCCL all_gather of (s,n_iter)",
         },
@@ -322,11 +343,7 @@ def main():
     # What the kernel itself must move per cell (the floor of ITS traffic): the band kernels keep E1/F1/E2/F2 in registers,
     # so only H crosses HBM (three loads + one store per cell: 16 bytes, 8 with the packed kernel's 16-bit rows), +1 traceback byte;
     # the generic kernel with E2/F2 in LDS moves 32 of the 48, 16 with its 16-bit ring rows.
-    tr = {}
-    try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-    except Exception:
-        pass
+    tr = TRAFFIC
     key = f"{pk.n}x{args.tl}@{args.div:g}{'c' if args.cigar else 's'}"
     prof = tr.get(key, {})
     rf = out["roofline"]
@@ -348,11 +365,23 @@ def main():
         cands.append({"bound": "valu issue", "achieved": vi / (k_ms * 1e-3) / 1e9, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
                       "frac": vi / (k_ms * 1e-3) / 1e9 / VALU_PEAK_GINST, "valu_lane_ops_per_cell": vi * 64 / prof.get("cells_per_launch", cells),
                       "source": prof.get("valu_source")})
-    rf["binding"] = max(cands, key=lambda c: c["frac"])
+    # The top-level roofline is the BINDING one: the largest fraction among the rooflines of what this kernel really does (its own
+    # HBM bytes, counter-measured HBM traffic, VALU issue).  SURVEY 8(d)'s nominal figure (the reference's 48 B per cell) is kept
+    # beside it as `nominal_48B`: a kernel that keeps four of the five wavefront arrays on chip can exceed 1 by that definition.
+    nominal = {"bound": "hbm (SURVEY 8(d): the reference's algorithmic bytes per cell)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": achieved / HBM_PEAK_GBS, "bytes_per_cell": bytes_per_cell}
+    if "traffic_gbs" in rf:
+        cands.append({"bound": "hbm (PMC traffic: 2 x FETCH_SIZE + WRITE_SIZE)", "achieved": rf["traffic_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": rf["traffic_gbs"] / HBM_PEAK_GBS, "source": rf.get("traffic_source")})
+    best = max(cands, key=lambda c: c["frac"])
+    rf.update({"bound": "hbm" if best["bound"].startswith("hbm") else best["bound"], "bound_detail": best["bound"], "achieved": best["achieved"], "peak": best["peak"],
+               "unit": best["unit"], "frac": best["frac"]})
+    rf["nominal_48B"] = nominal
+    rf["hbm_measured"] = {"bytes_per_launch": rf.get("traffic"), "gbs": rf.get("traffic_gbs"), "frac": (rf["traffic_gbs"] / HBM_PEAK_GBS) if "traffic_gbs" in rf else None}
     rf["candidates"] = cands
-    rf["note"] = ("frac follows SURVEY 8(d): the reference's 48 B per cell; a kernel that keeps wavefront arrays on chip can exceed 1 by that "
-                  "definition. `binding` is the largest fraction among the rooflines of what this kernel really does; what is left is "
-                  "per-penalty synchronisation latency (DESIGN.md section 4).")
+    rf["note"] = ("bound/achieved/peak/frac: the largest fraction among the rooflines of what this kernel really does (candidates); nominal_48B: "
+                  "SURVEY 8(d)'s figure, cells x the reference's bytes per cell / kernel time; neither binds — what is left is per-penalty "
+                  "synchronisation and single-wave issue latency (DESIGN.md section 4).")
 
     if world == 1 and args.extras:
         out["peak_device_bytes"] = int(st.dev_bytes_peak)

@@ -363,6 +363,7 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 	if (g->block == 0 && (geom_block == 64 || geom_block == 128) && range_ok) bg.block = geom_block, bg.packed = 1;
 	if (g->block == 0 && geom_block == 256) bg.block = 256, bg.packed = range_ok;
 	bg.span = bg.block / 64 * (bg.packed && bg.block != 768 ? 3 : 2) * 256;
+	if (getenv("MWF_B2_256X6") && bg.packed && bg.block == 512) bg.block = 256, bg.span = 4 * 6 * 256; // experiment (needs a library built with -DMWF_B2_EXP)
 	if (want_kind != 2 && max_len + 1 > 4 * (int64_t)bg.span) return; // windows will mostly outgrow the span: go generic at once
 	const int64_t lds_cap = bg.block >= 768 ? 140 * 1024 : bg.block >= 512 ? 70 * 1024 : bg.block == 256 ? 36 * 1024 : bg.block == 128 ? 18 * 1024 : 9 * 1024;
 	// the packed kernel's sequence copy holds 2 bits per base unless that is switched off (or this is the re-run of pairs that

@@ -100,7 +100,8 @@ struct SlotVars {
 	int32_t fresh;      // has just joined: nothing live, registers start dead
 	int32_t wl, wh;     // the slot's view of wf_lo / wf_hi
 	int32_t fin_seen;
-	int32_t pad[2];
+	int32_t cover_bad;  // the latest penalty whose window (this slot's view) does not cover all of the slot's 256 columns
+	int32_t pad[1];
 };
 
 struct SysLds {
@@ -135,7 +136,7 @@ __device__ __forceinline__ bool sys_grid_sync(uint32_t spin_limit, unsigned *syn
 			for (;;) {
 				seen = __hip_atomic_load(top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				if ((unsigned)(seen & 0xffffffffu) >= n_grp * epoch) break;
-				__builtin_amdgcn_s_sleep(1);
+				if (spins < 32) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(100); // (idle workgroups wait here for a whole epoch: they must not hammer the fabric the hand-offs travel on)
 				if (++spins > spin_limit || ((spins & 255u) == 0 && ld_ag(abort_flag))) { ok = 0; break; }
 			}
 			__hip_atomic_store(&grp_gen[4 * grp], (unsigned long long)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -143,7 +144,7 @@ __device__ __forceinline__ bool sys_grid_sync(uint32_t spin_limit, unsigned *syn
 			for (;;) {
 				seen = __hip_atomic_load(&grp_gen[4 * grp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				if ((unsigned)(seen & 0xffffffffu) >= epoch) break;
-				__builtin_amdgcn_s_sleep(1);
+				if (spins < 32) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(100);
 				if (++spins > spin_limit || ((spins & 255u) == 0 && ld_ag(abort_flag))) { ok = 0; break; }
 			}
 		}
@@ -169,7 +170,7 @@ __device__ __forceinline__ int32_t seg_effective(const int32_t *seg, int32_t n_s
 __device__ __forceinline__ int32_t floordiv(int32_t a, int32_t b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
 
 // grp / lb / G: this pair's group of workgroups, this workgroup's index in it, the group's size
-template <int E1, int E2, bool TB, int P>
+template <int E1, int E2, bool TB, int P, bool DEFER>
 __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, int32_t n_seg, int32_t grp, int32_t lb, int32_t G)
 {
 	constexpr int PL = P / 4;                 // halo lanes per side
@@ -257,7 +258,7 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 	if (lead) st_ag(&gflags[13], 0x7fffffff), st_ag(&gflags[14], -1), st_ag(&gflags[17], 0x7fffffff), st_ag(&gflags[18], -1), st_ag(&gflags[20], 0x7fffffff);
 	if (lane < kK) {
 		SlotVars z;
-		z.g = -1, z.part = 0, z.fresh = 1, z.wl = z.wh = 0, z.fin_seen = 0, z.pad[0] = z.pad[1] = 0;
+		z.g = -1, z.part = 0, z.fresh = 1, z.wl = z.wh = 0, z.fin_seen = 0, z.cover_bad = 0, z.pad[0] = 0;
 		L.sv[wv * kK + lane] = z;
 	}
 	if (!sys_grid_sync(spin_limit, sync, &gflags[15], (unsigned)lb, L, epoch, G)) { R.status = ST_INTERNAL; return R; }
@@ -283,7 +284,14 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 		po2 = *(const int4*)row_ptr(r, j2);
 	};
 
+#ifdef MWF_SYS_TIMING
+	unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}, t_blocks = 0, t_runs = 0;
+#define MWF_T(x) const unsigned long long x = __builtin_readcyclecounter()
+#else
+#define MWF_T(x)
+#endif
 	for (;;) { // ---- one epoch: penalties s+1 .. s+256
+		MWF_T(tt_e0);
 		const int32_t ep = s >> 8;
 		// chunks that take part: their owned columns meet [wf_lo - 257 - P, wf_hi + 257 + P]; then the chunk beyond the outermost
 		// one — which does not take part — holds no column the window can reach before the next shrink, and neither do the
@@ -325,7 +333,8 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 			if (!now && res == k) res = -1;
 			if (lane == 0) {
 				SlotVars z;
-				z.g = g, z.part = now ? 1 : 0, z.fresh = (now && !kept) ? 1 : (kept ? L.sv[sl].fresh : 1), z.wl = wf_lo, z.wh = wf_hi, z.fin_seen = 0, z.pad[0] = z.pad[1] = 0;
+				z.g = g, z.part = now ? 1 : 0, z.fresh = (now && !kept) ? 1 : (kept ? L.sv[sl].fresh : 1), z.wl = wf_lo, z.wh = wf_hi, z.fin_seen = 0, z.pad[0] = 0;
+				z.cover_bad = kept ? L.sv[sl].cover_bad : s; // (joins: no slice so far covers anything)
 				L.sv[sl] = z;
 			}
 		}
@@ -349,8 +358,12 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 				const int32_t r = gw + NWt * k, g = uni(L.sv[sl].g), cb = g * OW - P, c0 = cb + 4 * lane;
 				const int32_t oL = cb + P, oR = cb + kW - 1 - P;
 				const bool nbl = g - 1 >= gA, nbr = g + 1 <= gB;
+				MWF_T(tt_a);
 				make_resident(k);
-				int32_t wl = uni(L.sv[sl].wl), wh = uni(L.sv[sl].wh);
+				int32_t wl = uni(L.sv[sl].wl), wh = uni(L.sv[sl].wh), cover_bad = uni(L.sv[sl].cover_bad);
+#ifdef MWF_SYS_TIMING
+				unsigned long long tt_w = tt_a;
+#endif
 				// ---- hand-off: the halo becomes what the neighbours computed (nothing to fetch before the first block)
 				if (s0 > 0) {
 					const int32_t rl = r == 0 ? TC - 1 : r - 1, rr = r + 1 == TC ? 0 : r + 1;
@@ -371,6 +384,9 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 						}
 						__builtin_amdgcn_s_sleep(1);
 					}
+#ifdef MWF_SYS_TIMING
+					tt_w = __builtin_readcyclecounter();
+#endif
 					const int32_t par = (int32_t)((B - 1) & 1);
 					const int32_t *const bl = box + ((int64_t)rl * 2 + par) * BOX_INTS, *const br = box + ((int64_t)rr * 2 + par) * BOX_INTS;
 					// halo lanes: H rows of the last P penalties and the E/F registers from the neighbour's outer lanes
@@ -432,6 +448,7 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 						for (int i = 0; i < P; ++i) {
 							// the penalty s0-P+1+i had window [lo_i, hi_i] (this slot's view; exact if inside its columns)
 							if (lane == 0) L.hist[sl][j] = make_int2(min(max(lo_i, cb), cb + kW), max(min(hi_i, cb + kW - 1), cb - 1));
+							if (lo_i > cb || hi_i < cb + kW - 1) cover_bad = max(cover_bad, s0 - P + 1 + i);
 							j = j + 1 == nH ? 0 : j + 1;
 							const int32_t mwl = __builtin_amdgcn_readlane(mine, i), mwh = __builtin_amdgcn_readlane(mine, P + i);
 							const int32_t lwl = __builtin_amdgcn_readlane(left, i), lwh = __builtin_amdgcn_readlane(left, P + i);
@@ -451,7 +468,12 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 					asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 				}
 
-				// ---- P penalties without talking to anybody
+				MWF_T(tt_b);
+				// ---- P penalties without talking to anybody.  A penalty has two stages: (1) the recurrence, its traceback byte, edge
+				// liveness, and the REQUEST of the first eight bases behind every new offset; (2) the match extension proper — count,
+				// walk long runs, end-cell test — and the store of the H row.  Nothing of penalty s+1's stage 1 needs stage 2 of
+				// penalty s (E/F travel in registers; an extended H is read again no sooner than min-lag penalties later), so with
+				// DEFER stage 2 runs one penalty late, behind the next stage 1: the sequence bytes travel while the wave computes.
 				int32_t curHk = curH;
 				sid = sid0, seg_s = seg_s0, seg_c = seg_c0; // (every slot of the wave walks the same penalties)
 				if (!lag_one) prefetch(r, curHk + 1 == nH ? 0 : curHk + 1);
@@ -459,10 +481,70 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 				const bool own_fin = (uint32_t)(cfin - (cb + P)) < (uint32_t)OW; // this slot owns the end diagonal
 				bool fin_seen = uni(L.sv[sl].fin_seen) != 0;
 				const unsigned long long owned_lanes = (~0ull >> PL) & (~0ull << PL);
+				// A block deep inside the window — every slice its penalties read covers all of the slot's columns, the window's edges
+				// are outside them for good (an edge moves by at most one column per penalty), no shrink near, no checkpoint due:
+				// nothing of the window bookkeeping is looked at or written per penalty (it is written once, behind the block)
+				const bool deep_blk = !lag_one && (wl > 1 ? wl - 1 : 1) <= cb && (wh < cmax ? wh + 1 : cmax) >= cb + kW - 1 && cover_bad <= s0 + 1 - nH &&
+				                      blk * P + P <= kEpoch - nH && !(TB && seg_s >= s0 && seg_s < s0 + P);
+				// per column: the largest j = k+1 inside the matrix, min(tl, ql - d), and the query's address for j = 0
+				int32_t rj[4];
+				const uint8_t *const qsd = M.qs + (c0 - 1 - tl); // (column i: + i)
+#pragma unroll
+				for (int i = 0; i < 4; ++i) rj[i] = max(min(tl, ql - (c0 + i - 1 - tl)), 0);
+				// what stage 2 needs of a penalty
+				int32_t x_hv[4] = {0, 0, 0, 0}, x_snew = 0, x_newH = 0, x_t = 0;
+				uint64_t x_t8[4] = {0, 0, 0, 0}, x_q8[4] = {0, 0, 0, 0};
+				uint32_t x_tbw = 0;
 #pragma unroll 1
-				for (int t = 0; t < P; ++t) {
+				for (int t = 0; t < P + (DEFER ? 1 : 0); ++t) {
+					int32_t c_hv[4], c_snew = 0, c_newH = 0;
+					uint64_t c_t8[4], c_q8[4];
+					uint32_t c_tbw = 0;
+					// what stage 2a leaves for stage 2b
+					int32_t nmat[4] = {0, 0, 0, 0};
+					uint32_t pend = 0;
+					int32_t w_cl[4] = {-1, -1, -1, -1}, w_ci[4] = {0, 0, 0, 0}, w_cj[4] = {0, 0, 0, 0}, w_cq[4] = {0, 0, 0, 0}, w_crm[4] = {0, 0, 0, 0};
+					uint64_t w_t = 0, w_q = 0;
+					int32_t w_left = 0;
+					bool w_valid = false;
+					auto rj_at = [&](int32_t ii, int32_t src) -> int32_t { return max(min(tl, ql - (cb + 4 * src + ii - 1 - tl)), 0); };
+					auto stage2a = [&]() {
+						// count the first probe; a run of >= 8 matches continues (the cells on the alignment path, a few per penalty, all
+						// in one chunk — whose wave every other wave ends up waiting for).  Up to four such cells are walked at once:
+						// sixteen lanes each, eight bases per lane, i.e. the next 128 bases of every run in ONE round trip to the
+						// sequences, requested here and looked at in stage 2b — with DEFER a whole stage 1 later; a run that is longer
+						// still goes on with the whole wave (256 bases per trip).
+#pragma unroll
+						for (int i = 0; i < 4; ++i) {
+							const int32_t room = rj[i] - (int32_t)min((uint32_t)(x_hv[i] + 1), (uint32_t)rj[i]); // bases left on the diagonal; 0 for dead and phantom offsets
+							const uint64_t x = x_t8[i] ^ x_q8[i];
+							nmat[i] = min(x ? (int32_t)(__builtin_ctzll(x) >> 3) : 8, room);
+							pend |= ((uint32_t)(x == 0) & (uint32_t)(room > 8)) << i;
+						}
+						unsigned long long owners = __ballot(pend != 0);
+						if (owners) { // uniform
+#pragma unroll
+							for (int gi = 0; gi < 4; ++gi) {
+								if (!owners) continue; // uniform
+								const int32_t src = (int32_t)__builtin_ctzll(owners);
+								owners &= owners - 1;
+								const int32_t w = (int32_t)__builtin_ctz((uint32_t)__builtin_amdgcn_readlane((int32_t)pend, src)); // (its other columns, if any: the leftovers of stage 2b)
+								const int32_t hh = __builtin_amdgcn_readlane(pick4(w, x_hv[0], x_hv[1], x_hv[2], x_hv[3]), src);
+								w_cl[gi] = src, w_ci[gi] = w, w_cj[gi] = hh + 1, w_cq[gi] = cb + 4 * src + w - 1 - tl + hh + 1;
+								w_crm[gi] = rj_at(w, src) - (hh + 1);
+							}
+							const int32_t gi = lane >> 4, off = 8 + 8 * (lane & 15);
+							const int32_t mj = pick4(gi, w_cj[0], w_cj[1], w_cj[2], w_cj[3]), mq = pick4(gi, w_cq[0], w_cq[1], w_cq[2], w_cq[3]);
+							const int32_t mrm = pick4(gi, w_crm[0], w_crm[1], w_crm[2], w_crm[3]), mcl = pick4(gi, w_cl[0], w_cl[1], w_cl[2], w_cl[3]);
+							w_valid = mcl >= 0 && off < mrm;
+							w_left = mrm - off;
+							if (w_valid) w_t = ld8(M.ts + mj + off), w_q = ld8(M.qs + mq + off);
+						}
+					};
+					if (DEFER && t > 0) stage2a();
+					if (!DEFER || t < P) {
 					const int32_t sc = s0 + t; // penalties done so far
-					if (TB && seg_s == sc) { // checkpoint reset of the second pass (miniwfa.c:413-416): every slot knows the checkpoints
+					if (TB && !deep_blk && seg_s == sc) { // checkpoint reset of the second pass (miniwfa.c:413-416): every slot knows the checkpoints
 						wl = wh = seg_c;
 						++sid;
 						seg_s = sid < n_seg ? uni(M.seg[2 * sid]) : -1, seg_c = sid < n_seg ? uni(M.seg[2 * sid + 1]) : 0;
@@ -470,22 +552,30 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 					const int32_t s_new = sc + 1;
 					const int32_t newH = curHk + 1 == nH ? 0 : curHk + 1;
 					const int32_t nextH = newH + 1 == nH ? 0 : newH + 1;
-					int32_t jx = newH - lagx; if (jx < 0) jx += nH;
-					int32_t j1 = newH - lag1; if (j1 < 0) j1 += nH;
-					int32_t j2 = newH - lag2; if (j2 < 0) j2 += nH;
-					const bool track_good = (((256 - (s_new & 255)) & 255) < nH);
+					const bool track_good = !deep_blk && (((256 - (s_new & 255)) & 255) < nH);
 					const int32_t lo = wl > 1 ? wl - 1 : 1;       // miniwfa.c:417-418, on this slot's view
 					const int32_t hi = wh < cmax ? wh + 1 : cmax;
-					if (lag_one) prefetch(r, newH);
-					const int2 wx = L.hist[sl][jx], w1 = L.hist[sl][j1], w2 = L.hist[sl][j2];
-					if (lane == 0) L.hist[sl][newH] = make_int2(min(max(lo, cb), cb + kW), max(min(hi, cb + kW - 1), cb - 1));
-					const int32_t xlo = uni(wx.x), xhi = uni(wx.y), alo = uni(w1.x), ahi = uni(w1.y), blo = uni(w2.x), bhi = uni(w2.y);
-					// every column of the slot inside the window and inside every source window: no masks
-					const bool inner = max(max(lo, xlo), max(alo, blo)) <= cb && min(min(hi, xhi), min(ahi, bhi)) >= cb + kW - 1;
+					int32_t xlo = 0, xhi = 0, alo = 0, ahi = 0, blo = 0, bhi = 0;
+					bool inner = true;
+					if (!deep_blk) {
+						int32_t jx = newH - lagx; if (jx < 0) jx += nH;
+						int32_t j1 = newH - lag1; if (j1 < 0) j1 += nH;
+						int32_t j2 = newH - lag2; if (j2 < 0) j2 += nH;
+						if (lag_one) prefetch(r, newH);
+						const int2 wx = L.hist[sl][jx], w1 = L.hist[sl][j1], w2 = L.hist[sl][j2];
+						if (lane == 0) L.hist[sl][newH] = make_int2(min(max(lo, cb), cb + kW), max(min(hi, cb + kW - 1), cb - 1));
+						if (lo > cb || hi < cb + kW - 1) cover_bad = s_new;
+						xlo = uni(wx.x), xhi = uni(wx.y), alo = uni(w1.x), ahi = uni(w1.y), blo = uni(w2.x), bhi = uni(w2.y);
+						// every column of the slot inside the window and inside every source window: no masks
+						inner = max(max(lo, xlo), max(alo, blo)) <= cb && min(min(hi, xhi), min(ahi, bhi)) >= cb + kW - 1;
+					}
 					int32_t hx[4] = {phx.x, phx.y, phx.z, phx.w};
 					int32_t o1[6], o2[6];
 					o1[1] = po1.x, o1[2] = po1.y, o1[3] = po1.z, o1[4] = po1.w;
 					o2[1] = po2.x, o2[2] = po2.y, o2[3] = po2.z, o2[4] = po2.w;
+					// the next penalty's rows: requested at once — they are at least two penalties old (every lag >= 2 here), and a whole
+					// penalty's work lies between this request and their use
+					if (!lag_one && t + 1 < P) prefetch(r, nextH);
 					if (!inner) { // reads outside a source window yield "dead" (what the reference's pads supply, miniwfa.c:96-99)
 #pragma unroll
 						for (int i = 0; i < 4; ++i) {
@@ -508,8 +598,23 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 #pragma unroll
 					for (int i = 0; i < 3; ++i) g1p[i] = f1h[E1 - 1][i + 1], g2p[i] = f2h[E2 - 1][i + 1];
 
-					int32_t hv[4], room[4], nmat[4], ne1[4], nf1[4], ne2[4], nf2[4];
-					uint32_t tbw = 0, pend = 0, live = 0, fin = 0, gbits = 0;
+					int32_t ne1[4], nf1[4], ne2[4], nf2[4];
+					uint32_t tbw = 0, live = 0, gbits = 0;
+					if (inner && !track_good) {
+						// The common case — a chunk well inside the window, no shrink in sight: every column is computed, no source is
+						// masked, no edge column is among the slot's exact columns.  Validity of an offset folds into the probe address:
+						// j = k+1 clamped to Rj = min(tl, ql-d) leaves room Rj - j = 0 for dead (NEG_INF + drift: huge as unsigned) and
+						// phantom (beyond the matrix) offsets, and both addresses stay inside the sequences' slack.
+#pragma unroll
+						for (int i = 0; i < 4; ++i) {
+							const Cell v = wf_cell<TB>(hx[i], o1[i], g1m[i], o2[i], g2m[i], o1[i + 2], g1p[i], o2[i + 2], g2p[i]);
+							ne1[i] = v.e1, nf1[i] = v.f1, ne2[i] = v.e2, nf2[i] = v.f2;
+							const int32_t jc = (int32_t)min((uint32_t)(v.h + 1), (uint32_t)rj[i]);
+							c_t8[i] = ld8(M.ts + jc), c_q8[i] = ld8((qsd + jc) + i);
+							c_hv[i] = v.h;
+							tbw |= v.tb << (8 * i);
+						}
+					} else
 #pragma unroll
 					for (int i = 0; i < 4; ++i) {
 						const int32_t c = c0 + i, d = c - 1 - tl;
@@ -523,56 +628,14 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 						// edge rule (miniwfa.c:325-326): H is the max of the five, so "any live" == "H live"
 						const uint32_t lv = act & (uint32_t)(v.h >= -1);
 						live |= (lv & (uint32_t)(c == lo)) | ((lv & (uint32_t)(c == hi)) << 1);
-						const int32_t j = inm ? v.h + 1 : 0, q = inm ? d + v.h + 1 : 0;
-						room[i] = inm ? min(tl - j, ql - q) : 0;
-						const uint32_t x = probe4g(M, j, q);
-						nmat[i] = min(x ? (int32_t)(__builtin_ctz(x) >> 3) : 4, room[i]);
-						pend |= ((uint32_t)(x == 0) & (uint32_t)(room[i] > 4)) << i;
-						hv[i] = act ? v.h : kNegInf;
+						// first probe: eight bases (a random 4-mer matches in one cell of 256, i.e. once per chunk and penalty — and every
+						// such cell would send the whole wave on a walk); addresses clamped as above (a cell outside the window holds NEG_INF)
+						c_hv[i] = act ? v.h : kNegInf;
+						const int32_t jc = (int32_t)min((uint32_t)(c_hv[i] + 1), (uint32_t)rj[i]);
+						c_t8[i] = ld8(M.ts + jc), c_q8[i] = ld8((qsd + jc) + i);
 						tbw |= v.tb << (8 * i);
 					}
-					// the next penalty's rows: requested now, so that they travel while the runs are walked
-					if (!lag_one && t + 1 < P) prefetch(r, nextH);
-					// a run of >= 4 matches continues: the wave walks it together, one owning lane and column at a time
-					unsigned long long owners = __ballot(pend != 0);
-					while (owners) {
-						const int32_t src = (int32_t)__builtin_ctzll(owners);
-						owners &= owners - 1;
-						uint32_t bits = (uint32_t)__builtin_amdgcn_readlane((int32_t)pend, src);
-						const int32_t c0s = cb + 4 * src;
-						while (bits) {
-							const int32_t ii = (int32_t)__builtin_ctz(bits);
-							bits &= bits - 1;
-							const int32_t hh = __builtin_amdgcn_readlane(pick4(ii, hv[0], hv[1], hv[2], hv[3]), src);
-							const int32_t rm = __builtin_amdgcn_readlane(pick4(ii, room[0], room[1], room[2], room[3]), src);
-							const int32_t j = hh + 1, q = c0s + ii - 1 - tl + j;
-							const int32_t n = lcp_wave(M, j, q, rm, 4);
-#pragma unroll
-							for (int i = 0; i < 4; ++i) nmat[i] = (ii == i && lane == src) ? n : nmat[i];
-						}
-					}
-					int32_t done_info = 0;
-#pragma unroll
-					for (int i = 0; i < 4; ++i) {
-						const int32_t d = c0 + i - 1 - tl;
-						const uint32_t in = inm_bit(d, hv[i], tl, ql); // (cells outside the window hold NEG_INF)
-						const int32_t kk2 = hv[i] + nmat[i];
-						if (own_fin) {
-							const uint32_t f = in & (uint32_t)(c0 + i == cfin) & (uint32_t)(kk2 == tl - 1) & (uint32_t)(d + kk2 == ql - 1);
-							fin |= f;
-							done_info = f ? (nmat[i] == 0 ? (int32_t)((tbw >> (8 * i)) & 7u) : 0) : done_info;
-						}
-						hv[i] = kk2;
-					}
-					*(int4*)row_ptr(r, newH) = make_int4(hv[0], hv[1], hv[2], hv[3]);
-					// the outer owned columns, for the neighbours' halos
-					{
-						const bool ol = lane >= PL && lane < 2 * PL, orr = lane >= 64 - 2 * PL && lane < 64 - PL;
-						if (ol || orr) {
-							u64 *dst = (u64*)(box + ((int64_t)r * 2 + par) * BOX_INTS) + ((orr ? PL : 0) + (ol ? lane - PL : lane - (64 - 2 * PL))) * LANE_D2 + 2 * t;
-							st2_ag(dst, hv[0], hv[1]), st2_ag(dst + 1, hv[2], hv[3]);
-						}
-					}
+					c_tbw = tbw, c_snew = s_new, c_newH = newH;
 					if (TB) *(uint32_t*)(M.tb + ep_base + ((int64_t)(s_new - 1 - (ep << 8)) * n_ep + (g - gA)) * kW + 4 * lane) = tbw;
 					if (track_good) {
 						unsigned long long *gword = M.good + ((int64_t)newH * TC + r) * 4;
@@ -582,16 +645,8 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 							if (lane == 0) gword[i] = m;
 						}
 					}
-					if (own_fin && !fin_seen) {
-						const unsigned long long fm = __ballot(fin);
-						if (fm) {
-							fin_seen = true;
-							const int32_t info = __builtin_amdgcn_readlane(done_info, (int32_t)__builtin_ctzll(fm));
-							if (lane == 0) st_ag(&gflags[21], info), st_ag(&gflags[20], s_new), L.sv[sl].fin_seen = 1; // read after the epoch's barrier
-						}
-					}
 					// the slot's view of the window after this penalty: liveness of an edge cell counts where the cell is exact
-					{
+					if (!deep_blk) {
 						const int32_t vl = cb + 1 + t, vr = cb + kW - 2 - t;
 						if (lo >= vl && lo <= vr && __ballot(live & 1u)) wl = lo;
 						if (hi >= vl && hi <= vr && __ballot(live & 2u)) wh = hi;
@@ -609,10 +664,104 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 						for (int a = E2 - 1; a > 0; --a) e2h[a][i] = e2h[a - 1][i], f2h[a][i] = f2h[a - 1][i];
 						e1h[0][i] = ne1[i], f1h[0][i] = nf1[i], e2h[0][i] = ne2[i], f2h[0][i] = nf2[i];
 					}
-					if (lag_one) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 					curHk = newH;
+					}
+					if (!DEFER) {
+#pragma unroll
+						for (int i = 0; i < 4; ++i) x_hv[i] = c_hv[i], x_t8[i] = c_t8[i], x_q8[i] = c_q8[i];
+						x_tbw = c_tbw, x_snew = c_snew, x_newH = c_newH, x_t = t;
+						stage2a();
+					}
+					// ---- stage 2b, of this penalty or (DEFER) of the one before: resolve the walks, finish the H row
+					if (!DEFER || t > 0) {
+						uint32_t fin = 0;
+						if (w_cl[0] >= 0) { // uniform
+							int32_t m8 = 0; // matching bases among this lane's eight (0 beyond the room: stops the scan there)
+							if (w_valid) {
+								const uint64_t x = w_t ^ w_q;
+								m8 = min(x ? (int32_t)(__builtin_ctzll(x) >> 3) : 8, w_left);
+							}
+							const unsigned long long stop = __ballot(m8 < 8);
+#pragma unroll
+							for (int g4 = 0; g4 < 4; ++g4) {
+								if (w_cl[g4] < 0) continue; // uniform
+								const uint32_t sb = (uint32_t)((stop >> (16 * g4)) & 0xffffu);
+								int32_t n;
+								if (sb) {
+									const int32_t first = (int32_t)__builtin_ctz(sb);
+									n = min(8 + 8 * first + __builtin_amdgcn_readlane(m8, 16 * g4 + first), w_crm[g4]);
+								} else n = lcp_wave(M, w_cj[g4], w_cq[g4], w_crm[g4], 136);
+								if (lane == w_cl[g4]) {
+#pragma unroll
+									for (int i = 0; i < 4; ++i) nmat[i] = w_ci[g4] == i ? n : nmat[i];
+									pend &= ~(1u << w_ci[g4]);
+								}
+							}
+							// what did not fit the four groups (rare): one owning lane and column at a time, the whole wave on each
+							unsigned long long owners = __ballot(pend != 0);
+							while (owners) {
+								const int32_t src = (int32_t)__builtin_ctzll(owners);
+								owners &= owners - 1;
+								uint32_t bits = (uint32_t)__builtin_amdgcn_readlane((int32_t)pend, src);
+								while (bits) {
+									const int32_t ii = (int32_t)__builtin_ctz(bits);
+									bits &= bits - 1;
+									const int32_t hh = __builtin_amdgcn_readlane(pick4(ii, x_hv[0], x_hv[1], x_hv[2], x_hv[3]), src);
+									const int32_t rm = rj_at(ii, src) - (hh + 1);
+									const int32_t n = lcp_wave(M, hh + 1, cb + 4 * src + ii - 1 - tl + hh + 1, rm, 8);
+#pragma unroll
+									for (int i = 0; i < 4; ++i) nmat[i] = (ii == i && lane == src) ? n : nmat[i];
+								}
+							}
+						}
+						int32_t done_info = 0, hv[4];
+#pragma unroll
+						for (int i = 0; i < 4; ++i) {
+							const int32_t d = c0 + i - 1 - tl;
+							const uint32_t in = inm_bit(d, x_hv[i], tl, ql); // (cells outside the window hold NEG_INF)
+							const int32_t kk2 = x_hv[i] + nmat[i];
+							if (own_fin) {
+								const uint32_t f = in & (uint32_t)(c0 + i == cfin) & (uint32_t)(kk2 == tl - 1) & (uint32_t)(d + kk2 == ql - 1);
+								fin |= f;
+								done_info = f ? (nmat[i] == 0 ? (int32_t)((x_tbw >> (8 * i)) & 7u) : 0) : done_info;
+							}
+							hv[i] = kk2;
+						}
+						*(int4*)row_ptr(r, x_newH) = make_int4(hv[0], hv[1], hv[2], hv[3]);
+						// the outer owned columns, for the neighbours' halos
+						{
+							const bool ol = lane >= PL && lane < 2 * PL, orr = lane >= 64 - 2 * PL && lane < 64 - PL;
+							if (ol || orr) {
+								u64 *dst = (u64*)(box + ((int64_t)r * 2 + par) * BOX_INTS) + ((orr ? PL : 0) + (ol ? lane - PL : lane - (64 - 2 * PL))) * LANE_D2 + 2 * x_t;
+								st2_ag(dst, hv[0], hv[1]), st2_ag(dst + 1, hv[2], hv[3]);
+							}
+						}
+						if (own_fin && !fin_seen) {
+							const unsigned long long fm = __ballot(fin);
+							if (fm) {
+								fin_seen = true;
+								const int32_t info = __builtin_amdgcn_readlane(done_info, (int32_t)__builtin_ctzll(fm));
+								if (lane == 0) st_ag(&gflags[21], info), st_ag(&gflags[20], x_snew), L.sv[sl].fin_seen = 1; // read after the epoch's barrier
+							}
+						}
+						if (lag_one) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+					}
+					if (DEFER) {
+#pragma unroll
+						for (int i = 0; i < 4; ++i) x_hv[i] = c_hv[i], x_t8[i] = c_t8[i], x_q8[i] = c_q8[i];
+						x_tbw = c_tbw, x_snew = c_snew, x_newH = c_newH, x_t = t;
+					}
 				}
 
+				if (deep_blk && lane < P) { // what the penalties of a deep block did not write one by one
+					int32_t j = curH + 1 + lane;
+					if (j >= nH) j -= nH;
+					if (j >= nH) j %= nH;
+					L.hist[sl][j] = make_int2(cb, cb + kW - 1);
+					L.mywl[sl][lane] = wl, L.mywh[sl][lane] = wh;
+				}
+				if (lane == 0) L.sv[sl].cover_bad = cover_bad;
+				MWF_T(tt_c);
 				// ---- publish: E/F of the outer owned columns, the window views of the block, then the progress word
 				{
 					int32_t *const bx = box + ((int64_t)r * 2 + par) * BOX_INTS;
@@ -633,6 +782,12 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 					asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the payload has left before the progress word does
 					if (lane == 0) __hip_atomic_store(prog + (int64_t)r * 8, (u64)(B + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				}
+#ifdef MWF_SYS_TIMING
+				{
+					const unsigned long long tt_d = __builtin_readcyclecounter();
+					t_acc[0] += tt_w - tt_a, t_acc[1] += tt_b - tt_w, t_acc[2] += tt_c - tt_b, t_acc[3] += tt_d - tt_c, t_blocks += 1;
+				}
+#endif
 			}
 			// (a wave with two slots inside the window: the second one's hand-off waits for neighbours that may be this wave's
 			// other slot's neighbours' neighbours — every slot publishes before any slot of the NEXT block waits, so nothing cycles)
@@ -641,6 +796,7 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 			sid_blk = sid0;
 		}
 		pgA = gA, pgB = gB;
+		MWF_T(tt_e1);
 
 		// ---- end of the epoch: everybody meets; edges from the log, n_iter, stop rules, end cell, shrink
 		if (!sys_grid_sync(spin_limit, sync, &gflags[15], (unsigned)lb, L, epoch, G) || uni(L.red[0]) != 0) { R.status = ST_INTERNAL; break; }
@@ -733,7 +889,15 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 			wf_lo = glo, wf_hi = ghi;
 			if (lead) st_ag(&logL[s], glo), st_ag(&logH[s], ghi); // what the next slice grows from
 		}
+#ifdef MWF_SYS_TIMING
+		t_acc[4] += tt_e1 - tt_e0, t_acc[5] += __builtin_readcyclecounter() - tt_e1, t_runs += 1;
+#endif
 	}
+#ifdef MWF_SYS_TIMING
+	if (lane == 0 && t_blocks > 0 && (((wv == 0 || wv == 5) && (lb % 37) == 0) || t_acc[5] * 6 < t_acc[4]))
+		printf("wg %3d wave %d: %llu slot-blocks in %llu epochs | per slot-block: wait %.0f  refresh %.0f  steps %.0f  publish %.0f cycles | per epoch: blocks %.0f  end (barriers, scan, shrink) %.0f\n", lb, wv,
+		       t_blocks, t_runs, (double)t_acc[0] / t_blocks, (double)t_acc[1] / t_blocks, (double)t_acc[2] / t_blocks, (double)t_acc[3] / t_blocks, (double)t_acc[4] / t_runs, (double)t_acc[5] / t_runs);
+#endif
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	R.s = s, R.cells = cells;
 	return R;
@@ -750,7 +914,8 @@ __device__ __forceinline__ void sys_pair_mem(const BatchArgs &A, int32_t grp, in
 	if (A.sys_ep) M.ep = A.sys_ep + (int64_t)grp * A.sys_ep_stride, M.ep_ow = kW - 2 * A.sys_p, M.ep_p = A.sys_p;
 }
 
-template <int E1, int E2, int P>
+// DEFER: the match extension of a penalty runs behind the recurrence of the next one (every H lag >= 3)
+template <int E1, int E2, int P, bool DEFER, bool TB>
 __global__ __launch_bounds__(kT) void wfa_sys_kernel(const BatchArgs A)
 {
 	__shared__ SysLds L;
@@ -766,9 +931,7 @@ __global__ __launch_bounds__(kT) void wfa_sys_kernel(const BatchArgs A)
 		if (state[0] != ST_OK) return; // first pass failed: nothing to do, the finish kernel reports it
 		n_seg = state[3];
 	}
-	PassResult R;
-	if (A.want_cigar) R = sys_pass<E1, E2, true, P>(A, M, L, n_seg, grp, lb, G);
-	else R = sys_pass<E1, E2, false, P>(A, M, L, 0, grp, lb, G);
+	const PassResult R = sys_pass<E1, E2, TB, P, DEFER>(A, M, L, TB ? n_seg : 0, grp, lb, G);
 	if (lb == 0 && threadIdx.x == 0) {
 		int32_t *st = state + (A.coop_pass == 2 ? 8 : 0);
 		st[0] = R.status, st[1] = R.s, st[2] = R.info;
@@ -840,15 +1003,28 @@ __global__ __launch_bounds__(64) void sys_finish_kernel(const BatchArgs A)
 	finish_pair(A, M, grp, pair, R, status, cells1);
 }
 
-template <int E1, int E2>
+template <int E1, int E2, bool DEFER, bool TB>
 int launch_pass_p(const BatchArgs &a, int grid, hipStream_t st)
 {
 	switch (a.sys_p) {
-	case 4:  hipLaunchKernelGGL((wfa_sys_kernel<E1, E2, 4>), dim3(grid), dim3(kT), 0, st, a); break;
-	case 16: hipLaunchKernelGGL((wfa_sys_kernel<E1, E2, 16>), dim3(grid), dim3(kT), 0, st, a); break;
-	default: hipLaunchKernelGGL((wfa_sys_kernel<E1, E2, 8>), dim3(grid), dim3(kT), 0, st, a); break;
+#ifdef MWF_SYS_ALL_P // (experiments: profiles/coop_quick.py with MWF_SYS_P)
+	case 4:  hipLaunchKernelGGL((wfa_sys_kernel<E1, E2, 4, DEFER, TB>), dim3(grid), dim3(kT), 0, st, a); break;
+	case 16: hipLaunchKernelGGL((wfa_sys_kernel<E1, E2, 16, DEFER, TB>), dim3(grid), dim3(kT), 0, st, a); break;
+#endif
+	default: hipLaunchKernelGGL((wfa_sys_kernel<E1, E2, 8, DEFER, TB>), dim3(grid), dim3(kT), 0, st, a); break;
 	}
 	return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// DEFER needs every H lag >= 3 (the edit-distance preset, every lag 1, only ever takes the plain form)
+template <int E1, int E2, bool CAN_DEFER>
+int launch_pass_d(const BatchArgs &a, int grid, hipStream_t st)
+{
+	const bool defer = CAN_DEFER && a.pen.x >= 3 && a.pen.oe1 >= 3 && a.pen.oe2 >= 3;
+	if constexpr (CAN_DEFER) {
+		if (defer) return a.want_cigar ? launch_pass_p<E1, E2, true, true>(a, grid, st) : launch_pass_p<E1, E2, true, false>(a, grid, st);
+	}
+	return a.want_cigar ? launch_pass_p<E1, E2, false, true>(a, grid, st) : launch_pass_p<E1, E2, false, false>(a, grid, st);
 }
 
 } // namespace
@@ -862,15 +1038,15 @@ int sys_max_grid()
 	int dev = 0, n_cu = 0, per = 0;
 	if (hipGetDevice(&dev) != hipSuccess) return 0;
 	if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, wfa_sys_kernel<2, 1, 8>, kT, 0) != hipSuccess || per < 1) return 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, wfa_sys_kernel<2, 1, 8, true, true>, kT, 0) != hipSuccess || per < 1) return 0;
 	return n_cu; // one workgroup per CU: every one of them is resident, which the waits between them rely on
 }
 
 int launch_sys_pass(const BatchArgs &a, int grid, void *stream)
 {
-	if (a.pen.e1 == 2 && a.pen.e2 == 1) return launch_pass_p<2, 1>(a, grid, (hipStream_t)stream);
-	if (a.pen.e1 == 2 && a.pen.e2 == 2) return launch_pass_p<2, 2>(a, grid, (hipStream_t)stream);
-	if (a.pen.e1 == 1 && a.pen.e2 == 1) return launch_pass_p<1, 1>(a, grid, (hipStream_t)stream);
+	if (a.pen.e1 == 2 && a.pen.e2 == 1) return launch_pass_d<2, 1, true>(a, grid, (hipStream_t)stream);
+	if (a.pen.e1 == 2 && a.pen.e2 == 2) return launch_pass_d<2, 2, true>(a, grid, (hipStream_t)stream);
+	if (a.pen.e1 == 1 && a.pen.e2 == 1) return launch_pass_d<1, 1, false>(a, grid, (hipStream_t)stream);
 	return -1;
 }
 
