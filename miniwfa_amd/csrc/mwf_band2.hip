@@ -747,14 +747,8 @@ bool band2_supported(const Penalty &p)
 		if (a_e1 == 1 && a_e2 == 1) return FN<T, K, 1, 1>(__VA_ARGS__);             \
 	}
 #endif
-#ifdef MWF_B2_EXP // experiments: four waves per pair with six chunk slots each (four pairs per CU)
-#define MWF_BAND2_EXP(FN, ...) if (g.block == 256 && g.span == 4 * 6 * 256) { if (a_e1 == 2 && a_e2 == 1) return FN<256, 6, 2, 1>(__VA_ARGS__); }
-#else
-#define MWF_BAND2_EXP(FN, ...)
-#endif
 #define MWF_BAND2_DISPATCH(FN, ...)                                                 \
 	do {                                                                            \
-		MWF_BAND2_EXP(FN, __VA_ARGS__)                                              \
 		if (g.block == 512) MWF_BAND2_PEN(FN, 512, 3, __VA_ARGS__)                  \
 		if (g.block == 768) MWF_BAND2_PEN(FN, 768, 2, __VA_ARGS__)                  \
 		MWF_BAND2_REST(FN, __VA_ARGS__)                                             \

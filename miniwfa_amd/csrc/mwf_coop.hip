@@ -1,4 +1,7 @@
-// mwf_coop.hip — one sequence pair across the whole device (BASELINE configs 2 and 4: a 150 kb pair, a 5 Mb pair).
+// mwf_coop.hip — one sequence pair across the whole device, the per-penalty hand-off form of rounds 1-2.  Since round 3 every pass
+// but ONE runs on the systolic kernel (mwf_sys.hip); what is left here is the provenance pass of the two-pass low-memory mode
+// (coop_pass<.., SEG>, wfa_coop_seg_kernel) and the walk back through its snapshots (coop_trace_kernel).  The description below is
+// that of the whole family; the traceback / plain instantiations are no longer built.
 //
 // A single pair is a strictly sequential chain of penalties (reference miniwfa.c:397-426), so the only
 // parallelism is across the diagonals of one wavefront — tens to hundreds of thousands of them for these
@@ -857,31 +860,6 @@ __device__ PassResult coop_pass(const BatchArgs &A, const PairMem &M, Shared &sh
 __device__ __forceinline__ int32_t group_pair(const BatchArgs &A, int32_t grp) { return A.coop_pair_ids ? A.coop_pair_ids[grp] : A.coop_pair; }
 __device__ __forceinline__ int32_t *group_state(const BatchArgs &A, int32_t grp) { return (int32_t*)((char*)A.coop_flags + (int64_t)grp * A.coop_misc_stride + 2048); }
 
-template <int E1, int E2>
-__global__ __launch_bounds__(kT) void wfa_coop_kernel(const BatchArgs A)
-{
-	__shared__ Shared sh;
-	const int32_t G = A.coop_group_size, grp = (int32_t)blockIdx.x / G, lb = (int32_t)blockIdx.x % G;
-	const int32_t pair = group_pair(A, grp);
-	int32_t *const state = group_state(A, grp);
-	PairMem M;
-	pair_mem(A, grp, pair, M);
-	int32_t n_seg = 0;
-	if (A.coop_pass == 2) { // second pass of the low-memory mode: checkpoints left by the walk
-		if (state[0] != ST_OK) return; // first pass failed: nothing to do, the finish kernel reports it
-		n_seg = state[3];
-	}
-	PassResult R;
-	if (A.want_cigar) R = coop_pass<E1, E2, true>(A, M, sh, n_seg, grp, lb, G);
-	else R = coop_pass<E1, E2, false>(A, M, sh, 0, grp, lb, G);
-	if (lb == 0 && threadIdx.x == 0) {
-		int32_t *st = state + (A.coop_pass == 2 ? 8 : 0);
-		st[0] = R.status, st[1] = R.s, st[2] = R.info;
-		st[4] = (int32_t)(R.cells & 0xffffffff), st[5] = (int32_t)(R.cells >> 32);
-		st[6] = R.n_snap;
-	}
-}
-
 // The first pass of the true low-memory mode: a kernel of its own, so that the other passes keep their register allocation.
 template <int E1, int E2>
 __global__ __launch_bounds__(kT) void wfa_coop_seg_kernel(const BatchArgs A)
@@ -897,50 +875,6 @@ __global__ __launch_bounds__(kT) void wfa_coop_seg_kernel(const BatchArgs A)
 		st[4] = (int32_t)(R.cells & 0xffffffff), st[5] = (int32_t)(R.cells >> 32);
 		st[6] = R.n_snap;
 	}
-}
-
-// Checkpoints of the low-memory mode from the full traceback matrix of a first pass.
-//
-// The reference's first pass (miniwfa.c:495-549) gives every cell the index of the ring cell its optimal predecessor
-// chain went through at the last snapshot; chasing those indices from the end cell through all snapshots yields, for the
-// snapshot taken when the newest slice had penalty S_j = (j+1)*step-1, the (penalty, diagonal) of the LAST cell of that
-// chain with penalty <= S_j.  The chain itself is dictated by the traceback bits (:506-522): H follows its 3-bit source
-// state, a gap state follows its own "extended" bit to either the same gap state e penalties back or H o+e back, one
-// diagonal over.  Walking those bits here reproduces the same chain, hence the same checkpoints.
-__global__ void coop_walk_kernel(const BatchArgs A)
-{
-	if (threadIdx.x != 0) return;
-	const int32_t grp = (int32_t)blockIdx.x; // one block per pair
-	int32_t *st = group_state(A, grp);
-	st[3] = 0;
-	if (st[0] != ST_OK) return;
-	const Penalty &P = A.pen;
-	PairMem M;
-	pair_mem(A, grp, group_pair(A, grp), M);
-	const int32_t s_final = st[1], step = A.step;
-	const int32_t n_seg = s_final / step;
-	if (n_seg > A.seg_slot) { st[0] = ST_SNAP_OVERFLOW; return; }
-	int32_t arr = 0, s = s_final, col = M.ql - M.tl + M.tl + 1; // array 0=H 1=E1 2=F1 3=E2 4=F2; the end cell is on diagonal ql-tl
-	int32_t j = n_seg - 1;
-	while (j >= 0) {
-		const int32_t Sj = (j + 1) * step - 1;
-		if (s <= Sj) { // first cell of the chain that already existed at snapshot j
-			M.seg[2 * j] = s, M.seg[2 * j + 1] = col;
-			--j;
-			continue;
-		}
-		if (s <= 0) { st[0] = ST_INTERNAL; return; }
-		const uint32_t x = M.tb[M.row_off[s - 1] + (col - M.row_lo[s - 1])];
-		if (arr == 0) {
-			const uint32_t z = x & 7u;
-			if (z == 0) s -= P.x;
-			else arr = (int32_t)z == 1 ? 1 : (int32_t)z == 2 ? 2 : (int32_t)z == 3 ? 3 : 4;
-		} else if (arr == 1) { if (x & 0x08u) s -= P.e1; else s -= P.oe1, arr = 0; col -= 1; }
-		else if (arr == 2) { if (x & 0x10u) s -= P.e1; else s -= P.oe1, arr = 0; col += 1; }
-		else if (arr == 3) { if (x & 0x20u) s -= P.e2; else s -= P.oe2, arr = 0; col -= 1; }
-		else { if (x & 0x40u) s -= P.e2; else s -= P.oe2, arr = 0; col += 1; }
-	}
-	st[3] = n_seg;
 }
 
 // Checkpoints of the true low-memory mode: chase the provenance of the end cell back through the snapshots (reference
@@ -982,26 +916,11 @@ __global__ void coop_trace_kernel(const BatchArgs A)
 	st[3] = n_snap;
 }
 
-__global__ __launch_bounds__(64) void coop_finish_kernel(const BatchArgs A)
-{
-	const int32_t grp = (int32_t)blockIdx.x; // one block per pair
-	const int32_t pair = group_pair(A, grp);
-	PairMem M;
-	pair_mem(A, grp, pair, M);
-	const int32_t *st1 = group_state(A, grp), *st = A.step > 0 && A.want_cigar ? st1 + 8 : st1;
-	PassResult R;
-	int32_t status = st1[0] != ST_OK ? st1[0] : st[0];
-	R.status = status, R.s = st[1], R.info = st[2], R.n_snap = 0;
-	R.cells = (int64_t)(uint32_t)st[4] | (int64_t)st[5] << 32;
-	const int64_t cells1 = A.step > 0 && A.want_cigar ? ((int64_t)(uint32_t)st1[4] | (int64_t)st1[5] << 32) : 0;
-	finish_pair(A, M, grp, pair, R, status, cells1);
-}
-
 template <int E1, int E2>
 int launch_pass(const BatchArgs &a, int grid, hipStream_t st)
 {
-	if (a.coop_pass == 3) hipLaunchKernelGGL((wfa_coop_seg_kernel<E1, E2>), dim3(grid), dim3(kT), 0, st, a);
-	else hipLaunchKernelGGL((wfa_coop_kernel<E1, E2>), dim3(grid), dim3(kT), 0, st, a);
+	if (a.coop_pass != 3) return -1; // every other pass runs on the systolic kernel (mwf_sys.hip)
+	hipLaunchKernelGGL((wfa_coop_seg_kernel<E1, E2>), dim3(grid), dim3(kT), 0, st, a);
 	return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -1019,7 +938,7 @@ int coop_max_grid(bool)
 	int dev = 0, n_cu = 0, per = 0;
 	if (hipGetDevice(&dev) != hipSuccess) return 0;
 	if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, wfa_coop_kernel<2, 1>, kT, 0) != hipSuccess || per < 1) return 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, wfa_coop_seg_kernel<2, 1>, kT, 0) != hipSuccess || per < 1) return 0;
 	return n_cu; // one workgroup per CU: every one of them is resident, which the grid barrier relies on
 }
 
@@ -1031,21 +950,9 @@ int launch_coop_pass(const BatchArgs &a, int grid, void *stream)
 	return -1;
 }
 
-int launch_coop_walk(const BatchArgs &a, void *stream)
-{
-	hipLaunchKernelGGL(coop_walk_kernel, dim3(a.coop_groups > 0 ? a.coop_groups : 1), dim3(64), 0, (hipStream_t)stream, a);
-	return hipGetLastError() == hipSuccess ? 0 : -2;
-}
-
 int launch_coop_trace(const BatchArgs &a, void *stream)
 {
 	hipLaunchKernelGGL(coop_trace_kernel, dim3(a.coop_groups > 0 ? a.coop_groups : 1), dim3(64), 0, (hipStream_t)stream, a);
-	return hipGetLastError() == hipSuccess ? 0 : -2;
-}
-
-int launch_coop_finish(const BatchArgs &a, void *stream)
-{
-	hipLaunchKernelGGL(coop_finish_kernel, dim3(a.coop_groups > 0 ? a.coop_groups : 1), dim3(64), 0, (hipStream_t)stream, a);
 	return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -80,7 +80,6 @@ struct mwf_gpu_s {
 	int64_t coop_tb_cap = (int64_t)96 << 30; // whole-device traceback arena: first allocation never above this ...
 	int64_t coop_tb_mult = 1;                // ... times this; doubled after an overflow while memory lasts
 	int64_t lowmem_budget_mb = 0; // whole-device low-memory mode: first-pass traceback above this many MB -> true two-pass (0: automatic)
-	int sys = 1;               // whole-device passes on the systolic kernel (mwf_sys.hip); 0: every pass on mwf_coop.hip (comparison)
 	int sys_p = 8;             // its penalties per hand-off block (4, 8 or 16)
 	// workspace (per-stream pool)
 	DevBuf ring, sring, good, tb, row_off, row_lo, cig_scratch, snap, snap_meta, seg, queue, dbg, coop_edge, coop_misc;
@@ -363,7 +362,6 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 	if (g->block == 0 && (geom_block == 64 || geom_block == 128) && range_ok) bg.block = geom_block, bg.packed = 1;
 	if (g->block == 0 && geom_block == 256) bg.block = 256, bg.packed = range_ok;
 	bg.span = bg.block / 64 * (bg.packed && bg.block != 768 ? 3 : 2) * 256;
-	if (getenv("MWF_B2_256X6") && bg.packed && bg.block == 512) bg.block = 256, bg.span = 4 * 6 * 256; // experiment (needs a library built with -DMWF_B2_EXP)
 	if (want_kind != 2 && max_len + 1 > 4 * (int64_t)bg.span) return; // windows will mostly outgrow the span: go generic at once
 	const int64_t lds_cap = bg.block >= 768 ? 140 * 1024 : bg.block >= 512 ? 70 * 1024 : bg.block == 256 ? 36 * 1024 : bg.block == 128 ? 18 * 1024 : 9 * 1024;
 	// the packed kernel's sequence copy holds 2 bits per base unless that is switched off (or this is the re-run of pairs that
@@ -607,7 +605,7 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 	const int64_t TC = coop_chunk_slots(Gs);
 	const size_t NG = (size_t)n_groups;
 	// the systolic kernel (mwf_sys.hip) runs every pass but the provenance pass of the two-pass low-memory mode
-	const bool use_sys = g->sys != 0;
+	const bool use_sys = true;
 	const int sysP = g->sys_p;
 	if (ensure(g, g->ring, NG * (size_t)P.nH * W * 4 + 4096)) return -1;
 	if (ensure(g, g->good, NG * (size_t)P.nH * GW * 8)) return -1;
@@ -769,14 +767,14 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 	if (sys_first ? launch_sys_pass(as, Gs * n_groups, g->stream) : launch_coop_pass(a, Gs * n_groups, g->stream)) { g->err = "kernel launch failed (whole-device pass)"; return -1; }
 	g->stats.n_launches += 1;
 	if (low_mem) {
-		if (two_pass ? launch_coop_trace(a, g->stream) : sys_first ? launch_sys_walk(as, g->stream) : launch_coop_walk(a, g->stream)) { g->err = "kernel launch failed (checkpoints)"; return -1; }
-		if (use_sys ? reset_sys(false) : reset_sync(false)) return -1; // barrier counters (and the old kernel's flag ring and granules) of the second pass
+		if (two_pass ? launch_coop_trace(a, g->stream) : launch_sys_walk(as, g->stream)) { g->err = "kernel launch failed (checkpoints)"; return -1; }
+		if (reset_sys(false)) return -1; // barrier counters and progress words of the second pass
 		a.coop_pass = as.coop_pass = 2;
 		// the second pass is not traced: the band trace of a low-memory run is that of its second pass, traced below
-		if (use_sys ? launch_sys_pass(as, Gs * n_groups, g->stream) : launch_coop_pass(a, Gs * n_groups, g->stream)) { g->err = "kernel launch failed (second pass)"; return -1; }
+		if (launch_sys_pass(as, Gs * n_groups, g->stream)) { g->err = "kernel launch failed (second pass)"; return -1; }
 		g->stats.n_launches += 2;
 	}
-	if (use_sys ? launch_sys_finish(as, g->stream) : launch_coop_finish(a, g->stream)) { g->err = "kernel launch failed (traceback)"; return -1; }
+	if (launch_sys_finish(as, g->stream)) { g->err = "kernel launch failed (traceback)"; return -1; }
 	g->stats.n_launches += 1;
 	if (last) {
 		HIP_TRY(g, hipEventRecord(g->ev1, g->stream));
@@ -792,7 +790,7 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 // one pair with the device to itself
 int run_coop_pair(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, int32_t pair, bool first, bool last)
 {
-	const int G = coop_group_size(coop_grid_limit(g), (int64_t)b->h_tl[pair] + b->h_ql[pair], true, g->sys ? sys_owned_cols(g->sys_p) : 256);
+	const int G = coop_group_size(coop_grid_limit(g), (int64_t)b->h_tl[pair] + b->h_ql[pair], true, sys_owned_cols(g->sys_p));
 	return run_coop_group(g, b, opt, std::vector<int32_t>{pair}, G, first, last);
 }
 
@@ -1036,7 +1034,6 @@ int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value)
 	else if (!strcmp(name, "coop_spin_limit")) g->coop_spin_limit = std::max<int64_t>(0, std::min<int64_t>(value, 0x7fffffff));
 	else if (!strcmp(name, "coop_tb_cap_mb")) g->coop_tb_cap = std::max<int64_t>(1, value) << 20;
 	else if (!strcmp(name, "lowmem_budget_mb")) g->lowmem_budget_mb = std::max<int64_t>(0, value);
-	else if (!strcmp(name, "sys")) g->sys = value != 0;
 	else if (!strcmp(name, "sys_p") && (value == 4 || value == 8 || value == 16)) g->sys_p = (int)value;
 	else if (!strcmp(name, "trim")) { (void)hipSetDevice(g->device); trim(g); }
 	else return -1;
@@ -1133,7 +1130,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	int n_cu_coop = 0;
 	if (coop || (g->force_kind < 0 && max_len >= coop_len && coop_supported(P0))) {
 		n_cu_coop = coop_grid_limit(g);
-		const int coop_side_by_side = n_cu_coop > 0 ? std::max(1, n_cu_coop / coop_group_size(n_cu_coop, max_len, false, g->sys ? sys_owned_cols(g->sys_p) : 256)) : 1;
+		const int coop_side_by_side = n_cu_coop > 0 ? std::max(1, n_cu_coop / coop_group_size(n_cu_coop, max_len, false, sys_owned_cols(g->sys_p))) : 1;
 		const int64_t coop_max_pairs = std::max<int64_t>(1, std::min<int64_t>(256, max_len / 70000 * coop_side_by_side));
 		coop = coop || b->n <= coop_max_pairs;
 	}
@@ -1144,7 +1141,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		std::stable_sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) { return (int64_t)b->h_tl[x] + b->h_ql[x] > (int64_t)b->h_tl[y] + b->h_ql[y]; }); // longest first
 		for (size_t at = 0; at < idx.size();) {
 			const int64_t len0 = (int64_t)b->h_tl[idx[at]] + b->h_ql[idx[at]];
-			const int Gs = coop_group_size(n_cu_coop, len0, false, g->sys ? sys_owned_cols(g->sys_p) : 256);
+			const int Gs = coop_group_size(n_cu_coop, len0, false, sys_owned_cols(g->sys_p));
 			const size_t n_side = std::min<size_t>(idx.size() - at, (size_t)std::max(1, n_cu_coop / Gs));
 			const bool last = at + n_side == idx.size();
 			if (n_side <= 1 || b->debug_pair >= 0) { // alone (also: band traces are single-pair diagnostics)

@@ -134,10 +134,8 @@ struct BandGeom {
 bool coop_supported(const Penalty &p);
 int  coop_max_grid(bool cigar);
 int64_t coop_chunk_slots(int grid);                  // 256-column chunks a launch of `grid` workgroups holds (window capacity + 1)                      // co-resident workgroups the kernel may be launched with
-int  launch_coop_pass(const BatchArgs &a, int grid, void *stream);       // forward pass (score / traceback bytes)
-int  launch_coop_walk(const BatchArgs &a, void *stream);                 // checkpoints from the traceback matrix
+int  launch_coop_pass(const BatchArgs &a, int grid, void *stream);       // the provenance pass of the two-pass low-memory mode (coop_pass == 3)
 int  launch_coop_trace(const BatchArgs &a, void *stream);                // checkpoints from the snapshots of a provenance pass
-int  launch_coop_finish(const BatchArgs &a, void *stream);               // traceback + per-pair outputs
 // launch wrappers implemented in mwf_sys.hip (the systolic whole-device kernel: same penalties as mwf_coop.hip, every pass but
 // the provenance pass of the two-pass low-memory mode)
 int64_t sys_chunk_slots(int grid);                   // chunk slots a launch of `grid` workgroups holds

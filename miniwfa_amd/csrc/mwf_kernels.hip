@@ -793,7 +793,9 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 }
 
 // STREAM: the four-columns-per-lane passes (two kernels rather than one, so that neither pays for the other's registers)
-template <int T, bool STREAM, bool LDS2, bool H16>
+// MODE: -1 score or traceback by A.want_cigar (one kernel for both); 0 / 1: a kernel for score-only / traceback alone, so that
+// neither pays for the other's registers (the kernels with E2/F2 in LDS, whose workgroups share a CU)
+template <int T, bool STREAM, bool LDS2, bool H16, int MODE>
 __device__ void align_pair(const BatchArgs &A, Shared &sh, int32_t slot, int32_t pair)
 {
 	PairMem M;
@@ -818,7 +820,8 @@ __device__ void align_pair(const BatchArgs &A, Shared &sh, int32_t slot, int32_t
 		__syncthreads();
 	}
 	if (status == ST_OK) {
-		if (STREAM && LDS2 && H16) R = A.want_cigar ? stream_pass<T, true, LDS2, false, LDS2 && H16>(A, M, sh, n_seg, trace) : stream_pass<T, false, LDS2, false, LDS2 && H16>(A, M, sh, 0, trace);
+		if constexpr (STREAM && LDS2 && MODE >= 0) R = stream_pass<T, MODE == 1, LDS2, false, LDS2 && H16>(A, M, sh, MODE == 1 ? n_seg : 0, trace);
+		else if (STREAM && LDS2 && H16) R = A.want_cigar ? stream_pass<T, true, LDS2, false, LDS2 && H16>(A, M, sh, n_seg, trace) : stream_pass<T, false, LDS2, false, LDS2 && H16>(A, M, sh, 0, trace);
 		else if (STREAM) R = A.want_cigar ? stream_pass<T, true, LDS2>(A, M, sh, n_seg, trace) : stream_pass<T, false, LDS2>(A, M, sh, 0, trace);
 		else R = A.want_cigar ? forward_pass<T, true, false>(A, M, sh, n_seg, trace) : forward_pass<T, false, false>(A, M, sh, 0, trace);
 		status = R.status;
@@ -828,7 +831,7 @@ __device__ void align_pair(const BatchArgs &A, Shared &sh, int32_t slot, int32_t
 
 // Persistent workgroups: each pulls pairs from a shared counter until the batch is drained.
 // (H16: the kernel with 16-bit ring rows and a 64 KB LDS copy of E2/F2 — two 512-thread workgroups per CU, i.e. 128 VGPRs)
-template <int T, bool STREAM, bool LDS2 = false, bool H16 = false>
+template <int T, bool STREAM, bool LDS2 = false, bool H16 = false, int MODE = -1>
 __global__ __launch_bounds__(T, (H16 && T == 512) ? 4 : 1) void wfa_batch_kernel(const BatchArgs A)
 {
 	__shared__ Shared sh;
@@ -839,7 +842,7 @@ __global__ __launch_bounds__(T, (H16 && T == 512) ? 4 : 1) void wfa_batch_kernel
 		__syncthreads();
 		if (item >= A.n_pairs) break;
 		const int32_t pair = A.order ? A.order[item] : item;
-		align_pair<T, STREAM, LDS2, H16>(A, sh, (int32_t)blockIdx.x, pair);
+		align_pair<T, STREAM, LDS2, H16, MODE>(A, sh, (int32_t)blockIdx.x, pair);
 	}
 }
 
@@ -891,10 +894,17 @@ int launch_batch(const BatchArgs &a, int grid, int block, void *stream)
 			(void)hipGetLastError();
 			hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, (hipStream_t)stream, a);
 		};
-		if (a.ring16 && block == 768) go(&wfa_batch_kernel<768, true, true, true>, 768);
-		else if (a.ring16) go(&wfa_batch_kernel<512, true, true, true>, 512);
-		else if (block == 768) go(&wfa_batch_kernel<768, true, true>, 768);
-		else go(&wfa_batch_kernel<512, true, true>, 512);
+		if (a.want_cigar) {
+			if (a.ring16 && block == 768) go(&wfa_batch_kernel<768, true, true, true, 1>, 768);
+			else if (a.ring16) go(&wfa_batch_kernel<512, true, true, true, 1>, 512);
+			else if (block == 768) go(&wfa_batch_kernel<768, true, true, false, 1>, 768);
+			else go(&wfa_batch_kernel<512, true, true, false, 1>, 512);
+		} else {
+			if (a.ring16 && block == 768) go(&wfa_batch_kernel<768, true, true, true, 0>, 768);
+			else if (a.ring16) go(&wfa_batch_kernel<512, true, true, true, 0>, 512);
+			else if (block == 768) go(&wfa_batch_kernel<768, true, true, false, 0>, 768);
+			else go(&wfa_batch_kernel<512, true, true, false, 0>, 512);
+		}
 		return hipGetLastError() == hipSuccess ? 0 : -2;
 	}
 	return wants_stream(a) ? launch_batch_as<true>(a, grid, block, (hipStream_t)stream) : launch_batch_as<false>(a, grid, block, (hipStream_t)stream);
@@ -922,10 +932,11 @@ int batch_kernel_occupancy(int block, bool stream_pass, int lds_e2_cols, bool ri
 		int n = 0;
 		const size_t lds = (size_t)lds_e2_cols * (ring16 ? 4 : 8);
 		hipError_t e;
-		if (ring16) e = block == 768 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<768, true, true, true>, 768, lds)
-		                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<512, true, true, true>, 512, lds);
-		else e = block == 768 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<768, true, true>, 768, lds)
-		                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<512, true, true>, 512, lds);
+		// (the traceback kernels: the score-only ones never hold fewer workgroups)
+		if (ring16) e = block == 768 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<768, true, true, true, 1>, 768, lds)
+		                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<512, true, true, true, 1>, 512, lds);
+		else e = block == 768 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<768, true, true, false, 1>, 768, lds)
+		                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_batch_kernel<512, true, true, false, 1>, 512, lds);
 		return e == hipSuccess ? n : 0;
 	}
 	return stream_pass ? occupancy_as<true>(block) : occupancy_as<false>(block);

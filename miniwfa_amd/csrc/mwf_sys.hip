@@ -71,6 +71,25 @@ __device__ __forceinline__ int32_t pick4(int32_t i, int32_t a0, int32_t a1, int3
 	return i == 0 ? a0 : i == 1 ? a1 : i == 2 ? a2 : a3;
 }
 
+// The recurrence with its traceback byte (dev::wf_cell, miniwfa.c:267-278, :289-306), the byte read off the RESULTS so that few
+// values are live at once: H is the maximum of m, e1, e2, f1, f2 and the reference's tie-breaking (mismatch, then E1, E2, F1,
+// F2) is the first of them that equals it; a gap state was extended iff it differs from what opening it would have given.
+template <bool WANT_TB>
+__device__ __forceinline__ Cell sys_cell(int32_t hx, int32_t o1m, int32_t g1m, int32_t o2m, int32_t g2m, int32_t o1p, int32_t g1p, int32_t o2p, int32_t g2p)
+{
+	if (!WANT_TB) return wf_cell<false>(hx, o1m, g1m, o2m, g2m, o1p, g1p, o2p, g2p);
+	Cell c;
+	c.e1 = max(o1m, g1m);
+	c.e2 = max(o2m, g2m);
+	c.f1 = max(o1p, g1p) + 1;
+	c.f2 = max(o2p, g2p) + 1;
+	const int32_t m = hx + 1;
+	c.h = max(max(m, max(c.e1, c.e2)), max(c.f1, c.f2));
+	const uint32_t z = c.h == m ? 0u : c.h == c.e1 ? 1u : c.h == c.e2 ? 3u : c.h == c.f1 ? 2u : 4u;
+	c.tb = z | ((uint32_t)(c.e1 != o1m) << 3) | ((uint32_t)(c.f1 != o1p + 1) << 4) | ((uint32_t)(c.e2 != o2m) << 5) | ((uint32_t)(c.f2 != o2p + 1) << 6);
+	return c;
+}
+
 // The whole wave walks one diagonal: t[j+n..] vs q[i+n..], up to `room` bytes, starting after n0 matched bytes.
 // Every argument is wave-uniform; returns the total number of matching bytes (<= room).
 __device__ __forceinline__ int32_t lcp_wave(const PairMem &M, int32_t j, int32_t i, int32_t room, int32_t n0)
@@ -285,7 +304,7 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 	};
 
 #ifdef MWF_SYS_TIMING
-	unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}, t_blocks = 0, t_runs = 0;
+	unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}, t_blocks = 0, t_runs = 0, t_st[4] = {0, 0, 0, 0};
 #define MWF_T(x) const unsigned long long x = __builtin_readcyclecounter()
 #else
 #define MWF_T(x)
@@ -541,7 +560,12 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 							if (w_valid) w_t = ld8(M.ts + mj + off), w_q = ld8(M.qs + mq + off);
 						}
 					};
+					MWF_T(ts_0);
 					if (DEFER && t > 0) stage2a();
+#ifdef MWF_SYS_TIMING
+					if (DEFER && t > 0 && __ballot(nmat[0] == 0x7fffffff) == 0) {} // (forces the wait for the probe words here)
+#endif
+					MWF_T(ts_1);
 					if (!DEFER || t < P) {
 					const int32_t sc = s0 + t; // penalties done so far
 					if (TB && !deep_blk && seg_s == sc) { // checkpoint reset of the second pass (miniwfa.c:413-416): every slot knows the checkpoints
@@ -607,7 +631,7 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 						// phantom (beyond the matrix) offsets, and both addresses stay inside the sequences' slack.
 #pragma unroll
 						for (int i = 0; i < 4; ++i) {
-							const Cell v = wf_cell<TB>(hx[i], o1[i], g1m[i], o2[i], g2m[i], o1[i + 2], g1p[i], o2[i + 2], g2p[i]);
+							const Cell v = sys_cell<TB>(hx[i], o1[i], g1m[i], o2[i], g2m[i], o1[i + 2], g1p[i], o2[i + 2], g2p[i]);
 							ne1[i] = v.e1, nf1[i] = v.f1, ne2[i] = v.e2, nf2[i] = v.f2;
 							const int32_t jc = (int32_t)min((uint32_t)(v.h + 1), (uint32_t)rj[i]);
 							c_t8[i] = ld8(M.ts + jc), c_q8[i] = ld8((qsd + jc) + i);
@@ -619,7 +643,7 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 					for (int i = 0; i < 4; ++i) {
 						const int32_t c = c0 + i, d = c - 1 - tl;
 						const uint32_t act = inner ? 1u : (uint32_t)((c >= lo) & (c <= hi));
-						const Cell v = wf_cell<TB>(hx[i], o1[i], g1m[i], o2[i], g2m[i], o1[i + 2], g1p[i], o2[i + 2], g2p[i]);
+						const Cell v = sys_cell<TB>(hx[i], o1[i], g1m[i], o2[i], g2m[i], o1[i + 2], g1p[i], o2[i + 2], g2p[i]);
 						ne1[i] = act ? v.e1 : kNegInf, nf1[i] = act ? v.f1 : kNegInf;
 						ne2[i] = act ? v.e2 : kNegInf, nf2[i] = act ? v.f2 : kNegInf;
 						const uint32_t inm = act & inm_bit(d, v.h, tl, ql);
@@ -666,6 +690,7 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 					}
 					curHk = newH;
 					}
+					MWF_T(ts_2);
 					if (!DEFER) {
 #pragma unroll
 						for (int i = 0; i < 4; ++i) x_hv[i] = c_hv[i], x_t8[i] = c_t8[i], x_q8[i] = c_q8[i];
@@ -751,6 +776,12 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 						for (int i = 0; i < 4; ++i) x_hv[i] = c_hv[i], x_t8[i] = c_t8[i], x_q8[i] = c_q8[i];
 						x_tbw = c_tbw, x_snew = c_snew, x_newH = c_newH, x_t = t;
 					}
+#ifdef MWF_SYS_TIMING
+					if (deep_blk) {
+						const unsigned long long ts_3 = __builtin_readcyclecounter();
+						t_st[0] += ts_1 - ts_0, t_st[1] += ts_2 - ts_1, t_st[2] += ts_3 - ts_2, t_st[3] += 1;
+					}
+#endif
 				}
 
 				if (deep_blk && lane < P) { // what the penalties of a deep block did not write one by one
@@ -895,8 +926,8 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 	}
 #ifdef MWF_SYS_TIMING
 	if (lane == 0 && t_blocks > 0 && (((wv == 0 || wv == 5) && (lb % 37) == 0) || t_acc[5] * 6 < t_acc[4]))
-		printf("wg %3d wave %d: %llu slot-blocks in %llu epochs | per slot-block: wait %.0f  refresh %.0f  steps %.0f  publish %.0f cycles | per epoch: blocks %.0f  end (barriers, scan, shrink) %.0f\n", lb, wv,
-		       t_blocks, t_runs, (double)t_acc[0] / t_blocks, (double)t_acc[1] / t_blocks, (double)t_acc[2] / t_blocks, (double)t_acc[3] / t_blocks, (double)t_acc[4] / t_runs, (double)t_acc[5] / t_runs);
+		printf("wg %3d wave %d: deep-block iterations %llu: stage 2a (incl. wait for the probe words) %.0f  stage 1 %.0f  stage 2b %.0f cycles | %llu slot-blocks in %llu epochs | per slot-block: wait %.0f  refresh %.0f  steps %.0f  publish %.0f cycles | per epoch: blocks %.0f  end (barriers, scan, shrink) %.0f\n", lb, wv,
+		       t_st[3], (double)t_st[0] / (t_st[3] ? t_st[3] : 1), (double)t_st[1] / (t_st[3] ? t_st[3] : 1), (double)t_st[2] / (t_st[3] ? t_st[3] : 1), t_blocks, t_runs, (double)t_acc[0] / t_blocks, (double)t_acc[1] / t_blocks, (double)t_acc[2] / t_blocks, (double)t_acc[3] / t_blocks, (double)t_acc[4] / t_runs, (double)t_acc[5] / t_runs);
 #endif
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	R.s = s, R.cells = cells;

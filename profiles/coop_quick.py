@@ -8,7 +8,7 @@ cases = [("c4_like_150kb", synth_pair(2001, 150000, 0.035), [dict(), dict(flag=1
 if len(sys.argv) > 1: cases.append(("mhc_like_5Mb", synth_pair(2002, 5000000, 0.008, 3, 15000), [dict()]))
 for name, (t, q), modes in cases:
     eng = mw.Engine(0)
-    for name_, env in (("sys", "MWF_SYS"), ("sys_p", "MWF_SYS_P")):
+    for name_, env in (("sys_p", "MWF_SYS_P"),):
         if os.environ.get(env) is not None:
             eng.set(name_, int(os.environ[env]))
     b = eng.upload(PackedBatch([(t, q)]))
