@@ -133,7 +133,7 @@ struct PairMem {
 	int32_t *dbg;
 	// traceback bytes laid out per epoch of 256 penalties and chunk slot (mwf_sys.hip); null: rows back to back (row_off / row_lo)
 	const int64_t *ep;
-	int32_t ep_ow, ep_p;
+	int32_t ep_ow, ep_p, ep_kw;
 };
 
 // the traceback byte of (penalty row + 1, column col)
@@ -142,7 +142,7 @@ __device__ __forceinline__ uint32_t tb_byte(const PairMem &M, int32_t row, int32
 	if (M.ep) {
 		const int64_t base = M.ep[2 * (row >> 8)], gn = M.ep[2 * (row >> 8) + 1];
 		const int32_t g = col / M.ep_ow;
-		return M.tb[base + ((int64_t)(row & 255) * (int32_t)(gn >> 32) + (g - (int32_t)(gn & 0xffffffff))) * 256 + (col - (g * M.ep_ow - M.ep_p))];
+		return M.tb[base + ((int64_t)(row & 255) * (int32_t)(gn >> 32) + (g - (int32_t)(gn & 0xffffffff))) * M.ep_kw + (col - (g * M.ep_ow - M.ep_p))];
 	}
 	return M.tb[M.row_off[row] + (col - M.row_lo[row])];
 }
@@ -226,7 +226,7 @@ __device__ __forceinline__ void pair_mem(const BatchArgs &A, int32_t slot, int32
 	M.snap_meta = A.snap_meta ? A.snap_meta + (int64_t)slot * A.snap_meta_slot : 0;
 	M.seg = A.seg ? A.seg + (int64_t)slot * 2 * A.seg_slot : 0;
 	M.dbg = A.dbg;
-	M.ep = 0, M.ep_ow = 0, M.ep_p = 0;
+	M.ep = 0, M.ep_ow = 0, M.ep_p = 0, M.ep_kw = 0;
 }
 
 // After the forward pass(es): traceback on the first wave, CIGAR into the pool, per-pair outputs.

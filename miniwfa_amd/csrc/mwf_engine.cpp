@@ -80,7 +80,8 @@ struct mwf_gpu_s {
 	int64_t coop_tb_cap = (int64_t)96 << 30; // whole-device traceback arena: first allocation never above this ...
 	int64_t coop_tb_mult = 1;                // ... times this; doubled after an overflow while memory lasts
 	int64_t lowmem_budget_mb = 0; // whole-device low-memory mode: first-pass traceback above this many MB -> true two-pass (0: automatic)
-	int sys_p = 8;             // its penalties per hand-off block (4, 8 or 16)
+	int sys_p = 8;             // whole-device (systolic) kernel: penalties per hand-off block (4, 8 or 16)
+	int sys_c = 0;             // its columns per lane: 0 automatic (1 while the window is expected to fit the slots that way, else 4), 1, 4
 	// workspace (per-stream pool)
 	DevBuf ring, sring, good, tb, row_off, row_lo, cig_scratch, snap, snap_meta, seg, queue, dbg, coop_edge, coop_misc;
 	DevBuf sys_box, sys_prog, sys_log, sys_ep, sys_park, sys_ring, sys_good;
@@ -607,6 +608,18 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 	// the systolic kernel (mwf_sys.hip) runs every pass but the provenance pass of the two-pass low-memory mode
 	const bool use_sys = true;
 	const int sysP = g->sys_p;
+	// Columns per lane of the systolic kernel, per pass: one column per lane (64-column slots that own 48) quarters the
+	// per-column work a wave does per penalty — what a chain of penalties on a narrow window waits for — but needs five times
+	// the slots; taken while the window is EXPECTED to fit them (first pass: a fifth of tl+ql, real pairs stay far below;
+	// second pass of the low-memory mode: the band collapses at every checkpoint, miniwfa.c:413-416).  A pair whose window
+	// outgrows the slots comes back as ST_BAND_OVERFLOW and is re-run with four columns per lane (finalize()).
+	auto window_cap = [&](int c) -> int64_t { return (TC - 4) * (int64_t)sys_owned_cols(sysP, c) - 2 * (257 + sysP); };
+	bool wide_again = false;
+	for (int32_t pair : pairs) wide_again |= (b->h_flags[pair] & 16) != 0;
+	const int64_t est1 = std::min<int64_t>(len + 1, std::max<int64_t>(8192, len / 5));
+	const int64_t est2 = std::min<int64_t>(len + 1, 2 * ((int64_t)opt.step + 2 * P.nH) + 8);
+	const int c_first = g->sys_c ? g->sys_c : (!wide_again && est1 <= window_cap(1)) ? 1 : 4;
+	const int c_second = g->sys_c ? g->sys_c : (!wide_again && est2 <= window_cap(1)) ? 1 : 4;
 	if (ensure(g, g->ring, NG * (size_t)P.nH * W * 4 + 4096)) return -1;
 	if (ensure(g, g->good, NG * (size_t)P.nH * GW * 8)) return -1;
 	// Low-memory mode (opt.step > 0), two ways to the checkpoints:
@@ -620,7 +633,7 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 		// automatic: a quarter of the device (the 5 Mb pair's first-pass traceback, ~60 GB, fits a 288 GB device and the walk
 		// variant is several times faster than carrying provenance through the first pass)
 		const int64_t budget = g->lowmem_budget_mb > 0 ? g->lowmem_budget_mb << 20 : (int64_t)(g->total_mem / 4);
-		two_pass = std::max<int64_t>((int64_t)1 << 30, 6000 * len) * (int64_t)NG * g->coop_tb_mult * (use_sys ? 9 : 8) / 8 > budget;
+		two_pass = std::max<int64_t>((int64_t)1 << 30, 6000 * len) * (int64_t)NG * g->coop_tb_mult * (c_first == 1 ? 12 : 9) / 8 > budget;
 	}
 	// granules crossing waves: [nH][TC][2 sides][4] x 8 bytes (twice for the two-pass mode: values and their provenance);
 	// misc: flags, barrier words, pass state, then the flag ring
@@ -644,8 +657,9 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 		// to one diagonal at every checkpoint, miniwfa.c:413-416); s is guessed as 3 % of tl+ql
 		if (two_pass) guess = std::min<int64_t>(guess, std::max<int64_t>((int64_t)64 << 20, (len * 3 / 100 + 1024) * std::min<int64_t>(len + 1, 2 * (int64_t)(opt.step + 2 * P.nH) + 8)) * (int64_t)NG);
 		// (the systolic kernel stores 256 bytes per penalty and chunk slot that takes part, a few slots beyond the window included)
-		if (use_sys) guess = std::min<int64_t>(g->coop_tb_cap, guess / 8 * 9 + (rows_slot / 256 + 2) * 8 * 65536 * (int64_t)NG);
-		int64_t want = std::min(use_sys ? worst / 8 * 9 + (rows_slot / 256 + 2) * 8 * 65536 * (int64_t)NG : worst, g->tb_budget_mb > 0 ? (g->tb_budget_mb << 20) : guess * g->coop_tb_mult);
+		const int64_t lay = (two_pass ? c_second : std::min(c_first, low_mem ? c_second : c_first)) == 1 ? 12 : 9; // (64-column slots own 48: 4/3 of the exact rows; 256-column ones own 240)
+		if (use_sys) guess = std::min<int64_t>(g->coop_tb_cap, guess / 8 * lay + (rows_slot / 256 + 2) * 8 * 65536 * (int64_t)NG);
+		int64_t want = std::min(use_sys ? worst / 8 * lay + (rows_slot / 256 + 2) * 8 * 65536 * (int64_t)NG : worst, g->tb_budget_mb > 0 ? (g->tb_budget_mb << 20) : guess * g->coop_tb_mult);
 		if ((int64_t)g->tb.bytes >= want) want = (int64_t)g->tb.bytes;
 		else {
 			size_t fr = 0, tot = 0;
@@ -738,8 +752,7 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 	// the same launch on the systolic kernel: a private H ring per chunk slot, its own good-bit rows, hand-off boxes, edge log
 	BatchArgs as = a;
 	if (use_sys) {
-		as.ring = (int32_t*)g->sys_ring.p, as.ring_slot_ints = TC * P.nH * 256;
-		as.good = (unsigned long long*)g->sys_good.p, as.GW = (int32_t)(TC * 4);
+		as.ring = (int32_t*)g->sys_ring.p, as.good = (unsigned long long*)g->sys_good.p; // (sized for four columns per lane)
 		as.rows_slot = sys_rows;
 		as.sys_p = sysP;
 		as.sys_box = (int32_t*)g->sys_box.p, as.sys_box_stride = sys_box_group;
@@ -762,6 +775,8 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 	const bool sys_first = use_sys && !two_pass; // the provenance pass of the two-pass mode stays on mwf_coop.hip
 	if (sys_first ? reset_sys(true) : reset_sync(true)) return -1;
 	if (first) HIP_TRY(g, hipEventRecord(g->ev0, g->stream));
+	auto set_cols = [&](int c) { as.sys_c = c, as.ring_slot_ints = TC * P.nH * 64 * c, as.GW = (int32_t)(TC * c); };
+	set_cols(c_first);
 	a.coop_pass = as.coop_pass = two_pass ? 3 : low_mem ? 1 : 0;
 	g->stats.lowmem_two_pass = two_pass ? 1 : 0;
 	if (sys_first ? launch_sys_pass(as, Gs * n_groups, g->stream) : launch_coop_pass(a, Gs * n_groups, g->stream)) { g->err = "kernel launch failed (whole-device pass)"; return -1; }
@@ -770,6 +785,7 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 		if (two_pass ? launch_coop_trace(a, g->stream) : launch_sys_walk(as, g->stream)) { g->err = "kernel launch failed (checkpoints)"; return -1; }
 		if (reset_sys(false)) return -1; // barrier counters and progress words of the second pass
 		a.coop_pass = as.coop_pass = 2;
+		set_cols(c_second);
 		// the second pass is not traced: the band trace of a low-memory run is that of its second pass, traced below
 		if (launch_sys_pass(as, Gs * n_groups, g->stream)) { g->err = "kernel launch failed (second pass)"; return -1; }
 		g->stats.n_launches += 2;
@@ -782,7 +798,7 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 	}
 	g->stats.grid = Gs * n_groups, g->stats.block = 512, g->stats.kernel_kind = 1;
 	b->last_grid = std::max(b->last_grid, Gs * n_groups);
-	for (int32_t pair : pairs) b->h_kind[pair] = 1, b->h_flags[pair] = (int8_t)((b->h_flags[pair] & ~2) | (n_groups > 1 ? 2 : 0));
+	for (int32_t pair : pairs) b->h_kind[pair] = 1, b->h_flags[pair] = (int8_t)((b->h_flags[pair] & ~(2 | 32)) | (n_groups > 1 ? 2 : 0) | ((c_first == 1 || (low_mem && c_second == 1)) ? 32 : 0));
 	HIP_TRY(g, hipStreamSynchronize(g->stream)); // the device stays ours until the kernels are through
 	return 0;
 }
@@ -790,7 +806,7 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 // one pair with the device to itself
 int run_coop_pair(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, int32_t pair, bool first, bool last)
 {
-	const int G = coop_group_size(coop_grid_limit(g), (int64_t)b->h_tl[pair] + b->h_ql[pair], true, sys_owned_cols(g->sys_p));
+	const int G = coop_group_size(coop_grid_limit(g), (int64_t)b->h_tl[pair] + b->h_ql[pair], true, sys_owned_cols(g->sys_p, 4));
 	return run_coop_group(g, b, opt, std::vector<int32_t>{pair}, G, first, last);
 }
 
@@ -1035,6 +1051,7 @@ int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value)
 	else if (!strcmp(name, "coop_tb_cap_mb")) g->coop_tb_cap = std::max<int64_t>(1, value) << 20;
 	else if (!strcmp(name, "lowmem_budget_mb")) g->lowmem_budget_mb = std::max<int64_t>(0, value);
 	else if (!strcmp(name, "sys_p") && (value == 4 || value == 8 || value == 16)) g->sys_p = (int)value;
+	else if (!strcmp(name, "sys_c") && (value == 0 || value == 1 || value == 4)) g->sys_c = (int)value;
 	else if (!strcmp(name, "trim")) { (void)hipSetDevice(g->device); trim(g); }
 	else return -1;
 	return 0;
@@ -1130,7 +1147,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	int n_cu_coop = 0;
 	if (coop || (g->force_kind < 0 && max_len >= coop_len && coop_supported(P0))) {
 		n_cu_coop = coop_grid_limit(g);
-		const int coop_side_by_side = n_cu_coop > 0 ? std::max(1, n_cu_coop / coop_group_size(n_cu_coop, max_len, false, sys_owned_cols(g->sys_p))) : 1;
+		const int coop_side_by_side = n_cu_coop > 0 ? std::max(1, n_cu_coop / coop_group_size(n_cu_coop, max_len, false, sys_owned_cols(g->sys_p, 4))) : 1;
 		const int64_t coop_max_pairs = std::max<int64_t>(1, std::min<int64_t>(256, max_len / 70000 * coop_side_by_side));
 		coop = coop || b->n <= coop_max_pairs;
 	}
@@ -1141,7 +1158,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		std::stable_sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) { return (int64_t)b->h_tl[x] + b->h_ql[x] > (int64_t)b->h_tl[y] + b->h_ql[y]; }); // longest first
 		for (size_t at = 0; at < idx.size();) {
 			const int64_t len0 = (int64_t)b->h_tl[idx[at]] + b->h_ql[idx[at]];
-			const int Gs = coop_group_size(n_cu_coop, len0, false, sys_owned_cols(g->sys_p));
+			const int Gs = coop_group_size(n_cu_coop, len0, false, sys_owned_cols(g->sys_p, 4));
 			const size_t n_side = std::min<size_t>(idx.size() - at, (size_t)std::max(1, n_cu_coop / Gs));
 			const bool last = at + n_side == idx.size();
 			if (n_side <= 1 || b->debug_pair >= 0) { // alone (also: band traces are single-pair diagnostics)
@@ -1291,7 +1308,10 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 				to_generic[step0].push_back((int32_t)i);
 			} else if (kind == 1 && (st == ST_BAND_OVERFLOW || st == ST_TB_OVERFLOW || st == ST_SNAP_OVERFLOW)) {
 				if (b->h_flags[i] & 2) coop_alone.push_back((int32_t)i); // had a share of the workgroups and of the arena: now alone
-				else if (st == ST_BAND_OVERFLOW) {
+				else if (st == ST_BAND_OVERFLOW && (b->h_flags[i] & 32) && !(b->h_flags[i] & 16)) {
+					b->h_flags[i] |= 16; // its window outgrew the 64-column slots: again with 256-column ones
+					coop_alone.push_back((int32_t)i);
+				} else if (st == ST_BAND_OVERFLOW) {
 					if (!coop_warned) fprintf(stderr, "[libmwf_hip] warning: wavefront of pair %d outgrew the whole-device kernel's span; re-running it on one workgroup (slow)\n", (int)i);
 					coop_warned = true;
 					to_generic[step0].push_back((int32_t)i);

@@ -104,7 +104,8 @@ struct BatchArgs {
 	int32_t *coop_state;       // results of a pass handed to the next launch: [0]=status [1]=s [2]=info [3]=n_seg [4..5]=cells
 	// ---- systolic whole-device kernel (mwf_sys.hip): every chunk slot has a private H ring (`ring`: [group][slot][nH][256]) and
 	// hands its outer columns to its two neighbours once per block of `sys_p` penalties
-	int32_t sys_p;             // penalties per hand-off block (4, 8 or 16); a slot owns 256 - 2*sys_p columns, the rest is halo
+	int32_t sys_p;             // penalties per hand-off block (4, 8 or 16); a slot owns 64*sys_c - 2*sys_p columns, the rest is halo
+	int32_t sys_c;             // columns per lane (4 or 1): a slot computes 64*sys_c columns
 	int32_t *sys_box;          // [group][slot][2 parities][box ints]: outer columns' H rows of the block, E/F state at its end, window views
 	int64_t sys_box_stride;    // ints between two groups' boxes
 	unsigned long long *sys_prog; // [group][slot] x 64 bytes: blocks published
@@ -139,7 +140,7 @@ int  launch_coop_trace(const BatchArgs &a, void *stream);                // chec
 // launch wrappers implemented in mwf_sys.hip (the systolic whole-device kernel: same penalties as mwf_coop.hip, every pass but
 // the provenance pass of the two-pass low-memory mode)
 int64_t sys_chunk_slots(int grid);                   // chunk slots a launch of `grid` workgroups holds
-int  sys_owned_cols(int p);                          // columns a chunk slot owns: 256 - 2p
+int  sys_owned_cols(int p, int c);                   // columns a chunk slot owns: 64c - 2p
 int64_t sys_box_ints(int p);                         // ints of one hand-off box
 int  sys_max_grid();                                 // co-resident workgroups the kernel may be launched with (one per CU)
 int  launch_sys_pass(const BatchArgs &a, int grid, void *stream);        // forward pass (score / traceback bytes / second pass with band resets)

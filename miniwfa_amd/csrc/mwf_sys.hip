@@ -37,7 +37,6 @@ namespace {
 constexpr int kT = 512;          // threads per workgroup: 8 waves, up to 256 VGPRs each
 constexpr int kNW = kT / 64;
 constexpr int kK = 2;            // chunk slots per wave
-constexpr int kW = 256;          // columns a slot computes: 64 lanes x 4
 constexpr int kEpoch = 256;      // penalties between two band shrinks (reference miniwfa.c:429)
 constexpr int kMaxP = 16;
 
@@ -52,6 +51,20 @@ __device__ __forceinline__ u64 ld2_ag(const u64 *p) { return __hip_atomic_load(p
 __device__ __forceinline__ void st2_ag(u64 *p, int32_t a, int32_t b) { __hip_atomic_store(p, (u64)(uint32_t)a | (u64)(uint32_t)b << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int32_t lo32(u64 v) { return (int32_t)(uint32_t)v; }
 __device__ __forceinline__ int32_t hi32(u64 v) { return (int32_t)(uint32_t)(v >> 32); }
+template <int C>
+__device__ __forceinline__ void ld_box(const int32_t *p, int32_t (&v)[C])
+{
+	if constexpr (C == 4) { const u64 a = ld2_ag((const u64*)p), b = ld2_ag((const u64*)p + 1); v[0] = lo32(a), v[1] = hi32(a), v[2] = lo32(b), v[3] = hi32(b); }
+	else if constexpr (C == 2) { const u64 a = ld2_ag((const u64*)p); v[0] = lo32(a), v[1] = hi32(a); }
+	else v[0] = ld_ag(p);
+}
+template <int C>
+__device__ __forceinline__ void st_box(int32_t *p, const int32_t (&v)[C])
+{
+	if constexpr (C == 4) st2_ag((u64*)p, v[0], v[1]), st2_ag((u64*)p + 1, v[2], v[3]);
+	else if constexpr (C == 2) st2_ag((u64*)p, v[0], v[1]);
+	else st_ag(p, v[0]);
+}
 
 __device__ __forceinline__ uint32_t probe4g(const PairMem &M, int32_t j, int32_t i)
 {
@@ -69,6 +82,30 @@ __device__ __forceinline__ uint32_t inm_bit(int32_t d, int32_t k, int32_t tl, in
 __device__ __forceinline__ int32_t pick4(int32_t i, int32_t a0, int32_t a1, int32_t a2, int32_t a3)
 {
 	return i == 0 ? a0 : i == 1 ? a1 : i == 2 ? a2 : a3;
+}
+
+// C = columns per lane (4, 2 or 1): a slot computes 64 C columns.  The fewer, the fewer instructions a wave issues per penalty —
+// which is what a chain of penalties on few, narrow chunks waits for — and the more slots (and halo) a window of a given width costs.
+template <int C>
+__device__ __forceinline__ int32_t pickc(int32_t i, const int32_t (&a)[C])
+{
+	if constexpr (C == 4) return pick4(i, a[0], a[1], a[2], a[3]);
+	else if constexpr (C == 2) return i == 0 ? a[0] : a[1];
+	else return a[0];
+}
+template <int C>
+__device__ __forceinline__ void ld_cols(const int32_t *p, int32_t (&v)[C])
+{
+	if constexpr (C == 4) { const int4 x = *(const int4*)p; v[0] = x.x, v[1] = x.y, v[2] = x.z, v[3] = x.w; }
+	else if constexpr (C == 2) { const int2 x = *(const int2*)p; v[0] = x.x, v[1] = x.y; }
+	else v[0] = *p;
+}
+template <int C>
+__device__ __forceinline__ void st_cols(int32_t *p, const int32_t (&v)[C])
+{
+	if constexpr (C == 4) *(int4*)p = make_int4(v[0], v[1], v[2], v[3]);
+	else if constexpr (C == 2) *(int2*)p = make_int2(v[0], v[1]);
+	else *p = v[0];
 }
 
 // The recurrence with its traceback byte (dev::wf_cell, miniwfa.c:267-278, :289-306), the byte read off the RESULTS so that few
@@ -189,14 +226,16 @@ __device__ __forceinline__ int32_t seg_effective(const int32_t *seg, int32_t n_s
 __device__ __forceinline__ int32_t floordiv(int32_t a, int32_t b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
 
 // grp / lb / G: this pair's group of workgroups, this workgroup's index in it, the group's size
-template <int E1, int E2, bool TB, int P, bool DEFER>
+template <int E1, int E2, bool TB, int P, bool DEFER, int C>
 __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, int32_t n_seg, int32_t grp, int32_t lb, int32_t G)
 {
-	constexpr int PL = P / 4;                 // halo lanes per side
+	constexpr int kW = 64 * C;                // columns a slot computes
+	constexpr int PL = P / C;                 // halo lanes per side
 	constexpr int OW = kW - 2 * P;            // columns a slot owns
 	constexpr int NEF = 2 * E1 + 2 * E2;      // E/F register arrays per column
-	constexpr int LANE_D2 = (P + NEF) * 2;    // 8-byte words one outer lane publishes per block
-	constexpr int WIN_OFF = 2 * PL * LANE_D2 * 2; // ints in front of a box's window views
+	constexpr int LANE_INTS = (P + NEF) * C;  // ints one outer lane publishes per block
+	constexpr int WIN_OFF = 2 * PL * LANE_INTS; // ints in front of a box's window views
+	static_assert(P % C == 0 && (C == 1 || C == 2 || C == 4), "columns per lane");
 	constexpr int BOX_INTS = (WIN_OFF + 2 * P + 31) / 32 * 32;
 	constexpr int NBLK = kEpoch / P;
 	static_assert(P == 4 || P == 8 || P == 16, "block length");
@@ -220,12 +259,12 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 	unsigned epoch = 0; // the host zeroes the barrier words before every pass
 
 	// E/F wavefronts of the RESIDENT slot (four columns per lane; age 0 is the previous penalty) and its prefetched H rows
-	int32_t e1h[E1][4], f1h[E1][4], e2h[E2][4], f2h[E2][4];
-	int4 phx, po1, po2;
+	int32_t e1h[E1][C], f1h[E1][C], e2h[E2][C], f2h[E2][C];
+	int32_t phx[C], po1[C], po2[C];
 	int32_t res = -1; // slot of this wave whose E/F are in the registers
 	auto set_dead = [&]() {
 #pragma unroll
-		for (int i = 0; i < 4; ++i) {
+		for (int i = 0; i < C; ++i) {
 #pragma unroll
 			for (int a = 0; a < E1; ++a) e1h[a][i] = f1h[a][i] = kNegInf;
 #pragma unroll
@@ -235,20 +274,20 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 	set_dead();
 	// A wave holds up to kK slots but works on one at a time, a whole block of penalties each: the other slot's registers rest
 	// in HBM (six 16-byte words per lane; only waves whose two slots are both inside the window ever swap)
-	auto park_ptr = [&](int32_t r, int32_t a) -> int4* { return (int4*)(park + (((int64_t)r * NEF + a) * 64 + lane) * 4); };
+	auto park_ptr = [&](int32_t r, int32_t a) -> int32_t* { return park + (((int64_t)r * NEF + a) * 64 + lane) * C; };
 	auto make_resident = [&](int32_t k) {
 		if (res == k) return;
 		if (res >= 0 && uni(L.sv[wv * kK + res].part)) {
 			const int32_t r = gw + NWt * res;
 			int a = 0;
 #pragma unroll
-			for (int q = 0; q < E1; ++q, ++a) *park_ptr(r, a) = make_int4(e1h[q][0], e1h[q][1], e1h[q][2], e1h[q][3]);
+			for (int q = 0; q < E1; ++q, ++a) st_cols<C>(park_ptr(r, a), e1h[q]);
 #pragma unroll
-			for (int q = 0; q < E1; ++q, ++a) *park_ptr(r, a) = make_int4(f1h[q][0], f1h[q][1], f1h[q][2], f1h[q][3]);
+			for (int q = 0; q < E1; ++q, ++a) st_cols<C>(park_ptr(r, a), f1h[q]);
 #pragma unroll
-			for (int q = 0; q < E2; ++q, ++a) *park_ptr(r, a) = make_int4(e2h[q][0], e2h[q][1], e2h[q][2], e2h[q][3]);
+			for (int q = 0; q < E2; ++q, ++a) st_cols<C>(park_ptr(r, a), e2h[q]);
 #pragma unroll
-			for (int q = 0; q < E2; ++q, ++a) *park_ptr(r, a) = make_int4(f2h[q][0], f2h[q][1], f2h[q][2], f2h[q][3]);
+			for (int q = 0; q < E2; ++q, ++a) st_cols<C>(park_ptr(r, a), f2h[q]);
 		}
 		res = k;
 		if (uni(L.sv[wv * kK + k].fresh)) {
@@ -258,15 +297,14 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 		}
 		const int32_t r = gw + NWt * k;
 		int a = 0;
-		int4 v;
 #pragma unroll
-		for (int q = 0; q < E1; ++q, ++a) v = *park_ptr(r, a), e1h[q][0] = v.x, e1h[q][1] = v.y, e1h[q][2] = v.z, e1h[q][3] = v.w;
+		for (int q = 0; q < E1; ++q, ++a) ld_cols<C>(park_ptr(r, a), e1h[q]);
 #pragma unroll
-		for (int q = 0; q < E1; ++q, ++a) v = *park_ptr(r, a), f1h[q][0] = v.x, f1h[q][1] = v.y, f1h[q][2] = v.z, f1h[q][3] = v.w;
+		for (int q = 0; q < E1; ++q, ++a) ld_cols<C>(park_ptr(r, a), f1h[q]);
 #pragma unroll
-		for (int q = 0; q < E2; ++q, ++a) v = *park_ptr(r, a), e2h[q][0] = v.x, e2h[q][1] = v.y, e2h[q][2] = v.z, e2h[q][3] = v.w;
+		for (int q = 0; q < E2; ++q, ++a) ld_cols<C>(park_ptr(r, a), e2h[q]);
 #pragma unroll
-		for (int q = 0; q < E2; ++q, ++a) v = *park_ptr(r, a), f2h[q][0] = v.x, f2h[q][1] = v.y, f2h[q][2] = v.z, f2h[q][3] = v.w;
+		for (int q = 0; q < E2; ++q, ++a) ld_cols<C>(park_ptr(r, a), f2h[q]);
 	};
 
 	// ---- penalty 0: origin and its extension (the first wave of workgroup 0 walks it cooperatively)
@@ -293,14 +331,14 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 	const int32_t cfin = ql + 1; // the end cell (tl-1, ql-1) lies on diagonal ql-tl, i.e. in this column
 	const int32_t gmax = cmax / OW;
 
-	auto row_ptr = [&](int32_t r, int32_t j) -> int32_t* { return ring + (((int64_t)r * nH + j) * kW + 4 * lane); };
+	auto row_ptr = [&](int32_t r, int32_t j) -> int32_t* { return ring + (((int64_t)r * nH + j) * kW + C * lane); };
 	auto prefetch = [&](int32_t r, int32_t slotH) { // the three H rows the penalty that writes ring row slotH reads
 		int32_t jx = slotH - lagx; if (jx < 0) jx += nH;
 		int32_t j1 = slotH - lag1; if (j1 < 0) j1 += nH;
 		int32_t j2 = slotH - lag2; if (j2 < 0) j2 += nH;
-		phx = *(const int4*)row_ptr(r, jx);
-		po1 = *(const int4*)row_ptr(r, j1);
-		po2 = *(const int4*)row_ptr(r, j2);
+		ld_cols<C>(row_ptr(r, jx), phx);
+		ld_cols<C>(row_ptr(r, j1), po1);
+		ld_cols<C>(row_ptr(r, j2), po2);
 	};
 
 #ifdef MWF_SYS_TIMING
@@ -346,7 +384,7 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 				if (s == 0) { // the origin (reference wf_stripe_init, miniwfa.c:103-121)
 					const int32_t c0 = tl + 1;
 					if (lane == 0) L.hist[sl][0] = make_int2(min(max(c0, cb), cb + kW), max(min(c0, cb + kW - 1), cb - 1));
-					if ((uint32_t)(c0 - cb) < (uint32_t)kW && lane == ((c0 - cb) >> 2)) ring[((int64_t)r * nH + 0) * kW + (c0 - cb)] = k0;
+					if ((uint32_t)(c0 - cb) < (uint32_t)kW && lane == (c0 - cb) / C) ring[((int64_t)r * nH + 0) * kW + (c0 - cb)] = k0;
 				}
 			}
 			if (!now && res == k) res = -1;
@@ -374,7 +412,7 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 				const int32_t k = kK == 1 ? 0 : (kk == 0 ? kfirst : (kfirst + kk) % kK);
 				const int32_t sl = wv * kK + k;
 				if (!uni(L.sv[sl].part)) continue;
-				const int32_t r = gw + NWt * k, g = uni(L.sv[sl].g), cb = g * OW - P, c0 = cb + 4 * lane;
+				const int32_t r = gw + NWt * k, g = uni(L.sv[sl].g), cb = g * OW - P, c0 = cb + C * lane;
 				const int32_t oL = cb + P, oR = cb + kW - 1 - P;
 				const bool nbl = g - 1 >= gA, nbr = g + 1 <= gB;
 				MWF_T(tt_a);
@@ -413,30 +451,27 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 					if ((hal && hl) || (har && hr)) {
 						// left halo lane l <- left neighbour's right outer lane l (side 1); right halo lane 64-PL+l <- right neighbour's left outer lane l (side 0)
 						const int32_t l = hal ? lane : lane - (64 - PL);
-						const u64 *src = (const u64*)(hal ? bl : br) + ((hal ? PL : 0) + l) * LANE_D2;
+						const int32_t *src = (hal ? bl : br) + ((hal ? PL : 0) + l) * LANE_INTS;
 						{
-							u64 v[2 * P];
+							int32_t v[P][C];
 #pragma unroll
-							for (int q = 0; q < 2 * P; ++q) v[q] = ld2_ag(src + q);
+							for (int t = 0; t < P; ++t) ld_box<C>(src + t * C, v[t]);
 							int32_t j = (s0 - P + 1) % nH;
 #pragma unroll
 							for (int t = 0; t < P; ++t) {
-								*(int4*)row_ptr(r, j) = make_int4(lo32(v[2 * t]), hi32(v[2 * t]), lo32(v[2 * t + 1]), hi32(v[2 * t + 1]));
+								st_cols<C>(row_ptr(r, j), v[t]);
 								j = j + 1 == nH ? 0 : j + 1;
 							}
 						}
-						u64 v[2 * NEF];
+						const int32_t *q = src + P * C;
 #pragma unroll
-						for (int q = 0; q < 2 * NEF; ++q) v[q] = ld2_ag(src + 2 * P + q);
-						int q = 0;
+						for (int a = 0; a < E1; ++a, q += C) ld_box<C>(q, e1h[a]);
 #pragma unroll
-						for (int a = 0; a < E1; ++a, q += 2) e1h[a][0] = lo32(v[q]), e1h[a][1] = hi32(v[q]), e1h[a][2] = lo32(v[q + 1]), e1h[a][3] = hi32(v[q + 1]);
+						for (int a = 0; a < E1; ++a, q += C) ld_box<C>(q, f1h[a]);
 #pragma unroll
-						for (int a = 0; a < E1; ++a, q += 2) f1h[a][0] = lo32(v[q]), f1h[a][1] = hi32(v[q]), f1h[a][2] = lo32(v[q + 1]), f1h[a][3] = hi32(v[q + 1]);
+						for (int a = 0; a < E2; ++a, q += C) ld_box<C>(q, e2h[a]);
 #pragma unroll
-						for (int a = 0; a < E2; ++a, q += 2) e2h[a][0] = lo32(v[q]), e2h[a][1] = hi32(v[q]), e2h[a][2] = lo32(v[q + 1]), e2h[a][3] = hi32(v[q + 1]);
-#pragma unroll
-						for (int a = 0; a < E2; ++a, q += 2) f2h[a][0] = lo32(v[q]), f2h[a][1] = hi32(v[q]), f2h[a][2] = lo32(v[q + 1]), f2h[a][3] = hi32(v[q + 1]);
+						for (int a = 0; a < E2; ++a, q += C) ld_box<C>(q, f2h[a]);
 					} else if ((hal || har) && me) {
 						// no neighbour on that side (it does not take part, or has just joined): nothing there was ever inside the window
 						// (its H rows are masked by the window views below: the window never reached those columns)
@@ -506,27 +541,27 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 				const bool deep_blk = !lag_one && (wl > 1 ? wl - 1 : 1) <= cb && (wh < cmax ? wh + 1 : cmax) >= cb + kW - 1 && cover_bad <= s0 + 1 - nH &&
 				                      blk * P + P <= kEpoch - nH && !(TB && seg_s >= s0 && seg_s < s0 + P);
 				// per column: the largest j = k+1 inside the matrix, min(tl, ql - d), and the query's address for j = 0
-				int32_t rj[4];
+				int32_t rj[C];
 				const uint8_t *const qsd = M.qs + (c0 - 1 - tl); // (column i: + i)
 #pragma unroll
-				for (int i = 0; i < 4; ++i) rj[i] = max(min(tl, ql - (c0 + i - 1 - tl)), 0);
+				for (int i = 0; i < C; ++i) rj[i] = max(min(tl, ql - (c0 + i - 1 - tl)), 0);
 				// what stage 2 needs of a penalty
-				int32_t x_hv[4] = {0, 0, 0, 0}, x_snew = 0, x_newH = 0, x_t = 0;
-				uint64_t x_t8[4] = {0, 0, 0, 0}, x_q8[4] = {0, 0, 0, 0};
+				int32_t x_hv[C] = {}, x_snew = 0, x_newH = 0, x_t = 0;
+				uint64_t x_t8[C] = {}, x_q8[C] = {};
 				uint32_t x_tbw = 0;
 #pragma unroll 1
 				for (int t = 0; t < P + (DEFER ? 1 : 0); ++t) {
-					int32_t c_hv[4], c_snew = 0, c_newH = 0;
-					uint64_t c_t8[4], c_q8[4];
+					int32_t c_hv[C], c_snew = 0, c_newH = 0;
+					uint64_t c_t8[C], c_q8[C];
 					uint32_t c_tbw = 0;
 					// what stage 2a leaves for stage 2b
-					int32_t nmat[4] = {0, 0, 0, 0};
+					int32_t nmat[C] = {};
 					uint32_t pend = 0;
 					int32_t w_cl[4] = {-1, -1, -1, -1}, w_ci[4] = {0, 0, 0, 0}, w_cj[4] = {0, 0, 0, 0}, w_cq[4] = {0, 0, 0, 0}, w_crm[4] = {0, 0, 0, 0};
 					uint64_t w_t = 0, w_q = 0;
 					int32_t w_left = 0;
 					bool w_valid = false;
-					auto rj_at = [&](int32_t ii, int32_t src) -> int32_t { return max(min(tl, ql - (cb + 4 * src + ii - 1 - tl)), 0); };
+					auto rj_at = [&](int32_t ii, int32_t src) -> int32_t { return max(min(tl, ql - (cb + C * src + ii - 1 - tl)), 0); };
 					auto stage2a = [&]() {
 						// count the first probe; a run of >= 8 matches continues (the cells on the alignment path, a few per penalty, all
 						// in one chunk — whose wave every other wave ends up waiting for).  Up to four such cells are walked at once:
@@ -534,7 +569,7 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 						// sequences, requested here and looked at in stage 2b — with DEFER a whole stage 1 later; a run that is longer
 						// still goes on with the whole wave (256 bases per trip).
 #pragma unroll
-						for (int i = 0; i < 4; ++i) {
+						for (int i = 0; i < C; ++i) {
 							const int32_t room = rj[i] - (int32_t)min((uint32_t)(x_hv[i] + 1), (uint32_t)rj[i]); // bases left on the diagonal; 0 for dead and phantom offsets
 							const uint64_t x = x_t8[i] ^ x_q8[i];
 							nmat[i] = min(x ? (int32_t)(__builtin_ctzll(x) >> 3) : 8, room);
@@ -548,8 +583,8 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 								const int32_t src = (int32_t)__builtin_ctzll(owners);
 								owners &= owners - 1;
 								const int32_t w = (int32_t)__builtin_ctz((uint32_t)__builtin_amdgcn_readlane((int32_t)pend, src)); // (its other columns, if any: the leftovers of stage 2b)
-								const int32_t hh = __builtin_amdgcn_readlane(pick4(w, x_hv[0], x_hv[1], x_hv[2], x_hv[3]), src);
-								w_cl[gi] = src, w_ci[gi] = w, w_cj[gi] = hh + 1, w_cq[gi] = cb + 4 * src + w - 1 - tl + hh + 1;
+								const int32_t hh = __builtin_amdgcn_readlane(pickc<C>(w, x_hv), src);
+								w_cl[gi] = src, w_ci[gi] = w, w_cj[gi] = hh + 1, w_cq[gi] = cb + C * src + w - 1 - tl + hh + 1;
 								w_crm[gi] = rj_at(w, src) - (hh + 1);
 							}
 							const int32_t gi = lane >> 4, off = 8 + 8 * (lane & 15);
@@ -593,16 +628,15 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 						// every column of the slot inside the window and inside every source window: no masks
 						inner = max(max(lo, xlo), max(alo, blo)) <= cb && min(min(hi, xhi), min(ahi, bhi)) >= cb + kW - 1;
 					}
-					int32_t hx[4] = {phx.x, phx.y, phx.z, phx.w};
-					int32_t o1[6], o2[6];
-					o1[1] = po1.x, o1[2] = po1.y, o1[3] = po1.z, o1[4] = po1.w;
-					o2[1] = po2.x, o2[2] = po2.y, o2[3] = po2.z, o2[4] = po2.w;
+					int32_t hx[C], o1[C + 2], o2[C + 2];
+#pragma unroll
+					for (int i = 0; i < C; ++i) hx[i] = phx[i], o1[i + 1] = po1[i], o2[i + 1] = po2[i];
 					// the next penalty's rows: requested at once — they are at least two penalties old (every lag >= 2 here), and a whole
 					// penalty's work lies between this request and their use
 					if (!lag_one && t + 1 < P) prefetch(r, nextH);
 					if (!inner) { // reads outside a source window yield "dead" (what the reference's pads supply, miniwfa.c:96-99)
 #pragma unroll
-						for (int i = 0; i < 4; ++i) {
+						for (int i = 0; i < C; ++i) {
 							const int32_t c = c0 + i;
 							hx[i] = ((c >= xlo) & (c <= xhi)) ? hx[i] : kNegInf;
 							o1[i + 1] = ((c >= alo) & (c <= ahi)) ? o1[i + 1] : kNegInf;
@@ -610,19 +644,19 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 						}
 					}
 					// the columns next to the slot's 256 are nobody's business: its outermost columns are never exact anyway
-					o1[0] = from_left(o1[4], kNegInf), o1[5] = from_right(o1[1], kNegInf);
-					o2[0] = from_left(o2[4], kNegInf), o2[5] = from_right(o2[1], kNegInf);
-					int32_t g1m[4], g1p[4], g2m[4], g2p[4];
-					g1m[0] = from_left(e1h[E1 - 1][3], kNegInf);
-					g2m[0] = from_left(e2h[E2 - 1][3], kNegInf);
-					g1p[3] = from_right(f1h[E1 - 1][0], kNegInf);
-					g2p[3] = from_right(f2h[E2 - 1][0], kNegInf);
+					o1[0] = from_left(o1[C], kNegInf), o1[C + 1] = from_right(o1[1], kNegInf);
+					o2[0] = from_left(o2[C], kNegInf), o2[C + 1] = from_right(o2[1], kNegInf);
+					int32_t g1m[C], g1p[C], g2m[C], g2p[C];
+					g1m[0] = from_left(e1h[E1 - 1][C - 1], kNegInf);
+					g2m[0] = from_left(e2h[E2 - 1][C - 1], kNegInf);
+					g1p[C - 1] = from_right(f1h[E1 - 1][0], kNegInf);
+					g2p[C - 1] = from_right(f2h[E2 - 1][0], kNegInf);
 #pragma unroll
-					for (int i = 1; i < 4; ++i) g1m[i] = e1h[E1 - 1][i - 1], g2m[i] = e2h[E2 - 1][i - 1];
+					for (int i = 1; i < C; ++i) g1m[i] = e1h[E1 - 1][i - 1], g2m[i] = e2h[E2 - 1][i - 1];
 #pragma unroll
-					for (int i = 0; i < 3; ++i) g1p[i] = f1h[E1 - 1][i + 1], g2p[i] = f2h[E2 - 1][i + 1];
+					for (int i = 0; i < C - 1; ++i) g1p[i] = f1h[E1 - 1][i + 1], g2p[i] = f2h[E2 - 1][i + 1];
 
-					int32_t ne1[4], nf1[4], ne2[4], nf2[4];
+					int32_t ne1[C], nf1[C], ne2[C], nf2[C];
 					uint32_t tbw = 0, live = 0, gbits = 0;
 					if (inner && !track_good) {
 						// The common case — a chunk well inside the window, no shrink in sight: every column is computed, no source is
@@ -630,7 +664,7 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 						// j = k+1 clamped to Rj = min(tl, ql-d) leaves room Rj - j = 0 for dead (NEG_INF + drift: huge as unsigned) and
 						// phantom (beyond the matrix) offsets, and both addresses stay inside the sequences' slack.
 #pragma unroll
-						for (int i = 0; i < 4; ++i) {
+						for (int i = 0; i < C; ++i) {
 							const Cell v = sys_cell<TB>(hx[i], o1[i], g1m[i], o2[i], g2m[i], o1[i + 2], g1p[i], o2[i + 2], g2p[i]);
 							ne1[i] = v.e1, nf1[i] = v.f1, ne2[i] = v.e2, nf2[i] = v.f2;
 							const int32_t jc = (int32_t)min((uint32_t)(v.h + 1), (uint32_t)rj[i]);
@@ -640,7 +674,7 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 						}
 					} else
 #pragma unroll
-					for (int i = 0; i < 4; ++i) {
+					for (int i = 0; i < C; ++i) {
 						const int32_t c = c0 + i, d = c - 1 - tl;
 						const uint32_t act = inner ? 1u : (uint32_t)((c >= lo) & (c <= hi));
 						const Cell v = sys_cell<TB>(hx[i], o1[i], g1m[i], o2[i], g2m[i], o1[i + 2], g1p[i], o2[i + 2], g2p[i]);
@@ -660,11 +694,16 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 						tbw |= v.tb << (8 * i);
 					}
 					c_tbw = tbw, c_snew = s_new, c_newH = newH;
-					if (TB) *(uint32_t*)(M.tb + ep_base + ((int64_t)(s_new - 1 - (ep << 8)) * n_ep + (g - gA)) * kW + 4 * lane) = tbw;
+					if (TB) {
+						uint8_t *const tp = M.tb + ep_base + ((int64_t)(s_new - 1 - (ep << 8)) * n_ep + (g - gA)) * kW + C * lane;
+						if constexpr (C == 4) *(uint32_t*)tp = tbw;
+						else if constexpr (C == 2) *(uint16_t*)tp = (uint16_t)tbw;
+						else *tp = (uint8_t)tbw;
+					}
 					if (track_good) {
-						unsigned long long *gword = M.good + ((int64_t)newH * TC + r) * 4;
+						unsigned long long *gword = M.good + ((int64_t)newH * TC + r) * C;
 #pragma unroll
-						for (int i = 0; i < 4; ++i) {
+						for (int i = 0; i < C; ++i) {
 							const unsigned long long m = __ballot((gbits >> i) & 1u) & owned_lanes;
 							if (lane == 0) gword[i] = m;
 						}
@@ -681,7 +720,7 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 						}
 					}
 #pragma unroll
-					for (int i = 0; i < 4; ++i) {
+					for (int i = 0; i < C; ++i) {
 #pragma unroll
 						for (int a = E1 - 1; a > 0; --a) e1h[a][i] = e1h[a - 1][i], f1h[a][i] = f1h[a - 1][i];
 #pragma unroll
@@ -693,7 +732,7 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 					MWF_T(ts_2);
 					if (!DEFER) {
 #pragma unroll
-						for (int i = 0; i < 4; ++i) x_hv[i] = c_hv[i], x_t8[i] = c_t8[i], x_q8[i] = c_q8[i];
+						for (int i = 0; i < C; ++i) x_hv[i] = c_hv[i], x_t8[i] = c_t8[i], x_q8[i] = c_q8[i];
 						x_tbw = c_tbw, x_snew = c_snew, x_newH = c_newH, x_t = t;
 						stage2a();
 					}
@@ -718,7 +757,7 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 								} else n = lcp_wave(M, w_cj[g4], w_cq[g4], w_crm[g4], 136);
 								if (lane == w_cl[g4]) {
 #pragma unroll
-									for (int i = 0; i < 4; ++i) nmat[i] = w_ci[g4] == i ? n : nmat[i];
+									for (int i = 0; i < C; ++i) nmat[i] = w_ci[g4] == i ? n : nmat[i];
 									pend &= ~(1u << w_ci[g4]);
 								}
 							}
@@ -731,17 +770,17 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 								while (bits) {
 									const int32_t ii = (int32_t)__builtin_ctz(bits);
 									bits &= bits - 1;
-									const int32_t hh = __builtin_amdgcn_readlane(pick4(ii, x_hv[0], x_hv[1], x_hv[2], x_hv[3]), src);
+									const int32_t hh = __builtin_amdgcn_readlane(pickc<C>(ii, x_hv), src);
 									const int32_t rm = rj_at(ii, src) - (hh + 1);
-									const int32_t n = lcp_wave(M, hh + 1, cb + 4 * src + ii - 1 - tl + hh + 1, rm, 8);
+									const int32_t n = lcp_wave(M, hh + 1, cb + C * src + ii - 1 - tl + hh + 1, rm, 8);
 #pragma unroll
-									for (int i = 0; i < 4; ++i) nmat[i] = (ii == i && lane == src) ? n : nmat[i];
+									for (int i = 0; i < C; ++i) nmat[i] = (ii == i && lane == src) ? n : nmat[i];
 								}
 							}
 						}
-						int32_t done_info = 0, hv[4];
+						int32_t done_info = 0, hv[C];
 #pragma unroll
-						for (int i = 0; i < 4; ++i) {
+						for (int i = 0; i < C; ++i) {
 							const int32_t d = c0 + i - 1 - tl;
 							const uint32_t in = inm_bit(d, x_hv[i], tl, ql); // (cells outside the window hold NEG_INF)
 							const int32_t kk2 = x_hv[i] + nmat[i];
@@ -752,13 +791,12 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 							}
 							hv[i] = kk2;
 						}
-						*(int4*)row_ptr(r, x_newH) = make_int4(hv[0], hv[1], hv[2], hv[3]);
+						st_cols<C>(row_ptr(r, x_newH), hv);
 						// the outer owned columns, for the neighbours' halos
 						{
 							const bool ol = lane >= PL && lane < 2 * PL, orr = lane >= 64 - 2 * PL && lane < 64 - PL;
 							if (ol || orr) {
-								u64 *dst = (u64*)(box + ((int64_t)r * 2 + par) * BOX_INTS) + ((orr ? PL : 0) + (ol ? lane - PL : lane - (64 - 2 * PL))) * LANE_D2 + 2 * x_t;
-								st2_ag(dst, hv[0], hv[1]), st2_ag(dst + 1, hv[2], hv[3]);
+								st_box<C>(box + ((int64_t)r * 2 + par) * BOX_INTS + ((orr ? PL : 0) + (ol ? lane - PL : lane - (64 - 2 * PL))) * LANE_INTS + C * x_t, hv);
 							}
 						}
 						if (own_fin && !fin_seen) {
@@ -773,7 +811,7 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 					}
 					if (DEFER) {
 #pragma unroll
-						for (int i = 0; i < 4; ++i) x_hv[i] = c_hv[i], x_t8[i] = c_t8[i], x_q8[i] = c_q8[i];
+						for (int i = 0; i < C; ++i) x_hv[i] = c_hv[i], x_t8[i] = c_t8[i], x_q8[i] = c_q8[i];
 						x_tbw = c_tbw, x_snew = c_snew, x_newH = c_newH, x_t = t;
 					}
 #ifdef MWF_SYS_TIMING
@@ -798,15 +836,15 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 					int32_t *const bx = box + ((int64_t)r * 2 + par) * BOX_INTS;
 					const bool ol = lane >= PL && lane < 2 * PL, orr = lane >= 64 - 2 * PL && lane < 64 - PL;
 					if (ol || orr) {
-						u64 *dst = (u64*)bx + ((orr ? PL : 0) + (ol ? lane - PL : lane - (64 - 2 * PL))) * LANE_D2 + 2 * P;
+						int32_t *dst = bx + ((orr ? PL : 0) + (ol ? lane - PL : lane - (64 - 2 * PL))) * LANE_INTS + C * P;
 #pragma unroll
-						for (int a = 0; a < E1; ++a, dst += 2) st2_ag(dst, e1h[a][0], e1h[a][1]), st2_ag(dst + 1, e1h[a][2], e1h[a][3]);
+						for (int a = 0; a < E1; ++a, dst += C) st_box<C>(dst, e1h[a]);
 #pragma unroll
-						for (int a = 0; a < E1; ++a, dst += 2) st2_ag(dst, f1h[a][0], f1h[a][1]), st2_ag(dst + 1, f1h[a][2], f1h[a][3]);
+						for (int a = 0; a < E1; ++a, dst += C) st_box<C>(dst, f1h[a]);
 #pragma unroll
-						for (int a = 0; a < E2; ++a, dst += 2) st2_ag(dst, e2h[a][0], e2h[a][1]), st2_ag(dst + 1, e2h[a][2], e2h[a][3]);
+						for (int a = 0; a < E2; ++a, dst += C) st_box<C>(dst, e2h[a]);
 #pragma unroll
-						for (int a = 0; a < E2; ++a, dst += 2) st2_ag(dst, f2h[a][0], f2h[a][1]), st2_ag(dst + 1, f2h[a][2], f2h[a][3]);
+						for (int a = 0; a < E2; ++a, dst += C) st_box<C>(dst, f2h[a]);
 					}
 					if (lane < 2 * P) st_ag(bx + WIN_OFF + lane, lane < P ? L.mywl[sl][lane] : L.mywh[sl][lane - P]);
 					if (lane == 0) L.sv[sl].wl = wl, L.sv[sl].wh = wh;
@@ -894,20 +932,20 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 		{ // shrink (reference wf_stripe_shrink, miniwfa.c:144-171) on the good bits of the last nH slices
 			const int32_t rd = (ep & 1) ? 17 : 13;            // this epoch's reduction words; the other pair is reset for the next one
 			if (lead) st_ag(&gflags[(ep & 1) ? 13 : 17], 0x7fffffff), st_ag(&gflags[(ep & 1) ? 14 : 18], -1);
-			const int32_t gfirst = max(gA, wf_lo / OW), glast = min(gB, wf_hi / OW), n_words = (glast - gfirst + 1) * 4;
+			const int32_t gfirst = max(gA, wf_lo / OW), glast = min(gB, wf_hi / OW), n_words = (glast - gfirst + 1) * C;
 			int32_t mylo = 0x7fffffff, myhi = -1;
 			for (int32_t q = lb * kT + tid; q < n_words; q += G * kT) {
-				const int32_t gg = gfirst + (q >> 2), kq = q & 3, base = gg * OW - P, rr = gg % TC;
+				const int32_t gg = gfirst + q / C, kq = q % C, base = gg * OW - P, rr = gg % TC;
 				unsigned long long m = 0;
-				for (int32_t j = 0; j < nH; ++j) m |= M.good[((int64_t)j * TC + rr) * 4 + kq];
-				// bit l of word kq is column base + 4 l + kq
+				for (int32_t j = 0; j < nH; ++j) m |= M.good[((int64_t)j * TC + rr) * C + kq];
+				// bit l of word kq is column base + C l + kq
 				for (; m; m &= m - 1) {
-					const int32_t c = base + 4 * (int32_t)__builtin_ctzll(m) + kq;
+					const int32_t c = base + C * (int32_t)__builtin_ctzll(m) + kq;
 					if (c >= wf_lo && c <= wf_hi) { mylo = min(mylo, c); break; }
 				}
 				for (; m; ) {
 					const int32_t hb = 63 - (int32_t)__builtin_clzll(m);
-					const int32_t c = base + 4 * hb + kq;
+					const int32_t c = base + C * hb + kq;
 					if (c >= wf_lo && c <= wf_hi) { myhi = max(myhi, c); break; }
 					m &= ~(1ull << hb);
 				}
@@ -942,11 +980,11 @@ __device__ __forceinline__ void sys_pair_mem(const BatchArgs &A, int32_t grp, in
 {
 	pair_mem(A, grp, pair, M); // ring / good / tb slots are per group
 	M.good = A.good + (int64_t)grp * A.pen.nH * A.GW;
-	if (A.sys_ep) M.ep = A.sys_ep + (int64_t)grp * A.sys_ep_stride, M.ep_ow = kW - 2 * A.sys_p, M.ep_p = A.sys_p;
+	if (A.sys_ep) M.ep = A.sys_ep + (int64_t)grp * A.sys_ep_stride, M.ep_ow = 64 * A.sys_c - 2 * A.sys_p, M.ep_p = A.sys_p, M.ep_kw = 64 * A.sys_c;
 }
 
 // DEFER: the match extension of a penalty runs behind the recurrence of the next one (every H lag >= 3)
-template <int E1, int E2, int P, bool DEFER, bool TB>
+template <int E1, int E2, int P, bool DEFER, bool TB, int C>
 __global__ __launch_bounds__(kT) void wfa_sys_kernel(const BatchArgs A)
 {
 	__shared__ SysLds L;
@@ -962,7 +1000,7 @@ __global__ __launch_bounds__(kT) void wfa_sys_kernel(const BatchArgs A)
 		if (state[0] != ST_OK) return; // first pass failed: nothing to do, the finish kernel reports it
 		n_seg = state[3];
 	}
-	const PassResult R = sys_pass<E1, E2, TB, P, DEFER>(A, M, L, TB ? n_seg : 0, grp, lb, G);
+	const PassResult R = sys_pass<E1, E2, TB, P, DEFER, C>(A, M, L, TB ? n_seg : 0, grp, lb, G);
 	if (lb == 0 && threadIdx.x == 0) {
 		int32_t *st = state + (A.coop_pass == 2 ? 8 : 0);
 		st[0] = R.status, st[1] = R.s, st[2] = R.info;
@@ -1034,17 +1072,24 @@ __global__ __launch_bounds__(64) void sys_finish_kernel(const BatchArgs A)
 	finish_pair(A, M, grp, pair, R, status, cells1);
 }
 
-template <int E1, int E2, bool DEFER, bool TB>
-int launch_pass_p(const BatchArgs &a, int grid, hipStream_t st)
+template <int E1, int E2, bool DEFER, bool TB, int C>
+int launch_pass_c(const BatchArgs &a, int grid, hipStream_t st)
 {
 	switch (a.sys_p) {
 #ifdef MWF_SYS_ALL_P // (experiments: profiles/coop_quick.py with MWF_SYS_P)
-	case 4:  hipLaunchKernelGGL((wfa_sys_kernel<E1, E2, 4, DEFER, TB>), dim3(grid), dim3(kT), 0, st, a); break;
-	case 16: hipLaunchKernelGGL((wfa_sys_kernel<E1, E2, 16, DEFER, TB>), dim3(grid), dim3(kT), 0, st, a); break;
+	case 4:  hipLaunchKernelGGL((wfa_sys_kernel<E1, E2, 4, DEFER, TB, C>), dim3(grid), dim3(kT), 0, st, a); break;
+	case 16: hipLaunchKernelGGL((wfa_sys_kernel<E1, E2, 16, DEFER, TB, C>), dim3(grid), dim3(kT), 0, st, a); break;
 #endif
-	default: hipLaunchKernelGGL((wfa_sys_kernel<E1, E2, 8, DEFER, TB>), dim3(grid), dim3(kT), 0, st, a); break;
+	default: hipLaunchKernelGGL((wfa_sys_kernel<E1, E2, 8, DEFER, TB, C>), dim3(grid), dim3(kT), 0, st, a); break;
 	}
 	return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+template <int E1, int E2, bool DEFER, bool TB>
+int launch_pass_p(const BatchArgs &a, int grid, hipStream_t st)
+{
+	if (a.sys_c == 1) return launch_pass_c<E1, E2, DEFER, TB, 1>(a, grid, st);
+	return launch_pass_c<E1, E2, DEFER, TB, 4>(a, grid, st);
 }
 
 // DEFER needs every H lag >= 3 (the edit-distance preset, every lag 1, only ever takes the plain form)
@@ -1061,15 +1106,15 @@ int launch_pass_d(const BatchArgs &a, int grid, hipStream_t st)
 } // namespace
 
 int64_t sys_chunk_slots(int grid) { return (int64_t)grid * kNW * kK; }
-int sys_owned_cols(int p) { return kW - 2 * p; }
-int64_t sys_box_ints(int p) { return (2 * (p / 4) * (p + 8) * 2 * 2 + 2 * p + 31) / 32 * 32; }
+int sys_owned_cols(int p, int c) { return 64 * c - 2 * p; }
+int64_t sys_box_ints(int p) { return (2 * p * (p + 8) + 2 * p + 31) / 32 * 32; } // (whatever the columns per lane: 2 (p/c) lanes x (p + 8) c ints)
 
 int sys_max_grid()
 {
 	int dev = 0, n_cu = 0, per = 0;
 	if (hipGetDevice(&dev) != hipSuccess) return 0;
 	if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, wfa_sys_kernel<2, 1, 8, true, true>, kT, 0) != hipSuccess || per < 1) return 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, wfa_sys_kernel<2, 1, 8, true, true, 4>, kT, 0) != hipSuccess || per < 1) return 0;
 	return n_cu; // one workgroup per CU: every one of them is resident, which the waits between them rely on
 }
 
