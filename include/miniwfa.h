@@ -151,12 +151,15 @@ void mwf_gpu_get_stats(const mwf_gpu_t *g, mwf_gpu_stats_t *st);
 int32_t mwf_gpu_debug_band(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt, int32_t pair, int32_t *lohi, int32_t cap);
 
 /* Tunables (call before align): name in {"block", "slots_per_cu", "coop_min_len", "tb_budget_mb", "force_kind", "coop_tb_cap_mb", "band_pack",
- * "coop_spin_limit", "scalar_generic", "lds_e2", "lowmem_budget_mb", "seq2bit" (packed band kernel: 0 = always keep the byte-wise sequence
- * copy; default 1: pairs of plain A/C/G/T are held at 2 bits per base, any other pair is re-run byte-wise), "band3" (1: the balanced band
- * kernel of DESIGN.md section 4.5 for the wide class), "band3_block" (512, 768, 1024), "ring16" (generic kernel: 0 = always 32-bit ring rows; default 1: 16-bit rows — half the HBM traffic — for batches
- * of at least as many pairs as CUs while target length + penalty fits 16 bits, a pair that outgrows them is re-run with 32-bit rows; 2: also for
- * smaller batches), "ring16_block" (0, 512, 768)}; "trim" frees the engine's workspace pools (they grow
- * back on demand). */
+ * "coop_spin_limit", "scalar_generic", "lds_e2", "seq2bit" (packed band kernel: 0 = always keep the byte-wise sequence copy; default 1:
+ * pairs of plain A/C/G/T are held at 2 bits per base, any other pair is re-run byte-wise — batches built from HOST memory are classified
+ * while they are packed and never take that re-run), "ring16" (generic kernel: 0 = always 32-bit ring rows; default 1: 16-bit rows — half
+ * the HBM traffic — for batches of at least as many pairs as CUs while target length + penalty fits 16 bits, a pair that outgrows them is
+ * re-run with 32-bit rows; 2: also for smaller batches), "ring16_block" (0, 512, 768);
+ * whole-device (systolic) kernel: "lowmem_budget_mb" (low-memory mode: a first-pass traceback above this many MB switches to the two-pass
+ * form whose first pass stores none; 0 = a quarter of the device), "sys_p" (penalties per hand-off block: 4, 8, 16; default 8),
+ * "sys_c" (columns per lane: 0 = chosen per pass from the expected window, 1, 4), "coop_grid" (at most this many workgroups; 0 = one
+ * per CU)}; "trim" frees the engine's workspace pools (they grow back on demand). */
 int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value);
 
 #ifdef __cplusplus

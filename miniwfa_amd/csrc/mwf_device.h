@@ -171,6 +171,18 @@ static __device__ int32_t traceback_wave(const BatchArgs &A, const PairMem &M, u
 	while (i >= 0 && k >= 0 && !overflow) {
 		if (last == 0) { // greedy back-match, 64 bases per trip (miniwfa.c:335-341)
 			int32_t run = 0;
+			// far from the start of both sequences: eight bases per lane, 512 per trip (a long pair is mostly exact matches, and a
+			// trip is a round trip to the sequences)
+			while (i - run >= 511 && k - run >= 511) {
+				const int32_t ii = i - run - 8 * lane, kk = k - run - 8 * lane;
+				const uint64_t x = ld8(M.qs + ii - 7) ^ ld8(M.ts + kk - 7);
+				const int32_t m8 = x ? (int32_t)(__builtin_clzll(x) >> 3) : 8; // equal bases from the top byte down
+				const unsigned long long stop = __ballot(m8 < 8);
+				if (stop == 0) { run += 512; continue; }
+				const int32_t first = (int32_t)__builtin_ctzll(stop);
+				run += 8 * first + __builtin_amdgcn_readlane(m8, first);
+				goto matched;
+			}
 			for (;;) {
 				const int32_t ii = i - run - lane, kk = k - run - lane;
 				const bool eq = ii >= 0 && kk >= 0 && M.qs[ii] == M.ts[kk];
@@ -179,6 +191,7 @@ static __device__ int32_t traceback_wave(const BatchArgs &A, const PairMem &M, u
 				run += n;
 				if (n < 64) break;
 			}
+		matched:
 			if (run > 0) push(7, run);
 			i -= run, k -= run;
 			if (i < 0 || k < 0) break;

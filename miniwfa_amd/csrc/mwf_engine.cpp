@@ -97,6 +97,7 @@ struct mwf_gpu_s {
 	int64_t dev_bytes = 0, dev_bytes_peak = 0; // device memory this engine holds right now / held at most since the last "trim"
 	std::map<uint64_t, int> occ_cache;         // kernel variant -> resident workgroups per CU
 	int coop_grid = -1;
+	int coop_grid_cap = 0;      // "coop_grid": at most this many workgroups for the whole-device kernel (0: one per CU)
 };
 
 struct mwf_gpu_batch_s {
@@ -567,8 +568,8 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 
 int coop_grid_limit(mwf_gpu_t *g)
 {
-	if (g->coop_grid < 0) g->coop_grid = std::min(coop_max_grid(true), g->n_cu);
-	return g->coop_grid;
+	if (g->coop_grid < 0) g->coop_grid = std::min(std::min(coop_max_grid(true), sys_max_grid()), g->n_cu);
+	return g->coop_grid_cap > 0 ? std::min(g->coop_grid, g->coop_grid_cap) : g->coop_grid;
 }
 
 // Workgroups per pair when `n` pairs of at most `len` columns share the device: as many as the widest possible window can
@@ -657,7 +658,7 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 		// to one diagonal at every checkpoint, miniwfa.c:413-416); s is guessed as 3 % of tl+ql
 		if (two_pass) guess = std::min<int64_t>(guess, std::max<int64_t>((int64_t)64 << 20, (len * 3 / 100 + 1024) * std::min<int64_t>(len + 1, 2 * (int64_t)(opt.step + 2 * P.nH) + 8)) * (int64_t)NG);
 		// (the systolic kernel stores 256 bytes per penalty and chunk slot that takes part, a few slots beyond the window included)
-		const int64_t lay = (two_pass ? c_second : std::min(c_first, low_mem ? c_second : c_first)) == 1 ? 12 : 9; // (64-column slots own 48: 4/3 of the exact rows; 256-column ones own 240)
+		const int64_t lay = (two_pass ? c_second : c_first) == 1 ? 12 : 9; // the pass whose traceback sets the size: 64-column slots own 48 (4/3 of the exact rows), 256-column ones 240 (the second pass of the low-memory mode is narrow: it fits whatever the first needed)
 		if (use_sys) guess = std::min<int64_t>(g->coop_tb_cap, guess / 8 * lay + (rows_slot / 256 + 2) * 8 * 65536 * (int64_t)NG);
 		int64_t want = std::min(use_sys ? worst / 8 * lay + (rows_slot / 256 + 2) * 8 * 65536 * (int64_t)NG : worst, g->tb_budget_mb > 0 ? (g->tb_budget_mb << 20) : guess * g->coop_tb_mult);
 		if ((int64_t)g->tb.bytes >= want) want = (int64_t)g->tb.bytes;
@@ -755,6 +756,7 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 		as.ring = (int32_t*)g->sys_ring.p, as.good = (unsigned long long*)g->sys_good.p; // (sized for four columns per lane)
 		as.rows_slot = sys_rows;
 		as.sys_p = sysP;
+		as.sys_spread = 1; // consecutive chunks on consecutive workgroups: 763 against 787 ms on the 5 Mb pair, 63.5 against 65.0 on the 150 kb pair
 		as.sys_box = (int32_t*)g->sys_box.p, as.sys_box_stride = sys_box_group;
 		as.sys_prog = (unsigned long long*)g->sys_prog.p, as.sys_prog_stride = TC * 8;
 		as.sys_log = (int32_t*)g->sys_log.p, as.sys_log_stride = sys_log_ints;
@@ -936,10 +938,29 @@ mwf_gpu_batch_t *batch_from_host(mwf_gpu_t *g, int32_t n, const int32_t *tl, con
 	// the host touches every byte anyway: note which pairs the 2-bit sequence copy cannot hold, so that they never take the
 	// device round trip through ST_ALPHABET
 	b->h_acgt.resize((size_t)n);
-	for (int32_t i = 0; i < n; ++i) {
-		const uint8_t *pt = ts ? (const uint8_t*)ts[i] : (const uint8_t*)packed + p_t_off[i];
-		const uint8_t *pq = ts ? (const uint8_t*)qs[i] : (const uint8_t*)packed + p_q_off[i];
-		b->h_acgt[i] = plain_acgt(pt, (size_t)tl[i]) && plain_acgt(pq, (size_t)ql[i]) ? 1 : 0;
+	auto classify = [&](int32_t i0, int32_t i1) {
+		for (int32_t i = i0; i < i1; ++i) {
+			const uint8_t *pt = ts ? (const uint8_t*)ts[i] : (const uint8_t*)packed + p_t_off[i];
+			const uint8_t *pq = ts ? (const uint8_t*)qs[i] : (const uint8_t*)packed + p_q_off[i];
+			b->h_acgt[i] = plain_acgt(pt, (size_t)tl[i]) && plain_acgt(pq, (size_t)ql[i]) ? 1 : 0;
+		}
+	};
+	if (seq_bytes < ((int64_t)2 << 20) || n < 16) classify(0, n);
+	else { // megabytes of sequence: a few host threads, equal shares of the bytes (one thread does ~8 GB/s)
+		const int n_th = (int)std::min<int64_t>(8, std::min<int64_t>(std::max(1u, std::thread::hardware_concurrency()), seq_bytes >> 20));
+		std::vector<std::thread> th;
+		int32_t i0 = 0;
+		int64_t acc = 0, done_bytes = 0;
+		for (int k = 0; k < n_th; ++k) {
+			const int64_t want = (seq_bytes - done_bytes) / (n_th - k);
+			int32_t i1 = i0;
+			for (acc = 0; i1 < n && (acc < want || k + 1 == n_th); ++i1) acc += (int64_t)tl[i1] + ql[i1];
+			done_bytes += acc;
+			if (k + 1 == n_th) classify(i0, n);
+			else th.emplace_back(classify, i0, i1);
+			i0 = i1;
+		}
+		for (std::thread &t : th) t.join();
 	}
 	char *base = (char*)b->block.p;
 	b->d_t_off = (const int64_t*)(base + L.t_off), b->d_q_off = (const int64_t*)(base + L.q_off);
@@ -1050,6 +1071,7 @@ int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value)
 	else if (!strcmp(name, "coop_spin_limit")) g->coop_spin_limit = std::max<int64_t>(0, std::min<int64_t>(value, 0x7fffffff));
 	else if (!strcmp(name, "coop_tb_cap_mb")) g->coop_tb_cap = std::max<int64_t>(1, value) << 20;
 	else if (!strcmp(name, "lowmem_budget_mb")) g->lowmem_budget_mb = std::max<int64_t>(0, value);
+	else if (!strcmp(name, "coop_grid")) g->coop_grid_cap = (int)std::max<int64_t>(0, value);
 	else if (!strcmp(name, "sys_p") && (value == 4 || value == 8 || value == 16)) g->sys_p = (int)value;
 	else if (!strcmp(name, "sys_c") && (value == 0 || value == 1 || value == 4)) g->sys_c = (int)value;
 	else if (!strcmp(name, "trim")) { (void)hipSetDevice(g->device); trim(g); }

@@ -106,6 +106,7 @@ struct BatchArgs {
 	// hands its outer columns to its two neighbours once per block of `sys_p` penalties
 	int32_t sys_p;             // penalties per hand-off block (4, 8 or 16); a slot owns 64*sys_c - 2*sys_p columns, the rest is halo
 	int32_t sys_c;             // columns per lane (4 or 1): a slot computes 64*sys_c columns
+	int32_t sys_spread;        // 1: consecutive chunks on consecutive WORKGROUPS (a window of n chunks keeps n/grid waves per CU busy); 0: on consecutive waves of a workgroup
 	int32_t *sys_box;          // [group][slot][2 parities][box ints]: outer columns' H rows of the block, E/F state at its end, window views
 	int64_t sys_box_stride;    // ints between two groups' boxes
 	unsigned long long *sys_prog; // [group][slot] x 64 bytes: blocks published

@@ -241,7 +241,7 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 	static_assert(P == 4 || P == 8 || P == 16, "block length");
 	const int32_t NWt = G * kNW, TC = NWt * kK;
 	const int32_t tl = M.tl, ql = M.ql, cmax = tl + ql + 1;
-	const int32_t tid = threadIdx.x, lane = tid & 63, wv = uni(tid >> 6), gw = uni(lb * kNW + wv);
+	const int32_t tid = threadIdx.x, lane = tid & 63, wv = uni(tid >> 6), gw = uni(A.sys_spread ? wv * G + lb : lb * kNW + wv);
 	const bool lead = lb == 0 && tid == 0;
 	char *const misc = (char*)A.coop_flags + (int64_t)grp * A.coop_misc_stride; // this group's flags | barrier words | pass state
 	unsigned *const sync = (unsigned*)(misc + 1024);
@@ -342,7 +342,7 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 	};
 
 #ifdef MWF_SYS_TIMING
-	unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}, t_blocks = 0, t_runs = 0, t_st[4] = {0, 0, 0, 0};
+	unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}, t_blocks = 0, t_runs = 0, t_st[4] = {0, 0, 0, 0}, t_ee[3] = {0, 0, 0};
 #define MWF_T(x) const unsigned long long x = __builtin_readcyclecounter()
 #else
 #define MWF_T(x)
@@ -869,6 +869,7 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 
 		// ---- end of the epoch: everybody meets; edges from the log, n_iter, stop rules, end cell, shrink
 		if (!sys_grid_sync(spin_limit, sync, &gflags[15], (unsigned)lb, L, epoch, G) || uni(L.red[0]) != 0) { R.status = ST_INTERNAL; break; }
+		MWF_T(tt_e2);
 		{
 			// widths of the epoch's 256 slices from the log: lane l looks at penalties s-255+4l .. s-252+4l
 			const int32_t sb = s - kEpoch; // penalties sb+1 .. s
@@ -929,6 +930,7 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 			cells = ((int64_t)__builtin_amdgcn_readlane((int32_t)(tot >> 32), 63) << 32) | (uint32_t)__builtin_amdgcn_readlane((int32_t)(tot & 0xffffffff), 63);
 		}
 		wf_lo = uni(logL[s]), wf_hi = uni(logH[s]);
+		MWF_T(tt_e3);
 		{ // shrink (reference wf_stripe_shrink, miniwfa.c:144-171) on the good bits of the last nH slices
 			const int32_t rd = (ep & 1) ? 17 : 13;            // this epoch's reduction words; the other pair is reset for the next one
 			if (lead) st_ag(&gflags[(ep & 1) ? 13 : 17], 0x7fffffff), st_ag(&gflags[(ep & 1) ? 14 : 18], -1);
@@ -960,12 +962,13 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 		}
 #ifdef MWF_SYS_TIMING
 		t_acc[4] += tt_e1 - tt_e0, t_acc[5] += __builtin_readcyclecounter() - tt_e1, t_runs += 1;
+		t_ee[0] += tt_e2 - tt_e1, t_ee[1] += tt_e3 - tt_e2, t_ee[2] += __builtin_readcyclecounter() - tt_e3;
 #endif
 	}
 #ifdef MWF_SYS_TIMING
 	if (lane == 0 && t_blocks > 0 && (((wv == 0 || wv == 5) && (lb % 37) == 0) || t_acc[5] * 6 < t_acc[4]))
-		printf("wg %3d wave %d: deep-block iterations %llu: stage 2a (incl. wait for the probe words) %.0f  stage 1 %.0f  stage 2b %.0f cycles | %llu slot-blocks in %llu epochs | per slot-block: wait %.0f  refresh %.0f  steps %.0f  publish %.0f cycles | per epoch: blocks %.0f  end (barriers, scan, shrink) %.0f\n", lb, wv,
-		       t_st[3], (double)t_st[0] / (t_st[3] ? t_st[3] : 1), (double)t_st[1] / (t_st[3] ? t_st[3] : 1), (double)t_st[2] / (t_st[3] ? t_st[3] : 1), t_blocks, t_runs, (double)t_acc[0] / t_blocks, (double)t_acc[1] / t_blocks, (double)t_acc[2] / t_blocks, (double)t_acc[3] / t_blocks, (double)t_acc[4] / t_runs, (double)t_acc[5] / t_runs);
+		printf("wg %3d wave %d: deep-block iterations %llu: stage 2a (incl. wait for the probe words) %.0f  stage 1 %.0f  stage 2b %.0f cycles | %llu slot-blocks in %llu epochs | per slot-block: wait %.0f  refresh %.0f  steps %.0f  publish %.0f cycles | per epoch: blocks %.0f  end (barriers, scan, shrink) %.0f = first barrier %.0f + scan %.0f + shrink and second barrier %.0f\n", lb, wv,
+		       t_st[3], (double)t_st[0] / (t_st[3] ? t_st[3] : 1), (double)t_st[1] / (t_st[3] ? t_st[3] : 1), (double)t_st[2] / (t_st[3] ? t_st[3] : 1), t_blocks, t_runs, (double)t_acc[0] / t_blocks, (double)t_acc[1] / t_blocks, (double)t_acc[2] / t_blocks, (double)t_acc[3] / t_blocks, (double)t_acc[4] / t_runs, (double)t_acc[5] / t_runs, (double)t_ee[0] / t_runs, (double)t_ee[1] / t_runs, (double)t_ee[2] / t_runs);
 #endif
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	R.s = s, R.cells = cells;

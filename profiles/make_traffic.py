@@ -1,28 +1,51 @@
 #!/usr/bin/env python3
-"""profiles/traffic.json (what bench.py's `roofline.traffic` and `binding` quote) from the rocprofv3 summaries under profiles/r02/:
-per-launch means of FETCH_SIZE / WRITE_SIZE (KiB) and of the instruction counters, per kernel and batch."""
+"""profiles/traffic.json (what bench.py's `roofline.traffic` / candidates quote) from the rocprofv3 summaries under profiles/r03/:
+per-launch means of FETCH_SIZE / WRITE_SIZE (KiB) and of the instruction counters, per kernel and workload."""
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = {  # key in traffic.json -> summary file, kernel the numbers are taken from
-    "1024x10000@0.05s": ("profiles/r02/rocprof_band2_kernel_1024x10kb_score.txt", "wfa_band2_kernel<512, 3, 2, 1, false, true>"),
-    "1024x10000@0.05c": ("profiles/r02/rocprof_band2_kernel_1024x10kb_cigar.txt", "wfa_band2_kernel<512, 3, 2, 1, true, true>"),
-    "1250x50000@0.03s": ("profiles/r02/rocprof_generic_stream16_kernel_1250x50kb.txt", "wfa_batch_kernel<512, true, true, true>"),
+# key in traffic.json -> (summary file, kernel name prefix(es) the numbers are taken from, read width in bytes per lane)
+SRC = {
+    "1024x10000@0.05s": ("profiles/r03/rocprof_band2_kernel_1024x10kb_score.txt", ["wfa_band2_kernel<512, 3, 2, 1, false, true>"], 8),
+    "1024x10000@0.05c": ("profiles/r03/rocprof_band2_kernel_1024x10kb_cigar.txt", ["wfa_band2_kernel<512, 3, 2, 1, true, true>"], 8),
+    "1250x50000@0.03s": ("profiles/r03/rocprof_generic_stream16_kernel_1250x50kb.txt", ["wfa_batch_kernel<512, true, true, true, 0>"], 8),
+    "c4_like_150kb:score": ("profiles/r03/rocprof_sys_kernel_c4_score.txt", ["wfa_sys_kernel"], 4),
+    "c4_like_150kb:cigar_highmem": ("profiles/r03/rocprof_sys_kernel_c4_cigar.txt", ["wfa_sys_kernel"], 4),
+    "c4_like_150kb:cigar_lowmem_p5000": ("profiles/r03/rocprof_sys_kernel_c4_lowmem.txt", ["wfa_sys_kernel"], 4),
+    "mhc_like_5Mb:score": ("profiles/r03/rocprof_sys_kernel_mhc_score.txt", ["wfa_sys_kernel"], 16),
+    "mhc_like_5Mb:cigar_lowmem_p5000": ("profiles/r03/rocprof_sys_kernel_mhc_lowmem.txt", ["wfa_sys_kernel"], 16),
 }
 out = {}
-for key, (path, kern) in SRC.items():
-    txt = open(os.path.join(ROOT, path)).read()
-    pmc = {m.group(1): (float(m.group(2)), int(m.group(3))) for m in re.finditer(r"== pmc (\w+) = ([0-9.e+]+) per launch \((\d+) launches\) \[[^\]]*" + re.escape(kern.split("<")[0]), txt)}
-    cells = int(re.search(r"cells/launch (\d+)", txt).group(1))
-    n = pmc["FETCH_SIZE"][1]
-    note = (f"{path}: separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes over {kern.replace(', ', ',')}, means over {n} launches; "
+for key, (path, kerns, width) in SRC.items():
+    full = os.path.join(ROOT, path)
+    if not os.path.exists(full):
+        continue
+    txt = open(full).read()
+    pmc = {}
+    for m in re.finditer(r"== pmc (\w+) = ([0-9.e+]+) per launch \((\d+) launches\) \[([^\]]*)", txt):
+        name, val, n, kern = m.group(1), float(m.group(2)), int(m.group(3)), m.group(4)
+        if any(k.split("<")[0] in kern and (("<" not in k) or k[:40] in kern or k.replace(", ", ",")[:30] in kern.replace(", ", ",")) for k in kerns):
+            tot, cnt = pmc.get(name, (0.0, 0))
+            pmc[name] = (tot + val, max(cnt, n))     # a mode that launches the kernel in two forms (low-memory passes): their sum per call
+    if "FETCH_SIZE" not in pmc:
+        continue
+    forms = {m.group(4) for m in re.finditer(r"== pmc (FETCH_SIZE) = ([0-9.e+]+) per launch \((\d+) launches\) \[([^\]]*)", txt) if "wfa_sys_kernel" in m.group(4)}
+    if "lowmem" in key and len(forms) == 1:   # both passes of the low-memory mode ran the same kernel form: two launches per call
+        pmc = {k: (v[0] * 2, v[1]) for k, v in pmc.items()}
+    m = re.search(r"cells/launch (\d+)", txt)
+    cells = int(m.group(1)) if m else None
+    note = (f"{path}: separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes over {', '.join(kerns)}, means per launch; "
             "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950; "
-            "the band2 kernel's reads are 8 bytes per lane, a width the guide calls uncalibrated, so this is an upper estimate; WRITE_SIZE as is: it matches the H stores)")
+            f"this kernel's row reads are {width} bytes per lane" + (", a width the guide calls uncalibrated, so this is an upper estimate" if width != 16 else "") +
+            "; WRITE_SIZE as is)")
     out[key] = {
         "hbm_bytes_per_launch": (2 * pmc["FETCH_SIZE"][0] + pmc["WRITE_SIZE"][0]) * 1024,
         "fetch_size_kib": pmc["FETCH_SIZE"][0], "write_size_kib": pmc["WRITE_SIZE"][0],
-        "valu_insts_per_launch": pmc["SQ_INSTS_VALU"][0], "salu_insts_per_launch": pmc["SQ_INSTS_SALU"][0], "lds_insts_per_launch": pmc["SQ_INSTS_LDS"][0],
-        "cells_per_launch": cells, "source": note,
-        "valu_source": f"{path}: rocprofv3 --pmc SQ_INSTS_VALU (wave-instructions), mean over {pmc['SQ_INSTS_VALU'][1]} launches",
+        "valu_insts_per_launch": pmc.get("SQ_INSTS_VALU", (None,))[0], "salu_insts_per_launch": pmc.get("SQ_INSTS_SALU", (None,))[0],
+        "lds_insts_per_launch": pmc.get("SQ_INSTS_LDS", (None,))[0],
+        "source": note,
+        "valu_source": f"{path}: rocprofv3 --pmc SQ_INSTS_VALU (wave-instructions), mean per launch",
     }
+    if cells:
+        out[key]["cells_per_launch"] = cells
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 print(json.dumps({k: {kk: vv for kk, vv in v.items() if "source" not in kk} for k, v in out.items()}, indent=1))

@@ -968,3 +968,50 @@ def test_long_pair_and_batch_threads_share_the_device(oracle, capfd):
         t_.join()
     assert not errors, errors[:3]
     assert "gave up waiting" not in capfd.readouterr().err
+
+
+def test_whole_device_kernel_columns_per_lane(oracle, capfd):
+    """The systolic whole-device kernel with one and with four columns per lane (sys_c; chosen per pass from the expected window by
+    default): same s, n_iter and CIGAR in every mode, two-pass low-memory mode included; and a pair whose window outgrows the
+    64-column slots it was optimistically given comes back through the 256-column slots — not through the one-workgroup kernel."""
+    cases = [synth_pair(99000, 9000, 0.08), synth_pair(99001, 30000, 0.03, 2, 2500), synth_pair(99002, 700, 0.2), (b"A" * 3000, b"A" * 2990)]
+    opts = [make_opt(), make_opt(flag=1), make_opt(flag=1, step=600), make_opt(flag=1, o2=4, e2=2), make_opt(flag=1, x=1, o1=0, e1=1, o2=0, e2=1, step=150)]
+    expect = {j: [oracle.align(t, q, o) for t, q in cases] for j, o in enumerate(opts)}
+    for c, budget in ((1, 0), (4, 0), (1, 1)):          # (budget 1 MB: the two-pass low-memory mode, its second pass on the systolic kernel)
+        eng = mw.Engine(0)
+        eng.set("force_kind", 1)
+        eng.set("sys_c", c)
+        if budget:
+            eng.set("lowmem_budget_mb", budget)
+        for j, o in enumerate(opts):
+            b = eng.upload(PackedBatch(cases))
+            b.align(mw.opt_init(**{k: getattr(o, k) for k in OPT_KEYS}))
+            assert eng.stats().kernel_kind == 1
+            s, it, nc = b.results()
+            for i in range(len(cases)):
+                es, eit, ecig = expect[j][i]
+                assert (int(s[i]), int(it[i])) == (es, eit), (c, budget, j, i)
+                if ecig is not None:
+                    assert b.cigar(i, int(nc[i])).tolist() == ecig, (c, budget, j, i)
+            b.free()
+        assert eng.stats().n_retries == 0
+        eng.close()
+    # the whole-device kernel confined to 16 workgroups (256 slots): 64-column slots hold windows up to 11.5 k columns, 256-column
+    # ones up to 59.9 k; the expected window of a 20 kb pair (8192 columns at least) fits the former, the real one of this pair does not
+    t, q = synth_pair(99010, 20000, 0.25)
+    bands = oracle.band_trace(t, q, make_opt())                  # (one oracle run: penalty = slices, n_iter = sum of their widths)
+    es, eit = len(bands), sum(h - l + 1 for l, h in bands)
+    widest = max(h - l + 1 for l, h in bands)
+    assert 11600 < widest < 59000, widest
+    eng = mw.Engine(0)
+    eng.set("force_kind", 1)
+    eng.set("coop_grid", 16)
+    b = eng.upload(PackedBatch([(t, q)]))
+    b.align(mw.opt_init())
+    s, it, _ = b.results()
+    st = eng.stats()
+    assert (int(s[0]), int(it[0])) == (es, eit)
+    assert st.kernel_kind == 1 and st.n_retries == 1, (st.kernel_kind, st.n_retries)
+    assert "re-running it on one workgroup" not in capfd.readouterr().err
+    b.free()
+    eng.close()
