@@ -221,24 +221,78 @@ __device__ __forceinline__ int32_t run_wave2(int32_t j, int32_t aq, int32_t room
 template <int D, int NWK>
 struct alignas(16) Band2Lds {
 	Shared sh;
-	int32_t edge[D][NWK][4]; // per age and chunk slot: {E1 pair (c2,c3), E2 pair (c2,c3)} of lane 63, {F1 pair (c0,c1), F2 pair (c0,c1)} of lane 0
+	int32_t edge[D][NWK][4]; // per age and chunk slot: {E1, E2 of columns (c1,c3) of lane 63}, {F1, F2 of columns (c0,c2) of lane 0}
 };
+
+// ---- packed 16-bit arithmetic: two columns per register, every operation one VOP3P instruction
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+#define MWF_BC(T, v) __builtin_bit_cast(T, v)
+__device__ __forceinline__ int32_t pk_max(int32_t a, int32_t b) { return MWF_BC(int32_t, __builtin_elementwise_max(MWF_BC(s16x2, a), MWF_BC(s16x2, b))); }
+__device__ __forceinline__ int32_t pk_add(int32_t a, int32_t b) { return MWF_BC(int32_t, (s16x2)(MWF_BC(s16x2, a) + MWF_BC(s16x2, b))); }
+__device__ __forceinline__ int32_t pk_sub(int32_t a, int32_t b) { return MWF_BC(int32_t, (s16x2)(MWF_BC(s16x2, a) - MWF_BC(s16x2, b))); }
+__device__ __forceinline__ int32_t pk_minu(int32_t a, int32_t b) { return MWF_BC(int32_t, __builtin_elementwise_min(MWF_BC(u16x2, a), MWF_BC(u16x2, b))); }
+// max(a - b, 0) on unsigned halves (v_pk_sub_u16 clamp): zero iff a <= b
+__device__ __forceinline__ int32_t pk_subsat(int32_t a, int32_t b) { return MWF_BC(int32_t, __builtin_elementwise_sub_sat(MWF_BC(u16x2, a), MWF_BC(u16x2, b))); }
+// 0xffff in every half of x that is not zero (asm: the compiler turns the min into compares, selects and a v_perm)
+__device__ __forceinline__ int32_t pk_nonzero_mask(int32_t x)
+{
+	int32_t m;
+	asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]\n\tv_pk_sub_i16 %0, 0, %0 op_sel_hi:[0,1]" : "=&v"(m) : "v"(x));
+	return m;
+}
+// 1 in every half where a != b
+__device__ __forceinline__ int32_t pk_ne1(int32_t a, int32_t b)
+{
+	int32_t m;
+	asm("v_xor_b32 %0, %1, %2\n\tv_pk_min_u16 %0, %0, 1 op_sel_hi:[1,0]" : "=&v"(m) : "v"(a), "v"(b));
+	return m;
+}
+// a * b + c on unsigned halves
+__device__ __forceinline__ int32_t pk_mad(int32_t a, int32_t b, int32_t c)
+{
+	int32_t m;
+	asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(m) : "v"(a), "v"(b), "v"(c));
+	return m;
+}
+__device__ __forceinline__ int32_t bfi(int32_t mask, int32_t a, int32_t b) { return (a & mask) | (b & ~mask); } // mask ? a : b, bitwise
+__device__ __forceinline__ int32_t half_of(int32_t v, int hi) { return hi ? v >> 16 : (int32_t)(int16_t)(v & 0xffff); }
+__device__ __forceinline__ int32_t pair_of(int32_t lo, int32_t hi) { return (int32_t)(((uint32_t)hi << 16) | ((uint32_t)lo & 0xffffu)); }
+
+// A lane's four columns c0..c3 of a chunk live in two registers, A = (c0, c2) and B = (c1, c3): the columns to the left of A's
+// are (c-1, c1) — B shifted in from the lane to the left — and those to the left of B's are A itself; to the right of A's: B, to
+// the right of B's: (c2, c4).  `fill` supplies what lane 0 (lane 63) takes from beyond the chunk.
+__device__ __forceinline__ int32_t left_of_A(int32_t B, int32_t fill) { return __builtin_amdgcn_alignbit(B, from_left(B, fill), 16); }
+__device__ __forceinline__ int32_t right_of_B(int32_t A, int32_t fill) { return __builtin_amdgcn_alignbit(from_right(A, fill), A, 16); }
+
+// A new value enters a register history of depth N (1 or 2; [0] is the newest): the oldest register — read for the last time at
+// this penalty — takes it and, for N = 2, the two trade places (v_swap_b32: no copies, the same registers on every path).
+template <int N, int K>
+__device__ __forceinline__ void age(int32_t (*h)[K][2], int k, int i, int32_t v)
+{
+	static_assert(N == 1 || N == 2, "history depth");
+	h[N - 1][k][i] = v;
+	if (N == 2) asm volatile("v_swap_b32 %0, %1" : "+v"(h[0][k][i]), "+v"(h[1][k][i]));
+}
 
 template <int T, int K, int E1, int E2, bool TB, bool S2>
 __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &sh, int32_t (*edge)[(T / 64) * K][4], const int32_t qoff, bool trace_band)
 {
 	constexpr int NW = T / 64, NWK = NW * K, D = (E1 > E2 ? E1 : E2) + 1;
+	constexpr int FULL = S2 ? 16 : 8; // bases the first probe of the match extension looks at
 	const int32_t tl = M.tl, ql = M.ql, cmax = tl + ql + 1;
 	const int32_t tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
 	const int32_t W = A.W, nH = A.pen.nH, lagx = A.pen.x, lag1 = A.pen.oe1, lag2 = A.pen.oe2;
-	char *const Hb = (char*)M.H; // rows of W int16: (row, column) at byte (row * W + column) * 2
-	auto at = [&](int32_t row, int32_t col) -> char* { return Hb + (size_t)((uint32_t)(row * W + col) << 1); };
+	// H rows: W int16 per row, a quad of columns 4q..4q+3 stored as (c0, c2, c1, c3) — the two registers of a lane, one 8-byte load;
+	// 8 bytes of slack in front (lane 0 of chunk 0 looks one quad to the left; offsets are unsigned: the slack is part of `lane8`)
+	char *const Hb = (char*)M.H;
+	const uint32_t RS = (uint32_t)W << 1; // bytes per row
 	const int32_t min_lag = min(lagx, min(lag1, lag2));
 	const bool relaxed_stores = min_lag >= 3; // rows written now are first loaded two penalties from now: stores may cross the barrier
 	PassResult R;
 	R.status = ST_OK, R.s = 0, R.info = 0, R.n_snap = 0, R.cells = 0;
 
-	// per-thread wavefront state, two columns per register: [age][slot][pair]; age 0 is the previous penalty
+	// per-thread wavefront state, two columns per register: [age][slot][A / B]; age 0 is the previous penalty
 	int32_t e1h[E1][K][2], f1h[E1][K][2], e2h[E2][K][2], f2h[E2][K][2];
 #pragma unroll
 	for (int k = 0; k < K; ++k)
@@ -249,7 +303,20 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 #pragma unroll
 			for (int a = 0; a < E2; ++a) e2h[a][k][i] = f2h[a][k][i] = kDeadPair;
 		}
+	// lane constants: local columns of A and B, byte offset of the lane's quad, of the neighbouring word it fetches
+	const int32_t RA = pair_of(4 * lane, 4 * lane + 2), RB = pk_add(RA, 0x00010001), RB1 = pk_add(RA, 0x00020002);
+	const uint32_t lane8 = ((uint32_t)lane << 3) + 8u;
+	const int32_t nd = lane == 0 ? -4 : 8; // lane 0: B of the quad to the left; lane 63: A of the quad to the right
+	const int32_t T0 = both16(cmax), TLp = both16(tl), TL1 = both16(tl + 1);
 
+	// ---- every row read before it is written must read as dead around the origin: the chunks a window can reach within nH penalties
+	{
+		const int32_t g0 = (tl + 1) >> 8;
+		for (int32_t q = tid; q < nH * 5 * 64; q += T) {
+			const int32_t row = q / 320, rem = q - row * 320, g = g0 - 2 + (rem >> 6);
+			if (g >= 0) *(int2*)(Hb + (size_t)((uint32_t)row * RS + (uint32_t)(g * 512 + (rem & 63) * 8 + 8))) = make_int2(kDeadPair, kDeadPair);
+		}
+	}
 	// ---- penalty 0 (reference wf_stripe_init, miniwfa.c:103-121) and its extension
 	for (int32_t j = tid; j < D * NWK * 4; j += T) (&edge[0][0][0])[j] = kDeadPair;
 	if (tid == 0) {
@@ -257,10 +324,12 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 		for (int32_t j = 0; j < 12; ++j) (&sh.flags[0][0])[j] = 0;
 		sh.rng_lo[0] = sh.rng_hi[0] = tl + 1;
 	}
+	__syncthreads(); // (orders the dead rows before the origin's store)
 	if (tid < 64) { // the origin's run, walked by the first wave
 		const int32_t k0 = (S2 ? run_wave16(qoff, 0, 0, min(tl, ql), 0) : run_wave2(0, qoff, min(tl, ql), 0)) - 1;
 		if (tid == 0) {
-			*(int16_t*)at(0, tl + 1) = (int16_t)k0;
+			const int32_t c = tl + 1, e = c & 3;
+			*(int16_t*)(Hb + 8 + (size_t)(uint32_t)(((c & ~3) + ((e & 1) << 1) + (e >> 1)) << 1)) = (int16_t)k0;
 			sh.word[1] = k0;
 		}
 	}
@@ -290,17 +359,6 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 #pragma unroll
 	for (int k = 0; k < K; ++k) idle[k] = D;
 
-	// rows of one chunk: H at the three lags (four columns = one 8-byte load each) and the two neighbouring columns
-	struct Rows { int2 hx, o1, o2; int32_t v1, v2; };
-	auto load_rows = [&](Rows &r, int32_t g, int32_t jx, int32_t j1, int32_t j2) {
-		const int32_t c0 = g * kChunk + 4 * lane;
-		r.hx = *(const int2*)at(jx, c0);
-		r.o1 = *(const int2*)at(j1, c0);
-		r.o2 = *(const int2*)at(j2, c0);
-		const int32_t ce = lane == 0 ? max(c0, 1) - 1 : c0 + 4; // lane 0: the column to the left, lane 63: the one to the right
-		r.v1 = *(const int16_t*)at(j1, ce), r.v2 = *(const int16_t*)at(j2, ce);
-	};
-
 	for (;;) {
 #ifdef MWF_B2_TIMING
 		const uint64_t tm0 = __builtin_readcyclecounter();
@@ -323,13 +381,13 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 		int32_t jx = newH - lagx; if (jx < 0) jx += nH;
 		int32_t j1 = newH - lag1; if (j1 < 0) j1 += nH;
 		int32_t j2 = newH - lag2; if (j2 < 0) j2 += nH;
+		const char *const rowx = Hb + (size_t)((uint32_t)jx * RS), *const row1 = Hb + (size_t)((uint32_t)j1 * RS), *const row2 = Hb + (size_t)((uint32_t)j2 * RS);
+		char *const rown = Hb + (size_t)((uint32_t)newH * RS);
 		const bool track_good = (((256 - (s_new & 255)) & 255) < nH); // a shrink can still see this slice
 		// ages of the edge table to read: penalties s_new-E1 and s_new-E2
 		int32_t d1 = dnew - E1; if (d1 < 0) d1 += D;
 		int32_t d2 = dnew - E2; if (d2 < 0) d2 += D;
-		// chunk ranges: [ga, ga+gspan] meets the window; [gd, gd+dspan] lies nH+1 columns inside it (dspan < 0: none)
-		const int32_t ga = lo >> 8, gspan = (hi >> 8) - ga;
-		const int32_t gd = (lo + nH + 1 + kChunk - 1) >> 8, dspan = ((hi - nH) >> 8) - 1 - gd;
+		const int32_t ga = lo >> 8, gb = hi >> 8, gspan = gb - ga; // chunks [ga, gb] meet the window
 		const int32_t cfin = ql + 1; // the end cell (tl-1, ql-1) lies on diagonal ql-tl, i.e. in this column
 
 		if (tid == 0) {
@@ -352,26 +410,16 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 #ifdef MWF_B2_TIMING
 		const uint64_t tm1 = __builtin_readcyclecounter();
 #endif
-		// window history: only a chunk near a window edge needs it
-		int32_t xlo = 1, xhi = 0, alo = 1, ahi = 0, blo = 1, bhi = 0;
-		bool hist = false;
-		Rows cur;
 		int n_stores = 0;
 #pragma unroll
 		for (int k = 0; k < K; ++k) {
 			if (!act[k]) {
 				// a chunk outside the window: its columns were not computed at this penalty, i.e. their E/F are dead — once every
 				// age of the slot's registers and of its edge-table entries is dead (D penalties outside), there is nothing to do
-				if (!TB && idle[k] >= D) continue; // uniform
+				if (idle[k] >= D) continue; // uniform
 				++idle[k];
 #pragma unroll
-				for (int i = 0; i < 2; ++i) {
-#pragma unroll
-					for (int a = E1 - 1; a > 0; --a) e1h[a][k][i] = e1h[a - 1][k][i], f1h[a][k][i] = f1h[a - 1][k][i];
-#pragma unroll
-					for (int a = E2 - 1; a > 0; --a) e2h[a][k][i] = e2h[a - 1][k][i], f2h[a][k][i] = f2h[a - 1][k][i];
-					e1h[0][k][i] = f1h[0][k][i] = e2h[0][k][i] = f2h[0][k][i] = kDeadPair;
-				}
+				for (int i = 0; i < 2; ++i) age<E1>(e1h, k, i, kDeadPair), age<E1>(f1h, k, i, kDeadPair), age<E2>(e2h, k, i, kDeadPair), age<E2>(f2h, k, i, kDeadPair);
 				const int32_t r = wave + NW * k;
 				if (lane == 63) edge[dnew][r][0] = kDeadPair, edge[dnew][r][1] = kDeadPair;
 				if (lane == 0) edge[dnew][r][2] = kDeadPair, edge[dnew][r][3] = kDeadPair;
@@ -379,141 +427,143 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 			}
 			const int32_t r = wave + NW * k, g = gk[k], cb = g * kChunk, c0 = cb + 4 * lane;
 			idle[k] = 0;
-			load_rows(cur, g, jx, j1, j2);
+			// ---- rows: H at the three lags (one 8-byte load each) and the word next to the chunk for the two gap-open rows
+			const uint32_t off = (uint32_t)(cb << 1) + lane8, noff = off + (uint32_t)nd;
+			const int2 HX = *(const int2*)(rowx + off), O1 = *(const int2*)(row1 + off), O2 = *(const int2*)(row2 + off);
+			const int32_t N1 = *(const int32_t*)(row1 + noff), N2 = *(const int32_t*)(row2 + noff);
+			// gap-extension sources: E of column c-1, F of column c+1, e1 (e2) penalties ago; lane 0 / lane 63 take the neighbouring
+			// slot's outer columns from the edge table
+			const int32_t rl = r == 0 ? NWK - 1 : r - 1, rr = r + 1 == NWK ? 0 : r + 1;
+			const int32_t xE1 = edge[d1][rl][0], xE2 = edge[d2][rl][1], xF1 = edge[d1][rr][2], xF2 = edge[d2][rr][3];
+			const bool inside = cb >= lo && cb + kChunk - 1 <= hi; // uniform: every column of the chunk belongs to the window
 
-			const bool deep = (uint32_t)(g - gd) <= (uint32_t)dspan && dspan >= 0 && !track_good; // uniform
-			int32_t hx[4] = {lo16(cur.hx.x), hi16(cur.hx.x), lo16(cur.hx.y), hi16(cur.hx.y)};
-			int32_t o1[6], o2[6]; // o1[i+1] is column c0+i; o1[0], o1[5] the neighbours
-			o1[1] = lo16(cur.o1.x), o1[2] = hi16(cur.o1.x), o1[3] = lo16(cur.o1.y), o1[4] = hi16(cur.o1.y);
-			o2[1] = lo16(cur.o2.x), o2[2] = hi16(cur.o2.x), o2[3] = lo16(cur.o2.y), o2[4] = hi16(cur.o2.y);
-			int32_t v1 = cur.v1, v2 = cur.v2;
-			bool inner = true;
-			if (!deep) {
-				if (!hist) {
-					if (!TB) { // (with traceback the extra live registers cost more than the round trips: 34.2 against 33.8 ms)
-					// the six window words in ONE LDS round trip (lane L < 6 reads word L) instead of three dependent ones: this is
-					// the window-edge chunk, i.e. the wave the whole workgroup is waiting for
-					const int32_t sel = lane < 6 ? lane : 0, jj = sel < 2 ? jx : sel < 4 ? j1 : j2;
-					const int32_t wv = (sel & 1) ? sh.rng_hi[jj] : sh.rng_lo[jj];
-					xlo = __builtin_amdgcn_readlane(wv, 0), xhi = __builtin_amdgcn_readlane(wv, 1);
-					alo = __builtin_amdgcn_readlane(wv, 2), ahi = __builtin_amdgcn_readlane(wv, 3);
-					blo = __builtin_amdgcn_readlane(wv, 4), bhi = __builtin_amdgcn_readlane(wv, 5);
-					} else {
-					xlo = uni(sh.rng_lo[jx]), xhi = uni(sh.rng_hi[jx]);
-					alo = uni(sh.rng_lo[j1]), ahi = uni(sh.rng_hi[j1]);
-					blo = uni(sh.rng_lo[j2]), bhi = uni(sh.rng_hi[j2]);
-					}
-					hist = true;
+			// ---- recurrence (dev::wf_cell, miniwfa.c:267-278) on pairs of columns
+			const int32_t E1a = e1h[E1 - 1][k][0], E1b = e1h[E1 - 1][k][1], F1a = f1h[E1 - 1][k][0], F1b = f1h[E1 - 1][k][1];
+			const int32_t E2a = e2h[E2 - 1][k][0], E2b = e2h[E2 - 1][k][1], F2a = f2h[E2 - 1][k][0], F2b = f2h[E2 - 1][k][1];
+			const int32_t o1mA = left_of_A(O1.y, N1), o2mA = left_of_A(O2.y, N2), g1mA = left_of_A(E1b, xE1), g2mA = left_of_A(E2b, xE2);
+			const int32_t o1pB = right_of_B(O1.x, N1), o2pB = right_of_B(O2.x, N2), g1pB = right_of_B(F1a, xF1), g2pB = right_of_B(F2a, xF2);
+			const int32_t ONE = 0x00010001;
+			int32_t ne1A = pk_max(o1mA, g1mA), ne2A = pk_max(o2mA, g2mA);
+			int32_t ne1B = pk_max(O1.x, E1a), ne2B = pk_max(O2.x, E2a);
+			const int32_t pf1A = pk_max(O1.y, F1b), pf2A = pk_max(O2.y, F2b); // F before its + 1
+			const int32_t pf1B = pk_max(o1pB, g1pB), pf2B = pk_max(o2pB, g2pB);
+			int32_t nf1A = pk_add(pf1A, ONE), nf2A = pk_add(pf2A, ONE), nf1B = pk_add(pf1B, ONE), nf2B = pk_add(pf2B, ONE);
+			const int32_t mA = pk_add(HX.x, ONE), mB = pk_add(HX.y, ONE);
+			int32_t hA = pk_max(pk_max(mA, pk_max(ne1A, ne2A)), pk_max(nf1A, nf2A));
+			int32_t hB = pk_max(pk_max(mB, pk_max(ne1B, ne2B)), pk_max(nf1B, nf2B));
+			uint32_t tbw = 0;
+			if (TB) {
+				// The byte from the RESULTS (miniwfa.c:289-306): H is the maximum of m, e1, e2, f1, f2 and the reference's tie-breaking
+				// (mismatch, then E1, E2, F1, F2 = codes 0, 1, 3, 2, 4) is the first of them that equals it; a gap state was extended iff it
+				// differs from what opening it would have given.  n* = 1 where different: z = nm (1 + ne1 (2 + ne2 (2 nf1 - 1))).
+				const int32_t TWO = 0x00020002, NEG1 = (int32_t)0xffffffffu, EIGHT = 0x00080008, C16 = 0x00100010, C32 = 0x00200020, C64 = 0x00400040;
+				int32_t zA = pk_mad(pk_ne1(hA, nf1A), TWO, NEG1), zB = pk_mad(pk_ne1(hB, nf1B), TWO, NEG1);
+				zA = pk_mad(pk_ne1(hA, ne2A), zA, TWO), zB = pk_mad(pk_ne1(hB, ne2B), zB, TWO);
+				zA = pk_mad(pk_ne1(hA, ne1A), zA, ONE), zB = pk_mad(pk_ne1(hB, ne1B), zB, ONE);
+				zA = pk_mad(pk_ne1(hA, mA), zA, 0), zB = pk_mad(pk_ne1(hB, mB), zB, 0);
+				zA = pk_mad(pk_ne1(ne1A, o1mA), EIGHT, zA), zB = pk_mad(pk_ne1(ne1B, O1.x), EIGHT, zB);
+				zA = pk_mad(pk_ne1(pf1A, O1.y), C16, zA), zB = pk_mad(pk_ne1(pf1B, o1pB), C16, zB);
+				zA = pk_mad(pk_ne1(ne2A, o2mA), C32, zA), zB = pk_mad(pk_ne1(ne2B, O2.x), C32, zB);
+				zA = pk_mad(pk_ne1(pf2A, O2.y), C64, zA), zB = pk_mad(pk_ne1(pf2B, o2pB), C64, zB);
+				tbw = (uint32_t)zA | ((uint32_t)zB << 8); // bytes in column order: c0 = A.lo, c1 = B.lo, c2 = A.hi, c3 = B.hi
+			}
+			// ---- a chunk that sticks out of the window: the columns outside are not computed by the reference — dead
+			int32_t outA = 0, outB = 0; // 0xffff in the halves of columns outside [lo, hi]
+			if (!inside) { // uniform
+				const int32_t lo_r = both16(min(max(lo - cb, 0), 256)), hi_r1 = both16(min(max(hi - cb + 1, 0), 256));
+				outA = pk_nonzero_mask(pk_subsat(lo_r, RA) | pk_subsat(RB, hi_r1));
+				outB = pk_nonzero_mask(pk_subsat(lo_r, RB) | pk_subsat(RB1, hi_r1));
+				hA = bfi(outA, kDeadPair, hA), hB = bfi(outB, kDeadPair, hB);
+				ne1A = bfi(outA, kDeadPair, ne1A), ne1B = bfi(outB, kDeadPair, ne1B);
+				ne2A = bfi(outA, kDeadPair, ne2A), ne2B = bfi(outB, kDeadPair, ne2B);
+				nf1A = bfi(outA, kDeadPair, nf1A), nf1B = bfi(outB, kDeadPair, nf1B);
+				nf2A = bfi(outA, kDeadPair, nf2A), nf2B = bfi(outB, kDeadPair, nf2B);
+			}
+			// ---- edge rule (miniwfa.c:325-326): H is the max of the five, so "any live" == "H live"; one lane holds the edge column
+			uint32_t bits = 0;
+			if (g == ga || g == gb) { // uniform
+				if (g == ga) {
+					const int32_t rel = lo - cb;
+					const int32_t v = half_of(__builtin_amdgcn_readlane((rel & 1) ? hB : hA, rel >> 2), (rel >> 1) & 1);
+					bits |= v >= -1 ? 1u : 0u;
 				}
-				// columns whose every H read (c and c+-1) falls inside its source window and that are inside [lo,hi]
-				const int32_t ilo = max(max(lo, xlo), max(alo, blo) + 1), ihi = min(min(hi, xhi), min(ahi, bhi) - 1);
-				inner = cb >= ilo && cb + kChunk - 1 <= ihi;
-				if (!inner) { // reads outside a source window yield "dead" (what the reference's pads supply, miniwfa.c:96-99)
-#pragma unroll
-					for (int i = 0; i < 4; ++i) {
-						const int32_t c = c0 + i;
-						hx[i] = ((c >= xlo) & (c <= xhi)) ? hx[i] : kDead16;
-						o1[i + 1] = ((c >= alo) & (c <= ahi)) ? o1[i + 1] : kDead16;
-						o2[i + 1] = ((c >= blo) & (c <= bhi)) ? o2[i + 1] : kDead16;
-					}
-					const int32_t ce = lane == 0 ? c0 - 1 : c0 + 4;
-					v1 = ((ce >= alo) & (ce <= ahi)) ? v1 : kDead16;
-					v2 = ((ce >= blo) & (ce <= bhi)) ? v2 : kDead16;
+				if (g == gb) {
+					const int32_t rel = hi - cb;
+					const int32_t v = half_of(__builtin_amdgcn_readlane((rel & 1) ? hB : hA, rel >> 2), (rel >> 1) & 1);
+					bits |= v >= -1 ? 2u : 0u;
 				}
 			}
-			o1[0] = from_left(o1[4], v1), o1[5] = from_right(o1[1], v1);
-			o2[0] = from_left(o2[4], v2), o2[5] = from_right(o2[1], v2);
-			// gap-extension sources: E of column c-1, F of column c+1, e1 (e2) penalties ago.  Lanes shift whole pairs; lane 0 /
-			// lane 63 take the neighbouring wave's pair from the edge table.
-			int32_t g1m[4], g1p[4], g2m[4], g2p[4];
-			{
-				const int32_t rl = r == 0 ? NWK - 1 : r - 1, rr = r + 1 == NWK ? 0 : r + 1;
-				const int32_t E1l = from_left(e1h[E1 - 1][k][1], edge[d1][rl][0]), E2l = from_left(e2h[E2 - 1][k][1], edge[d2][rl][1]);
-				const int32_t F1r = from_right(f1h[E1 - 1][k][0], edge[d1][rr][2]), F2r = from_right(f2h[E2 - 1][k][0], edge[d2][rr][3]);
-				g1m[0] = hi16(E1l), g1m[1] = lo16(e1h[E1 - 1][k][0]), g1m[2] = hi16(e1h[E1 - 1][k][0]), g1m[3] = lo16(e1h[E1 - 1][k][1]);
-				g2m[0] = hi16(E2l), g2m[1] = lo16(e2h[E2 - 1][k][0]), g2m[2] = hi16(e2h[E2 - 1][k][0]), g2m[3] = lo16(e2h[E2 - 1][k][1]);
-				g1p[0] = hi16(f1h[E1 - 1][k][0]), g1p[1] = lo16(f1h[E1 - 1][k][1]), g1p[2] = hi16(f1h[E1 - 1][k][1]), g1p[3] = lo16(F1r);
-				g2p[0] = hi16(f2h[E2 - 1][k][0]), g2p[1] = lo16(f2h[E2 - 1][k][1]), g2p[2] = hi16(f2h[E2 - 1][k][1]), g2p[3] = lo16(F2r);
+			// ---- lane geometry of the chunk: j = k + 1 may reach rj = min(tl, ql - d); query index = j + d, d = c - 1 - tl
+			const int32_t cbp = both16(cb);
+			const int32_t xA = pk_sub(pk_sub(T0, cbp), RA);                  // ql - d of A's columns (garbage beyond cmax, where H is dead)
+			const int32_t rjA = pk_minu(xA, TLp), rjB = pk_minu(pk_sub(xA, ONE), TLp);
+			const int32_t dA = pk_sub(pk_add(RA, cbp), TL1), dB = pk_add(dA, ONE);
+			// good bits: some array holds an in-matrix offset (miniwfa.c:139-142) <=> j <= rj for a live value (dead: j is huge)
+			uint32_t gbits = 0;
+			if (track_good) { // uniform
+				auto bad = [&](int32_t v, int32_t rj) { return pk_subsat(pk_add(v, ONE), rj); }; // zero iff good
+				const int32_t bA = pk_minu(pk_minu(bad(hA, rjA), pk_minu(bad(ne1A, rjA), bad(nf1A, rjA))), pk_minu(bad(ne2A, rjA), bad(nf2A, rjA))) | outA;
+				const int32_t bB = pk_minu(pk_minu(bad(hB, rjB), pk_minu(bad(ne1B, rjB), bad(nf1B, rjB))), pk_minu(bad(ne2B, rjB), bad(nf2B, rjB))) | outB;
+				gbits = (uint32_t)((bA & 0xffff) == 0) | (uint32_t)((bB & 0xffff) == 0) << 1 | (uint32_t)(((uint32_t)bA >> 16) == 0) << 2 | (uint32_t)(((uint32_t)bB >> 16) == 0) << 3;
 			}
+			// ---- the new E/F are final: age the registers, publish this chunk's outer columns for the neighbouring slots
+			age<E1>(e1h, k, 0, ne1A), age<E1>(e1h, k, 1, ne1B), age<E1>(f1h, k, 0, nf1A), age<E1>(f1h, k, 1, nf1B);
+			age<E2>(e2h, k, 0, ne2A), age<E2>(e2h, k, 1, ne2B), age<E2>(f2h, k, 0, nf2A), age<E2>(f2h, k, 1, nf2B);
+			if (lane == 63) edge[dnew][r][0] = ne1B, edge[dnew][r][1] = ne2B;
+			if (lane == 0) edge[dnew][r][2] = nf1A, edge[dnew][r][3] = nf2A;
 
-			int32_t hv[4], nmat[4], ne1[4], nf1[4], ne2[4], nf2[4];
-			int32_t pe1[2], pf1[2], pe2[2], pf2[2]; // the new E/F, packed as soon as a pair of columns is done
-			uint32_t tbw = 0, pend = 0, live = 0, fin = 0, gbits = 0;
-			{
-				// ---- recurrence, then the first probe of the match extension (8 bytes), two columns at a time: half the probe words
-				// in flight, the new pair packed at once.  A chunk deep inside the window needs nothing else; an edge chunk masks
-				// the columns outside the window (their offsets probe as dead: room 0), notes edge liveness and the good bits.
-				// (2-bit copy: aq is the query INDEX d + j, the copy's offset is added where it is read; FULL bases per first probe)
-				constexpr int FULL = S2 ? 16 : 8;
-				const int32_t t0 = ql + tl + 1 - c0, dq0 = c0 - 1 - tl + (S2 ? 0 : qoff);
-				int32_t m9[4];
+			// ---- match extension, first probe (FULL bases): j clamped to rj makes room = rj - j zero for dead and phantom offsets
+			const int32_t jA = pk_minu(pk_add(hA, ONE), rjA), jB = pk_minu(pk_add(hB, ONE), rjB);
+			const int32_t iqA = pk_add(jA, dA), iqB = pk_add(jB, dB);
+			int32_t cnt[4]; // columns c0 (A.lo), c1 (B.lo), c2 (A.hi), c3 (B.hi)
+			if (S2) {
+				Probe16 ps[4];
 #pragma unroll
-				for (int h2 = 0; h2 < 2; ++h2) {
-					int32_t jc[2], aq[2], rj[2];
-					Probe8 pr[2];
-					Probe16 ps[2];
-#pragma unroll
-					for (int u = 0; u < 2; ++u) {
-						const int i = 2 * h2 + u;
-						const Cell v = cell16<TB>(hx[i], o1[i], g1m[i], o2[i], g2m[i], o1[i + 2], g1p[i], o2[i + 2], g2p[i]);
-						ne1[i] = v.e1, nf1[i] = v.f1, ne2[i] = v.e2, nf2[i] = v.f2;
-						hv[i] = v.h;
-						tbw |= v.tb << (8 * i);
-						int32_t hq = v.h;
-						if (!deep) { // uniform
-							const int32_t c = c0 + i;
-							const uint32_t a = inner ? 1u : (uint32_t)((c >= lo) & (c <= hi));
-							ne1[i] = a ? v.e1 : kDead16, nf1[i] = a ? v.f1 : kDead16;
-							ne2[i] = a ? v.e2 : kDead16, nf2[i] = a ? v.f2 : kDead16;
-							hq = a ? v.h : kDead16;
-							if (track_good) { // uniform
-								const int32_t d = c - 1 - tl;
-								gbits |= (a & (inm_bit(d, v.h, tl, ql) | inm_bit(d, v.e1, tl, ql) | inm_bit(d, v.f1, tl, ql) | inm_bit(d, v.e2, tl, ql) | inm_bit(d, v.f2, tl, ql))) << i;
-							}
-							// edge rule (miniwfa.c:325-326): H is the max of the five, so "any live" == "H live"
-							const uint32_t lv = (uint32_t)(v.h >= -1);
-							live |= (lv & (uint32_t)(c == lo)) | ((lv & (uint32_t)(c == hi)) << 1);
-						}
-						rj[u] = min(tl, t0 - i);                                           // min(tl, ql - d): the largest j = k+1 inside the matrix
-						jc[u] = (int32_t)min((uint32_t)(hq + 1), (uint32_t)rj[u]);         // dead and phantom offsets clamp to it: room 0
-						aq[u] = jc[u] + dq0 + i;                                           // byte offset of q[d + j] in the LDS copy
-						if (S2) probe16_issue(ps[u], qoff, jc[u], aq[u]);
-						else probe8_issue(pr[u], jc[u], aq[u]);
-					}
-					pe1[h2] = pack2(ne1[2 * h2], ne1[2 * h2 + 1]), pf1[h2] = pack2(nf1[2 * h2], nf1[2 * h2 + 1]);
-					pe2[h2] = pack2(ne2[2 * h2], ne2[2 * h2 + 1]), pf2[h2] = pack2(nf2[2 * h2], nf2[2 * h2 + 1]);
-#pragma unroll
-					for (int u = 0; u < 2; ++u) {
-						const int i = 2 * h2 + u;
-						// leading equal bytes, capped at 9 and at the room: 9 <=> all eight equal and more than eight to go
-						m9[i] = min(S2 ? probe16_count(ps[u], jc[u], aq[u]) : probe8_count(pr[u], jc[u], aq[u]), rj[u] - jc[u]);
-						nmat[i] = min(m9[i], FULL);
-					}
+				for (int u = 0; u < 4; ++u) {
+					const uint32_t J = (uint32_t)((u & 1) ? jB : jA), Q = (uint32_t)((u & 1) ? iqB : iqA);
+					const uint32_t ta = (u & 2) ? (J >> 18) & 0x3ffcu : (J >> 2) & 0x3ffcu;
+					const uint32_t qa = ((u & 2) ? (Q >> 20) : ((Q >> 4) & 0xfffu)) * 4u + (uint32_t)qoff;
+					const uint32_t *pt = (const uint32_t*)(lds2 + ta), *pq = (const uint32_t*)(lds2 + qa);
+					ps[u].t0 = pt[0], ps[u].t1 = pt[1], ps[u].q0 = pq[0], ps[u].q1 = pq[1];
 				}
-				if (__ballot(max(max(m9[0], m9[1]), max(m9[2], m9[3])) == FULL + 1))
-					pend = (uint32_t)(m9[0] == FULL + 1) | (uint32_t)(m9[1] == FULL + 1) << 1 | (uint32_t)(m9[2] == FULL + 1) << 2 | (uint32_t)(m9[3] == FULL + 1) << 3;
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					const uint32_t J = (uint32_t)((u & 1) ? jB : jA), Q = (uint32_t)((u & 1) ? iqB : iqA);
+					const uint32_t tsh = (u & 2) ? J >> 15 : J << 1, qsh = (u & 2) ? Q >> 15 : Q << 1; // v_alignbit uses bits 4:0
+					cnt[u] = lead_eq2(__builtin_amdgcn_alignbit(ps[u].t1, ps[u].t0, tsh) ^ __builtin_amdgcn_alignbit(ps[u].q1, ps[u].q0, qsh));
+				}
+			} else {
+				Probe8 pr[4];
+				int32_t jj[4], aq[4];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					jj[u] = (int32_t)((uint32_t)((u & 1) ? jB : jA) >> ((u & 2) ? 16 : 0) & 0xffffu);
+					aq[u] = (int32_t)((uint32_t)((u & 1) ? iqB : iqA) >> ((u & 2) ? 16 : 0) & 0xffffu) + qoff;
+					probe8_issue(pr[u], jj[u], aq[u]);
+				}
+#pragma unroll
+				for (int u = 0; u < 4; ++u) cnt[u] = probe8_count(pr[u], jj[u], aq[u]);
 			}
-			// ---- the new E/F are final: age the registers, publish this chunk's outer pairs for the neighbouring waves
-#pragma unroll
-			for (int i = 0; i < 2; ++i) {
-#pragma unroll
-				for (int a = E1 - 1; a > 0; --a) e1h[a][k][i] = e1h[a - 1][k][i], f1h[a][k][i] = f1h[a - 1][k][i];
-#pragma unroll
-				for (int a = E2 - 1; a > 0; --a) e2h[a][k][i] = e2h[a - 1][k][i], f2h[a][k][i] = f2h[a - 1][k][i];
-				e1h[0][k][i] = pe1[i], f1h[0][k][i] = pf1[i], e2h[0][k][i] = pe2[i], f2h[0][k][i] = pf2[i];
-			}
-			if (lane == 63) edge[dnew][r][0] = e1h[0][k][1], edge[dnew][r][1] = e2h[0][k][1];
-			if (lane == 0) edge[dnew][r][2] = f1h[0][k][0], edge[dnew][r][3] = f2h[0][k][0];
-
-			// ---- a run of >= 4 matches continues (one cell in 256 by chance, plus the cells near the alignment path).  Each lane
-			// first walks its own runs 8 bytes per trip, four trips at most; what is still open then the whole wave walks, 256 per trip.
-			if (__ballot(pend != 0)) {
+			typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+			const int32_t cA = MWF_BC(int32_t, (us2_t)__builtin_amdgcn_cvt_pk_u16((uint32_t)cnt[0], (uint32_t)cnt[2])); // saturating
+			const int32_t cB = MWF_BC(int32_t, (us2_t)__builtin_amdgcn_cvt_pk_u16((uint32_t)cnt[1], (uint32_t)cnt[3]));
+			const int32_t FULLp = both16(FULL);
+			const int32_t m9A = pk_minu(cA, pk_sub(rjA, jA)), m9B = pk_minu(cB, pk_sub(rjB, jB)); // > FULL: the whole probe matched, room left
+			int32_t nmA = pk_minu(m9A, FULLp), nmB = pk_minu(m9B, FULLp);
+			const int32_t pendp = pk_subsat(m9A, FULLp) | pk_subsat(m9B, FULLp);
+			// ---- a run of >= FULL matches continues (the cells near the alignment path, and one first probe in 4^FULL by chance).  Each
+			// lane first walks its own runs, four trips at most; what is still open then the whole wave walks.
+			if (__ballot(pendp != 0)) {
+				int32_t hv[4] = {half_of(hA, 0), half_of(hB, 0), half_of(hA, 1), half_of(hB, 1)};
+				int32_t nmat[4] = {(int32_t)((uint32_t)nmA & 0xffffu), (int32_t)((uint32_t)nmB & 0xffffu), (int32_t)((uint32_t)nmA >> 16), (int32_t)((uint32_t)nmB >> 16)};
+				const uint32_t pend = (uint32_t)(((uint32_t)m9A & 0xffffu) > (uint32_t)FULL) | (uint32_t)(((uint32_t)m9B & 0xffffu) > (uint32_t)FULL) << 1 |
+				                      (uint32_t)(((uint32_t)m9A >> 16) > (uint32_t)FULL) << 2 | (uint32_t)(((uint32_t)m9B >> 16) > (uint32_t)FULL) << 3;
 				uint32_t open = 0;
 #pragma unroll
 				for (int i = 0; i < 4; ++i) {
 					if (__ballot((pend >> i) & 1u) == 0) continue; // uniform
 					if ((pend >> i) & 1u) {
-						int32_t n = S2 ? 16 : 8; // pend is only set for a full first probe of an in-matrix cell with room left
+						int32_t n = FULL; // pend is only set for a full first probe of an in-matrix cell with room left
 						const int32_t j = hv[i] + 1, q = c0 + i - 1 - tl + j, rm = min(tl - j, ql - q), aqq = qoff + q;
 						for (int trip = 0; n < rm; ++trip) {
 							if (trip == 4) { open |= 1u << i; break; }
@@ -533,32 +583,30 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 				for (unsigned long long owners = __ballot(open != 0); owners; owners &= owners - 1) {
 					const int32_t src = (int32_t)__builtin_ctzll(owners);
 					const int32_t c0s = cb + 4 * src;
-					const uint32_t bits = (uint32_t)__builtin_amdgcn_readlane((int32_t)open, src);
+					const uint32_t ob = (uint32_t)__builtin_amdgcn_readlane((int32_t)open, src);
 #pragma unroll
 					for (int i = 0; i < 4; ++i) {
-						if (!((bits >> i) & 1u)) continue; // uniform
+						if (!((ob >> i) & 1u)) continue; // uniform
 						const int32_t hh = __builtin_amdgcn_readlane(hv[i], src);
 						const int32_t j = hh + 1, q = c0s + i - 1 - tl + j, rm = min(tl - j, ql - q);
 						const int32_t n = S2 ? run_wave16(qoff, j, q, rm, 80) : run_wave2(j, qoff + q, rm, 40);
 						nmat[i] = lane == src ? n : nmat[i];
 					}
 				}
+				nmA = pair_of(nmat[0], nmat[2]), nmB = pair_of(nmat[1], nmat[3]);
 			}
+			const int32_t hxA = pk_add(hA, nmA), hxB = pk_add(hB, nmB); // extended
 			// ---- termination test of the extension sweep (miniwfa.c:405-409): only column ql+1 can hold the end cell
-			int32_t done_info = 0;
 			unsigned long long fm = 0;
-#pragma unroll
-			for (int i = 0; i < 4; ++i) hv[i] += nmat[i];
+			int32_t done_info = 0;
 			if ((uint32_t)(cfin - cb) < (uint32_t)kChunk && cfin >= lo && cfin <= hi) { // uniform
-#pragma unroll
-				for (int i = 0; i < 4; ++i) {
-					const uint32_t f = (uint32_t)(c0 + i == cfin) & (uint32_t)(hv[i] == tl - 1) & inm_bit(ql - tl, hv[i] - nmat[i], tl, ql);
-					fin |= f;
-					done_info = f ? (nmat[i] == 0 ? (int32_t)((tbw >> (8 * i)) & 7u) : 0) : done_info;
-				}
-				fm = __ballot(fin != 0);
+				const int32_t rel = cfin - cb, hi_half = (rel >> 1) & 1;
+				const int32_t hv = half_of((rel & 1) ? hxB : hxA, hi_half), nm = (int32_t)((uint32_t)((rel & 1) ? nmB : nmA) >> (hi_half ? 16 : 0) & 0xffffu);
+				const uint32_t f = (uint32_t)(lane == (rel >> 2)) & (uint32_t)(hv == tl - 1) & inm_bit(ql - tl, hv - nm, tl, ql);
+				done_info = (f && nm == 0) ? (int32_t)((tbw >> (8 * (rel & 3))) & 7u) : 0;
+				fm = __ballot(f != 0);
 			}
-			*(int2*)at(newH, c0) = make_int2(pack2(hv[0], hv[1]), pack2(hv[2], hv[3]));
+			*(int2*)(rown + off) = make_int2(hxA, hxB);
 			++n_stores;
 			if (TB && c0 >= origin && c0 <= hi) *(uint32_t*)(M.tb + tb_used - origin + c0) = tbw;
 			if (track_good) {
@@ -569,12 +617,13 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 					if (lane == 0) gword[i] = m;
 				}
 			}
-			if (!deep || fm) { // uniform; a deep chunk can only have the end cell to report
-				uint32_t bits = (__ballot(live & 1u) ? 1u : 0u) | (__ballot(live & 2u) ? 2u : 0u);
-				if (fm) bits |= 4u | (uint32_t)__builtin_amdgcn_readlane(done_info, (int32_t)__builtin_ctzll(fm)) << 4;
-				if (bits && lane == 0) atomicOr((unsigned int*)&sh.flags[npar][0], bits);
-			}
+			if (fm) bits |= 4u | (uint32_t)__builtin_amdgcn_readlane(done_info, (int32_t)__builtin_ctzll(fm)) << 4;
+			if (bits && lane == 0) atomicOr((unsigned int*)&sh.flags[npar][0], bits);
 		}
+		// ---- every row must read as dead next to the chunks it was computed for (a later window reaches at most nH + 1 columns
+		// beyond this one: the reference's pads, miniwfa.c:96-99); the waves next to the window's ends hold the fewest chunks
+		if (ga >= 1 && wave == (ga - 1) % NW) *(int2*)(rown + ((uint32_t)((ga - 1) << 9) + lane8)) = make_int2(kDeadPair, kDeadPair), ++n_stores;
+		if (wave == (gb + 1) % NW) *(int2*)(rown + ((uint32_t)((gb + 1) << 9) + lane8)) = make_int2(kDeadPair, kDeadPair), ++n_stores;
 
 		// Everything older than this penalty's last operations must be complete before another wave may load it (vmcnt retires
 		// in issue order).  With every lag >= 3 the rows written now are first loaded two penalties from now: the youngest store
