@@ -22,6 +22,7 @@
 //     without: the co-resident workgroup already hides the load latency; registers are what is scarce — the 512-thread
 //     variant lives in 128 VGPRs so that two workgroups share a CU.)
 // Results are bit-identical to the other kernels (tests/test_gpu_parity.py).
+#include <cstddef>
 #include <type_traits>
 #include "mwf_device.h"
 
@@ -221,7 +222,10 @@ __device__ __forceinline__ int32_t run_wave2(int32_t j, int32_t aq, int32_t room
 template <int D, int NWK>
 struct alignas(16) Band2Lds {
 	Shared sh;
-	int32_t edge[D][NWK][4]; // per age and chunk slot: {E1, E2 of columns (c1,c3) of lane 63}, {F1, F2 of columns (c0,c2) of lane 0}
+	// per age and chunk slot r (entry r + 1): {E1, E2 of columns (c1,c3) of lane 63 | F1, F2 of columns (c0,c2) of lane 0}; entry 0 mirrors
+	// slot NWK-1 and entry NWK+1 slot 0, so that a slot finds its neighbours at fixed distances from its own entry
+	int32_t edge[D][NWK + 2][4];
+	int32_t dump[64 * 2 + (2 * NWK + 4) * 4]; // where the lanes that do not hold an outer column put theirs (no exec-mask games around the stores)
 };
 
 // ---- packed 16-bit arithmetic: two columns per register, every operation one VOP3P instruction
@@ -265,21 +269,13 @@ __device__ __forceinline__ int32_t pair_of(int32_t lo, int32_t hi) { return (int
 __device__ __forceinline__ int32_t left_of_A(int32_t B, int32_t fill) { return __builtin_amdgcn_alignbit(B, from_left(B, fill), 16); }
 __device__ __forceinline__ int32_t right_of_B(int32_t A, int32_t fill) { return __builtin_amdgcn_alignbit(from_right(A, fill), A, 16); }
 
-// A new value enters a register history of depth N (1 or 2; [0] is the newest): the oldest register — read for the last time at
-// this penalty — takes it and, for N = 2, the two trade places (v_swap_b32: no copies, the same registers on every path).
-template <int N, int K>
-__device__ __forceinline__ void age(int32_t (*h)[K][2], int k, int i, int32_t v)
-{
-	static_assert(N == 1 || N == 2, "history depth");
-	h[N - 1][k][i] = v;
-	if (N == 2) asm volatile("v_swap_b32 %0, %1" : "+v"(h[0][k][i]), "+v"(h[1][k][i]));
-}
-
-template <int T, int K, int E1, int E2, bool TB, bool S2>
-__device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &sh, int32_t (*edge)[(T / 64) * K][4], const int32_t qoff, bool trace_band)
+template <int T, int K, int E1, int E2, bool TB, bool S2, typename ArgsT>
+__device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, const int32_t edge_base, const int32_t qoff, bool trace_band)
 {
 	constexpr int NW = T / 64, NWK = NW * K, D = (E1 > E2 ? E1 : E2) + 1;
 	constexpr int FULL = S2 ? 16 : 8; // bases the first probe of the match extension looks at
+	constexpr int kAge = (NWK + 2) * 16; // bytes of one age of the edge table
+	static_assert(D == 2 || D == 3, "edge-table ages");
 	const int32_t tl = M.tl, ql = M.ql, cmax = tl + ql + 1;
 	const int32_t tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
 	const int32_t W = A.W, nH = A.pen.nH, lagx = A.pen.x, lag1 = A.pen.oe1, lag2 = A.pen.oe2;
@@ -292,7 +288,8 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 	PassResult R;
 	R.status = ST_OK, R.s = 0, R.info = 0, R.n_snap = 0, R.cells = 0;
 
-	// per-thread wavefront state, two columns per register: [age][slot][A / B]; age 0 is the previous penalty
+	// per-thread wavefront state, two columns per register: [age - 1][slot][A / B]
+	static_assert((E1 == 1 || E1 == 2) && (E2 == 1 || E2 == 2), "history depth");
 	int32_t e1h[E1][K][2], f1h[E1][K][2], e2h[E2][K][2], f2h[E2][K][2];
 #pragma unroll
 	for (int k = 0; k < K; ++k)
@@ -304,10 +301,17 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 			for (int a = 0; a < E2; ++a) e2h[a][k][i] = f2h[a][k][i] = kDeadPair;
 		}
 	// lane constants: local columns of A and B, byte offset of the lane's quad, of the neighbouring word it fetches
-	const int32_t RA = pair_of(4 * lane, 4 * lane + 2), RB = pk_add(RA, 0x00010001), RB1 = pk_add(RA, 0x00020002);
+	const int32_t RA = pair_of(4 * lane, 4 * lane + 2); // (RB = RA + 1, RB1 = RA + 2 per half are recomputed where needed: registers are scarcer than adds)
 	const uint32_t lane8 = ((uint32_t)lane << 3) + 8u;
 	const int32_t nd = lane == 0 ? -4 : 8; // lane 0: B of the quad to the left; lane 63: A of the quad to the right
 	const int32_t T0 = both16(cmax), TLp = both16(tl), TL1 = both16(tl + 1);
+	// edge-table addresses: a slot's entry sits (k NW + 1) entries behind the wave's base.  Every lane stores its outer columns —
+	// lane 63 (E) and lane 0 (F) into the table, the others into a dump — so that no store needs an exec mask.
+	const int32_t ebase = edge_base + wave * 16, dump_base = edge_base + D * kAge + NW * 16; // (the mirror store reaches NW-1 entries back)
+	const int32_t dump_lane = dump_base + lane * 8;
+	int32_t epos[D]; // byte offset of the table of age a + 1 (penalty s_new - a - 1); the oldest is overwritten and becomes age 1
+#pragma unroll
+	for (int a = 0; a < D; ++a) epos[a] = a * kAge;
 
 	// ---- every row read before it is written must read as dead around the origin: the chunks a window can reach within nH penalties
 	{
@@ -318,7 +322,7 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 		}
 	}
 	// ---- penalty 0 (reference wf_stripe_init, miniwfa.c:103-121) and its extension
-	for (int32_t j = tid; j < D * NWK * 4; j += T) (&edge[0][0][0])[j] = kDeadPair;
+	for (int32_t j = tid; j < D * (NWK + 2) * 4; j += T) *(int32_t*)(lds2 + edge_base + 4 * j) = kDeadPair;
 	if (tid == 0) {
 		for (int32_t j = 0; j < nH; ++j) sh.rng_lo[j] = 1, sh.rng_hi[j] = 0;
 		for (int32_t j = 0; j < 12; ++j) (&sh.flags[0][0])[j] = 0;
@@ -340,8 +344,13 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 	}
 
 	int32_t s = 0, wf_lo = tl + 1, wf_hi = tl + 1;
-	int32_t curH = 0, par = 0, dcur = 0;
+	int32_t curH = 0, par = 0;
+	const uint32_t ring_bytes = (uint32_t)nH * RS;
+	uint32_t bn = 0, bx = (uint32_t)(nH - lagx) * RS, b1 = (uint32_t)(nH - lag1) * RS, b2 = (uint32_t)(nH - lag2) * RS; // rows of penalty 0 and its lags
 	int64_t cells = 0, tb_used = 0;
+	const int64_t iter_limit = A.max_iter > 0 ? A.max_iter : INT64_MAX;
+	const int32_t s_limit = A.max_s > 0 ? A.max_s : INT32_MAX;
+	const int64_t rows_slot = TB ? A.rows_slot : 0, tb_slot_bytes = TB ? A.tb_slot_bytes : 0;
 
 	// chunk of every slot of this wave under the mapping that starts at chunk gl (changes only when gl does)
 	int32_t gl = (wf_lo > 1 ? wf_lo - 1 : 1) >> 8, gk[K];
@@ -359,53 +368,71 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 #pragma unroll
 	for (int k = 0; k < K; ++k) idle[k] = D;
 
-	for (;;) {
+	// One penalty; returns true when the pass ends.  A depth-2 history is two registers, [0] the newer: the penalty reads [1] for the last
+	// time, overwrites it, and the two trade places (v_swap_b32) — no copies, and a slot that is skipped leaves its registers alone.
+	auto step = [&]() __attribute__((always_inline)) -> bool {
+		constexpr int P1 = E1 - 1, P2 = E2 - 1;
 #ifdef MWF_B2_TIMING
 		const uint64_t tm0 = __builtin_readcyclecounter();
 #endif
 		const int32_t lo = wf_lo > 1 ? wf_lo - 1 : 1;       // miniwfa.c:417-418
 		const int32_t hi = wf_hi < cmax ? wf_hi + 1 : cmax;
+		const int32_t lo_p = lo, hi_p = hi;
 		const int32_t s_new = s + 1;
 		const int32_t newH = curH + 1 == nH ? 0 : curH + 1;
 		const int32_t npar = par + 1 == 3 ? 0 : par + 1;
-		const int32_t dnew = dcur + 1 == D ? 0 : dcur + 1;
 		const int32_t origin = lo & ~3;
 		const int32_t row_bytes = (hi | 3) - origin + 1;
 		if (TB) {
-			if (s_new - 1 >= A.rows_slot) { R.status = ST_ROWS_OVERFLOW; break; }
-			if (tb_used + row_bytes > A.tb_slot_bytes) { R.status = ST_TB_OVERFLOW; break; }
+			if (s_new - 1 >= rows_slot) { R.status = ST_ROWS_OVERFLOW; return true; }
+			if (tb_used + row_bytes > tb_slot_bytes) { R.status = ST_TB_OVERFLOW; return true; }
 		}
 		// the window of penalty s_new+1 lies inside [lo-1, hi+1] whatever the flags say; it must fit the register span
 		const int32_t gl_next = (lo > 1 ? lo - 1 : 1) >> 8;
-		if (((hi < cmax ? hi + 1 : cmax) >> 8) - gl_next + 1 > NWK - 1) { R.status = ST_BAND_OVERFLOW; break; }
-		int32_t jx = newH - lagx; if (jx < 0) jx += nH;
-		int32_t j1 = newH - lag1; if (j1 < 0) j1 += nH;
-		int32_t j2 = newH - lag2; if (j2 < 0) j2 += nH;
-		const char *const rowx = Hb + (size_t)((uint32_t)jx * RS), *const row1 = Hb + (size_t)((uint32_t)j1 * RS), *const row2 = Hb + (size_t)((uint32_t)j2 * RS);
-		char *const rown = Hb + (size_t)((uint32_t)newH * RS);
+		if ((hi >> 8) - (lo >> 8) + 3 > NWK - 1) // (only then can the exact test fail)
+			if (((hi < cmax ? hi + 1 : cmax) >> 8) - gl_next + 1 > NWK - 1) { R.status = ST_BAND_OVERFLOW; return true; }
+		// ring rows as byte offsets that advance by one row per penalty
+		bn = bn + RS == ring_bytes ? 0u : bn + RS, bx = bx + RS == ring_bytes ? 0u : bx + RS;
+		b1 = b1 + RS == ring_bytes ? 0u : b1 + RS, b2 = b2 + RS == ring_bytes ? 0u : b2 + RS;
+		const char *const rowx = Hb + bx, *const row1 = Hb + b1, *const row2 = Hb + b2;
+		char *const rown = Hb + bn;
 		const bool track_good = (((256 - (s_new & 255)) & 255) < nH); // a shrink can still see this slice
-		// ages of the edge table to read: penalties s_new-E1 and s_new-E2
-		int32_t d1 = dnew - E1; if (d1 < 0) d1 += D;
-		int32_t d2 = dnew - E2; if (d2 < 0) d2 += D;
+		// edge table: the ages to read (penalties s_new-E1 and s_new-E2) and the one to overwrite, as LDS addresses
+		const int32_t rE1 = ebase + epos[E1 - 1], rE2 = ebase + epos[E2 - 1];
+		const int32_t wE = lane == 63 ? ebase + epos[D - 1] : dump_lane, wF = lane == 0 ? ebase + epos[D - 1] : dump_lane;
+		auto put_edge = [&](int k, int32_t e1b, int32_t e2b, int32_t f1a, int32_t f2a) {
+			*(int2*)(lds2 + wE + (k * NW + 1) * 16) = make_int2(e1b, e2b);
+			*(int2*)(lds2 + wF + (k * NW + 1) * 16 + 8) = make_int2(f1a, f2a);
+			if (k == K - 1 && wave == NW - 1) *(int2*)(lds2 + wE - (NW - 1) * 16) = make_int2(e1b, e2b);  // slot NWK-1 is slot 0's left neighbour
+			if (k == 0 && wave == 0) *(int2*)(lds2 + wF + (NWK + 1) * 16 + 8) = make_int2(f1a, f2a);       // slot 0 is slot NWK-1's right neighbour
+		};
 		const int32_t ga = lo >> 8, gb = hi >> 8, gspan = gb - ga; // chunks [ga, gb] meet the window
 		const int32_t cfin = ql + 1; // the end cell (tl-1, ql-1) lies on diagonal ql-tl, i.e. in this column
 
-		if (tid == 0) {
+		if (wave == 0) { // (the whole wave stores the same words: no exec mask to set up)
 			sh.rng_lo[newH] = lo, sh.rng_hi[newH] = hi;
 			sh.flags[npar + 1 == 3 ? 0 : npar + 1][0] = 0; // the flag word of the NEXT penalty (its last readers passed the previous barrier)
 			if (TB) M.row_off[s_new - 1] = tb_used, M.row_lo[s_new - 1] = origin;
 #ifndef MWF_B2_TIMING // (the timing build keeps per-phase cycle counts in the trace buffer instead)
-			if (trace_band && s_new - 1 < A.dbg_cap) M.dbg[2 * (s_new - 1)] = lo, M.dbg[2 * (s_new - 1) + 1] = hi;
+			if (trace_band && s_new - 1 < fresh(A).dbg_cap) M.dbg[2 * (s_new - 1)] = lo, M.dbg[2 * (s_new - 1) + 1] = hi;
 #endif
 		}
 
 		bool act[K];
+#pragma unroll
+		for (int k = 0; k < K; ++k) act[k] = (uint32_t)(gk[k] - ga) <= (uint32_t)gspan;
+		// the waves with the most chunks to do set the pace of the penalty: let them issue first.  Chunks are dealt round-robin from
+		// chunk ga on: the wave at distance p from it holds ceil((n - p) / NW) of the n active chunks.
+		bool busy;
+		if ((NW & (NW - 1)) == 0) busy = ((wave - ga) & (NW - 1)) < gspan + 1 - NW;
+		else busy = (int)act[0] + (int)act[1] + (K > 2 ? (int)act[K - 1] : 0) >= 2;
+		if (busy) __builtin_amdgcn_s_setprio(3);
+		else __builtin_amdgcn_s_setprio(0);
+#ifdef MWF_B2_TIMING
 		int n_act = 0;
 #pragma unroll
-		for (int k = 0; k < K; ++k) act[k] = (uint32_t)(gk[k] - ga) <= (uint32_t)gspan, n_act += act[k] ? 1 : 0;
-		// the waves with the most chunks to do set the pace of the penalty: let them issue first
-		if (n_act >= 2) __builtin_amdgcn_s_setprio(3);
-		else __builtin_amdgcn_s_setprio(0);
+		for (int k = 0; k < K; ++k) n_act += act[k] ? 1 : 0;
+#endif
 
 #ifdef MWF_B2_TIMING
 		const uint64_t tm1 = __builtin_readcyclecounter();
@@ -413,33 +440,31 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 		int n_stores = 0;
 #pragma unroll
 		for (int k = 0; k < K; ++k) {
+			// a chunk that left the window: its columns are not computed any more, i.e. their E/F are dead.  It runs through the ordinary
+			// code D more times (every column outside the window: masked dead — rare, a window edge crosses a chunk boundary inwards only
+			// at a shrink), which ages the slot's registers and edge-table entries; after that there is nothing left to do.
 			if (!act[k]) {
-				// a chunk outside the window: its columns were not computed at this penalty, i.e. their E/F are dead — once every
-				// age of the slot's registers and of its edge-table entries is dead (D penalties outside), there is nothing to do
 				if (idle[k] >= D) continue; // uniform
 				++idle[k];
-#pragma unroll
-				for (int i = 0; i < 2; ++i) age<E1>(e1h, k, i, kDeadPair), age<E1>(f1h, k, i, kDeadPair), age<E2>(e2h, k, i, kDeadPair), age<E2>(f2h, k, i, kDeadPair);
-				const int32_t r = wave + NW * k;
-				if (lane == 63) edge[dnew][r][0] = kDeadPair, edge[dnew][r][1] = kDeadPair;
-				if (lane == 0) edge[dnew][r][2] = kDeadPair, edge[dnew][r][3] = kDeadPair;
-				continue;
-			}
-			const int32_t r = wave + NW * k, g = gk[k], cb = g * kChunk, c0 = cb + 4 * lane;
-			idle[k] = 0;
+			} else idle[k] = 0;
+			// (the window bounds are laundered per slot: what the chunk code derives from them stays inside this branch instead of being
+			// computed up front by waves that hold no active chunk)
+			int32_t lo = uni(lo_p), hi = uni(hi_p);
+			asm volatile("" : "+s"(lo), "+s"(hi));
+			const int32_t g = gk[k], cb = g * kChunk, c0 = cb + 4 * lane;
 			// ---- rows: H at the three lags (one 8-byte load each) and the word next to the chunk for the two gap-open rows
 			const uint32_t off = (uint32_t)(cb << 1) + lane8, noff = off + (uint32_t)nd;
 			const int2 HX = *(const int2*)(rowx + off), O1 = *(const int2*)(row1 + off), O2 = *(const int2*)(row2 + off);
 			const int32_t N1 = *(const int32_t*)(row1 + noff), N2 = *(const int32_t*)(row2 + noff);
 			// gap-extension sources: E of column c-1, F of column c+1, e1 (e2) penalties ago; lane 0 / lane 63 take the neighbouring
 			// slot's outer columns from the edge table
-			const int32_t rl = r == 0 ? NWK - 1 : r - 1, rr = r + 1 == NWK ? 0 : r + 1;
-			const int32_t xE1 = edge[d1][rl][0], xE2 = edge[d2][rl][1], xF1 = edge[d1][rr][2], xF2 = edge[d2][rr][3];
+			const int32_t xE1 = *(const int32_t*)(lds2 + rE1 + k * NW * 16), xE2 = *(const int32_t*)(lds2 + rE2 + k * NW * 16 + 4);
+			const int32_t xF1 = *(const int32_t*)(lds2 + rE1 + (k * NW + 2) * 16 + 8), xF2 = *(const int32_t*)(lds2 + rE2 + (k * NW + 2) * 16 + 12);
 			const bool inside = cb >= lo && cb + kChunk - 1 <= hi; // uniform: every column of the chunk belongs to the window
 
 			// ---- recurrence (dev::wf_cell, miniwfa.c:267-278) on pairs of columns
-			const int32_t E1a = e1h[E1 - 1][k][0], E1b = e1h[E1 - 1][k][1], F1a = f1h[E1 - 1][k][0], F1b = f1h[E1 - 1][k][1];
-			const int32_t E2a = e2h[E2 - 1][k][0], E2b = e2h[E2 - 1][k][1], F2a = f2h[E2 - 1][k][0], F2b = f2h[E2 - 1][k][1];
+			const int32_t E1a = e1h[P1][k][0], E1b = e1h[P1][k][1], F1a = f1h[P1][k][0], F1b = f1h[P1][k][1];
+			const int32_t E2a = e2h[P2][k][0], E2b = e2h[P2][k][1], F2a = f2h[P2][k][0], F2b = f2h[P2][k][1];
 			const int32_t o1mA = left_of_A(O1.y, N1), o2mA = left_of_A(O2.y, N2), g1mA = left_of_A(E1b, xE1), g2mA = left_of_A(E2b, xE2);
 			const int32_t o1pB = right_of_B(O1.x, N1), o2pB = right_of_B(O2.x, N2), g1pB = right_of_B(F1a, xF1), g2pB = right_of_B(F2a, xF2);
 			const int32_t ONE = 0x00010001;
@@ -471,6 +496,7 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 			int32_t outA = 0, outB = 0; // 0xffff in the halves of columns outside [lo, hi]
 			if (!inside) { // uniform
 				const int32_t lo_r = both16(min(max(lo - cb, 0), 256)), hi_r1 = both16(min(max(hi - cb + 1, 0), 256));
+				const int32_t RB = pk_add(RA, 0x00010001), RB1 = pk_add(RA, 0x00020002);
 				outA = pk_nonzero_mask(pk_subsat(lo_r, RA) | pk_subsat(RB, hi_r1));
 				outB = pk_nonzero_mask(pk_subsat(lo_r, RB) | pk_subsat(RB1, hi_r1));
 				hA = bfi(outA, kDeadPair, hA), hB = bfi(outB, kDeadPair, hB);
@@ -507,10 +533,20 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 				gbits = (uint32_t)((bA & 0xffff) == 0) | (uint32_t)((bB & 0xffff) == 0) << 1 | (uint32_t)(((uint32_t)bA >> 16) == 0) << 2 | (uint32_t)(((uint32_t)bB >> 16) == 0) << 3;
 			}
 			// ---- the new E/F are final: age the registers, publish this chunk's outer columns for the neighbouring slots
-			age<E1>(e1h, k, 0, ne1A), age<E1>(e1h, k, 1, ne1B), age<E1>(f1h, k, 0, nf1A), age<E1>(f1h, k, 1, nf1B);
-			age<E2>(e2h, k, 0, ne2A), age<E2>(e2h, k, 1, ne2B), age<E2>(f2h, k, 0, nf2A), age<E2>(f2h, k, 1, nf2B);
-			if (lane == 63) edge[dnew][r][0] = ne1B, edge[dnew][r][1] = ne2B;
-			if (lane == 0) edge[dnew][r][2] = nf1A, edge[dnew][r][3] = nf2A;
+			e1h[P1][k][0] = ne1A, e1h[P1][k][1] = ne1B, f1h[P1][k][0] = nf1A, f1h[P1][k][1] = nf1B;
+			e2h[P2][k][0] = ne2A, e2h[P2][k][1] = ne2B, f2h[P2][k][0] = nf2A, f2h[P2][k][1] = nf2B;
+#pragma unroll
+			for (int i = 0; i < 2; ++i) {
+				if (E1 == 2) {
+					asm volatile("v_swap_b32 %0, %1" : "+v"(e1h[0][k][i]), "+v"(e1h[1][k][i]));
+					asm volatile("v_swap_b32 %0, %1" : "+v"(f1h[0][k][i]), "+v"(f1h[1][k][i]));
+				}
+				if (E2 == 2) {
+					asm volatile("v_swap_b32 %0, %1" : "+v"(e2h[0][k][i]), "+v"(e2h[1][k][i]));
+					asm volatile("v_swap_b32 %0, %1" : "+v"(f2h[0][k][i]), "+v"(f2h[1][k][i]));
+				}
+			}
+			put_edge(k, ne1B, ne2B, nf1A, nf2A);
 
 			// ---- match extension, first probe (FULL bases): j clamped to rj makes room = rj - j zero for dead and phantom offsets
 			const int32_t jA = pk_minu(pk_add(hA, ONE), rjA), jB = pk_minu(pk_add(hB, ONE), rjB);
@@ -526,6 +562,7 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 					const uint32_t *pt = (const uint32_t*)(lds2 + ta), *pq = (const uint32_t*)(lds2 + qa);
 					ps[u].t0 = pt[0], ps[u].t1 = pt[1], ps[u].q0 = pq[0], ps[u].q1 = pq[1];
 				}
+				__builtin_amdgcn_sched_barrier(0); // all eight LDS reads in flight before the first is looked at (one round trip, not four)
 #pragma unroll
 				for (int u = 0; u < 4; ++u) {
 					const uint32_t J = (uint32_t)((u & 1) ? jB : jA), Q = (uint32_t)((u & 1) ? iqB : iqA);
@@ -533,16 +570,22 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 					cnt[u] = lead_eq2(__builtin_amdgcn_alignbit(ps[u].t1, ps[u].t0, tsh) ^ __builtin_amdgcn_alignbit(ps[u].q1, ps[u].q0, qsh));
 				}
 			} else {
-				Probe8 pr[4];
-				int32_t jj[4], aq[4];
+				// six probe words per column: two columns in flight (one where three slots of state must fit 128 VGPRs)
+				constexpr int PF = (K >= 3 && T >= 512) ? 1 : 2;
 #pragma unroll
-				for (int u = 0; u < 4; ++u) {
-					jj[u] = (int32_t)((uint32_t)((u & 1) ? jB : jA) >> ((u & 2) ? 16 : 0) & 0xffffu);
-					aq[u] = (int32_t)((uint32_t)((u & 1) ? iqB : iqA) >> ((u & 2) ? 16 : 0) & 0xffffu) + qoff;
-					probe8_issue(pr[u], jj[u], aq[u]);
+				for (int h2 = 0; h2 < 4 / PF; ++h2) {
+					Probe8 pr[PF];
+					int32_t jj[PF], aq[PF];
+#pragma unroll
+					for (int v = 0; v < PF; ++v) {
+						const int u = PF * h2 + v;
+						jj[v] = (int32_t)((uint32_t)((u & 1) ? jB : jA) >> ((u & 2) ? 16 : 0) & 0xffffu);
+						aq[v] = (int32_t)((uint32_t)((u & 1) ? iqB : iqA) >> ((u & 2) ? 16 : 0) & 0xffffu) + qoff;
+						probe8_issue(pr[v], jj[v], aq[v]);
+					}
+#pragma unroll
+					for (int v = 0; v < PF; ++v) cnt[PF * h2 + v] = probe8_count(pr[v], jj[v], aq[v]);
 				}
-#pragma unroll
-				for (int u = 0; u < 4; ++u) cnt[u] = probe8_count(pr[u], jj[u], aq[u]);
 			}
 			typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
 			const int32_t cA = MWF_BC(int32_t, (us2_t)__builtin_amdgcn_cvt_pk_u16((uint32_t)cnt[0], (uint32_t)cnt[2])); // saturating
@@ -610,7 +653,7 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 			++n_stores;
 			if (TB && c0 >= origin && c0 <= hi) *(uint32_t*)(M.tb + tb_used - origin + c0) = tbw;
 			if (track_good) {
-				unsigned long long *gword = M.good + (int64_t)newH * A.GW + g * 4;
+				unsigned long long *gword = M.good + (int64_t)newH * fresh(A).GW + g * 4;
 #pragma unroll
 				for (int i = 0; i < 4; ++i) {
 					const unsigned long long m = __ballot((gbits >> i) & 1u);
@@ -642,7 +685,7 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 		// ---- bookkeeping, identical on every thread
 		const uint32_t fl = (uint32_t)uni(sh.flags[npar][0]);
 #ifdef MWF_B2_TIMING
-		if (trace_band && tid == (A.max_iter < 0 ? (int32_t)-A.max_iter : 0) && s_new - 1 < A.dbg_cap) { // cycles: header | chunks, drain | barrier+flags; chunks this wave ran in bits 28..
+		if (trace_band && tid == (fresh(A).max_iter < 0 ? (int32_t)-fresh(A).max_iter : 0) && s_new - 1 < fresh(A).dbg_cap) { // cycles: header | chunks, drain | barrier+flags; chunks this wave ran in bits 28..
 			const uint64_t tm4 = __builtin_readcyclecounter();
 			M.dbg[2 * (s_new - 1)] = (int32_t)(min((uint32_t)(tm1 - tm0), 65535u) | min((uint32_t)(tm2 - tm1), 65535u) << 16);
 			M.dbg[2 * (s_new - 1) + 1] = (int32_t)(min((uint32_t)(tm3 - tm2), 4095u) | min((uint32_t)(tm4 - tm3), 65535u) << 12 | (uint32_t)n_act << 28);
@@ -651,18 +694,24 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 		if (fl & 1u) wf_lo = lo;
 		if (fl & 2u) wf_hi = hi;
 		const int32_t done = (int32_t)((fl >> 2) & 1u), payload = (int32_t)((fl >> 4) & 7u);
-		s = s_new, curH = newH, par = npar, dcur = dnew;
+		s = s_new, curH = newH, par = npar;
+		{
+			const int32_t oldest = epos[D - 1];
+#pragma unroll
+			for (int a = D - 1; a > 0; --a) epos[a] = epos[a - 1];
+			epos[0] = oldest;
+		}
 		if (gl_next != gl) gl = gl_next, remap(gl);
 		if (TB) tb_used += row_bytes;
 		if ((s & 0xff) == 0) { // shrink (reference wf_stripe_shrink, miniwfa.c:144-171) on the interleaved good bits
 			if (tid == 0) sh.red[0] = 0x7fffffff, sh.red[1] = -1;
 			__syncthreads();
-			const int32_t gfirst = wf_lo >> 8, n_words = ((wf_hi >> 8) - gfirst + 1) * 4;
+			const int32_t gfirst = wf_lo >> 8, n_words = ((wf_hi >> 8) - gfirst + 1) * 4, GWc = fresh(A).GW;
 			for (int32_t q = tid; q < n_words; q += T) {
 				const int32_t gg = gfirst + (q >> 2), kq = q & 3, base = gg * kChunk;
 				unsigned long long m = 0;
 				for (int32_t j = 0; j < nH; ++j)
-					if (sh.rng_lo[j] <= sh.rng_hi[j] && sh.rng_lo[j] <= base + kChunk - 1 && sh.rng_hi[j] >= base) m |= M.good[(int64_t)j * A.GW + gg * 4 + kq];
+					if (sh.rng_lo[j] <= sh.rng_hi[j] && sh.rng_lo[j] <= base + kChunk - 1 && sh.rng_hi[j] >= base) m |= M.good[(int64_t)j * GWc + gg * 4 + kq];
 				m &= lane_mask(base, kq, wf_lo, wf_hi);
 				if (m) {
 					atomicMin(&sh.red[0], base + 4 * (int32_t)__builtin_ctzll(m) + kq);
@@ -671,19 +720,22 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 			}
 			__syncthreads();
 			const int32_t glo = uni(sh.red[0]), ghi = uni(sh.red[1]);
-			if (ghi < 0) { R.status = ST_INTERNAL; break; }
+			if (ghi < 0) { R.status = ST_INTERNAL; return true; }
 			wf_lo = glo, wf_hi = ghi;
 		}
 		cells += hi - lo + 1;
-		if ((A.max_iter > 0 && cells > A.max_iter) || (A.max_s > 0 && s > A.max_s)) { // miniwfa.c:422-425
+		if (cells > iter_limit || s > s_limit) { // miniwfa.c:422-425
 			R.status = ST_STOPPED;
-			break;
+			return true;
 		}
 		if (done) {
 			R.info = payload;
-			break;
+			return true;
 		}
-	}
+		return false;
+	};
+	for (;;)
+		if (step()) break;
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	R.s = s, R.cells = cells;
 	return R;
@@ -692,15 +744,20 @@ __device__ PassResult band2_pass(const BatchArgs &A, const PairMem &M, Shared &s
 // Workgroups share a CU: 2 x 512, 4 x 256, 8 x 128 or 16 x 64 threads = 4 waves per SIMD, i.e. at most 128 VGPRs; with traceback
 // the smaller ones get 168 (3 per SIMD).  768 threads: one workgroup per CU.
 template <int T, int K, int E1, int E2, bool TB, bool S2>
-__global__ __launch_bounds__(T, T <= 512 ? ((TB && T < 512) ? 3 : 4) : 1) void wfa_band2_kernel(const BatchArgs A)
+__global__ __launch_bounds__(T, T <= 512 ? ((TB && T < 512) ? 3 : 4) : 1) void wfa_band2_kernel(const BatchArgs)
 {
 	constexpr int NWK = (T / 64) * K, D = (E1 > E2 ? E1 : E2) + 1;
+	// the arguments are read from the kernarg segment where they are used (dev::kernel_args / dev::fresh), never held for the kernel's lifetime
+	KArgs &A0 = kernel_args();
 	// the sequence copy starts at LDS offset 0; the bookkeeping words and the edge table sit behind it
-	Band2Lds<D, NWK> *const L = (Band2Lds<D, NWK>*)(lds2 + A.band_lds_seq);
+	typedef Band2Lds<D, NWK> LdsT;
+	const int32_t lds_seq = A0.band_lds_seq;
+	LdsT *const L = (LdsT*)(lds2 + lds_seq);
 	Shared &sh = L->sh;
-	int32_t (*const edge)[NWK][4] = L->edge;
+	const int32_t edge_base = lds_seq + (int32_t)offsetof(LdsT, edge);
 	for (;;) {
-		if (threadIdx.x == 0) sh.item = (int32_t)atomicAdd(A.queue, 1);
+		KArgs &A = fresh(A0);
+		if (threadIdx.x == 0) sh.item = (int32_t)atomicAdd(A.queue, 1), sh.word[2] = 0;
 		__syncthreads();
 		const int32_t item = uni(sh.item);
 		__syncthreads();
@@ -715,15 +772,17 @@ __global__ __launch_bounds__(T, T <= 512 ? ((TB && T < 512) ? 3 : 4) : 1) void w
 			uint32_t bad = pack2bit<T>(M.ts, M.tl, 0);
 			bad |= pack2bit<T>(M.qs, M.ql, qoff);
 			// a base other than A/C/G/T: the host re-runs the pair on the byte-wise copy of this kernel
-			if (__syncthreads_or(bad != 0)) R.status = ST_ALPHABET;
+			if (bad) sh.word[2] = 1;
+			__syncthreads();
+			if (uni(sh.word[2])) R.status = ST_ALPHABET;
 		} else {
 			for (int32_t j = threadIdx.x; j < M.tl; j += T) lds2[j] = M.ts[j];
 			for (int32_t j = threadIdx.x; j < M.ql; j += T) lds2[qoff + j] = M.qs[j];
 			__syncthreads();
 		}
 		const bool trace = A.dbg && pair == A.debug_pair;
-		if (R.status == ST_OK) R = band2_pass<T, K, E1, E2, TB, S2>(A, M, sh, edge, qoff, trace);
-		finish_pair(A, M, (int32_t)blockIdx.x, pair, R, R.status, 0);
+		if (R.status == ST_OK) R = band2_pass<T, K, E1, E2, TB, S2>(A, M, sh, edge_base, qoff, trace);
+		finish_pair(fresh(A0), M, (int32_t)blockIdx.x, pair, R, R.status, 0);
 	}
 }
 

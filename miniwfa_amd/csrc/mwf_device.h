@@ -26,6 +26,26 @@ struct PassResult {
 
 __device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// A kernel's BatchArgs read from the kernarg segment WHERE they are needed: the compiler otherwise loads every field it will ever
+// use at the top of the kernel and keeps it in an SGPR for the kernel's lifetime (the band kernels spilled 130-150 SGPRs that way).
+// `fresh` hides the pointer's origin, so loads through its result can neither be hoisted above it nor merged with earlier ones.
+typedef const BatchArgs __attribute__((address_space(4))) KArgs;
+__device__ __forceinline__ KArgs &kernel_args()
+{
+	KArgs *p = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr(); // BatchArgs is the kernel's only parameter
+	asm volatile("" : "+s"(p));
+	return *p;
+}
+template <typename T>
+__device__ __forceinline__ const T &fresh(const T &a)
+{
+	// (the halves go through v_readfirstlane first: the compiler must see a scalar going into the asm)
+	const uint64_t v = (uint64_t)(uintptr_t)(const void*)&a;
+	uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)(v >> 32));
+	asm volatile("" : "+s"(lo), "+s"(hi));
+	return *(const T*)(uintptr_t)((uint64_t)hi << 32 | lo);
+}
+
 __device__ __forceinline__ uint64_t ld8(const uint8_t *p)
 {
 	uint64_t x;
@@ -150,10 +170,12 @@ __device__ __forceinline__ uint32_t tb_byte(const PairMem &M, int32_t row, int32
 // Traceback on one wave (reference wf_traceback, miniwfa.c:329-377).  Ops are emitted from the end of
 // the alignment to its start, so writing them backwards from the end of the scratch buffer leaves the
 // CIGAR in input order.  Returns n_cigar (>= 0) or -1 when the scratch buffer is too small.
-static __device__ int32_t traceback_wave(const BatchArgs &A, const PairMem &M, uint32_t *scratch, int64_t cap,
+// (ArgsT: BatchArgs, or BatchArgs in the constant address space when a kernel reads its arguments where it needs them)
+template <typename ArgsT>
+static __device__ int32_t traceback_wave(const ArgsT &A, const PairMem &M, uint32_t *scratch, int64_t cap,
                                   int32_t s_final, int32_t last, int32_t *end_state)
 {
-	const Penalty &P = A.pen;
+	const auto &P = A.pen;
 	const int32_t lane = threadIdx.x & 63;
 	int32_t i = M.ql - 1, k = M.tl - 1, row = s_final - 1;
 	int64_t pos = cap;
@@ -218,9 +240,10 @@ static __device__ int32_t traceback_wave(const BatchArgs &A, const PairMem &M, u
 
 
 // Set up the per-slot memory views of one pair.
-__device__ __forceinline__ void pair_mem(const BatchArgs &A, int32_t slot, int32_t pair, PairMem &M)
+template <typename ArgsT>
+__device__ __forceinline__ void pair_mem(const ArgsT &A, int32_t slot, int32_t pair, PairMem &M)
 {
-	const Penalty &P = A.pen;
+	const auto &P = A.pen;
 	M.tl = A.tl[pair], M.ql = A.ql[pair];
 	M.ts = A.seqs + A.t_off[pair], M.qs = A.seqs + A.q_off[pair];
 	const int64_t W = A.W;
@@ -243,7 +266,8 @@ __device__ __forceinline__ void pair_mem(const BatchArgs &A, int32_t slot, int32
 }
 
 // After the forward pass(es): traceback on the first wave, CIGAR into the pool, per-pair outputs.
-__device__ __forceinline__ void finish_pair(const BatchArgs &A, const PairMem &M, int32_t slot, int32_t pair,
+template <typename ArgsT>
+__device__ __forceinline__ void finish_pair(const ArgsT &A, const PairMem &M, int32_t slot, int32_t pair,
                                             const PassResult &R, int32_t status, int64_t cells1)
 {
 	int32_t n_cigar = 0;

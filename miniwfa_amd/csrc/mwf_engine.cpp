@@ -372,6 +372,12 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 	const int64_t need_lds = seq2 ? ((max_len >> 4) + 4) * 4 : max_seq_lds;
 	bg.lds_bytes = need_lds <= lds_cap ? (int)((need_lds + 15) / 16 * 16) : 0;
 	bg.seq2 = seq2 && bg.lds_bytes > 0;
+	// byte-wise copy (pairs outside plain ACGT) with wide windows: three slots of state plus six probe words per column do not fit the 128
+	// VGPRs two 512-thread workgroups per CU leave each wave (~500 bytes of scratch); 768 x 2 holds the same 24 chunks without spilling
+	if (bg.packed && !bg.seq2 && bg.block == 512 && g->block == 0 && max_seq_lds <= 140 * 1024) {
+		bg.block = 768, bg.span = 768 / 64 * 2 * 256;
+		bg.lds_bytes = (int)((max_seq_lds + 15) / 16 * 16);
+	}
 	if (bg.packed && bg.lds_bytes == 0) { // the packed kernel keeps the sequences in LDS
 		bg.lds_bytes = max_seq_lds <= lds_cap ? (int)((max_seq_lds + 15) / 16 * 16) : 0; // (the unpacked kernel's copy is byte-wise)
 		if (!can_plain) return;

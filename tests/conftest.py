@@ -5,6 +5,11 @@ import sys
 
 import pytest
 
+try:  # torch first: its bundled HIP runtime must be the one the process loads (a second copy, loaded after
+    import torch  # noqa: F401  # libmwf_hip.so pulled in /opt/rocm's, finds no device)
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
