@@ -346,7 +346,20 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 	int32_t s = 0, wf_lo = tl + 1, wf_hi = tl + 1;
 	int32_t curH = 0, par = 0;
 	const uint32_t ring_bytes = (uint32_t)nH * RS;
-	uint32_t bn = 0, bx = (uint32_t)(nH - lagx) * RS, b1 = (uint32_t)(nH - lag1) * RS, b2 = (uint32_t)(nH - lag2) * RS; // rows of penalty 0 and its lags
+	// rows of the coming penalty and of its three lags, as byte offsets that advance by one row per penalty (penalty 1 first)
+	uint32_t bn = (uint32_t)(1 % nH) * RS, bx = (uint32_t)((nH - lagx + 1) % nH) * RS, b1 = (uint32_t)((nH - lag1 + 1) % nH) * RS, b2 = (uint32_t)((nH - lag2 + 1) % nH) * RS;
+	// The rows of ONE chunk: H at the three lags (one 8-byte load each) and the word next to the chunk for the two gap-open rows.  These
+	// registers are where every chunk's rows land; at the end of a penalty they are loaded with the coming penalty's rows of the wave's
+	// first active chunk (`pre_g`), which travel while the wave waits at the barrier — every lag >= 2: those rows are final by then.
+	struct Rows { int2 HX, O1, O2; int32_t N1, N2; } pre;
+	pre.HX = pre.O1 = pre.O2 = make_int2(0, 0), pre.N1 = pre.N2 = 0;
+	int32_t pre_g = -1;
+	const bool xpref = false && min_lag >= 2; // (measured: 18.9 -> 19.7 ms on 1024 x 10 kb — the row loads are not what a chunk waits for)
+	auto load_rows = [&](Rows &r, const char *rx, const char *r1, const char *r2, uint32_t off) {
+		const uint32_t noff = off + (uint32_t)nd;
+		r.HX = *(const int2*)(rx + off), r.O1 = *(const int2*)(r1 + off), r.O2 = *(const int2*)(r2 + off);
+		r.N1 = *(const int32_t*)(r1 + noff), r.N2 = *(const int32_t*)(r2 + noff);
+	};
 	int64_t cells = 0, tb_used = 0;
 	const int64_t iter_limit = A.max_iter > 0 ? A.max_iter : INT64_MAX;
 	const int32_t s_limit = A.max_s > 0 ? A.max_s : INT32_MAX;
@@ -391,9 +404,6 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 		const int32_t gl_next = (lo > 1 ? lo - 1 : 1) >> 8;
 		if ((hi >> 8) - (lo >> 8) + 3 > NWK - 1) // (only then can the exact test fail)
 			if (((hi < cmax ? hi + 1 : cmax) >> 8) - gl_next + 1 > NWK - 1) { R.status = ST_BAND_OVERFLOW; return true; }
-		// ring rows as byte offsets that advance by one row per penalty
-		bn = bn + RS == ring_bytes ? 0u : bn + RS, bx = bx + RS == ring_bytes ? 0u : bx + RS;
-		b1 = b1 + RS == ring_bytes ? 0u : b1 + RS, b2 = b2 + RS == ring_bytes ? 0u : b2 + RS;
 		const char *const rowx = Hb + bx, *const row1 = Hb + b1, *const row2 = Hb + b2;
 		char *const rown = Hb + bn;
 		const bool track_good = (((256 - (s_new & 255)) & 255) < nH); // a shrink can still see this slice
@@ -438,6 +448,10 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 		const uint64_t tm1 = __builtin_readcyclecounter();
 #endif
 		int n_stores = 0;
+#if MWF_B2_TIMING == 2
+		bool chunk_timed = false;
+		uint32_t ct[4] = {0, 0, 0, 0};
+#endif
 #pragma unroll
 		for (int k = 0; k < K; ++k) {
 			// a chunk that left the window: its columns are not computed any more, i.e. their E/F are dead.  It runs through the ordinary
@@ -453,9 +467,16 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 			asm volatile("" : "+s"(lo), "+s"(hi));
 			const int32_t g = gk[k], cb = g * kChunk, c0 = cb + 4 * lane;
 			// ---- rows: H at the three lags (one 8-byte load each) and the word next to the chunk for the two gap-open rows
-			const uint32_t off = (uint32_t)(cb << 1) + lane8, noff = off + (uint32_t)nd;
-			const int2 HX = *(const int2*)(rowx + off), O1 = *(const int2*)(row1 + off), O2 = *(const int2*)(row2 + off);
-			const int32_t N1 = *(const int32_t*)(row1 + noff), N2 = *(const int32_t*)(row2 + noff);
+#if MWF_B2_TIMING == 2
+			uint64_t tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0, tc4 = 0;
+			const bool timed = !chunk_timed;
+			if (timed) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc0) :: "memory");
+#endif
+			const uint32_t off = (uint32_t)(cb << 1) + lane8;
+			if (g != pre_g) load_rows(pre, rowx, row1, row2, off); // uniform; (else they were requested before the last barrier)
+			pre_g = -1;
+			const int2 HX = pre.HX, O1 = pre.O1, O2 = pre.O2;
+			const int32_t N1 = pre.N1, N2 = pre.N2;
 			// gap-extension sources: E of column c-1, F of column c+1, e1 (e2) penalties ago; lane 0 / lane 63 take the neighbouring
 			// slot's outer columns from the edge table
 			const int32_t xE1 = *(const int32_t*)(lds2 + rE1 + k * NW * 16), xE2 = *(const int32_t*)(lds2 + rE2 + k * NW * 16 + 4);
@@ -476,6 +497,9 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 			const int32_t mA = pk_add(HX.x, ONE), mB = pk_add(HX.y, ONE);
 			int32_t hA = pk_max(pk_max(mA, pk_max(ne1A, ne2A)), pk_max(nf1A, nf2A));
 			int32_t hB = pk_max(pk_max(mB, pk_max(ne1B, ne2B)), pk_max(nf1B, nf2B));
+#if MWF_B2_TIMING == 2
+			if (timed) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc1) : "v"(hA), "v"(hB) : "memory");
+#endif
 			uint32_t tbw = 0;
 			if (TB) {
 				// The byte from the RESULTS (miniwfa.c:289-306): H is the maximum of m, e1, e2, f1, f2 and the reference's tie-breaking
@@ -548,26 +572,33 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 			}
 			put_edge(k, ne1B, ne2B, nf1A, nf2A);
 
+#if MWF_B2_TIMING == 2
+			if (timed) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc2) : "v"(hA), "v"(hB), "v"(rjA), "v"(dA) : "memory");
+#endif
 			// ---- match extension, first probe (FULL bases): j clamped to rj makes room = rj - j zero for dead and phantom offsets
 			const int32_t jA = pk_minu(pk_add(hA, ONE), rjA), jB = pk_minu(pk_add(hB, ONE), rjB);
 			const int32_t iqA = pk_add(jA, dA), iqB = pk_add(jB, dB);
 			int32_t cnt[4]; // columns c0 (A.lo), c1 (B.lo), c2 (A.hi), c3 (B.hi)
 			if (S2) {
-				Probe16 ps[4];
+				// Eight LDS reads (two dwords of each sequence for each of the four columns) go out back to back and are waited for ONCE:
+				// left to itself the compiler recycles one register quad and pays four dependent LDS round trips.  Inline asm: the
+				// reads keep their order (volatile), the single wait takes every result as an operand so that no use can move above it.
+				// (Addresses are LDS byte addresses: the dynamic LDS of this kernel starts at 0 — it has no static LDS.)
+				uint64_t tw[4], qw[4];
 #pragma unroll
 				for (int u = 0; u < 4; ++u) {
 					const uint32_t J = (uint32_t)((u & 1) ? jB : jA), Q = (uint32_t)((u & 1) ? iqB : iqA);
 					const uint32_t ta = (u & 2) ? (J >> 18) & 0x3ffcu : (J >> 2) & 0x3ffcu;
 					const uint32_t qa = ((u & 2) ? (Q >> 20) : ((Q >> 4) & 0xfffu)) * 4u + (uint32_t)qoff;
-					const uint32_t *pt = (const uint32_t*)(lds2 + ta), *pq = (const uint32_t*)(lds2 + qa);
-					ps[u].t0 = pt[0], ps[u].t1 = pt[1], ps[u].q0 = pq[0], ps[u].q1 = pq[1];
+					asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(tw[u]) : "v"(ta));
+					asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(qw[u]) : "v"(qa));
 				}
-				__builtin_amdgcn_sched_barrier(0); // all eight LDS reads in flight before the first is looked at (one round trip, not four)
+				asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tw[0]), "+v"(tw[1]), "+v"(tw[2]), "+v"(tw[3]), "+v"(qw[0]), "+v"(qw[1]), "+v"(qw[2]), "+v"(qw[3]));
 #pragma unroll
 				for (int u = 0; u < 4; ++u) {
 					const uint32_t J = (uint32_t)((u & 1) ? jB : jA), Q = (uint32_t)((u & 1) ? iqB : iqA);
 					const uint32_t tsh = (u & 2) ? J >> 15 : J << 1, qsh = (u & 2) ? Q >> 15 : Q << 1; // v_alignbit uses bits 4:0
-					cnt[u] = lead_eq2(__builtin_amdgcn_alignbit(ps[u].t1, ps[u].t0, tsh) ^ __builtin_amdgcn_alignbit(ps[u].q1, ps[u].q0, qsh));
+					cnt[u] = lead_eq2(__builtin_amdgcn_alignbit((uint32_t)(tw[u] >> 32), (uint32_t)tw[u], tsh) ^ __builtin_amdgcn_alignbit((uint32_t)(qw[u] >> 32), (uint32_t)qw[u], qsh));
 				}
 			} else {
 				// six probe words per column: two columns in flight (one where three slots of state must fit 128 VGPRs)
@@ -590,6 +621,9 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 			typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
 			const int32_t cA = MWF_BC(int32_t, (us2_t)__builtin_amdgcn_cvt_pk_u16((uint32_t)cnt[0], (uint32_t)cnt[2])); // saturating
 			const int32_t cB = MWF_BC(int32_t, (us2_t)__builtin_amdgcn_cvt_pk_u16((uint32_t)cnt[1], (uint32_t)cnt[3]));
+#if MWF_B2_TIMING == 2
+			if (timed) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc3) : "v"(cA), "v"(cB) : "memory");
+#endif
 			const int32_t FULLp = both16(FULL);
 			const int32_t m9A = pk_minu(cA, pk_sub(rjA, jA)), m9B = pk_minu(cB, pk_sub(rjB, jB)); // > FULL: the whole probe matched, room left
 			int32_t nmA = pk_minu(m9A, FULLp), nmB = pk_minu(m9B, FULLp);
@@ -651,6 +685,14 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 			}
 			*(int2*)(rown + off) = make_int2(hxA, hxB);
 			++n_stores;
+#if MWF_B2_TIMING == 2
+			if (timed) {
+				asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc4) : "v"(hxA), "v"(hxB) : "memory");
+				chunk_timed = true;
+				ct[0] = (uint32_t)min(tc1 - tc0, (uint64_t)4095), ct[1] = (uint32_t)min(tc2 - tc1, (uint64_t)4095);
+				ct[2] = (uint32_t)min(tc3 - tc2, (uint64_t)4095), ct[3] = (uint32_t)min(tc4 - tc3, (uint64_t)4095);
+			}
+#endif
 			if (TB && c0 >= origin && c0 <= hi) *(uint32_t*)(M.tb + tb_used - origin + c0) = tbw;
 			if (track_good) {
 				unsigned long long *gword = M.good + (int64_t)newH * fresh(A).GW + g * 4;
@@ -674,8 +716,25 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 #ifdef MWF_B2_TIMING
 		const uint64_t tm2 = __builtin_readcyclecounter();
 #endif
-		if (relaxed_stores && n_stores > 0 && !TB && !track_good) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
-		else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+		// the coming penalty: its rows, and the request for the first active chunk's (five loads, younger than every store)
+		bn = bn + RS == ring_bytes ? 0u : bn + RS, bx = bx + RS == ring_bytes ? 0u : bx + RS;
+		b1 = b1 + RS == ring_bytes ? 0u : b1 + RS, b2 = b2 + RS == ring_bytes ? 0u : b2 + RS;
+		bool requested = false;
+		if (xpref) {
+			const int32_t gf = act[0] ? gk[0] : act[1] ? gk[1] : (K > 2 && act[K - 1]) ? gk[K - 1] : -1;
+			if (gf >= 0) {
+				load_rows(pre, Hb + bx, Hb + b1, Hb + b2, (uint32_t)(gf << 9) + lane8);
+				pre_g = gf, requested = true;
+			}
+		}
+		const bool young_store = relaxed_stores && n_stores > 0 && !TB && !track_good;
+		if (requested) {
+			if (young_store) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+			else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+		} else {
+			if (young_store) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+			else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+		}
 #ifdef MWF_B2_TIMING
 		const uint64_t tm3 = __builtin_readcyclecounter();
 #endif
@@ -687,8 +746,14 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 #ifdef MWF_B2_TIMING
 		if (trace_band && tid == (fresh(A).max_iter < 0 ? (int32_t)-fresh(A).max_iter : 0) && s_new - 1 < fresh(A).dbg_cap) { // cycles: header | chunks, drain | barrier+flags; chunks this wave ran in bits 28..
 			const uint64_t tm4 = __builtin_readcyclecounter();
+#if MWF_B2_TIMING == 2 // the first active chunk of the wave: rows + recurrence | masks, liveness, geometry, edge stores | first probe | walks, store
+			M.dbg[2 * (s_new - 1)] = (int32_t)(ct[0] | ct[1] << 12 | (uint32_t)n_act << 28);
+			M.dbg[2 * (s_new - 1) + 1] = (int32_t)(ct[2] | ct[3] << 12);
+			(void)tm4;
+#else
 			M.dbg[2 * (s_new - 1)] = (int32_t)(min((uint32_t)(tm1 - tm0), 65535u) | min((uint32_t)(tm2 - tm1), 65535u) << 16);
 			M.dbg[2 * (s_new - 1) + 1] = (int32_t)(min((uint32_t)(tm3 - tm2), 4095u) | min((uint32_t)(tm4 - tm3), 65535u) << 12 | (uint32_t)n_act << 28);
+#endif
 		}
 #endif
 		if (fl & 1u) wf_lo = lo;
