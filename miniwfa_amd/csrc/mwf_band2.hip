@@ -34,6 +34,13 @@ namespace {
 
 extern __shared__ __attribute__((aligned(16))) uint8_t lds2[];
 
+#ifndef MWF_B2_XPREF
+#define MWF_B2_XPREF 0 // 1: request the first active chunk's rows of the coming penalty before the barrier (measured: slower)
+#endif
+#ifndef MWF_B2_WIDE_T
+#define MWF_B2_WIDE_T 512 // threads x chunk slots per wave of the widest geometry (24 chunks): 512 x 3; experiments: 256 x 6, 384 x 4
+#define MWF_B2_WIDE_K 3
+#endif
 constexpr int kChunk = 256;
 constexpr int32_t kDead16 = -32768;
 constexpr int32_t kDeadPair = (int32_t)0x80008000u;
@@ -354,7 +361,7 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 	struct Rows { int2 HX, O1, O2; int32_t N1, N2; } pre;
 	pre.HX = pre.O1 = pre.O2 = make_int2(0, 0), pre.N1 = pre.N2 = 0;
 	int32_t pre_g = -1;
-	const bool xpref = false && min_lag >= 2; // (measured: 18.9 -> 19.7 ms on 1024 x 10 kb — the row loads are not what a chunk waits for)
+	const bool xpref = MWF_B2_XPREF && min_lag >= 2; // (measured: 18.9 -> 19.7 ms on 1024 x 10 kb — the row loads are not what a chunk waits for)
 	auto load_rows = [&](Rows &r, const char *rx, const char *r1, const char *r2, uint32_t off) {
 		const uint32_t noff = off + (uint32_t)nd;
 		r.HX = *(const int2*)(rx + off), r.O1 = *(const int2*)(r1 + off), r.O2 = *(const int2*)(r2 + off);
@@ -436,8 +443,12 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 		bool busy;
 		if ((NW & (NW - 1)) == 0) busy = ((wave - ga) & (NW - 1)) < gspan + 1 - NW;
 		else busy = (int)act[0] + (int)act[1] + (K > 2 ? (int)act[K - 1] : 0) >= 2;
+#ifndef MWF_B2_NOPRIO
 		if (busy) __builtin_amdgcn_s_setprio(3);
 		else __builtin_amdgcn_s_setprio(0);
+#else
+		(void)busy;
+#endif
 #ifdef MWF_B2_TIMING
 		int n_act = 0;
 #pragma unroll
@@ -448,6 +459,11 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 		const uint64_t tm1 = __builtin_readcyclecounter();
 #endif
 		int n_stores = 0;
+		// ---- every row must read as dead next to the chunks it was computed for (a later window reaches at most nH + 1 columns
+		// beyond this one: the reference's pads, miniwfa.c:96-99); the waves next to the window's ends hold the fewest chunks.  These
+		// stores go first: the store that may stay in flight across the barrier (relaxed_stores) is then a chunk's own.
+		if (ga >= 1 && wave == (ga - 1) % NW) *(int2*)(rown + ((uint32_t)((ga - 1) << 9) + lane8)) = make_int2(kDeadPair, kDeadPair);
+		if (wave == (gb + 1) % NW) *(int2*)(rown + ((uint32_t)((gb + 1) << 9) + lane8)) = make_int2(kDeadPair, kDeadPair);
 #if MWF_B2_TIMING == 2
 		bool chunk_timed = false;
 		uint32_t ct[4] = {0, 0, 0, 0};
@@ -705,10 +721,6 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 			if (fm) bits |= 4u | (uint32_t)__builtin_amdgcn_readlane(done_info, (int32_t)__builtin_ctzll(fm)) << 4;
 			if (bits && lane == 0) atomicOr((unsigned int*)&sh.flags[npar][0], bits);
 		}
-		// ---- every row must read as dead next to the chunks it was computed for (a later window reaches at most nH + 1 columns
-		// beyond this one: the reference's pads, miniwfa.c:96-99); the waves next to the window's ends hold the fewest chunks
-		if (ga >= 1 && wave == (ga - 1) % NW) *(int2*)(rown + ((uint32_t)((ga - 1) << 9) + lane8)) = make_int2(kDeadPair, kDeadPair), ++n_stores;
-		if (wave == (gb + 1) % NW) *(int2*)(rown + ((uint32_t)((gb + 1) << 9) + lane8)) = make_int2(kDeadPair, kDeadPair), ++n_stores;
 
 		// Everything older than this penalty's last operations must be complete before another wave may load it (vmcnt retires
 		// in issue order).  With every lag >= 3 the rows written now are first loaded two penalties from now: the youngest store
@@ -922,7 +934,7 @@ bool band2_supported(const Penalty &p)
 #endif
 #define MWF_BAND2_DISPATCH(FN, ...)                                                 \
 	do {                                                                            \
-		if (g.block == 512) MWF_BAND2_PEN(FN, 512, 3, __VA_ARGS__)                  \
+		if (g.block == 512) MWF_BAND2_PEN(FN, MWF_B2_WIDE_T, MWF_B2_WIDE_K, __VA_ARGS__) \
 		if (g.block == 768) MWF_BAND2_PEN(FN, 768, 2, __VA_ARGS__)                  \
 		MWF_BAND2_REST(FN, __VA_ARGS__)                                             \
 	} while (0)
