@@ -47,6 +47,7 @@ HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # VALU issue peak: 256 CUs x 4 SIMD-32 per CU x 2.4 GHz, a wave64 VALU instruction occupies its SIMD for 2 cycles
 # (MI355X_MICROARCH.md: "issues each VALU instruction over 2 cycles (32 lanes/cycle x 2)", v_fma_f32 row: 2 cyc)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2
+ISSUE_PEAK_GINST = 256 * 4 * 2.4 / 1.28   # what 1024 SIMDs issue with four ready waves each: one instruction per 1.28 cycles (measured, any VALU/SALU mix)
 
 
 def host_cores() -> int:
@@ -77,7 +78,7 @@ class _DevPtr:
 
 KERNEL_NAMES = {0: "wfa_batch_kernel (generic: one workgroup per pair, ring in HBM)", 1: "wfa_sys_kernel (one pair across the device, systolic hand-offs)",
                 2: "wfa_band_kernel (one workgroup per pair, E/F in registers, 32-bit H rows in HBM)",
-                3: "wfa_band2_kernel (one workgroup per pair, E/F in registers, 16-bit H rows in HBM, sequences in LDS at 2 bits per base)"}
+                3: "wfa_band2_kernel (one workgroup per pair, recurrence in packed int16 (two columns per VOP3P instruction), E/F in registers, 16-bit H rows in HBM, sequences in LDS at 2 bits per base)"}
 
 
 def call_latency(mw, synth_pair, reps=40):
@@ -365,6 +366,13 @@ def main():
         cands.append({"bound": "valu issue", "achieved": vi / (k_ms * 1e-3) / 1e9, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
                       "frac": vi / (k_ms * 1e-3) / 1e9 / VALU_PEAK_GINST, "valu_lane_ops_per_cell": vi * 64 / prof.get("cells_per_launch", cells),
                       "source": prof.get("valu_source")})
+    if prof.get("valu_insts_per_launch") and prof.get("salu_insts_per_launch"):
+        # every instruction a SIMD issued, against what one SIMD issues with four ready waves (profiles/r02/valu_issue_rates_microbench.txt:
+        # 1.28 cycles per instruction, i.e. 0.78 per cycle and SIMD, for any mix of VALU / SALU) x 1024 SIMDs x 2.4 GHz
+        ai = prof["valu_insts_per_launch"] + prof["salu_insts_per_launch"] + (prof.get("lds_insts_per_launch") or 0) + (prof.get("vmem_insts_per_launch") or 0)
+        cands.append({"bound": "instruction issue (all types)", "achieved": ai / (k_ms * 1e-3) / 1e9, "peak": ISSUE_PEAK_GINST, "unit": "G wave-instructions/s",
+                      "frac": ai / (k_ms * 1e-3) / 1e9 / ISSUE_PEAK_GINST, "instructions_per_cell_lane": ai * 64 / prof.get("cells_per_launch", cells),
+                      "wait_any_over_wave_cycles": prof.get("wait_any_over_wave_cycles"), "source": prof.get("valu_source", "").replace("SQ_INSTS_VALU", "SQ_INSTS_VALU/SALU/LDS/VMEM_RD/VMEM_WR")})
     # The top-level roofline is the BINDING one: the largest fraction among the rooflines of what this kernel really does (its own
     # HBM bytes, counter-measured HBM traffic, VALU issue).  SURVEY 8(d)'s nominal figure (the reference's 48 B per cell) is kept
     # beside it as `nominal_48B`: a kernel that keeps four of the five wavefront arrays on chip can exceed 1 by that definition.
@@ -380,8 +388,8 @@ def main():
     rf["hbm_measured"] = {"bytes_per_launch": rf.get("traffic"), "gbs": rf.get("traffic_gbs"), "frac": (rf["traffic_gbs"] / HBM_PEAK_GBS) if "traffic_gbs" in rf else None}
     rf["candidates"] = cands
     rf["note"] = ("bound/achieved/peak/frac: the largest fraction among the rooflines of what this kernel really does (candidates); nominal_48B: "
-                  "SURVEY 8(d)'s figure, cells x the reference's bytes per cell / kernel time; neither binds — what is left is per-penalty "
-                  "synchronisation and single-wave issue latency (DESIGN.md section 4).")
+                  "SURVEY 8(d)'s figure, cells x the reference's bytes per cell / kernel time; none binds — what is left is per-penalty "
+                  "synchronisation (wait_any_over_wave_cycles) and single-wave issue latency (DESIGN.md section 4).")
 
     if world == 1 and args.extras:
         out["peak_device_bytes"] = int(st.dev_bytes_peak)

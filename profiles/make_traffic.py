@@ -34,14 +34,17 @@ for key, (path, kerns, width) in SRC.items():
     m = re.search(r"cells/launch (\d+)", txt)
     cells = int(m.group(1)) if m else None
     note = (f"{path}: separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes over {', '.join(kerns)}, means per launch; "
-            "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950; "
-            f"this kernel's row reads are {width} bytes per lane" + (", a width the guide calls uncalibrated, so this is an upper estimate" if width != 16 else "") +
-            "; WRITE_SIZE as is)")
+            "bytes = 2048 x FETCH_SIZE + 1024 x WRITE_SIZE: the units measured on this device by profiles/micro/fetch_calib.hip "
+            "(kernels that move exactly 1 GiB with 4-, 8- and 16-byte coalesced accesses per lane: 2048 bytes per FETCH_SIZE unit at every "
+            "width, 1024 per WRITE_SIZE unit; profiles/r03/fetch_calibration.txt) — the doubling MI355X_MICROARCH.md prescribes; "
+            f"this kernel's row reads are {width} bytes per lane")
     out[key] = {
         "hbm_bytes_per_launch": (2 * pmc["FETCH_SIZE"][0] + pmc["WRITE_SIZE"][0]) * 1024,
         "fetch_size_kib": pmc["FETCH_SIZE"][0], "write_size_kib": pmc["WRITE_SIZE"][0],
         "valu_insts_per_launch": pmc.get("SQ_INSTS_VALU", (None,))[0], "salu_insts_per_launch": pmc.get("SQ_INSTS_SALU", (None,))[0],
         "lds_insts_per_launch": pmc.get("SQ_INSTS_LDS", (None,))[0],
+        "vmem_insts_per_launch": (pmc.get("SQ_INSTS_VMEM_RD", (0,))[0] or 0) + (pmc.get("SQ_INSTS_VMEM_WR", (0,))[0] or 0),
+        "wait_any_over_wave_cycles": (pmc["SQ_WAIT_ANY"][0] / pmc["SQ_WAVE_CYCLES"][0]) if "SQ_WAIT_ANY" in pmc and "SQ_WAVE_CYCLES" in pmc else None,
         "source": note,
         "valu_source": f"{path}: rocprofv3 --pmc SQ_INSTS_VALU (wave-instructions), mean per launch",
     }
