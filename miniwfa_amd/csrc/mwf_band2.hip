@@ -1,26 +1,19 @@
 // mwf_band2.hip — the packed band kernel: the fast path for batches of pairs whose offsets fit 16 bits (targets below
 // ~32 kb: BASELINE configs[2], read-length batches, chain-mode gap fills).
 //
-// Same decomposition as mwf_band.hip (one workgroup per pair, a wave owns 256-column chunks, four columns per lane, E/F
-// wavefronts in registers, one barrier per penalty; reference loops miniwfa.c:261-308 and :212-226, driver :397-426),
-// rebuilt around what the profile of that kernel showed: a wave issues at most one instruction every ~5 cycles, the
-// workgroup moves at the pace of its busiest wave, and that wave executed ~1500 instructions per penalty — two thirds of
-// them bookkeeping.  Here
-//   * everything is 16 bits where it rests: the H rows in HBM (8 instead of 16 bytes per cell of traffic, one 8-byte load
-//     per lane and row), the E/F state, the edge table; arithmetic is 32-bit on sign-extended halves (SDWA operands, free);
-//   * a chunk that lies nH+1 columns inside the window can read no column outside any source window (an edge moves
-//     outwards by at most one column per penalty), so it runs a lean copy of the column code: no window history, no
-//     masks, validity of an offset as ONE unsigned comparison (a live offset always has k >= -1 and d+k >= -1), clamped
-//     probe addresses, "full probe with room left" read off one min3;
-//   * the sequence copy starts at LDS offset 0, so a probe address is the byte index itself;
-//   * the first probe of the match extension looks at eight bytes, so the per-lane loop that walks longer runs is entered
-//     for the cells near the alignment path only (a random 4-mer matches in one cell of 256, i.e. in most chunks);
-//   * the per-penalty header is scalar arithmetic on a handful of loop-carried values (chunk indices change only when the
-//     mapping does), the three per-penalty flags travel as one LDS word, rows are loaded only for chunks that are active.
-//     (Measured and dropped: requesting the next chunk's rows while the current one computes, the next penalty's first
-//     rows before the barrier, all active chunks' rows at the start of the penalty — 30.8, 29.3 and 38.6 ms against 28.6
-//     without: the co-resident workgroup already hides the load latency; registers are what is scarce — the 512-thread
-//     variant lives in 128 VGPRs so that two workgroups share a CU.)
+// One workgroup per pair, a wave owns 256-column chunks (four columns per lane, K chunk slots per wave), E/F wavefronts in
+// registers, one barrier per penalty; reference loops miniwfa.c:261-308 and :212-226, driver :397-426.  What makes it fast
+// (DESIGN.md section 4.2 has the measurements):
+//   * two columns per instruction: a lane's columns c0..c3 live in two registers (c0,c2) and (c1,c3) — the 16-bit H rows in HBM
+//     hold a quad in that order — and the recurrence, the validity / room arithmetic of the match extension, the good bits and the
+//     traceback byte are v_pk_* instructions on those pairs; neighbouring columns come from one DPP shift + one v_alignbit;
+//   * rows read as DEAD beyond the window they were computed for (columns outside the window are stored dead, the chunk on either
+//     side of the window is stored dead every penalty), so no read is ever masked and no window history is consulted;
+//   * the sequence copy (2 bits per base, or bytes) starts at LDS address 0; the first probe of the match extension looks at 16
+//     bases (8 bytes), its eight LDS reads are issued together; longer runs are walked per lane, then by the whole wave;
+//   * kernel arguments are read from the kernarg segment where they are used (no SGPR spills from holding them for ever), the edge
+//     table between neighbouring waves is addressed by immediates and written without exec masks, register histories are aged by
+//     v_swap, the three per-penalty flags travel as one LDS word, rows are loaded only for chunks that are active.
 // Results are bit-identical to the other kernels (tests/test_gpu_parity.py).
 #include <cstddef>
 #include <type_traits>
