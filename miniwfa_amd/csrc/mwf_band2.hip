@@ -354,7 +354,8 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 	struct Rows { int2 HX, O1, O2; int32_t N1, N2; } pre;
 	pre.HX = pre.O1 = pre.O2 = make_int2(0, 0), pre.N1 = pre.N2 = 0;
 	int32_t pre_g = -1;
-	const bool xpref = MWF_B2_XPREF && min_lag >= 2; // (measured: 18.9 -> 19.7 ms on 1024 x 10 kb — the row loads are not what a chunk waits for)
+	constexpr bool XPREF = MWF_B2_XPREF != 0; // (measured: +1 % on 1024 x 10 kb — the row loads are not what the critical wave waits for; off)
+	const bool xpref = XPREF && min_lag >= 2;
 	auto load_rows = [&](Rows &r, const char *rx, const char *r1, const char *r2, uint32_t off) {
 		const uint32_t noff = off + (uint32_t)nd;
 		r.HX = *(const int2*)(rx + off), r.O1 = *(const int2*)(r1 + off), r.O2 = *(const int2*)(r2 + off);
@@ -482,8 +483,8 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 			if (timed) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc0) :: "memory");
 #endif
 			const uint32_t off = (uint32_t)(cb << 1) + lane8;
-			if (g != pre_g) load_rows(pre, rowx, row1, row2, off); // uniform; (else they were requested before the last barrier)
-			pre_g = -1;
+			if (!XPREF || g != pre_g) load_rows(pre, rowx, row1, row2, off); // uniform; (else they were requested before the last barrier)
+			if (XPREF) pre_g = -1;
 			const int2 HX = pre.HX, O1 = pre.O1, O2 = pre.O2;
 			const int32_t N1 = pre.N1, N2 = pre.N2;
 			// gap-extension sources: E of column c-1, F of column c+1, e1 (e2) penalties ago; lane 0 / lane 63 take the neighbouring
@@ -725,7 +726,7 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 		bn = bn + RS == ring_bytes ? 0u : bn + RS, bx = bx + RS == ring_bytes ? 0u : bx + RS;
 		b1 = b1 + RS == ring_bytes ? 0u : b1 + RS, b2 = b2 + RS == ring_bytes ? 0u : b2 + RS;
 		bool requested = false;
-		if (xpref) {
+		if (XPREF && xpref) {
 			const int32_t gf = act[0] ? gk[0] : act[1] ? gk[1] : (K > 2 && act[K - 1]) ? gk[K - 1] : -1;
 			if (gf >= 0) {
 				load_rows(pre, Hb + bx, Hb + b1, Hb + b2, (uint32_t)(gf << 9) + lane8);
