@@ -607,7 +607,9 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 #pragma unroll
 				for (int u = 0; u < 4; ++u) {
 					const uint32_t J = (uint32_t)((u & 1) ? jB : jA), Q = (uint32_t)((u & 1) ? iqB : iqA);
-					const uint32_t tsh = (u & 2) ? J >> 15 : J << 1, qsh = (u & 2) ? Q >> 15 : Q << 1; // v_alignbit uses bits 4:0
+					// v_alignbit uses bits 4:0 of the shift.  Bit 15 of the LOW half must not leak into a high half's shift: j never has it (j <= rj <=
+					// tl < 32767), a query index can — column 0 (the pad column, lane 0 of chunk 0) clamps to index -1
+					const uint32_t tsh = (u & 2) ? J >> 15 : J << 1, qsh = (u & 2) ? (Q >> 15) & 30u : Q << 1;
 					cnt[u] = lead_eq2(__builtin_amdgcn_alignbit((uint32_t)(tw[u] >> 32), (uint32_t)tw[u], tsh) ^ __builtin_amdgcn_alignbit((uint32_t)(qw[u] >> 32), (uint32_t)qw[u], qsh));
 				}
 			} else {

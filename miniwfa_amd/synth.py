@@ -123,6 +123,45 @@ def synth_batch(base_seed: int, n: int, tl: int, p: float) -> list[tuple[bytes, 
     return [synth_pair(base_seed + i, tl, p) for i in range(n)]
 
 
+def fuzz_pairs(seed: int, n: int, max_len: int = 4000) -> list[tuple[bytes, bytes]]:
+    """Pairs that stress the band kernels' corner cases: lengths around the 16-base / 64-lane / 256-column granularities, random,
+    homopolymer, tandem-repeat and low-complexity targets (long exact runs), queries mutated at 0 ... 40 %, and — every seventh —
+    UNRELATED queries of another length (windows that reach both corners of the matrix, many shrinks, chunks that leave and re-enter
+    the window).  Used by profiles/fuzz_band2_oracle.py and tests/test_gpu_parity.py."""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+    def rand_seq(m, kind):
+        if kind == 0:
+            return acgt[rng.integers(0, 4, m)]
+        if kind == 1:
+            return np.full(m, acgt[rng.integers(0, 4)], dtype=np.uint8)
+        if kind == 2:
+            return np.resize(acgt[rng.integers(0, 4, rng.integers(1, 40))], m)
+        return acgt[rng.choice(4, m, p=[0.85, 0.05, 0.05, 0.05])]
+
+    def mutate(t, p):
+        out = []
+        for b, r in zip(t, rng.random(len(t))):
+            if r < p / 3:
+                continue
+            if r < 2 * p / 3:
+                out.append(acgt[rng.integers(0, 4)])
+            if r < p:
+                out.append(acgt[rng.integers(0, 4)])
+                continue
+            out.append(b)
+        return np.array(out, dtype=np.uint8)
+
+    pairs = []
+    for i in range(n):
+        m = int(rng.choice([0, 1, 15, 16, 17, 63, 64, 65, 255, 256, 257, 511, 512, 1023, 1024, 1025, 2047, 2048])) if i % 3 == 0 else int(rng.integers(0, max_len))
+        t = rand_seq(min(m, max_len), i % 4)
+        q = mutate(t, float(rng.choice([0.0, 0.01, 0.05, 0.2, 0.4]))) if i % 7 else rand_seq(int(rng.integers(0, max(1, max_len * 3 // 8))), (i + 1) % 4)
+        pairs.append((t.tobytes(), q.tobytes()))
+    return pairs
+
+
 class PackedBatch:
     """Pairs packed back to back in one byte buffer (+16 bytes of slack so word-sized device
     reads past the last sequence stay inside the allocation)."""

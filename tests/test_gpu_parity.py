@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import miniwfa_amd as mw
-from miniwfa_amd.synth import synth_pair, PackedBatch
+from miniwfa_amd.synth import synth_pair, fuzz_pairs, PackedBatch
 from conftest import load_golden, golden_inputs
 from oracle.pyoracle import make_opt, cigar_str as ocig
 
@@ -593,6 +593,30 @@ def test_kalloc_arena_owns_the_cigar():
     s, n_iter, cig = mw.wfa_exact(t, q, mw.opt_init(flag=mw.MWF_F_CIGAR), km=km)   # _take() kfree()s into km
     assert s > 0 and mw.cigar2score(mw.opt_init(), cig) == (s, len(t), len(q))
     L.km_destroy(km)
+
+
+@pytest.mark.parametrize("block", [0, 512, 768])
+def test_packed_band_kernel_fuzz_against_oracle(block, oracle):
+    """Seeded fuzz of the packed band kernel (profiles/fuzz_band2_oracle.py runs more seeds): granular lengths, low-complexity and
+    repetitive sequences, and unrelated pairs whose window reaches both corners of the matrix — the case that caught a query-index
+    bit leaking from the pad column into its neighbour's probe shift.  s, n_iter and CIGAR equal the oracle's."""
+    pairs = fuzz_pairs(13, 120, 3000)
+    pk = PackedBatch(pairs)
+    for kw in (dict(), dict(flag=1), dict(flag=1, o2=4, e2=2)):
+        o = make_opt(**kw)
+        eng = mw.Engine(0)
+        if block:
+            eng.set("force_kind", 2), eng.set("block", block), eng.set("band_pack", 1)
+        b = eng.upload(pk)
+        b.align(mw.opt_init(**kw))
+        s, it, nc = b.results()
+        for i, (t, q) in enumerate(pairs):
+            es, eit, ecig = oracle.align(t, q, o)
+            assert (int(s[i]), int(it[i])) == (es, eit), (block, kw, i, len(t), len(q))
+            if ecig is not None:
+                assert b.cigar(i, int(nc[i])).tolist() == ecig, (block, kw, i)
+        b.free()
+        eng.close()
 
 
 def test_full_size_batch_properties(engine, oracle):
