@@ -28,14 +28,13 @@ namespace {
 extern __shared__ __attribute__((aligned(16))) uint8_t lds2[];
 
 #ifndef MWF_B2_XPREF
-#define MWF_B2_XPREF 0 // 1: request the first active chunk's rows of the coming penalty before the barrier (measured: slower)
+#define MWF_B2_XPREF 0 // request the first active chunk's rows of the coming penalty 1: before the barrier, 2: straight behind it (measured: no gain)
 #endif
 #ifndef MWF_B2_WIDE_T
 #define MWF_B2_WIDE_T 512 // threads x chunk slots per wave of the widest geometry (24 chunks): 512 x 3; experiments: 256 x 6, 384 x 4
 #define MWF_B2_WIDE_K 3
 #endif
 constexpr int kChunk = 256;
-constexpr int32_t kDead16 = -32768;
 constexpr int32_t kDeadPair = (int32_t)0x80008000u;
 
 __device__ __forceinline__ int32_t from_left(int32_t v, int32_t fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
@@ -728,12 +727,10 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 		bn = bn + RS == ring_bytes ? 0u : bn + RS, bx = bx + RS == ring_bytes ? 0u : bx + RS;
 		b1 = b1 + RS == ring_bytes ? 0u : b1 + RS, b2 = b2 + RS == ring_bytes ? 0u : b2 + RS;
 		bool requested = false;
-		if (XPREF && xpref) {
-			const int32_t gf = act[0] ? gk[0] : act[1] ? gk[1] : (K > 2 && act[K - 1]) ? gk[K - 1] : -1;
-			if (gf >= 0) {
-				load_rows(pre, Hb + bx, Hb + b1, Hb + b2, (uint32_t)(gf << 9) + lane8);
-				pre_g = gf, requested = true;
-			}
+		const int32_t gf = !XPREF ? -1 : act[0] ? gk[0] : act[1] ? gk[1] : (K > 2 && act[K - 1]) ? gk[K - 1] : -1;
+		if (MWF_B2_XPREF == 1 && xpref && gf >= 0) { // variant 1: before the barrier
+			load_rows(pre, Hb + bx, Hb + b1, Hb + b2, (uint32_t)(gf << 9) + lane8);
+			pre_g = gf, requested = true;
 		}
 		const bool young_store = relaxed_stores && n_stores > 0 && !TB && !track_good;
 		if (requested) {
@@ -748,6 +745,10 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 #endif
 		__builtin_amdgcn_s_barrier();
 		asm volatile("" ::: "memory");
+		if (MWF_B2_XPREF == 2 && gf >= 0) { // variant 2: straight behind the barrier, on the guess that the wave's first chunk stays what it was
+			load_rows(pre, Hb + bx, Hb + b1, Hb + b2, (uint32_t)(gf << 9) + lane8);
+			pre_g = gf;
+		}
 
 		// ---- bookkeeping, identical on every thread
 		const uint32_t fl = (uint32_t)uni(sh.flags[npar][0]);

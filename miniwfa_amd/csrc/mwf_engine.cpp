@@ -98,6 +98,7 @@ struct mwf_gpu_s {
 	std::map<uint64_t, int> occ_cache;         // kernel variant -> resident workgroups per CU
 	int coop_grid = -1;
 	int coop_grid_cap = 0;      // "coop_grid": at most this many workgroups for the whole-device kernel (0: one per CU)
+	int coop_launch = 1;        // "coop_launch": whole-device kernel through hipLaunchCooperativeKernel (0: plain launch)
 };
 
 struct mwf_gpu_batch_s {
@@ -762,6 +763,7 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 		as.ring = (int32_t*)g->sys_ring.p, as.good = (unsigned long long*)g->sys_good.p; // (sized for four columns per lane)
 		as.rows_slot = sys_rows;
 		as.sys_p = sysP;
+		as.sys_coop_launch = g->coop_launch;
 		as.sys_spread = 1; // consecutive chunks on consecutive workgroups: 763 against 787 ms on the 5 Mb pair, 63.5 against 65.0 on the 150 kb pair
 		as.sys_box = (int32_t*)g->sys_box.p, as.sys_box_stride = sys_box_group;
 		as.sys_prog = (unsigned long long*)g->sys_prog.p, as.sys_prog_stride = TC * 8;
@@ -1078,6 +1080,7 @@ int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value)
 	else if (!strcmp(name, "coop_tb_cap_mb")) g->coop_tb_cap = std::max<int64_t>(1, value) << 20;
 	else if (!strcmp(name, "lowmem_budget_mb")) g->lowmem_budget_mb = std::max<int64_t>(0, value);
 	else if (!strcmp(name, "coop_grid")) g->coop_grid_cap = (int)std::max<int64_t>(0, value);
+	else if (!strcmp(name, "coop_launch")) g->coop_launch = value != 0;
 	else if (!strcmp(name, "sys_p") && (value == 4 || value == 8 || value == 16)) g->sys_p = (int)value;
 	else if (!strcmp(name, "sys_c") && (value == 0 || value == 1 || value == 4)) g->sys_c = (int)value;
 	else if (!strcmp(name, "trim")) { (void)hipSetDevice(g->device); trim(g); }

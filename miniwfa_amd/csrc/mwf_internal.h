@@ -117,6 +117,7 @@ struct BatchArgs {
 	int64_t sys_park_stride;   // ints between two groups' parking areas
 	int64_t *sys_ep;           // [group][epochs][2]: traceback layout per epoch of 256 penalties: base offset, first chunk | chunks << 32
 	int64_t sys_ep_stride;     // int64 words between two groups' tables
+	int32_t sys_coop_launch;   // host side only: 1 = launch through hipLaunchCooperativeKernel (the runtime then guarantees that every workgroup is resident)
 };
 
 // launch wrappers implemented in mwf_kernels.hip (generic kernel: any penalties, any band, low-memory mode)

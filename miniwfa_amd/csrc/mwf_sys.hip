@@ -1083,7 +1083,19 @@ int launch_pass_c(const BatchArgs &a, int grid, hipStream_t st)
 	case 4:  hipLaunchKernelGGL((wfa_sys_kernel<E1, E2, 4, DEFER, TB, C>), dim3(grid), dim3(kT), 0, st, a); break;
 	case 16: hipLaunchKernelGGL((wfa_sys_kernel<E1, E2, 16, DEFER, TB, C>), dim3(grid), dim3(kT), 0, st, a); break;
 #endif
-	default: hipLaunchKernelGGL((wfa_sys_kernel<E1, E2, 8, DEFER, TB, C>), dim3(grid), dim3(kT), 0, st, a); break;
+	default: {
+		// The waits between workgroups rely on every workgroup being resident.  The grid is sized for that (one per CU, sys_max_grid) and
+		// the engine keeps this library's other kernels off the device meanwhile; a cooperative launch makes the runtime refuse a grid
+		// that could not be resident whatever else the process runs.  (A plain launch if the runtime refuses: the waits are bounded.)
+		if (a.sys_coop_launch) {
+			BatchArgs arg = a;
+			void *args[] = {(void*)&arg};
+			if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&wfa_sys_kernel<E1, E2, 8, DEFER, TB, C>), dim3(grid), dim3(kT), args, 0, st) == hipSuccess) return 0;
+			(void)hipGetLastError();
+		}
+		hipLaunchKernelGGL((wfa_sys_kernel<E1, E2, 8, DEFER, TB, C>), dim3(grid), dim3(kT), 0, st, a);
+		break;
+	}
 	}
 	return hipGetLastError() == hipSuccess ? 0 : -2;
 }
