@@ -141,7 +141,7 @@ typedef struct {
 	int32_t kernel_kind;   /* 0: one workgroup per pair (generic); 1: one pair across the whole device; 2: one workgroup per pair (band) */
 	int64_t dev_bytes;     /* device memory the engine holds now: workspace pools + recycled batch allocations (live batches hold their own) */
 	int64_t dev_bytes_peak;/* ... and the most it held since creation or the last mwf_gpu_set(g, "trim", 0) */
-	int32_t packed;        /* band kernel: 1 = the 16-bit variant (mwf_band2.hip), 2 = the balanced kernel with E/F in LDS and 2-bit sequences (mwf_band3.hip); generic kernel: 16 = 16-bit ring rows */
+	int32_t packed;        /* band kernel: 1 = the packed 16-bit variant (mwf_band2.hip); generic kernel: 16 = 16-bit ring rows */
 	int32_t lowmem_two_pass; /* low-memory mode: 1 = the first pass stored no traceback (provenance + snapshots), 0 = checkpoints walked off a full traceback */
 } mwf_gpu_stats_t;
 void mwf_gpu_get_stats(const mwf_gpu_t *g, mwf_gpu_stats_t *st);
@@ -154,12 +154,13 @@ int32_t mwf_gpu_debug_band(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *op
  * "coop_spin_limit", "scalar_generic", "lds_e2", "seq2bit" (packed band kernel: 0 = always keep the byte-wise sequence copy; default 1:
  * pairs of plain A/C/G/T are held at 2 bits per base, any other pair is re-run byte-wise — batches built from HOST memory are classified
  * while they are packed and never take that re-run), "ring16" (generic kernel: 0 = always 32-bit ring rows; default 1: 16-bit rows — half
- * the HBM traffic — for batches of at least as many pairs as CUs while target length + penalty fits 16 bits, a pair that outgrows them is
- * re-run with 32-bit rows; 2: also for smaller batches), "ring16_block" (0, 512, 768);
+ * the HBM traffic — for batches of at least as many pairs as CUs while target length + penalty fits 16 bits, with 2-bit copies of the
+ * sequences in device memory; a pair that outgrows 16 bits or holds a byte outside A/C/G/T is re-run with 32-bit rows and byte probes;
+ * 2: also for smaller batches), "ring16_block" (0, 512, 768);
  * whole-device (systolic) kernel: "lowmem_budget_mb" (low-memory mode: a first-pass traceback above this many MB switches to the two-pass
  * form whose first pass stores none; 0 = a quarter of the device), "sys_p" (penalties per hand-off block: 4, 8, 16; default 8),
  * "sys_c" (columns per lane: 0 = chosen per pass from the expected window, 1, 4), "coop_grid" (at most this many workgroups; 0 = one
- * per CU)}; "trim" frees the engine's workspace pools (they grow back on demand). */
+ * per CU), "coop_launch" (default 1: launched through hipLaunchCooperativeKernel; 0: plain launch)}; "trim" frees the engine's workspace pools (they grow back on demand). */
 int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value);
 
 #ifdef __cplusplus

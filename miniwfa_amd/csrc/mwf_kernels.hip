@@ -342,6 +342,37 @@ __device__ __forceinline__ uint32_t probe4g(const PairMem &M, int32_t j, int32_t
 	return a ^ b;
 }
 
+// ---- 2-bit sequence copies in GLOBAL memory (the kernel with 16-bit ring rows, pairs of plain A/C/G/T): sixteen bases per dword, base j
+// at bits 2*(j & 15) of dword j >> 4.  The byte sequences of the pairs resident on an XCD (64 x 100 KB for the 50 kb configuration) do
+// not fit its 4 MB of L2 and every first probe of the match extension — two unaligned loads per cell — went out to the fabric (a third
+// of the kernel's fetch traffic); a quarter of the bytes does fit, and a probe then looks at sixteen bases
+// instead of four, so the per-lane walk is entered for the cells near the alignment path only.
+__device__ __forceinline__ uint32_t seq16g(const uint32_t *p2, int32_t j)
+{
+	uint32_t w[2];
+	__builtin_memcpy(w, p2 + (j >> 4), 8); // one global_load_dwordx2 (4-byte aligned)
+	return __builtin_amdgcn_alignbit(w[1], w[0], (uint32_t)j << 1);
+}
+// Bytes -> 2 bits per base (two dwords of slack behind the last base); nonzero when a byte is not one of A, C, G, T.
+// code = (byte >> 1) & 3: A 0, C 1, T 2, G 3.
+template <int T>
+__device__ __forceinline__ uint32_t pack2bit_global(const uint8_t *src, int32_t len, uint32_t *dst)
+{
+	uint32_t bad = 0;
+	const int32_t n_dw = (len >> 4) + 2;
+	for (int32_t w = threadIdx.x; w < n_dw; w += T) {
+		uint32_t out = 0;
+#pragma unroll 1
+		for (int32_t k = 0, b0 = w << 4; k < 16 && b0 + k < len; ++k) {
+			const uint32_t x = src[b0 + k], code = (x >> 1) & 3u;
+			bad |= x ^ ((0x47544341u >> (8 * code)) & 0xffu);
+			out |= code << (2 * k);
+		}
+		dst[w] = out;
+	}
+	return bad;
+}
+
 __device__ __forceinline__ uint32_t inm_bit(int32_t d, int32_t k, int32_t tl, int32_t ql)
 {
 	return (uint32_t)((uint32_t)(k + 1) < (uint32_t)(tl + 1)) & (uint32_t)((uint32_t)(d + k + 1) < (uint32_t)(ql + 1));
@@ -441,6 +472,17 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 	const int64_t W = A.W;
 	PassResult R;
 	R.status = ST_OK, R.s = 0, R.info = 0, R.n_snap = 0, R.cells = 0;
+
+	// H16: 2-bit copies of the two sequences in the unused upper half of this slot's H rows (16-bit rows fill the lower half);
+	// a pair with any other byte goes back to the host like one whose offsets outgrow 16 bits and is re-run with 32-bit rows
+	constexpr int FULLG = H16 ? 16 : 4; // bases the first probe of the match extension looks at
+	uint32_t *const t2 = H16 ? (uint32_t*)((char*)M.H + (((int64_t)P.nH * A.W) << 1)) : nullptr;
+	uint32_t *const q2 = H16 ? t2 + ((tl >> 4) + 2) : nullptr;
+	if constexpr (H16) {
+		uint32_t bad = pack2bit_global<T>(M.ts, tl, t2);
+		bad |= pack2bit_global<T>(M.qs, ql, q2);
+		if (__syncthreads_or(bad != 0)) { R.status = ST_BAND_OVERFLOW; return R; }
+	}
 
 	// ---- penalty 0 (reference wf_stripe_init, miniwfa.c:103-121) and its extension
 	if (tid == 0) {
@@ -651,9 +693,15 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 						gbits |= (act & (inm | inm_bit(d, v.e1, tl, ql) | inm_bit(d, v.f1, tl, ql) | inm_bit(d, v.e2, tl, ql) | inm_bit(d, v.f2, tl, ql))) << i;
 					const int32_t j = inm ? v.h + 1 : 0, q = inm ? d + v.h + 1 : 0;
 					const int32_t room = inm ? min(tl - j, ql - q) : 0;
-					const uint32_t x = probe4g(M, j, q);
-					nmat[i] = min(min((int32_t)((uint32_t)(__builtin_ffs((int)x) - 1) >> 3), 4), room);
-					pend |= ((uint32_t)(x == 0) & (uint32_t)(room > 4)) << i;
+					if constexpr (H16) {
+						const uint32_t x = seq16g(t2, j) ^ seq16g(q2, q);
+						nmat[i] = min(min((int32_t)((uint32_t)(__builtin_ffs((int)x) - 1) >> 1), 16), room);
+						pend |= ((uint32_t)(x == 0) & (uint32_t)(room > 16)) << i;
+					} else {
+						const uint32_t x = probe4g(M, j, q);
+						nmat[i] = min(min((int32_t)((uint32_t)(__builtin_ffs((int)x) - 1) >> 3), 4), room);
+						pend |= ((uint32_t)(x == 0) & (uint32_t)(room > 4)) << i;
+					}
 					hv[i] = v.h;
 					tbw |= v.tb << (8 * i);
 				}
@@ -693,7 +741,7 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 				while (pend) {
 					const int32_t ii = __builtin_ctz(pend);
 					const int32_t hh = pick4(ii, hv[0], hv[1], hv[2], hv[3]);
-					int32_t n = 4;
+					int32_t n = FULLG;
 					const int32_t j = hh + 1, q = c0 + ii - 1 - tl + j, rm = min(tl - j, ql - q);
 					for (int trip = 0; n < rm; ++trip) {
 						if (trip == 4) { open |= 1u << ii; break; }
@@ -713,7 +761,7 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 						const int32_t ii = (int32_t)__builtin_ctz(bits);
 						const int32_t hh = __builtin_amdgcn_readlane(pick4(ii, hv[0], hv[1], hv[2], hv[3]), src);
 						const int32_t j = hh + 1, q = c0s + ii - 1 - tl + j, rm = min(tl - j, ql - q);
-						const int32_t n = run_wave_g(M, j, q, rm, 36);
+						const int32_t n = run_wave_g(M, j, q, rm, FULLG + 32);
 #pragma unroll
 						for (int i = 0; i < 4; ++i) nmat[i] = (ii == i && lane == src) ? n : nmat[i];
 					}
