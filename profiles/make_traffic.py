@@ -35,7 +35,7 @@ for key, (path, kerns, width) in SRC.items():
     cells = int(m.group(1)) if m else None
     note = (f"{path}: separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes over {', '.join(kerns)}, means per launch; "
             "bytes = 2048 x FETCH_SIZE + 1024 x WRITE_SIZE: the units measured on this device by profiles/micro/fetch_calib.hip "
-            "(kernels that move exactly 1 GiB with 4-, 8- and 16-byte coalesced accesses per lane: 2048 bytes per FETCH_SIZE unit at every "
+            "(kernels that move exactly 1 GiB with 2-, 4-, 8- and 16-byte coalesced accesses per lane: 2048 bytes per FETCH_SIZE unit at every "
             "width, 1024 per WRITE_SIZE unit; profiles/r03/fetch_calibration.txt) — the doubling MI355X_MICROARCH.md prescribes; "
             f"this kernel's row reads are {width} bytes per lane")
     out[key] = {

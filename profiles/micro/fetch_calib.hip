@@ -15,7 +15,7 @@ __global__ void read_kernel(const V *p, size_t n, uint32_t *sink)
 		const uint32_t *w = (const uint32_t*)&v;
 		for (unsigned k = 0; k < (sizeof(V) + 3) / 4; ++k) acc ^= sizeof(V) >= 4 ? w[k] : (uint32_t)*(const uint16_t*)&v;
 	}
-	if (acc == 0x12345678u) *sink = acc; // never true: keeps the loads
+	if (acc == 0x1234u) *sink = acc; // (practically) never true: keeps the loads
 }
 template <typename V>
 __global__ void write_kernel(V *p, size_t n)
