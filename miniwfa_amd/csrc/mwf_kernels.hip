@@ -342,6 +342,40 @@ __device__ __forceinline__ uint32_t probe4g(const PairMem &M, int32_t j, int32_t
 	return a ^ b;
 }
 
+// ---- packed 16-bit arithmetic on the codes of the 16-bit ring rows (two columns per register, one VOP3P instruction each)
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+#define MWF_BC(T, v) __builtin_bit_cast(T, v)
+__device__ __forceinline__ int32_t pk_maxu(int32_t a, int32_t b) { return MWF_BC(int32_t, __builtin_elementwise_max(MWF_BC(u16x2, a), MWF_BC(u16x2, b))); }
+__device__ __forceinline__ int32_t pk_minu(int32_t a, int32_t b) { return MWF_BC(int32_t, __builtin_elementwise_min(MWF_BC(u16x2, a), MWF_BC(u16x2, b))); }
+__device__ __forceinline__ int32_t pk_add(int32_t a, int32_t b) { return MWF_BC(int32_t, (u16x2)(MWF_BC(u16x2, a) + MWF_BC(u16x2, b))); }
+__device__ __forceinline__ int32_t pk_sub(int32_t a, int32_t b) { return MWF_BC(int32_t, (u16x2)(MWF_BC(u16x2, a) - MWF_BC(u16x2, b))); }
+__device__ __forceinline__ int32_t pk_subsat(int32_t a, int32_t b) { return MWF_BC(int32_t, __builtin_elementwise_sub_sat(MWF_BC(u16x2, a), MWF_BC(u16x2, b))); } // max(a - b, 0)
+__device__ __forceinline__ int32_t pk_mad(int32_t a, int32_t b, int32_t c)
+{
+	int32_t m;
+	asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(m) : "v"(a), "v"(b), "v"(c));
+	return m;
+}
+__device__ __forceinline__ int32_t pk_ne1(int32_t a, int32_t b) // 1 in every half where a != b
+{
+	int32_t m;
+	asm("v_xor_b32 %0, %1, %2\n\tv_pk_min_u16 %0, %0, 1 op_sel_hi:[1,0]" : "=&v"(m) : "v"(a), "v"(b));
+	return m;
+}
+__device__ __forceinline__ int32_t pk_nonzero_mask(int32_t x) // 0xffff in every half of x that is not zero
+{
+	int32_t m;
+	asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]\n\tv_pk_sub_i16 %0, 0, %0 op_sel_hi:[0,1]" : "=&v"(m) : "v"(x));
+	return m;
+}
+__device__ __forceinline__ int32_t both16(int32_t v) { return (int32_t)(((uint32_t)v << 16) | ((uint32_t)v & 0xffffu)); }
+// code + 1 for a live code (>= 2), 0 for a dead one (0, or the 1 a dead code picked up): the collapse of what outlives a penalty
+__device__ __forceinline__ int32_t pk_live_inc(int32_t x)
+{
+	const int32_t t = pk_subsat(x, 0x00010001);
+	return pk_mad(pk_minu(t, 0x00010001), 0x00020002, t);
+}
+
 // ---- 2-bit sequence copies in GLOBAL memory (the kernel with 16-bit ring rows, pairs of plain A/C/G/T): sixteen bases per dword, base j
 // at bits 2*(j & 15) of dword j >> 4.  The byte sequences of the pairs resident on an XCD (64 x 100 KB for the 50 kb configuration) do
 // not fit its 4 MB of L2 and every first probe of the match extension — two unaligned loads per cell — went out to the fabric (a third
@@ -443,7 +477,7 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 	auto rowp = [&](const int32_t *base, int32_t r) -> char* { return (char*)base + (((int64_t)r * A.W) << ESH); };
 	auto ld4 = [&](const char *row, int32_t c) -> Raw4 { return *(const Raw4*)(row + ((int64_t)c << ESH)); };
 	auto ld1 = [&](const char *row, int32_t c) -> int32_t {
-		if constexpr (H16) return dec16(*(const uint16_t*)(row + ((int64_t)c << 1)));
+		if constexpr (H16) return (int32_t)*(const uint16_t*)(row + ((int64_t)c << 1)); // (the code itself: the packed column code works on codes)
 		else return *(const int32_t*)(row + ((int64_t)c << 2));
 	};
 	auto unpack4 = [&](const Raw4 &v, int32_t *o) {
@@ -479,6 +513,7 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 	uint32_t *const t2 = H16 ? (uint32_t*)((char*)M.H + (((int64_t)P.nH * A.W) << 1)) : nullptr;
 	uint32_t *const q2 = H16 ? t2 + ((tl >> 4) + 2) : nullptr;
 	if constexpr (H16) {
+		if (ql > 65532) { R.status = ST_BAND_OVERFLOW; return R; } // (query indices are computed mod 2^16 as well)
 		uint32_t bad = pack2bit_global<T>(M.ts, tl, t2);
 		bad |= pack2bit_global<T>(M.qs, ql, q2);
 		if (__syncthreads_or(bad != 0)) { R.status = ST_BAND_OVERFLOW; return R; }
@@ -598,6 +633,186 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 			if (g + NW <= g_last) issue(g + NW, in_next);
 			const int32_t cb = g * kChunk, c0 = cb + 4 * lane;
 			const bool inner = cb >= ilo && cb + kChunk - 1 <= ihi; // uniform: no window test needed anywhere
+			if constexpr (H16) {
+				// ---- The 16-bit-ring kernel computes on the CODES, two columns per instruction: a register
+				// holds columns (c0,c1) [x] or (c2,c3) [y] as they lie in the rows; a live code is k + 3 >= 2, a dead one 0, the order of
+				// codes is the order of offsets, so the recurrence is v_pk_max_u16 and a "+1" that keeps dead dead (pk_live_inc).
+				const int32_t ONE = 0x00010001, TWO = 0x00020002;
+				int32_t HXx = (int32_t)in_cur.hx4.x, HXy = (int32_t)in_cur.hx4.y, O1x = (int32_t)in_cur.a4.x, O1y = (int32_t)in_cur.a4.y;
+				int32_t O2x = (int32_t)in_cur.b4.x, O2y = (int32_t)in_cur.b4.y, E1x = (int32_t)in_cur.e14.x, E1y = (int32_t)in_cur.e14.y;
+				int32_t F1x = (int32_t)in_cur.f14.x, F1y = (int32_t)in_cur.f14.y, E2x, E2y, F2x, F2y;
+				{
+					const Raw4 e = (LDS2 && prev_in_lds) ? ld4(lE2, c0 & cap_mask) : ld4(sE2, c0), f = (LDS2 && prev_in_lds) ? ld4(lF2, c0 & cap_mask) : ld4(sF2, c0);
+					E2x = (int32_t)e.x, E2y = (int32_t)e.y, F2x = (int32_t)f.x, F2y = (int32_t)f.y;
+				}
+				const int32_t ce = lane == 0 ? max(c0 - 1, 0) : c0 + 4;
+				int32_t va = in_cur.va, vb = in_cur.vb, vg1 = in_cur.vg1, vg2;
+				if (LDS2 && prev_in_lds) vg2 = lane == 0 ? e2_edge[epar ^ 1][(g - 1) & 63][1] : e2_edge[epar ^ 1][(g + 1) & 63][0];
+				else vg2 = ld1(lane == 0 ? sE2 : sF2, ce);
+				// local columns of the two registers' halves: x = (4l, 4l+1), y = (4l+2, 4l+3)
+				const int32_t RX = (int32_t)((uint32_t)(4 * lane) | (uint32_t)(4 * lane + 1) << 16), RY = pk_add(RX, TWO);
+				int32_t outx = 0, outy = 0; // 0xffff in the halves of columns outside [lo, hi]
+				if (!inner) { // reads outside a source window yield dead (what the reference's pads supply, miniwfa.c:96-99): dead is 0, so a mask is an AND
+					auto out_of = [&](int32_t wlo, int32_t whi, int32_t &mx, int32_t &my) { // halves of the columns outside [wlo, whi]
+						const int32_t lo_r = both16(min(max(wlo - cb, 0), 256)), hi_r1 = both16(min(max(whi - cb + 1, 0), 256));
+						mx = pk_nonzero_mask(pk_subsat(lo_r, RX) | pk_subsat(pk_add(RX, ONE), hi_r1));
+						my = pk_nonzero_mask(pk_subsat(lo_r, RY) | pk_subsat(pk_add(RY, ONE), hi_r1));
+					};
+					int32_t mx, my;
+					out_of(xlo, xhi, mx, my), HXx &= ~mx, HXy &= ~my;
+					out_of(alo, ahi, mx, my), O1x &= ~mx, O1y &= ~my;
+					out_of(blo, bhi, mx, my), O2x &= ~mx, O2y &= ~my;
+					out_of(p1lo, p1hi, mx, my), E1x &= ~mx, E1y &= ~my, F1x &= ~mx, F1y &= ~my;
+					out_of(p2lo, p2hi, mx, my), E2x &= ~mx, E2y &= ~my, F2x &= ~mx, F2y &= ~my;
+					out_of(lo, hi, outx, outy);
+					const int32_t cn = lane == 0 ? c0 - 1 : c0 + 4;
+					va = ((cn >= alo) & (cn <= ahi)) ? va : 0;
+					vb = ((cn >= blo) & (cn <= bhi)) ? vb : 0;
+					vg1 = ((cn >= p1lo) & (cn <= p1hi)) ? vg1 : 0;
+					vg2 = ((cn >= p2lo) & (cn <= p2hi)) ? vg2 : 0;
+				}
+				// neighbouring columns: the column to the left of (c0,c1) is (c-1,c0) — y of the lane to the left shifted in —, of (c2,c3): (c1,c2);
+				// to the right of (c0,c1): (c1,c2), of (c2,c3): (c3,c4).  Lane 0 / lane 63 take the neighbouring chunk's outer column (both halves of the fill).
+				const int32_t fa = both16(va), fb = both16(vb), fg1 = both16(vg1), fg2 = both16(vg2);
+				const int32_t O1Lx = __builtin_amdgcn_alignbit(O1x, from_left(O1y, fa), 16), O1M = __builtin_amdgcn_alignbit(O1y, O1x, 16), O1Ry = __builtin_amdgcn_alignbit(from_right(O1x, fa), O1y, 16);
+				const int32_t O2Lx = __builtin_amdgcn_alignbit(O2x, from_left(O2y, fb), 16), O2M = __builtin_amdgcn_alignbit(O2y, O2x, 16), O2Ry = __builtin_amdgcn_alignbit(from_right(O2x, fb), O2y, 16);
+				const int32_t E1Lx = __builtin_amdgcn_alignbit(E1x, from_left(E1y, fg1), 16), E1Ly = __builtin_amdgcn_alignbit(E1y, E1x, 16);
+				const int32_t E2Lx = __builtin_amdgcn_alignbit(E2x, from_left(E2y, fg2), 16), E2Ly = __builtin_amdgcn_alignbit(E2y, E2x, 16);
+				const int32_t F1Rx = __builtin_amdgcn_alignbit(F1y, F1x, 16), F1Ry = __builtin_amdgcn_alignbit(from_right(F1x, fg1), F1y, 16);
+				const int32_t F2Rx = __builtin_amdgcn_alignbit(F2y, F2x, 16), F2Ry = __builtin_amdgcn_alignbit(from_right(F2x, fg2), F2y, 16);
+				// ---- recurrence (dev::wf_cell, miniwfa.c:267-278)
+				int32_t e1x = pk_maxu(O1Lx, E1Lx), e1y = pk_maxu(O1M, E1Ly), e2x = pk_maxu(O2Lx, E2Lx), e2y = pk_maxu(O2M, E2Ly);
+				const int32_t pf1x = pk_maxu(O1M, F1Rx), pf1y = pk_maxu(O1Ry, F1Ry), pf2x = pk_maxu(O2M, F2Rx), pf2y = pk_maxu(O2Ry, F2Ry); // F before its + 1
+				int32_t f1x = pk_live_inc(pf1x), f1y = pk_live_inc(pf1y), f2x = pk_live_inc(pf2x), f2y = pk_live_inc(pf2y);
+				const int32_t mx_ = pk_live_inc(HXx), my_ = pk_live_inc(HXy);
+				int32_t hx_ = pk_maxu(pk_maxu(mx_, pk_maxu(e1x, e2x)), pk_maxu(f1x, f2x)), hy_ = pk_maxu(pk_maxu(my_, pk_maxu(e1y, e2y)), pk_maxu(f1y, f2y));
+				uint32_t tbw = 0;
+				if (WTB) { // the byte from the results (miniwfa.c:289-306), as in the packed band kernel: z = nm (1 + ne1 (2 + ne2 (2 nf1 - 1))) + extension bits
+					const int32_t NEG1 = (int32_t)0xffffffffu, EIGHT = 0x00080008, C16 = 0x00100010, C32 = 0x00200020, C64 = 0x00400040;
+					int32_t zx = pk_mad(pk_ne1(hx_, f1x), TWO, NEG1), zy = pk_mad(pk_ne1(hy_, f1y), TWO, NEG1);
+					zx = pk_mad(pk_ne1(hx_, e2x), zx, TWO), zy = pk_mad(pk_ne1(hy_, e2y), zy, TWO);
+					zx = pk_mad(pk_ne1(hx_, e1x), zx, ONE), zy = pk_mad(pk_ne1(hy_, e1y), zy, ONE);
+					zx = pk_mad(pk_ne1(hx_, mx_), zx, 0), zy = pk_mad(pk_ne1(hy_, my_), zy, 0);
+					zx = pk_mad(pk_ne1(e1x, O1Lx), EIGHT, zx), zy = pk_mad(pk_ne1(e1y, O1M), EIGHT, zy);
+					zx = pk_mad(pk_ne1(pf1x, O1M), C16, zx), zy = pk_mad(pk_ne1(pf1y, O1Ry), C16, zy);
+					zx = pk_mad(pk_ne1(e2x, O2Lx), C32, zx), zy = pk_mad(pk_ne1(e2y, O2M), C32, zy);
+					zx = pk_mad(pk_ne1(pf2x, O2M), C64, zx), zy = pk_mad(pk_ne1(pf2y, O2Ry), C64, zy);
+					tbw = __builtin_amdgcn_perm((uint32_t)zy, (uint32_t)zx, 0x06040200u); // bytes c0 c1 c2 c3 from the low bytes of the four halves
+				}
+				if (!inner) e1x &= ~outx, e1y &= ~outy, e2x &= ~outx, e2y &= ~outy, f1x &= ~outx, f1y &= ~outy, f2x &= ~outx, f2y &= ~outy, hx_ &= ~outx, hy_ &= ~outy;
+				// E/F of this penalty: final, store now
+				*(uint2*)(dE1 + ((int64_t)c0 << 1)) = make_uint2((uint32_t)e1x, (uint32_t)e1y);
+				*(uint2*)(dF1 + ((int64_t)c0 << 1)) = make_uint2((uint32_t)f1x, (uint32_t)f1y);
+				if (LDS2 && cur_in_lds) {
+					*(uint2*)(lE2 + ((int64_t)(c0 & cap_mask) << 1)) = make_uint2((uint32_t)e2x, (uint32_t)e2y);
+					*(uint2*)(lF2 + ((int64_t)(c0 & cap_mask) << 1)) = make_uint2((uint32_t)f2x, (uint32_t)f2y);
+					if (lane == 0) e2_edge[epar][g & 63][0] = (int32_t)((uint32_t)f2x & 0xffffu);
+					if (lane == 63) e2_edge[epar][g & 63][1] = (int32_t)((uint32_t)e2y >> 16);
+				} else {
+					*(uint2*)(dE2 + ((int64_t)c0 << 1)) = make_uint2((uint32_t)e2x, (uint32_t)e2y);
+					*(uint2*)(dF2 + ((int64_t)c0 << 1)) = make_uint2((uint32_t)f2x, (uint32_t)f2y);
+				}
+				// edge rule (miniwfa.c:325-326): H is the max of the five, so "any live" == "H live" == its code is not 0; one lane holds the edge column
+				uint32_t lv = 0;
+				if ((uint32_t)(lo - cb) < (uint32_t)kChunk) {
+					const int32_t rel = lo - cb, w = __builtin_amdgcn_readlane((rel & 2) ? hy_ : hx_, rel >> 2);
+					lv |= (((uint32_t)w >> ((rel & 1) ? 16 : 0)) & 0xffffu) ? 1u : 0u;
+				}
+				if ((uint32_t)(hi - cb) < (uint32_t)kChunk) {
+					const int32_t rel = hi - cb, w = __builtin_amdgcn_readlane((rel & 2) ? hy_ : hx_, rel >> 2);
+					lv |= (((uint32_t)w >> ((rel & 1) ? 16 : 0)) & 0xffffu) ? 2u : 0u;
+				}
+				// ---- lane geometry: j = k + 1 = code - 2 may reach rj = min(tl, ql - d); query index = j + d, d = c - 1 - tl (mod 2^16: the true value fits)
+				const int32_t x0 = min(cmax - c0, 65535), d0 = c0 - 1 - tl;
+				const int32_t Xx = (int32_t)(((uint32_t)x0 & 0xffffu) | (uint32_t)(x0 - 1) << 16), TLp = both16(tl);
+				const int32_t rjx = pk_minu(Xx, TLp), rjy = pk_minu(pk_sub(Xx, TWO), TLp);
+				const int32_t Dx = (int32_t)(((uint32_t)d0 & 0xffffu) | (uint32_t)(d0 + 1) << 16), Dy = pk_add(Dx, TWO);
+				uint32_t gbits = 0;
+				if (track_good) { // some array holds an in-matrix offset (miniwfa.c:139-142) <=> j <= rj for a live code (dead: j wraps to 65534)
+					auto bad = [&](int32_t v, int32_t rj) { return pk_subsat(pk_sub(v, TWO), rj); }; // zero iff good
+					const int32_t bx = pk_minu(pk_minu(bad(hx_, rjx), pk_minu(bad(e1x, rjx), bad(f1x, rjx))), pk_minu(bad(e2x, rjx), bad(f2x, rjx))) | outx;
+					const int32_t by = pk_minu(pk_minu(bad(hy_, rjy), pk_minu(bad(e1y, rjy), bad(f1y, rjy))), pk_minu(bad(e2y, rjy), bad(f2y, rjy))) | outy;
+					gbits = (uint32_t)((bx & 0xffff) == 0) | (uint32_t)(((uint32_t)bx >> 16) == 0) << 1 | (uint32_t)((by & 0xffff) == 0) << 2 | (uint32_t)(((uint32_t)by >> 16) == 0) << 3;
+				}
+				// ---- match extension, first probe (sixteen bases of the 2-bit copies): j clamped to rj makes room = rj - j zero for dead and phantom offsets
+				const int32_t jx_ = pk_minu(pk_sub(hx_, TWO), rjx), jy_ = pk_minu(pk_sub(hy_, TWO), rjy);
+				const int32_t iqx = pk_add(jx_, Dx), iqy = pk_add(jy_, Dy);
+				uint32_t cnt[4];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					const uint32_t J = (uint32_t)((u & 2) ? jy_ : jx_), Q = (uint32_t)((u & 2) ? iqy : iqx);
+					const int32_t j = (int32_t)((u & 1) ? J >> 16 : J & 0xffffu), q = (int32_t)((u & 1) ? Q >> 16 : Q & 0xffffu);
+					const uint32_t x = seq16g(t2, j) ^ seq16g(q2, q);
+					cnt[u] = (uint32_t)(__builtin_ffs((int)x) - 1) >> 1; // huge for "no difference"
+				}
+				typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+				const int32_t cx = MWF_BC(int32_t, (us2_t)__builtin_amdgcn_cvt_pk_u16(cnt[0], cnt[1])), cy = MWF_BC(int32_t, (us2_t)__builtin_amdgcn_cvt_pk_u16(cnt[2], cnt[3])); // saturating
+				const int32_t FULLp = both16(16);
+				const int32_t m9x = pk_minu(cx, pk_sub(rjx, jx_)), m9y = pk_minu(cy, pk_sub(rjy, jy_)); // > 16: the whole probe matched, room left
+				int32_t nmx = pk_minu(m9x, FULLp), nmy = pk_minu(m9y, FULLp);
+				const int32_t pendp = pk_subsat(m9x, FULLp) | pk_subsat(m9y, FULLp);
+				if (__ballot(pendp != 0)) { // a run of >= 16 matches continues: its lane walks it 8 bytes per trip for four trips, then the whole wave does
+					int32_t hv[4] = {(int32_t)((uint32_t)hx_ & 0xffffu) - 3, (int32_t)((uint32_t)hx_ >> 16) - 3, (int32_t)((uint32_t)hy_ & 0xffffu) - 3, (int32_t)((uint32_t)hy_ >> 16) - 3};
+					int32_t nmat[4] = {(int32_t)((uint32_t)nmx & 0xffffu), (int32_t)((uint32_t)nmx >> 16), (int32_t)((uint32_t)nmy & 0xffffu), (int32_t)((uint32_t)nmy >> 16)};
+					uint32_t pend = (uint32_t)(((uint32_t)m9x & 0xffffu) > 16u) | (uint32_t)(((uint32_t)m9x >> 16) > 16u) << 1 | (uint32_t)(((uint32_t)m9y & 0xffffu) > 16u) << 2 | (uint32_t)(((uint32_t)m9y >> 16) > 16u) << 3;
+					uint32_t open = 0;
+					while (pend) {
+						const int32_t ii = __builtin_ctz(pend);
+						const int32_t hh = pick4(ii, hv[0], hv[1], hv[2], hv[3]);
+						int32_t n = 16;
+						const int32_t j = hh + 1, q = c0 + ii - 1 - tl + j, rm = min(tl - j, ql - q);
+						for (int trip = 0; n < rm; ++trip) {
+							if (trip == 4) { open |= 1u << ii; break; }
+							const uint64_t x = ld8(M.ts + j + n) ^ ld8(M.qs + q + n);
+							if (x) { n += (int32_t)(__builtin_ctzll(x) >> 3); break; }
+							n += 8;
+						}
+						n = min(n, rm);
+#pragma unroll
+						for (int i = 0; i < 4; ++i) nmat[i] = ii == i ? n : nmat[i];
+						pend &= pend - 1;
+					}
+					for (unsigned long long owners = __ballot(open != 0); owners; owners &= owners - 1) {
+						const int32_t src = (int32_t)__builtin_ctzll(owners);
+						const int32_t c0s = cb + 4 * src;
+						for (uint32_t bits = (uint32_t)__builtin_amdgcn_readlane((int32_t)open, src); bits; bits &= bits - 1) {
+							const int32_t ii = (int32_t)__builtin_ctz(bits);
+							const int32_t hh = __builtin_amdgcn_readlane(pick4(ii, hv[0], hv[1], hv[2], hv[3]), src);
+							const int32_t j = hh + 1, q = c0s + ii - 1 - tl + j, rm = min(tl - j, ql - q);
+							const int32_t n = run_wave_g(M, j, q, rm, 48);
+#pragma unroll
+							for (int i = 0; i < 4; ++i) nmat[i] = (ii == i && lane == src) ? n : nmat[i];
+						}
+					}
+					nmx = (int32_t)(((uint32_t)nmat[0] & 0xffffu) | (uint32_t)nmat[1] << 16), nmy = (int32_t)(((uint32_t)nmat[2] & 0xffffu) | (uint32_t)nmat[3] << 16);
+				}
+				const int32_t hxx = pk_add(hx_, nmx), hxy = pk_add(hy_, nmy); // extended
+				// termination test of the extension sweep (miniwfa.c:405-409): only column ql+1 can hold the end cell
+				uint32_t fin = 0;
+				int32_t done_info = 0;
+				if (cfin >= cb && cfin < cb + kChunk && cfin >= lo && cfin <= hi) { // uniform
+					const int32_t rel = cfin - cb, sh16 = (rel & 1) ? 16 : 0;
+					const int32_t hv = (int32_t)(((uint32_t)((rel & 2) ? hxy : hxx) >> sh16) & 0xffffu) - 3, nm = (int32_t)(((uint32_t)((rel & 2) ? nmy : nmx) >> sh16) & 0xffffu);
+					fin = (uint32_t)(lane == (rel >> 2)) & (uint32_t)(hv == tl - 1) & inm_bit(ql - tl, hv - nm, tl, ql);
+					done_info = (fin && nm == 0) ? (int32_t)((tbw >> (8 * (rel & 3))) & 7u) : 0;
+				}
+				*(uint2*)(dH + ((int64_t)c0 << 1)) = make_uint2((uint32_t)hxx, (uint32_t)hxy);
+				if (TB && c0 >= origin && c0 <= hi) *(uint32_t*)(M.tb + tb_used - origin + c0) = tbw;
+				if (track_good) {
+					unsigned long long *gword = M.good + (int64_t)newH * A.GW + (int64_t)g * 4;
+#pragma unroll
+					for (int i = 0; i < 4; ++i) {
+						const unsigned long long m = __ballot((gbits >> i) & 1u);
+						if (lane == 0) gword[i] = m;
+					}
+				}
+				if (lv & 1u) sh.flags[npar][0] = 1;   // uniform; every lane stores the same word
+				if (lv & 2u) sh.flags[npar][1] = 1;
+				if (__ballot(fin)) {
+					if (fin) sh.flags[npar][2] = 1, sh.flags[npar][3] = done_info;
+				}
+				continue;
+			}
 			int32_t hx[4], o1[6], o2[6], e1s[4], f1s[4], e2s[4], f2s[4];
 			o1[0] = o1[5] = o2[0] = o2[5] = 0;
 			unpack4(in_cur.hx4, hx), unpack4(in_cur.a4, o1 + 1), unpack4(in_cur.b4, o2 + 1), unpack4(in_cur.e14, e1s), unpack4(in_cur.f14, f1s);

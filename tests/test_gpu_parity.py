@@ -193,6 +193,34 @@ def test_generic_kernel_16_bit_ring_rows(oracle):
     assert res[0][:2] == res[1][:2] and res[0][2] == 0 and res[1][2] == 1 and res[0][0] + 52000 > 65532, res
 
 
+def test_generic_kernel_16_bit_ring_rows_fuzz(oracle):
+    """The 16-bit-ring kernel (packed recurrence on the codes, 2-bit sequence copies in device memory) on the fuzz pairs of
+    synth.fuzz_pairs — granular lengths, repeats, unrelated pairs that fill the whole matrix — plus one 9 kb unrelated pair that makes
+    the batch take the kernel's wide form: s, n_iter and CIGAR equal the oracle's; a pair outside plain ACGT comes back through the
+    32-bit rows."""
+    pairs = fuzz_pairs(43, 90, 2500)
+    rng = np.random.default_rng(1043)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    pairs.append((acgt[rng.integers(0, 4, 5200)].tobytes(), acgt[rng.integers(0, 4, 3900)].tobytes()))
+    pairs.append((pairs[5][0].replace(b"A", b"N", 1) if b"A" in pairs[5][0] else b"NNAC", pairs[5][1]))
+    for kw in (dict(), dict(flag=1)):
+        o = make_opt(**kw)
+        eng = mw.Engine(0)
+        eng.set("force_kind", 0), eng.set("ring16", 2)
+        b = eng.upload(PackedBatch(pairs))
+        b.align(mw.opt_init(**kw))
+        assert eng.stats().packed == 16
+        s, it, nc = b.results()
+        assert eng.stats().n_retries >= 1          # the pair with an N
+        for i, (t, q) in enumerate(pairs):
+            es, eit, ecig = oracle.align(t, q, o)
+            assert (int(s[i]), int(it[i])) == (es, eit), (kw, i, len(t), len(q))
+            if ecig is not None:
+                assert b.cigar(i, int(nc[i])).tolist() == ecig, (kw, i)
+        b.free()
+        eng.close()
+
+
 def test_generic_kernel_takes_16_bit_rows_for_big_batches():
     """Default admission of the 16-bit ring rows: a batch of at least as many long pairs as CUs takes them (stats.packed == 16),
     a small one does not, and both give what 32-bit rows give."""
