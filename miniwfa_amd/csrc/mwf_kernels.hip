@@ -43,11 +43,20 @@ namespace {
 // Flatten the shadow ring into the next snapshot and renumber it (reference wf_snapshot1, miniwfa.c:451-474).
 // Snapshot record in snap_meta, stride 4+4*NS ints: [arena offset lo, hi, penalty, n] then per array-slice
 // [penalty of the slice, first column, width, first index].  Array-slices are listed H slots, then E1, F1, E2, F2.
-template <int T>
-__device__ bool take_snapshot(const BatchArgs &A, const PairMem &M, Shared &sh, int32_t n_snap, int64_t &snap_used,
+template <typename ArgsT>
+__device__ __forceinline__ Penalty load_penalty(const ArgsT &A)
+{
+	Penalty P;
+	P.x = A.pen.x, P.oe1 = A.pen.oe1, P.e1 = A.pen.e1, P.oe2 = A.pen.oe2, P.e2 = A.pen.e2, P.o1 = A.pen.o1, P.o2 = A.pen.o2;
+	P.nH = A.pen.nH, P.n1 = A.pen.n1, P.n2 = A.pen.n2;
+	return P;
+}
+
+template <int T, typename ArgsT>
+__device__ bool take_snapshot(const ArgsT &A, const PairMem &M, Shared &sh, int32_t n_snap, int64_t &snap_used,
                               int32_t s, int32_t curH, int32_t cur1, int32_t cur2)
 {
-	const Penalty &P = A.pen;
+	const Penalty P = load_penalty(A);
 	const int32_t NS = P.nH + 2 * P.n1 + 2 * P.n2, MS = 4 + 4 * NS;
 	int32_t *meta = M.snap_meta + (int64_t)n_snap * MS;
 	if (threadIdx.x == 0) {
@@ -103,9 +112,10 @@ __device__ bool take_snapshot(const BatchArgs &A, const PairMem &M, Shared &sh, 
 }
 
 // Walk the provenance chain back through the snapshots (reference wf_traceback_seg, miniwfa.c:528-549). One thread.
-__device__ int32_t trace_checkpoints(const BatchArgs &A, const PairMem &M, int32_t n_snap, int32_t last)
+template <typename ArgsT>
+__device__ int32_t trace_checkpoints(const ArgsT &A, const PairMem &M, int32_t n_snap, int32_t last)
 {
-	const Penalty &P = A.pen;
+	const Penalty P = load_penalty(A);
 	const int32_t NS = P.nH + 2 * P.n1 + 2 * P.n2, MS = 4 + 4 * NS;
 	if (n_snap > A.seg_slot) return ST_SNAP_OVERFLOW;
 	for (int32_t j = n_snap - 1; j >= 0; --j) {
@@ -127,10 +137,10 @@ __device__ int32_t trace_checkpoints(const BatchArgs &A, const PairMem &M, int32
 // One forward pass over a pair.
 //   TB : store traceback bytes, honour checkpoints (core pass with MWF_F_CIGAR)
 //   SEG: low-memory first pass (shadow ring + snapshots, no traceback bytes, no stop rules, miniwfa.c:569-589)
-template <int T, bool TB, bool SEG>
-__device__ PassResult forward_pass(const BatchArgs &A, const PairMem &M, Shared &sh, int32_t n_seg, bool trace_band)
+template <int T, bool TB, bool SEG, typename ArgsT>
+__device__ PassResult forward_pass(const ArgsT &A, const PairMem &M, Shared &sh, int32_t n_seg, bool trace_band)
 {
-	const Penalty &P = A.pen;
+	const Penalty P = load_penalty(A);
 	const int32_t tl = M.tl, ql = M.ql, cmax = tl + ql + 1; // columns 1..cmax hold diagonals -tl..ql
 	const int32_t tid = threadIdx.x, lane = tid & 63, wave0 = tid & ~63;
 	const int64_t W = A.W;
@@ -467,14 +477,15 @@ extern __shared__ __attribute__((aligned(16))) int32_t lds_e2f2[];
 __device__ __forceinline__ int32_t dec16(uint32_t u) { return (int32_t)u - 3; }
 __device__ __forceinline__ uint32_t enc16(int32_t k) { return k < -1 ? 0u : (uint32_t)(k + 3); }
 
-template <int T, bool TB, bool LDS2, bool SEG = false, bool H16 = false>
-__device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &sh, int32_t n_seg, bool trace_band)
+template <int T, bool TB, bool LDS2, bool SEG = false, bool H16 = false, typename ArgsT = BatchArgs>
+__device__ PassResult stream_pass(const ArgsT &A, const PairMem &M, Shared &sh, int32_t n_seg, bool trace_band)
 {
 	static_assert(!(SEG && (TB || LDS2)), "the low-memory first pass stores no traceback and keeps every array in HBM");
 	static_assert(!(SEG && H16), "16-bit ring rows: not in the low-memory first pass");
 	using Raw4 = std::conditional_t<H16, uint2, int4>; // four columns of a ring row as they lie in memory
 	constexpr int ESH = H16 ? 1 : 2;                    // log2(bytes per element)
-	auto rowp = [&](const int32_t *base, int32_t r) -> char* { return (char*)base + (((int64_t)r * A.W) << ESH); };
+	const int64_t Wrow = A.W;
+	auto rowp = [&](const int32_t *base, int32_t r) -> char* { return (char*)base + (((int64_t)r * Wrow) << ESH); };
 	auto ld4 = [&](const char *row, int32_t c) -> Raw4 { return *(const Raw4*)(row + ((int64_t)c << ESH)); };
 	auto ld1 = [&](const char *row, int32_t c) -> int32_t {
 		if constexpr (H16) return (int32_t)*(const uint16_t*)(row + ((int64_t)c << 1)); // (the code itself: the packed column code works on codes)
@@ -500,7 +511,7 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 	constexpr int32_t kChunk = 256;
 	__shared__ int32_t e2_edge[2][64][2]; // [penalty parity][chunk mod 64]{first column's F2, last column's E2}
 	bool prev_in_lds = false; // where the previous penalty left its E2/F2
-	const Penalty &P = A.pen;
+	const Penalty P = load_penalty(A);
 	const int32_t tl = M.tl, ql = M.ql, cmax = tl + ql + 1;
 	const int32_t tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
 	const int64_t W = A.W;
@@ -510,7 +521,7 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 	// H16: 2-bit copies of the two sequences in the unused upper half of this slot's H rows (16-bit rows fill the lower half);
 	// a pair with any other byte goes back to the host like one whose offsets outgrow 16 bits and is re-run with 32-bit rows
 	constexpr int FULLG = H16 ? 16 : 4; // bases the first probe of the match extension looks at
-	uint32_t *const t2 = H16 ? (uint32_t*)((char*)M.H + (((int64_t)P.nH * A.W) << 1)) : nullptr;
+	uint32_t *const t2 = H16 ? (uint32_t*)((char*)M.H + (((int64_t)P.nH * Wrow) << 1)) : nullptr;
 	uint32_t *const q2 = H16 ? t2 + ((tl >> 4) + 2) : nullptr;
 	if constexpr (H16) {
 		if (ql > 65532) { R.status = ST_BAND_OVERFLOW; return R; } // (query indices are computed mod 2^16 as well)
@@ -543,7 +554,11 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 	int32_t s = 0, wf_lo = tl + 1, wf_hi = tl + 1;
 	int32_t curH = 0, cur1 = 0, cur2 = 0, par = 0, sid = 0;
 	int64_t cells = 0, tb_used = 0, snap_used = 0;
-	int32_t snap_ctr = A.step == 1 ? 0 : 1, n_snap = 0; // SEG: (s+1) % step, snapshots taken
+	const int32_t step_ = SEG ? A.step : 0;
+	const int64_t rows_slot = TB ? A.rows_slot : 0, tb_slot_bytes = TB ? A.tb_slot_bytes : 0;
+	const int64_t iter_limit = A.max_iter > 0 ? A.max_iter : INT64_MAX;
+	const int32_t s_limit = A.max_s > 0 ? A.max_s : INT32_MAX;
+	int32_t snap_ctr = step_ == 1 ? 0 : 1, n_snap = 0; // SEG: (s+1) % step, snapshots taken
 	const int32_t cfin = ql + 1; // the end cell (tl-1, ql-1) lies on diagonal ql-tl, i.e. in this column
 
 	for (;;) {
@@ -562,7 +577,7 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 				if (!take_snapshot<T>(A, M, sh, n_snap, snap_used, s, curH, cur1, cur2)) { R.status = ST_SNAP_OVERFLOW; break; }
 				++n_snap;
 			}
-			snap_ctr = snap_ctr + 1 == A.step ? 0 : snap_ctr + 1;
+			snap_ctr = snap_ctr + 1 == step_ ? 0 : snap_ctr + 1;
 		}
 		const int32_t s_new = s + 1;
 		const int32_t newH = curH + 1 == P.nH ? 0 : curH + 1;
@@ -572,8 +587,8 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 		const int32_t origin = lo & ~3;                     // traceback rows start on a dword: one 4-byte store per lane
 		const int32_t row_bytes = (hi | 3) - origin + 1;
 		if (TB) {
-			if (s_new - 1 >= A.rows_slot) { R.status = ST_ROWS_OVERFLOW; break; }
-			if (tb_used + row_bytes > A.tb_slot_bytes) { R.status = ST_TB_OVERFLOW; break; }
+			if (s_new - 1 >= rows_slot) { R.status = ST_ROWS_OVERFLOW; break; }
+			if (tb_used + row_bytes > tb_slot_bytes) { R.status = ST_TB_OVERFLOW; break; }
 		}
 		if (H16 && tl + s_new + 3 > 65532) { R.status = ST_BAND_OVERFLOW; break; } // an offset (a target index, or past the matrix by at most one per penalty) may no longer fit
 		// source slices (reference wf_next_prep, miniwfa.c:243-259) and their windows
@@ -612,7 +627,7 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 			const int32_t nn = npar + 1 == 3 ? 0 : npar + 1; // flags of the NEXT penalty (see forward_pass)
 			sh.flags[nn][0] = sh.flags[nn][1] = sh.flags[nn][2] = sh.flags[nn][3] = 0;
 			if (TB) M.row_off[s_new - 1] = tb_used, M.row_lo[s_new - 1] = origin;
-			if (trace_band && s_new - 1 < A.dbg_cap) M.dbg[2 * (s_new - 1)] = lo, M.dbg[2 * (s_new - 1) + 1] = hi;
+			if (trace_band && s_new - 1 < fresh(A).dbg_cap) M.dbg[2 * (s_new - 1)] = lo, M.dbg[2 * (s_new - 1) + 1] = hi;
 		}
 
 		const int32_t g_first = lo >> 8, g_last = hi >> 8;
@@ -799,7 +814,7 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 				*(uint2*)(dH + ((int64_t)c0 << 1)) = make_uint2((uint32_t)hxx, (uint32_t)hxy);
 				if (TB && c0 >= origin && c0 <= hi) *(uint32_t*)(M.tb + tb_used - origin + c0) = tbw;
 				if (track_good) {
-					unsigned long long *gword = M.good + (int64_t)newH * A.GW + (int64_t)g * 4;
+					unsigned long long *gword = M.good + (int64_t)newH * fresh(A).GW + (int64_t)g * 4;
 #pragma unroll
 					for (int i = 0; i < 4; ++i) {
 						const unsigned long long m = __ballot((gbits >> i) & 1u);
@@ -997,7 +1012,7 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 			st4(dH, c0, hv);
 			if (TB && c0 >= origin && c0 <= hi) *(uint32_t*)(M.tb + tb_used - origin + c0) = tbw;
 			if (track_good) {
-				unsigned long long *gword = M.good + (int64_t)newH * A.GW + (int64_t)g * 4;
+				unsigned long long *gword = M.good + (int64_t)newH * fresh(A).GW + (int64_t)g * 4;
 #pragma unroll
 				for (int i = 0; i < 4; ++i) {
 					const unsigned long long m = __ballot((gbits >> i) & 1u);
@@ -1024,12 +1039,12 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 		if ((s & 0xff) == 0) { // shrink (reference wf_stripe_shrink, miniwfa.c:144-171) on the interleaved good bits
 			if (tid == 0) sh.red[0] = 0x7fffffff, sh.red[1] = -1;
 			__syncthreads();
-			const int32_t gfirst = wf_lo >> 8, n_words = ((wf_hi >> 8) - gfirst + 1) * 4;
+			const int32_t gfirst = wf_lo >> 8, n_words = ((wf_hi >> 8) - gfirst + 1) * 4, GWc = fresh(A).GW;
 			for (int32_t q = tid; q < n_words; q += T) {
 				const int32_t gg = gfirst + (q >> 2), kq = q & 3, base = gg * kChunk;
 				unsigned long long m = 0;
 				for (int32_t j = 0; j < P.nH; ++j)
-					if (sh.rng_lo[j] <= sh.rng_hi[j] && sh.rng_lo[j] <= base + kChunk - 1 && sh.rng_hi[j] >= base) m |= M.good[(int64_t)j * A.GW + (int64_t)gg * 4 + kq];
+					if (sh.rng_lo[j] <= sh.rng_hi[j] && sh.rng_lo[j] <= base + kChunk - 1 && sh.rng_hi[j] >= base) m |= M.good[(int64_t)j * GWc + (int64_t)gg * 4 + kq];
 				m &= lane_mask4(base, kq, wf_lo, wf_hi);
 				if (m) {
 					atomicMin(&sh.red[0], base + 4 * (int32_t)__builtin_ctzll(m) + kq);
@@ -1042,7 +1057,7 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 			wf_lo = glo, wf_hi = ghi;
 		}
 		cells += hi - lo + 1;
-		if (!SEG && ((A.max_iter > 0 && cells > A.max_iter) || (A.max_s > 0 && s > A.max_s))) { // miniwfa.c:422-425
+		if (!SEG && (cells > iter_limit || s > s_limit)) { // miniwfa.c:422-425
 			R.status = ST_STOPPED;
 			break;
 		}
@@ -1058,8 +1073,8 @@ __device__ PassResult stream_pass(const BatchArgs &A, const PairMem &M, Shared &
 // STREAM: the four-columns-per-lane passes (two kernels rather than one, so that neither pays for the other's registers)
 // MODE: -1 score or traceback by A.want_cigar (one kernel for both); 0 / 1: a kernel for score-only / traceback alone, so that
 // neither pays for the other's registers (the kernels with E2/F2 in LDS, whose workgroups share a CU)
-template <int T, bool STREAM, bool LDS2, bool H16, int MODE>
-__device__ void align_pair(const BatchArgs &A, Shared &sh, int32_t slot, int32_t pair)
+template <int T, bool STREAM, bool LDS2, bool H16, int MODE, typename ArgsT>
+__device__ void align_pair(const ArgsT &A, Shared &sh, int32_t slot, int32_t pair)
 {
 	PairMem M;
 	pair_mem(A, slot, pair, M);
@@ -1089,16 +1104,19 @@ __device__ void align_pair(const BatchArgs &A, Shared &sh, int32_t slot, int32_t
 		else R = A.want_cigar ? forward_pass<T, true, false>(A, M, sh, n_seg, trace) : forward_pass<T, false, false>(A, M, sh, 0, trace);
 		status = R.status;
 	}
-	finish_pair(A, M, slot, pair, R, status, cells1);
+	finish_pair(fresh(A), M, slot, pair, R, status, cells1);
 }
 
 // Persistent workgroups: each pulls pairs from a shared counter until the batch is drained.
 // (H16: the kernel with 16-bit ring rows and a 64 KB LDS copy of E2/F2 — two 512-thread workgroups per CU, i.e. 128 VGPRs)
 template <int T, bool STREAM, bool LDS2 = false, bool H16 = false, int MODE = -1>
-__global__ __launch_bounds__(T, (H16 && T == 512) ? 4 : 1) void wfa_batch_kernel(const BatchArgs A)
+__global__ __launch_bounds__(T, (H16 && T == 512) ? 4 : 1) void wfa_batch_kernel(const BatchArgs)
 {
 	__shared__ Shared sh;
+	// the arguments are read from the kernarg segment where they are used (dev::kernel_args / dev::fresh), never held for the kernel's lifetime
+	KArgs &A0 = kernel_args();
 	for (;;) {
+		KArgs &A = fresh(A0);
 		if (threadIdx.x == 0) sh.item = (int32_t)atomicAdd(A.queue, 1);
 		__syncthreads();
 		const int32_t item = uni(sh.item);
