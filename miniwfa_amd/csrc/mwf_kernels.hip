@@ -352,6 +352,9 @@ __device__ __forceinline__ uint32_t probe4g(const PairMem &M, int32_t j, int32_t
 	return a ^ b;
 }
 
+#ifndef MWF_H16_RELAX
+#define MWF_H16_RELAX 1 // 16-bit-ring kernel: the last chunk's stores may cross the per-penalty barrier (0: drain everything)
+#endif
 // ---- packed 16-bit arithmetic on the codes of the 16-bit ring rows (two columns per register, one VOP3P instruction each)
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 #define MWF_BC(T, v) __builtin_bit_cast(T, v)
@@ -632,6 +635,7 @@ __device__ PassResult stream_pass(const ArgsT &A, const PairMem &M, Shared &sh, 
 
 		const int32_t g_first = lo >> 8, g_last = hi >> 8;
 		int32_t g = g_first + (wave - g_first % NW + NW) % NW; // this wave's first chunk of the window
+		const int32_t g_mine = g;
 		// what a chunk reads from HBM; the next chunk's loads are issued before the current chunk's arithmetic
 		struct ChunkIn { Raw4 hx4, a4, b4, e14, f14; int32_t va, vb, vg1; };
 		auto issue = [&](int32_t gq, ChunkIn &x) {
@@ -1026,8 +1030,21 @@ __device__ PassResult stream_pass(const ArgsT &A, const PairMem &M, Shared &sh, 
 			}
 		}
 		// rows written now are read by other waves from the next penalty on: drain, then one barrier
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		__syncthreads();
+		if constexpr (H16) {
+			// ... unless nothing written now is loaded before the penalty after next (every H lag and e1 >= 2, E2/F2 in LDS, no good
+			// bits for a shrink to read): the last chunk's youngest stores (vmcnt retires in issue order, and
+			// every load of this penalty has been waited for) may then stay in flight across this barrier — they are complete at the next
+			const bool relax = MWF_H16_RELAX && min(min(P.x, P.oe1), min(P.oe2, P.e1)) >= 2 && cur_in_lds && !track_good && g_mine <= g_last;
+			// (three: every chunk issues at least its E1, F1 and H stores, so whatever a wave leaves in flight here is older than the three
+			// youngest operations of its next penalty — or that penalty drains everything)
+			if (relax) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+			else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+			__builtin_amdgcn_s_barrier();
+			asm volatile("" ::: "memory");
+		} else {
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__syncthreads();
+		}
 
 		// ---- bookkeeping, identical on every thread
 		if (uni(sh.flags[npar][0])) wf_lo = lo;
