@@ -438,9 +438,12 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 		else busy = (int)act[0] + (int)act[1] + (K > 2 ? (int)act[K - 1] : 0) >= 2;
 #ifndef MWF_B2_NOPRIO
 		// One priority level per active chunk of the wave (0 ... 3), kept through the barrier and the next header: 18.4 -> 17.7 ms on
-		// 1024 x 10 kb against "two or more chunks: 3, else 0"; stepping it down as chunks complete 19.1, other maps 17.8 ... 18.3.
+		// 1024 x 10 kb against "two or more chunks: 3, else 0"; stepping it down as chunks complete 19.1, other maps 17.8 ... 18.3, one more
+		// level for a wave that walked a long run at the last penalty: no change.
 		if ((NW & (NW - 1)) == 0) {
-			const int32_t left = gspan + 1 - ((wave - ga) & (NW - 1)); // this wave holds ceil(left / NW) chunks
+			// this wave holds ceil(left / NW) chunks; the waves that hold the window's first or last chunk (masks, liveness) count one more (17.7 -> 17.45 ms)
+			const int32_t pos = (wave - ga) & (NW - 1);
+			const int32_t left = gspan + 1 - pos + ((pos == 0 || ((gb - wave) & (NW - 1)) == 0) ? NW : 0);
 			if (left > 2 * NW) __builtin_amdgcn_s_setprio(3);
 			else if (left > NW) __builtin_amdgcn_s_setprio(2);
 			else if (left > 0) __builtin_amdgcn_s_setprio(1);
