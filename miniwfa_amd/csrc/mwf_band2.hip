@@ -312,12 +312,13 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 #pragma unroll
 	for (int a = 0; a < D; ++a) epos[a] = a * kAge;
 
-	// ---- every row read before it is written must read as dead around the origin: the chunks a window can reach within nH penalties
+	// ---- every row read before it is written must read as dead around the origin: a slot that no penalty has written yet is only read
+	// during the first nH - 1 penalties, whose windows (and the columns next to them) stay within nH + 1 columns of the origin
 	{
-		const int32_t g0 = (tl + 1) >> 8;
-		for (int32_t q = tid; q < nH * 5 * 64; q += T) {
-			const int32_t row = q / 320, rem = q - row * 320, g = g0 - 2 + (rem >> 6);
-			if (g >= 0) *(int2*)(Hb + (size_t)((uint32_t)row * RS + (uint32_t)(g * 512 + (rem & 63) * 8 + 8))) = make_int2(kDeadPair, kDeadPair);
+		const int32_t reach = nH + 1 + 8, g_a = max(tl + 1 - reach, 0) >> 8, n_g = ((tl + 1 + reach) >> 8) - g_a + 1, per_row = n_g * 64;
+		for (int32_t q = tid; q < nH * per_row; q += T) {
+			const int32_t row = q / per_row, rem = q - row * per_row;
+			*(int2*)(Hb + (size_t)((uint32_t)row * RS + (uint32_t)(g_a * 512 + rem * 8 + 8))) = make_int2(kDeadPair, kDeadPair);
 		}
 	}
 	// ---- penalty 0 (reference wf_stripe_init, miniwfa.c:103-121) and its extension
