@@ -842,7 +842,10 @@ __global__ __launch_bounds__(T, T <= 512 ? ((TB && T < 512) ? 3 : 4) : 1) void w
 	constexpr int NWK = (T / 64) * K, D = (E1 > E2 ? E1 : E2) + 1;
 	// the arguments are read from the kernarg segment where they are used (dev::kernel_args / dev::fresh), never held for the kernel's lifetime
 	KArgs &A0 = kernel_args();
-	// the sequence copy starts at LDS offset 0; the bookkeeping words and the edge table sit behind it
+	// the sequence copy starts at LDS offset 0 (the probes' inline-asm reads take LDS byte addresses): true while this kernel has no
+	// static LDS — trap rather than compute on the wrong bytes should that ever change
+	if ((uint32_t)(uintptr_t)lds2 != 0u) __builtin_trap();
+	// the bookkeeping words and the edge table sit behind the sequence copy
 	typedef Band2Lds<D, NWK> LdsT;
 	const int32_t lds_seq = A0.band_lds_seq;
 	LdsT *const L = (LdsT*)(lds2 + lds_seq);
