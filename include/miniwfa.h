@@ -154,9 +154,9 @@ int32_t mwf_gpu_debug_band(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *op
  * "coop_spin_limit", "scalar_generic", "lds_e2", "seq2bit" (packed band kernel: 0 = always keep the byte-wise sequence copy; default 1:
  * pairs of plain A/C/G/T are held at 2 bits per base, any other pair is re-run byte-wise — batches built from HOST memory are classified
  * while they are packed and never take that re-run), "ring16" (generic kernel: 0 = always 32-bit ring rows; default 1: 16-bit rows — half
- * the HBM traffic — for batches of at least as many pairs as CUs while target length + penalty fits 16 bits, with 2-bit copies of the
+ * the HBM traffic — while target length + penalty fits 16 bits, with 2-bit copies of the
  * sequences in device memory; a pair that outgrows 16 bits or holds a byte outside A/C/G/T is re-run with 32-bit rows and byte probes;
- * 2: also for smaller batches), "ring16_block" (0, 512, 768);
+ * 2: the same), "ring16_block" (0, 512, 768);
  * whole-device (systolic) kernel: "lowmem_budget_mb" (low-memory mode: a first-pass traceback above this many MB switches to the two-pass
  * form whose first pass stores none; 0 = a quarter of the device), "sys_p" (penalties per hand-off block: 4, 8, 16; default 8),
  * "sys_c" (columns per lane: 0 = chosen per pass from the expected window, 1, 4), "coop_grid" (at most this many workgroups; 0 = one

@@ -448,9 +448,11 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 			// at most one per penalty), so they hold while target length + penalty < 65530: taken optimistically for pairs whose
 			// penalty would have to exceed an eighth of their length to break that; a pair that does comes back as
 			// ST_BAND_OVERFLOW and is re-run with 32-bit rows.  The LDS copy of E2/F2 is coded the same way: 64 KB instead of 128.
-			// Only where the kernel IS HBM-bound — every CU streaming a pair of its own: with fewer pairs than CUs the coding and
-			// decoding is pure overhead (64 x 50 kb: 88 ms against 73 ms).  ring16 = 2 forces it (tests).
-			ring16 = g->ring16 != 0 && !g->ring16_off_once && max_tl + max_len / 8 < 65500 && (n_items >= g->n_cu || g->ring16 == 2);
+			// Round 2 took them only for batches of at least as many pairs as CUs (with fewer the decoding and coding of the rows was pure
+			// overhead: 64 x 50 kb 88 ms against 73).  With the recurrence on the packed codes and 2-bit sequence copies the 16-bit kernel is
+			// the faster one at every batch size (profiles/ring16_small_batches.py: 8 pairs 63.8 against 67.4 ms, 64: 67.9 / 71.3, 200: 72.6 /
+			// 90.7; with traceback 67.6 / 77.8 ... 71.9 / 103.9): taken whenever the offsets fit.
+			ring16 = g->ring16 != 0 && !g->ring16_off_once && max_tl + max_len / 8 < 65500;
 			// 32-bit: one workgroup per CU either way (128 KB of LDS): twelve waves fit its 168-VGPR budget, 490 ms against 519 ms with eight
 			// 16-bit: 512 threads, two workgroups per CU (64 KB of LDS each, 128 VGPRs) — 354 ms on 1250 x 50 kb against 375 ms for
 			// 768 threads and one per CU (479 ms with 32-bit rows); with traceback the 512-thread copy spills too much: 768 (451 against 477 ms)

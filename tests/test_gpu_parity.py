@@ -133,28 +133,29 @@ def test_generic_kernel_wide_windows(oracle):
     pairs = [synth_pair(89992, 9000, 0.1), synth_pair(89993, 20000, 0.12)]
     expect = {flag: [oracle.align(t, q, make_opt(flag=flag)) for t, q in pairs] for flag in (0, 1)}
     assert max(h - l + 1 for l, h in oracle.band_trace(*pairs[1], make_opt())) > 16384
-    for lds in (1, 0):
+    for lds, r16 in ((1, 0), (1, 1), (0, 0)):   # 32-bit rows; 16-bit rows (the default: packed recurrence on the codes); everything in HBM
         eng = mw.Engine(0)
         eng.set("force_kind", 0)
         eng.set("lds_e2", lds)
+        eng.set("ring16", r16)
         for flag in (0, 1):
             b = eng.upload(PackedBatch(pairs))
             b.align(mw.opt_init(flag=flag))
             st = eng.stats()
-            assert (st.kernel_kind, st.block) == (0, 768 if lds else 512)
+            assert (st.kernel_kind, st.block, st.packed) == (0, (512 if r16 and not flag else 768) if lds else 512, 16 if r16 else 0)
             s, it, nc = b.results()
             for i in range(len(pairs)):
                 es, eit, ecig = expect[flag][i]
-                assert (int(s[i]), int(it[i])) == (es, eit), (lds, flag, i)
+                assert (int(s[i]), int(it[i])) == (es, eit), (lds, r16, flag, i)
                 if ecig is not None:
-                    assert b.cigar(i, int(nc[i])).tolist() == ecig, (lds, flag, i)
+                    assert b.cigar(i, int(nc[i])).tolist() == ecig, (lds, r16, flag, i)
             b.free()
         assert eng.stats().n_retries == 0
         eng.close()
 
 
 def test_generic_kernel_16_bit_ring_rows(oracle):
-    """The generic kernel's 16-bit ring rows (ring16; forced here with 2 — by default only batches of at least as many pairs as
+    """The generic kernel's 16-bit ring rows (ring16; 2 = 1 since round 3 — round 2 took them only for batches of at least as many pairs as
     CUs take them): same s, n_iter and CIGAR as with 32-bit rows on ragged 13-33 kb pairs (tl = 21000 puts a window edge on a
     chunk boundary: what outlives a penalty in LDS must be collapsed like the coded rows), the oracle's answers on the shortest
     ones, and a pair whose offsets outgrow 16 bits (target + penalty > 65532) comes back through the 32-bit rows."""
@@ -222,8 +223,8 @@ def test_generic_kernel_16_bit_ring_rows_fuzz(oracle):
 
 
 def test_generic_kernel_takes_16_bit_rows_for_big_batches():
-    """Default admission of the 16-bit ring rows: a batch of at least as many long pairs as CUs takes them (stats.packed == 16),
-    a small one does not, and both give what 32-bit rows give."""
+    """Default admission of the 16-bit ring rows: long pairs on the generic kernel take them (stats.packed == 16) whatever the batch
+    size (round 2: only batches of at least as many pairs as CUs), and give what 32-bit rows give."""
     pairs = [synth_pair(7400 + i, 12600 + 40 * (i % 11), 0.02) for i in range(300)]
     res = {}
     for r16, n in ((0, 300), (1, 300), (1, 40)):
@@ -236,7 +237,7 @@ def test_generic_kernel_takes_16_bit_rows_for_big_batches():
         b.free()
         eng.close()
     assert res[(0, 300)][3] == 0 and res[(0, 300)][2] == 0
-    assert res[(1, 300)][2] == 16 and res[(1, 40)][2] == 0
+    assert res[(1, 300)][2] == 16 and res[(1, 40)][2] == 16
     assert (res[(0, 300)][0] == res[(1, 300)][0]).all() and (res[(0, 300)][1] == res[(1, 300)][1]).all()
     assert (res[(0, 300)][0][:40] == res[(1, 40)][0]).all() and (res[(0, 300)][1][:40] == res[(1, 40)][1]).all()
 
@@ -673,6 +674,7 @@ def test_config5_shaped_batch_properties(oracle):
     CIGAR re-scores to s and consumes both sequences."""
     engine = mw.Engine(0)
     engine.set("force_kind", 0)   # (a dozen such pairs alone would go side by side on the whole-device kernel)
+    engine.set("ring16", 0)       # (32-bit ring rows: the default, 16-bit rows, is test_config5_default_kernel_at_full_pair_size)
     pairs = [synth_pair(60000 + i, 50000, 0.03) for i in range(12)]
     b = engine.upload(PackedBatch(pairs))
     b.align(mw.opt_init())
