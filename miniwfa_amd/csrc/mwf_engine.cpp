@@ -351,6 +351,13 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 	// (measured alternatives on the 1024 x 10 kb batch: 1024 threads x 2 chunks spills and runs 50 ms, 512 x 3 unpacked 49 ms, 768 x 2 42 ms)
 	const bool range_ok = can_packed && max_tl + max_bound < 32767;
 	if (!range_ok && !can_plain) return;
+	// Pairs too long for 16-bit offsets in the band kernel: the generic kernel with 16-bit ring rows (packed recurrence on the codes,
+	// round 3) is faster than the unpacked band kernel even where that one's span would hold the window (512 x 20 kb @ 1 %: 5.4 against
+	// 8.0 ms, 512 x 50 kb @ 0.3 %: 4.2 / 5.9) and does not come back with window overflows (1024 x 12 kb @ 5 %: 42 ms against 101 ms
+	// for the band attempt plus the re-run of 925 pairs; profiles/r03/mid_pairs_kernels.txt).  The unpacked band kernel stays for what
+	// the 16-bit rows cannot hold, and for forced geometries.
+	if (!range_ok && want_kind != 2 && g->block == 0 && g->ring16 != 0 && g->lds_e2 && !g->scalar_generic && P.e2 == 1 &&
+	    max_tl + max_len / 8 < 65500) return;
 	const bool cigar = (opt.flag & MWF_F_CIGAR) != 0;
 	if (range_ok) {
 		bg.packed = 1;
@@ -1231,7 +1238,10 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 			// A window cannot outgrow min(tl+ql+1, 2 x penalty bound + 3); in practice it stays far below tl+ql (a quarter of
 			// it at 5 % divergence), so a pair is also given to a small kernel when it is merely short — if its window does
 			// outgrow that span, finalize() moves it to the wide band kernel, and from there to the generic one.
-			if (packable && (window <= kBandMicroWindow || len + 1 <= 2 * (int64_t)(1 * 3 * 256))) c = 4;
+			// (a pair too long for the packed band kernel goes to the generic kernel with 16-bit ring rows where those apply: faster than
+			// the unpacked band kernel and no window overflows to re-run, see choose_kernel)
+			if (!packable && g->ring16 != 0 && g->lds_e2 && !g->scalar_generic && P0.e2 == 1 && (int64_t)b->h_tl[i] + len / 8 < 65500) c = 0;
+			else if (packable && (window <= kBandMicroWindow || len + 1 <= 2 * (int64_t)(1 * 3 * 256))) c = 4;
 			else if (packable && (window <= kBandTinyWindow || len + 1 <= 3 * (int64_t)(2 * 3 * 256))) c = 3;
 			else if (packable ? (window <= kBandSmallWindow || len + 1 <= 3 * (int64_t)(4 * 3 * 256)) : (plain_ok && window <= 8 * 256 - 256 - 64)) c = 2;
 			else if ((packable || plain_ok) && len + 1 <= 4 * (int64_t)(8 * 3 * 256)) c = 1;
