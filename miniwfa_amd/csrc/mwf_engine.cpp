@@ -1179,16 +1179,16 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	// a few long pairs: each one gets the whole device in turn
 	const Penalty P0 = make_penalty(*opt);
 	const int64_t coop_len = g->coop_min_len > 0 ? g->coop_min_len : 65536;
-	// The whole-device kernel takes time ~ (tl+ql) per pair — and several pairs fit side by side, each on its own group of
-	// workgroups; the generic kernel runs up to 256 pairs side by side in time ~ (tl+ql)^2.  Measured at 3 % divergence
-	// (profiles/few_long_pairs.py): 100 kb pairs 88 ms each against 250 ms for any number of them, 150 kb pairs 128 ms
-	// against 550 ms — the whole-device kernel wins while the batch has fewer than about (tl+ql)/70000 pairs per group.
+	// The whole-device kernel takes time ~ (tl+ql) per round of pairs side by side (each on its own group of workgroups); the generic kernel
+	// runs up to 256 (512) pairs at once in time ~ (tl+ql)^2.  Measured at 3 % divergence (profiles/few_long_pairs.py, round 3): 50 kb pairs
+	// 22 ms per round of 16 against 60 ms for any number of them on the generic kernel, 100 kb pairs 44 ms per round of 8 against 245 ms,
+	// 150 kb pairs 68 ms against 545 ms — the whole-device kernel wins while the batch needs fewer than about 2.7 (tl+ql)/100 000 rounds.
 	bool coop = g->force_kind == 1;
 	int n_cu_coop = 0;
 	if (coop || (g->force_kind < 0 && max_len >= coop_len && coop_supported(P0))) {
 		n_cu_coop = coop_grid_limit(g);
 		const int coop_side_by_side = n_cu_coop > 0 ? std::max(1, n_cu_coop / coop_group_size(n_cu_coop, max_len, false, sys_owned_cols(g->sys_p, 4))) : 1;
-		const int64_t coop_max_pairs = std::max<int64_t>(1, std::min<int64_t>(256, max_len / 70000 * coop_side_by_side));
+		const int64_t coop_max_pairs = std::max<int64_t>(1, std::min<int64_t>(256, std::max<int64_t>(1, max_len * 27 / 1000000) * coop_side_by_side));
 		coop = coop || b->n <= coop_max_pairs;
 	}
 	if (coop) {
