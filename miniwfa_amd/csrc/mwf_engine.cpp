@@ -1178,7 +1178,10 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	std::fill(b->h_flags.begin(), b->h_flags.end(), 0);
 	// a few long pairs: each one gets the whole device in turn
 	const Penalty P0 = make_penalty(*opt);
-	const int64_t coop_len = g->coop_min_len > 0 ? g->coop_min_len : 65536;
+	// (round 3: from 20 000 bases of target + query on, a batch of up to sixteen pairs is faster on the whole-device kernel than one
+	// workgroup per pair on any other — 1 x 12 kb 4.1 against 6.4 ms, 16 x 25 kb 11.5 / 20.5, 1 x 32 kb 9.6 / 26.1, a single 10 kb pair
+	// 3.4 against 5.8 ms on the packed band kernel; profiles/r03/few_long_pairs.txt)
+	const int64_t coop_len = g->coop_min_len > 0 ? g->coop_min_len : 20000;
 	// The whole-device kernel takes time ~ (tl+ql) per round of pairs side by side (each on its own group of workgroups); the generic kernel
 	// runs up to 256 (512) pairs at once in time ~ (tl+ql)^2.  Measured at 3 % divergence (profiles/few_long_pairs.py, round 3): 50 kb pairs
 	// 22 ms per round of 16 against 60 ms for any number of them on the generic kernel, 100 kb pairs 44 ms per round of 8 against 245 ms,
@@ -1188,7 +1191,8 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	if (coop || (g->force_kind < 0 && max_len >= coop_len && coop_supported(P0))) {
 		n_cu_coop = coop_grid_limit(g);
 		const int coop_side_by_side = n_cu_coop > 0 ? std::max(1, n_cu_coop / coop_group_size(n_cu_coop, max_len, false, sys_owned_cols(g->sys_p, 4))) : 1;
-		const int64_t coop_max_pairs = std::max<int64_t>(1, std::min<int64_t>(256, std::max<int64_t>(1, max_len * 27 / 1000000) * coop_side_by_side));
+		int64_t coop_max_pairs = std::max<int64_t>(1, std::min<int64_t>(256, std::max<int64_t>(1, max_len * 27 / 1000000) * coop_side_by_side));
+		if (max_len < 65536) coop_max_pairs = std::min<int64_t>(coop_max_pairs, 16); // (measured up to sixteen)
 		coop = coop || b->n <= coop_max_pairs;
 	}
 	if (coop) {
