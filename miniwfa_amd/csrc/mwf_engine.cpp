@@ -1181,7 +1181,8 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	// (round 3: from 20 000 bases of target + query on, a batch of up to sixteen pairs is faster on the whole-device kernel than one
 	// workgroup per pair on any other — 1 x 12 kb 4.1 against 6.4 ms, 16 x 25 kb 11.5 / 20.5, 1 x 32 kb 9.6 / 26.1, a single 10 kb pair
 	// 3.4 against 5.8 ms on the packed band kernel; profiles/r03/few_long_pairs.txt)
-	const int64_t coop_len = g->coop_min_len > 0 ? g->coop_min_len : 20000;
+	// (with traceback already from 15 000 on: 1 x 10 kb 5.1 against 7.2 ms on the packed band kernel, 16 x 8 kb 5.2 / 6.2)
+	const int64_t coop_len = g->coop_min_len > 0 ? g->coop_min_len : ((opt->flag & MWF_F_CIGAR) ? 15000 : 20000);
 	// The whole-device kernel takes time ~ (tl+ql) per round of pairs side by side (each on its own group of workgroups); the generic kernel
 	// runs up to 256 (512) pairs at once in time ~ (tl+ql)^2.  Measured at 3 % divergence (profiles/few_long_pairs.py, round 3): 50 kb pairs
 	// 22 ms per round of 16 against 60 ms for any number of them on the generic kernel, 100 kb pairs 44 ms per round of 8 against 245 ms,
