@@ -68,6 +68,8 @@ struct mwf_gpu_s {
 	int64_t coop_min_len = 0;
 	int64_t tb_budget_mb = 0;   // 0: automatic
 	int force_kind = -1;
+	int lane_chunks = 4;       // its window: 64-column chunks of LDS rows (1-4); a penalty only passes over the chunks the window has reached
+	int lane_max_len = 320;    // pairs whose longer sequence has at most this many bases try the one-diagonal-per-lane kernel first (0: never)
 	int band_pack = -1;        // int16-packed E/F registers in the band kernel: 0 never, otherwise whenever the value ranges allow
 	int ring16 = 1;            // generic kernel with E2/F2 in LDS: 16-bit ring rows in HBM while target length + penalty fits 16 bits (0: never)
 	int ring16_block = 0;      // its threads per workgroup (0: 512 score-only — two workgroups per CU with the 64 KB LDS copy —, 768 with traceback)
@@ -91,6 +93,7 @@ struct mwf_gpu_s {
 	void *pin = nullptr;
 	size_t pin_half = 0;
 	hipEvent_t pin_ev[2] = {nullptr, nullptr};
+	bool pin_busy[2] = {false, false}; // a copy out of that half may still be in flight (pin_ev tells)
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	bool ev_pending = false;
 	mwf_gpu_stats_t stats{};
@@ -225,6 +228,7 @@ int pin_reserve(mwf_gpu_t *g, size_t half)
 	half = std::min(std::max<size_t>(align_up(half, 4096), (size_t)64 << 10), kPinHalfMax);
 	if (g->pin && g->pin_half >= half) return 0;
 	HIP_TRY(g, hipStreamSynchronize(g->stream));
+	g->pin_busy[0] = g->pin_busy[1] = false;
 	if (g->pin) (void)hipHostFree(g->pin);
 	g->pin = nullptr, g->pin_half = 0;
 	HIP_TRY(g, hipHostMalloc(&g->pin, 2 * half, hipHostMallocDefault));
@@ -237,7 +241,10 @@ int pin_reserve(mwf_gpu_t *g, size_t half)
 struct Seg { const void *src; size_t len; }; // src == nullptr: `len` zero bytes
 
 // The concatenation of `segs` to device memory at `dst`: packed into the pinned halves by the host while the previous
-// half is on its way.  One copy for a call whose inputs fit a half.  Returns after the last copy completed.
+// half is on its way.  One copy for a call whose inputs fit a half — and then the call does not wait for it: the sources have
+// been read, everything that uses `dst` is ordered behind the copy on the engine's stream, and the half is only written again
+// once its event has fired (a single short pair: 17 us of upload down to the packing and the enqueue).  A longer upload
+// returns after its last copy completed.
 int upload_segments(mwf_gpu_t *g, char *dst, const std::vector<Seg> &segs)
 {
 	size_t total = 0;
@@ -246,10 +253,13 @@ int upload_segments(mwf_gpu_t *g, char *dst, const std::vector<Seg> &segs)
 	if (pin_reserve(g, total)) return -1;
 	const size_t half = g->pin_half;
 	size_t si = 0, so = 0, done = 0;
-	bool used[2] = {false, false};
-	for (int h = 0; done < total; h ^= 1) {
+	const bool one_copy = total <= half;
+	for (int h = g->pin_busy[0] && !g->pin_busy[1] ? 1 : 0; done < total; h ^= 1) {
 		char *buf = (char*)g->pin + (size_t)h * half;
-		if (used[h]) HIP_TRY(g, hipEventSynchronize(g->pin_ev[h]));
+		if (g->pin_busy[h]) {
+			HIP_TRY(g, hipEventSynchronize(g->pin_ev[h]));
+			g->pin_busy[h] = false;
+		}
 		size_t fill = 0;
 		while (fill < half && si < segs.size()) {
 			const size_t take = std::min(half - fill, segs[si].len - so);
@@ -260,10 +270,12 @@ int upload_segments(mwf_gpu_t *g, char *dst, const std::vector<Seg> &segs)
 		}
 		HIP_TRY(g, hipMemcpyAsync(dst + done, buf, fill, hipMemcpyHostToDevice, g->stream));
 		HIP_TRY(g, hipEventRecord(g->pin_ev[h], g->stream));
-		used[h] = true;
+		g->pin_busy[h] = true;
 		done += fill;
 	}
+	if (one_copy) return 0;
 	HIP_TRY(g, hipStreamSynchronize(g->stream));
+	g->pin_busy[0] = g->pin_busy[1] = false;
 	return 0;
 }
 
@@ -272,8 +284,10 @@ int download(mwf_gpu_t *g, void *dst, const void *src, size_t bytes)
 {
 	if (bytes == 0) return 0;
 	if (bytes <= kPinHalfMax && pin_reserve(g, bytes) == 0) {
+		// (an upload still on its way out of the pinned buffer is ahead of this copy on the stream)
 		HIP_TRY(g, hipMemcpyAsync(g->pin, src, bytes, hipMemcpyDeviceToHost, g->stream));
 		HIP_TRY(g, hipStreamSynchronize(g->stream));
+		g->pin_busy[0] = g->pin_busy[1] = false;
 		memcpy(dst, g->pin, bytes);
 		return 0;
 	}
@@ -318,7 +332,7 @@ constexpr int64_t kBandMicroWindow = (1 * 3 - 1) * 256 - 64, kBandTinyWindow = (
 
 struct Plan {
 	int kind = 0;              // 0: generic kernel, 2: band kernel
-	BandGeom band{0, 0, 0, 0, 0};
+	BandGeom band{0, 0, 0, 0, 0, 0};
 	int block = 256, grid = 1;
 	int32_t W = 0, GW = 0;
 	int64_t ring_slot_ints = 0, rows_slot = 0, tb_slot_bytes = 0, cig_scratch_slot = 0;
@@ -335,10 +349,15 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 	const bool low_mem = (opt.flag & MWF_F_CIGAR) && opt.step > 0;
 	// packed kernel (mwf_band2.hip): 16-bit offsets; unpacked kernel (mwf_band.hip): every H lag >= 2, long targets
 	const bool can_packed = band2_supported(P) && g->band_pack != 0, can_plain = band_supported(P);
+	if (geom_block == 32 && want_kind != 0 && !low_mem && lane_supported(P)) { // the short-pair class: one wave per pair, one diagonal per lane
+		BandGeom lg{64, 1, 64 * g->lane_chunks, lane_lds_bytes(P, g->lane_chunks, max_seq_lds), 0, 1};
+		pl.kind = 2, pl.band = lg;
+		return;
+	}
 	if (want_kind == 0 || low_mem || (!can_packed && !can_plain)) return;
 	const int64_t max_window = std::min<int64_t>(max_len + 1, 2 * max_bound + 3);
 	BandGeom bg;
-	bg.packed = 0, bg.seq2 = 0;
+	bg.packed = 0, bg.seq2 = 0, bg.lane = 0;
 	// Packed variants (E/F registers as int16 pairs): valid when no offset (a target index, plus at most one per penalty for
 	// offsets that ran past the matrix) and no penalty count can reach 32767.  They halve the state registers, which is
 	// what lets several workgroups share a CU — one pair's barrier phase then overlaps another's compute:
@@ -401,11 +420,12 @@ int cached_occupancy(mwf_gpu_t *g, const Penalty &P, const Plan &pl, int lds_e2_
 	uint64_t key;
 	if (pl.kind == 2)
 		key = 1ull | (uint64_t)pl.band.block << 4 | (uint64_t)(pl.band.packed == 1) << 16 | (uint64_t)(pl.band.lds_bytes > 0) << 17 | (uint64_t)pl.cigar << 18 |
-		      (uint64_t)(pl.band.seq2 != 0) << 3 | (uint64_t)P.e1 << 20 | (uint64_t)P.e2 << 28 | (uint64_t)pl.band.lds_bytes << 36;
+		      (uint64_t)(pl.band.seq2 != 0) << 3 | (uint64_t)(pl.band.lane != 0) << 2 | (uint64_t)P.e1 << 20 | (uint64_t)P.e2 << 28 | (uint64_t)pl.band.lds_bytes << 36;
 	else key = 2ull | (uint64_t)pl.block << 4 | (uint64_t)stream_pass << 16 | (uint64_t)ring16 << 17 | (uint64_t)lds_e2_cols << 20;
 	auto it = g->occ_cache.find(key);
 	if (it != g->occ_cache.end()) return it->second;
-	const int per = pl.kind == 2 ? (pl.band.packed ? band2_kernel_occupancy(P, pl.band, pl.cigar) : band_kernel_occupancy(P, pl.band, pl.cigar))
+	const int per = pl.kind == 2 && pl.band.lane ? lane_kernel_occupancy(pl.band.lds_bytes, pl.cigar)
+	              : pl.kind == 2 ? (pl.band.packed ? band2_kernel_occupancy(P, pl.band, pl.cigar) : band_kernel_occupancy(P, pl.band, pl.cigar))
 	                             : batch_kernel_occupancy(pl.block, stream_pass, lds_e2_cols, ring16);
 	g->occ_cache[key] = per;
 	return per;
@@ -476,6 +496,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	pl.W = (int32_t)((max_len + 3 + 255) / 256 * 256 + 512);
 	pl.GW = pl.W / 64 + 2;
 	pl.ring_slot_ints = (int64_t)(P.nH + 2 * P.n1 + 2 * P.n2) * pl.W;
+	if (pl.kind == 2 && pl.band.lane) pl.ring_slot_ints = 64; // its rings are in LDS
 	const size_t S = (size_t)pl.grid;
 
 	if (ensure(g, g->ring, S * pl.ring_slot_ints * 4)) return -1;
@@ -530,6 +551,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	a.scalar_generic = g->scalar_generic;
 	a.lds_e2_cols = lds_e2_cols;
 	a.ring16 = ring16 ? 1 : 0;
+	a.lane_chunks = g->lane_chunks;
 	a.pen = P;
 	a.want_cigar = pl.cigar ? 1 : 0;
 	a.step = pl.low_mem ? opt.step : 0;
@@ -556,7 +578,8 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	// HIP events bracket the kernel only: every workspace allocation above is already done
 	if (timed) HIP_TRY(g, hipEventRecord(g->ev0, g->stream));
 	std::shared_lock<std::shared_mutex> gate(g_dev_gate[g->device % kMaxDevices]); // not while a whole-device kernel runs
-	const int lrc = pl.kind == 2 ? (pl.band.packed ? launch_band2(a, pl.grid, pl.band, g->stream) : launch_band(a, pl.grid, pl.band, g->stream))
+	const int lrc = pl.kind == 2 && pl.band.lane ? launch_lane(a, pl.grid, pl.band.lds_bytes, g->stream)
+	              : pl.kind == 2 ? (pl.band.packed ? launch_band2(a, pl.grid, pl.band, g->stream) : launch_band(a, pl.grid, pl.band, g->stream))
 	                             : launch_batch(a, pl.grid, pl.block, g->stream);
 	gate.unlock();
 	if (lrc != 0) {
@@ -570,7 +593,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	}
 	g->stats.n_launches += 1;
 	g->stats.grid = std::max(g->stats.grid, pl.grid), g->stats.block = pl.block, g->stats.kernel_kind = pl.kind;
-	g->stats.packed = pl.kind == 2 ? pl.band.packed : (ring16 ? 16 : 0);
+	g->stats.packed = pl.kind == 2 ? (pl.band.lane ? 32 : pl.band.packed) : (ring16 ? 16 : 0);
 	g->stats.lowmem_two_pass = pl.low_mem ? 1 : 0;
 	if (ran_kind) *ran_kind = pl.kind;
 	return 0;
@@ -1083,6 +1106,8 @@ int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value)
 	else if (!strcmp(name, "ring16")) g->ring16 = (int)value;
 	else if (!strcmp(name, "ring16_block") && (value == 0 || value == 512 || value == 768)) g->ring16_block = (int)value;
 	else if (!strcmp(name, "band_pack")) g->band_pack = (int)value;
+	else if (!strcmp(name, "lane_chunks") && value >= 1 && value <= 4) g->lane_chunks = (int)value;
+	else if (!strcmp(name, "lane_max_len")) g->lane_max_len = (int)std::max<int64_t>(0, std::min<int64_t>(value, 8000));
 	else if (!strcmp(name, "lds_e2")) g->lds_e2 = value != 0;
 	else if (!strcmp(name, "scalar_generic")) g->scalar_generic = value != 0;
 	else if (!strcmp(name, "coop_spin_limit")) g->coop_spin_limit = std::max<int64_t>(0, std::min<int64_t>(value, 0x7fffffff));
@@ -1229,7 +1254,9 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	const bool classes = g->force_kind < 0 && g->block == 0 && (band_supported(P0) || (band2_supported(P0) && g->band_pack != 0));
 	// groups 0-4: the size classes, 5: two-pass low-memory pairs, 6-9: classes 1-4 again for the pairs the host knows not to be
 	// plain A/C/G/T (byte-wise sequence copy from the start)
-	struct Group { std::vector<int32_t> ids; int64_t max_len = 0, max_bound = 0, max_bound1 = 0, max_tl = 0, max_seq_lds = 0; } grp[10];
+	// 10: short pairs on the one-diagonal-per-lane kernel (mwf_lane.hip); what outgrows its 64 columns moves to the band classes
+	struct Group { std::vector<int32_t> ids; int64_t max_len = 0, max_bound = 0, max_bound1 = 0, max_tl = 0, max_seq_lds = 0; } grp[11];
+	const bool lane_ok = g->lane_max_len > 0 && lane_supported(P0);
 	const bool know_acgt = !b->h_acgt.empty() && g->seq2bit != 0;
 	for (int32_t i = 0; i < b->n; ++i) {
 		const int64_t len = (int64_t)b->h_tl[i] + b->h_ql[i], bound = penalty_bound(*opt, b->h_tl[i], b->h_ql[i], true);
@@ -1253,6 +1280,10 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		}
 		b->h_class[i] = (int8_t)(c == 5 ? 0 : c);
 		b->h_flags[i] = (int8_t)(step0 ? 1 : 0);
+		// short pairs: a window of 64 diagonals holds them while the penalty stays below ~45 (a 200 bp pair at 5 %)
+		const bool to_lane = classes && lane_ok && c >= 1 && c <= 4 && std::max(b->h_tl[i], b->h_ql[i]) <= g->lane_max_len &&
+		                     std::abs(b->h_tl[i] - b->h_ql[i]) <= 24;
+		if (to_lane) c = 10, b->h_class[i] = 4;
 		if (c >= 1 && c <= 4 && know_acgt && !b->h_acgt[i] && (int64_t)b->h_tl[i] + bound < 32767 && g->band_pack != 0 && band2_supported(P0)) c += 5;
 		Group &G = grp[c];
 		G.ids.push_back(i);
@@ -1261,7 +1292,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		G.max_tl = std::max<int64_t>(G.max_tl, b->h_tl[i]);
 		G.max_seq_lds = std::max<int64_t>(G.max_seq_lds, (((int64_t)b->h_tl[i] + 3) & ~3LL) + 8 + (((int64_t)b->h_ql[i] + 3) & ~3LL) + 16);
 	}
-	static const int run_order[10] = {5, 0, 1, 6, 2, 7, 3, 8, 4, 9}; // largest workspace first
+	static const int run_order[11] = {5, 0, 1, 6, 2, 7, 3, 8, 4, 9, 10}; // largest workspace first
 	std::vector<int32_t> order;
 	order.reserve((size_t)b->n);
 	for (int c : run_order) {
@@ -1285,11 +1316,11 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		if (G.ids.empty()) continue;
 		++done_groups;
 		int ran = 0;
-		const int cc = c > 5 ? c - 5 : c;
-		g->acgt_off_once = c > 5;
+		const int cc = c == 10 ? 5 : c > 5 ? c - 5 : c;
+		g->acgt_off_once = c > 5 && c < 10;
 		const int rc = run_batch_kernel(g, b, c == 5 ? *opt : opt_hi, b->d_order + at, (int32_t)G.ids.size(), slots, G.max_len, G.max_bound, G.max_bound1,
 		                                done_groups == 1, classes ? (c == 0 || c == 5 ? 0 : 2) : -1, G.max_tl, G.max_seq_lds, done_groups == n_groups,
-		                                cc == 4 ? 64 : cc == 3 ? 128 : cc == 2 ? 256 : 0, &ran);
+		                                cc == 5 ? 32 : cc == 4 ? 64 : cc == 3 ? 128 : cc == 2 ? 256 : 0, &ran);
 		g->acgt_off_once = false;
 		if (rc) return -1;
 		for (int32_t i : G.ids) b->h_kind[i] = (int8_t)ran;

@@ -648,6 +648,44 @@ def test_packed_band_kernel_fuzz_against_oracle(block, oracle):
         eng.close()
 
 
+@pytest.mark.parametrize("chunks", [1, 2, 4])
+def test_lane_kernel_short_pairs_fuzz_against_oracle(chunks, oracle):
+    """The one-diagonal-per-lane kernel (mwf_lane.hip) takes pairs of up to `lane_max_len` bases first; what outgrows its
+    64 x `lane_chunks` columns is re-run on the band kernels.  Seeded fuzz (profiles/lane_kernel_probe.py runs more): corner-case
+    lengths, empty sequences, bytes outside ACGT, read-like pairs, several penalty sets (the kernel is not specialised on them),
+    max_s stops.  s, n_iter and CIGAR equal the oracle's."""
+    rng = np.random.default_rng(77 + chunks)
+    pairs = fuzz_pairs(31 + chunks, 90, 320)
+    pairs += [(b"", b""), (b"A", b""), (b"", b"ACGT"), (b"ACGT", b"ACGT"), (b"ACGTNNRYACGT" * 9, b"ACGTNNRYACGA" * 9), (b"A" * 300, b"A" * 290)]
+    pairs += [synth_pair(int(rng.integers(1 << 30)), int(rng.integers(60, 320)), float(rng.choice([0.01, 0.05, 0.1]))) for _ in range(60)]
+    pk = PackedBatch(pairs)
+    for kw in (dict(), dict(flag=1), dict(flag=1, o2=4, e2=2), dict(x=2, o1=3, e1=1, o2=6, e2=1), dict(flag=1, max_s=20)):
+        o = make_opt(**kw)
+        eng = mw.Engine(0)
+        eng.set("lane_chunks", chunks)
+        b = eng.upload(pk)
+        b.align(mw.opt_init(**kw))
+        s, it, nc = b.results()
+        st = eng.stats()
+        if "max_s" in kw:  # nothing outgrows the window before penalty 20: one launch, of the lane kernel
+            assert (st.n_retries, st.block, st.packed) == (0, 64, 32)
+        for i, (t, q) in enumerate(pairs):
+            es, eit, ecig = oracle.align(t, q, o)
+            assert (int(s[i]), int(it[i])) == (es, eit), (chunks, kw, i, len(t), len(q))
+            if ecig is not None and es >= 0:
+                assert b.cigar(i, int(nc[i])).tolist() == ecig, (chunks, kw, i)
+        b.free()
+        eng.close()
+    eng = mw.Engine(0)
+    eng.set("lane_max_len", 0)  # switched off: the band kernels take the short pairs
+    b = eng.upload(pk)
+    b.align(mw.opt_init(max_s=20))
+    b.results()
+    assert eng.stats().packed == 1
+    b.free()
+    eng.close()
+
+
 def test_full_size_batch_properties(engine, oracle):
     """BASELINE config 3 at full size (1024 x 10 kb, 5 %): spot-check against the oracle, and check the
     size-independent properties on every pair: CIGAR re-scores to s and consumes both sequences."""
