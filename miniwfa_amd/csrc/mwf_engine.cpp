@@ -68,6 +68,7 @@ struct mwf_gpu_s {
 	int64_t coop_min_len = 0;
 	int64_t tb_budget_mb = 0;   // 0: automatic
 	int force_kind = -1;
+	int res_pin_on = 1;        // small score-only batches: results written straight into pinned host memory (0: always copied back)
 	int lane_chunks = 4;       // its window: 64-column chunks of LDS rows (1-4); a penalty only passes over the chunks the window has reached
 	int lane_max_len = 320;    // pairs whose longer sequence has at most this many bases try the one-diagonal-per-lane kernel first (0: never)
 	int band_pack = -1;        // int16-packed E/F registers in the band kernel: 0 never, otherwise whenever the value ranges allow
@@ -93,6 +94,8 @@ struct mwf_gpu_s {
 	void *pin = nullptr;
 	size_t pin_half = 0;
 	hipEvent_t pin_ev[2] = {nullptr, nullptr};
+	void *res_pin = nullptr;            // 4 KB of pinned host memory the kernels write a small score-only batch's results into (no copy back)
+	const void *res_pin_owner = nullptr; // the batch whose result pointers currently lie in it
 	bool pin_busy[2] = {false, false}; // a copy out of that half may still be in flight (pin_ev tells)
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	bool ev_pending = false;
@@ -130,6 +133,7 @@ struct mwf_gpu_batch_s {
 	int32_t *d_status = nullptr, *d_s = nullptr, *d_ncig = nullptr, *d_dbg4 = nullptr;
 	int64_t *d_iter = nullptr, *d_cigoff = nullptr, *d_cells1 = nullptr;
 	size_t out_off = 0, out_bytes = 0;
+	bool out_in_pin = false;        // the result arrays lie in the engine's pinned result page (small score-only batches)
 	DevBuf cig;                     // CIGAR pool (allocated by the first CIGAR-mode align)
 	uint32_t *d_cig_pool = nullptr;
 	int64_t cig_pool_words = 0;
@@ -1084,6 +1088,7 @@ void mwf_gpu_destroy(mwf_gpu_t *g)
 	trim(g);
 	release(g, g->queue);
 	if (g->pin) (void)hipHostFree(g->pin);
+	if (g->res_pin) (void)hipHostFree(g->res_pin);
 	for (hipEvent_t e : {g->ev0, g->ev1, g->pin_ev[0], g->pin_ev[1]})
 		if (e) (void)hipEventDestroy(e);
 	if (g->own_stream) (void)hipStreamDestroy(g->stream);
@@ -1107,6 +1112,7 @@ int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value)
 	else if (!strcmp(name, "ring16_block") && (value == 0 || value == 512 || value == 768)) g->ring16_block = (int)value;
 	else if (!strcmp(name, "band_pack")) g->band_pack = (int)value;
 	else if (!strcmp(name, "lane_chunks") && value >= 1 && value <= 4) g->lane_chunks = (int)value;
+	else if (!strcmp(name, "host_results")) g->res_pin_on = value != 0;
 	else if (!strcmp(name, "lane_max_len")) g->lane_max_len = (int)std::max<int64_t>(0, std::min<int64_t>(value, 8000));
 	else if (!strcmp(name, "lds_e2")) g->lds_e2 = value != 0;
 	else if (!strcmp(name, "scalar_generic")) g->scalar_generic = value != 0;
@@ -1169,6 +1175,7 @@ void mwf_gpu_batch_free(mwf_gpu_batch_t *b)
 	mwf_gpu_t *g = b->g;
 	(void)hipSetDevice(g->device);
 	if (b->busy) (void)hipStreamSynchronize(g->stream); // kernels of an align nobody waited for may still use the block
+	if (g->res_pin_owner == b) g->res_pin_owner = nullptr;
 	give_block(g, g->spare_block, b->block);
 	give_block(g, g->spare_cig, b->cig);
 	delete b;
@@ -1185,6 +1192,22 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	g->stats = mwf_gpu_stats_t{};
 	if (b->n == 0) { b->aligned = b->finalized = true; return 0; }
 	const bool cigar = (opt->flag & MWF_F_CIGAR) != 0;
+	{ // Where the result arrays lie.  A small score-only batch (the single pair of a drop-in call) gets them in a page of pinned host
+	  // memory that the kernels write directly: results() then waits for the stream and reads them — no copy to enqueue and wait
+	  // for (a 200 bp call: ~8 us).  The CIGAR counter is device-side atomics: CIGAR-mode batches keep everything in the block.
+		const BlockLayout L = layout_block((size_t)b->n, 0, false); // (only differences between result offsets are used)
+		bool pin = g->res_pin_on && !cigar && b->n <= 64 && L.out_end - L.head <= 4096 && (g->res_pin_owner == nullptr || g->res_pin_owner == b);
+		if (pin && !g->res_pin && hipHostMalloc(&g->res_pin, 4096, hipHostMallocDefault) != hipSuccess) (void)hipGetLastError(), g->res_pin = nullptr, pin = false;
+		if (pin != b->out_in_pin || (pin && g->res_pin_owner != b)) {
+			if (b->busy) HIP_TRY(g, hipStreamSynchronize(g->stream)); // an align nobody waited for still writes the old arrays
+			char *base = pin ? (char*)g->res_pin - L.head : (char*)b->block.p + (b->out_off - L.head);
+			b->d_status = (int32_t*)(base + L.status), b->d_s = (int32_t*)(base + L.s), b->d_ncig = (int32_t*)(base + L.ncig);
+			b->d_iter = (int64_t*)(base + L.iter), b->d_cigoff = (int64_t*)(base + L.cigoff), b->d_cells1 = (int64_t*)(base + L.cells1);
+			if (g->res_pin_owner == b && !pin) g->res_pin_owner = nullptr;
+			if (pin) g->res_pin_owner = b;
+			b->out_in_pin = pin;
+		}
+	}
 	if (cigar && !b->d_cig_pool) {
 		if (take_block(g, g->spare_cig, b->cig, (size_t)b->cig_pool_words * 4)) return -1;
 		b->d_cig_pool = (uint32_t*)b->cig.p;
@@ -1349,7 +1372,11 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 	const BlockLayout L = layout_block(n, 0, false); // (only differences between result offsets are used)
 	auto fetch = [&]() -> int {
 		if (n == 0) { HIP_TRY(g, hipStreamSynchronize(g->stream)); return 0; }
-		if (download(g, host.data(), (const char*)b->block.p + b->out_off, b->out_bytes)) return -1;
+		if (b->out_in_pin) { // the kernels wrote the engine's pinned result page (score-only: no CIGAR words)
+			HIP_TRY(g, hipStreamSynchronize(g->stream));
+			memcpy(host.data(), g->res_pin, b->out_bytes);
+			memset(host.data(), 0, 8);
+		} else if (download(g, host.data(), (const char*)b->block.p + b->out_off, b->out_bytes)) return -1;
 		const char *o = host.data() - L.head;
 		memcpy(&b->cig_used, o + L.head, 8);
 		memcpy(b->h_status.data(), o + L.status, n * 4), memcpy(b->h_s.data(), o + L.s, n * 4), memcpy(b->h_ncig.data(), o + L.ncig, n * 4);
