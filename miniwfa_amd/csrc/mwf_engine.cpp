@@ -69,7 +69,7 @@ struct mwf_gpu_s {
 	int64_t tb_budget_mb = 0;   // 0: automatic
 	int force_kind = -1;
 	int res_pin_on = 1;        // small score-only batches: results written straight into pinned host memory (0: always copied back)
-	int lane_chunks = 4;       // its window: 64-column chunks of LDS rows (1-4); a penalty only passes over the chunks the window has reached
+	int lane_chunks = 0;       // its window: 64-column chunks of LDS rows (1-4; 0: three for pairs of up to 400 bases of target + query, else four); a penalty only passes over the chunks the window has reached
 	int lane_max_len = 320;    // pairs whose longer sequence has at most this many bases try the one-diagonal-per-lane kernel first (0: never)
 	int band_pack = -1;        // int16-packed E/F registers in the band kernel: 0 never, otherwise whenever the value ranges allow
 	int ring16 = 1;            // generic kernel with E2/F2 in LDS: 16-bit ring rows in HBM while target length + penalty fits 16 bits (0: never)
@@ -354,7 +354,11 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 	// packed kernel (mwf_band2.hip): 16-bit offsets; unpacked kernel (mwf_band.hip): every H lag >= 2, long targets
 	const bool can_packed = band2_supported(P) && g->band_pack != 0, can_plain = band_supported(P);
 	if (geom_block == 32 && want_kind != 0 && !low_mem && lane_supported(P)) { // the short-pair class: one wave per pair, one diagonal per lane
-		BandGeom lg{64, 1, 64 * g->lane_chunks, lane_lds_bytes(P, g->lane_chunks, max_seq_lds), 0, 1};
+		// The rows of all chunks are allocated whatever the window does, and LDS is what bounds the waves per CU (four chunks with the default
+		// penalties: 14.5 KB, eleven waves; three: thirteen).  Three hold penalties up to ~110: 40 000 x 150 bp @ 5 % 0.68 against 0.79 ms with one
+		// pair re-run, 20 000 x 200 bp 0.52 / 0.61 with ten, 20 000 x 150 bp @ 10 % 0.75 / 0.93 with 499 (profiles/r03/lane_kernel_probe.txt).
+		const int chunks = g->lane_chunks > 0 ? g->lane_chunks : max_len <= 400 ? 3 : 4;
+		BandGeom lg{64, 1, 64 * chunks, lane_lds_bytes(P, chunks, max_seq_lds), 0, 1};
 		pl.kind = 2, pl.band = lg;
 		return;
 	}
@@ -555,7 +559,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	a.scalar_generic = g->scalar_generic;
 	a.lds_e2_cols = lds_e2_cols;
 	a.ring16 = ring16 ? 1 : 0;
-	a.lane_chunks = g->lane_chunks;
+	a.lane_chunks = pl.kind == 2 && pl.band.lane ? pl.band.span / 64 : 0;
 	a.pen = P;
 	a.want_cigar = pl.cigar ? 1 : 0;
 	a.step = pl.low_mem ? opt.step : 0;
@@ -1111,7 +1115,7 @@ int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value)
 	else if (!strcmp(name, "ring16")) g->ring16 = (int)value;
 	else if (!strcmp(name, "ring16_block") && (value == 0 || value == 512 || value == 768)) g->ring16_block = (int)value;
 	else if (!strcmp(name, "band_pack")) g->band_pack = (int)value;
-	else if (!strcmp(name, "lane_chunks") && value >= 1 && value <= 4) g->lane_chunks = (int)value;
+	else if (!strcmp(name, "lane_chunks") && value >= 0 && value <= 4) g->lane_chunks = (int)value;
 	else if (!strcmp(name, "host_results")) g->res_pin_on = value != 0;
 	else if (!strcmp(name, "lane_max_len")) g->lane_max_len = (int)std::max<int64_t>(0, std::min<int64_t>(value, 8000));
 	else if (!strcmp(name, "lds_e2")) g->lds_e2 = value != 0;
