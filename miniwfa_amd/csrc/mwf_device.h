@@ -154,6 +154,8 @@ struct PairMem {
 	// traceback bytes laid out per epoch of 256 penalties and chunk slot (mwf_sys.hip); null: rows back to back (row_off / row_lo)
 	const int64_t *ep;
 	int32_t ep_ow, ep_p, ep_kw;
+	// rows of a fixed width that all start at the same column (mwf_lane.hip): byte of (row, col) at row * tb_stride + col - tb_left; 0: not this layout
+	int32_t tb_stride, tb_left;
 };
 
 // the traceback byte of (penalty row + 1, column col)
@@ -164,6 +166,7 @@ __device__ __forceinline__ uint32_t tb_byte(const PairMem &M, int32_t row, int32
 		const int32_t g = col / M.ep_ow;
 		return M.tb[base + ((int64_t)(row & 255) * (int32_t)(gn >> 32) + (g - (int32_t)(gn & 0xffffffff))) * M.ep_kw + (col - (g * M.ep_ow - M.ep_p))];
 	}
+	if (M.tb_stride) return M.tb[row * M.tb_stride + (col - M.tb_left)]; // (no row table to read first: one memory round trip per traceback step)
 	return M.tb[M.row_off[row] + (col - M.row_lo[row])];
 }
 
@@ -263,6 +266,7 @@ __device__ __forceinline__ void pair_mem(const ArgsT &A, int32_t slot, int32_t p
 	M.seg = A.seg ? A.seg + (int64_t)slot * 2 * A.seg_slot : 0;
 	M.dbg = A.dbg;
 	M.ep = 0, M.ep_ow = 0, M.ep_p = 0, M.ep_kw = 0;
+	M.tb_stride = 0, M.tb_left = 0;
 }
 
 // After the forward pass(es): traceback on the first wave, CIGAR into the pool, per-pair outputs.

@@ -519,6 +519,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 			worst = std::min(worst, (max_bound + 1) * std::min<int64_t>(max_len + 1, 2 * (int64_t)(opt.step + 2 * P.nH) + 8));
 		}
 		worst += 8 * (max_bound + 2);
+		if (pl.kind == 2 && pl.band.lane) worst = (std::min<int64_t>(max_bound, 256) + 2) * pl.band.span; // its rows: the span wide, fewer than 256 of them
 		// the device is only asked how much is free when the arena at hand cannot hold the worst case
 		int64_t per = worst;
 		if ((int64_t)g->tb.bytes < (int64_t)S * worst || g->tb_budget_mb > 0) per = std::min(per, std::max<int64_t>(tb_budget_bytes(g), (int64_t)g->tb.bytes) / (int64_t)S);
@@ -1380,7 +1381,27 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 			HIP_TRY(g, hipStreamSynchronize(g->stream));
 			memcpy(host.data(), g->res_pin, b->out_bytes);
 			memset(host.data(), 0, 8);
-		} else if (download(g, host.data(), (const char*)b->block.p + b->out_off, b->out_bytes)) return -1;
+			b->h_cig_valid = false;
+		} else {
+			// a small CIGAR-mode batch (the single pair of a drop-in call): the head of its CIGAR pool comes back with the results, one wait
+			// for both copies — when the pool's used part turns out to fit it, fetch_cigars() has nothing left to copy
+			const size_t spec = (b->opt.flag & MWF_F_CIGAR) && b->d_cig_pool && n <= 64 ? (size_t)std::min<int64_t>(b->cig_pool_words, 1024) : 0;
+			const size_t cig_at = align_up(b->out_bytes, 64);
+			b->h_cig_valid = false;
+			if (spec > 0 && pin_reserve(g, cig_at + spec * 4) == 0) {
+				HIP_TRY(g, hipMemcpyAsync(g->pin, (const char*)b->block.p + b->out_off, b->out_bytes, hipMemcpyDeviceToHost, g->stream));
+				HIP_TRY(g, hipMemcpyAsync((char*)g->pin + cig_at, b->d_cig_pool, spec * 4, hipMemcpyDeviceToHost, g->stream));
+				HIP_TRY(g, hipStreamSynchronize(g->stream));
+				g->pin_busy[0] = g->pin_busy[1] = false;
+				memcpy(host.data(), g->pin, b->out_bytes);
+				unsigned long long used = 0;
+				memcpy(&used, host.data(), 8);
+				if (used <= spec) {
+					b->h_cig.assign((const uint32_t*)((const char*)g->pin + cig_at), (const uint32_t*)((const char*)g->pin + cig_at) + used);
+					b->h_cig_valid = true; // (a re-run below fetches again and decides again)
+				}
+			} else if (download(g, host.data(), (const char*)b->block.p + b->out_off, b->out_bytes)) return -1;
+		}
 		const char *o = host.data() - L.head;
 		memcpy(&b->cig_used, o + L.head, 8);
 		memcpy(b->h_status.data(), o + L.status, n * 4), memcpy(b->h_s.data(), o + L.s, n * 4), memcpy(b->h_ncig.data(), o + L.ncig, n * 4);
@@ -1508,6 +1529,7 @@ int fetch_cigars(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 {
 	if (b->h_cig_valid) return 0;
 	if (int rc = finalize(g, b)) return rc;
+	if (b->h_cig_valid) return 0; // came back with the results (small batch)
 	b->h_cig.resize((size_t)std::max<int64_t>(b->cig_used, 0));
 	if (b->cig_used > 0 && download(g, b->h_cig.data(), b->d_cig_pool, (size_t)b->cig_used * 4)) return -1;
 	b->h_cig_valid = true;

@@ -18,7 +18,8 @@
 //     first band shrink);
 //   * a wave executes its LDS instructions in order and no other wave shares the rows: no barrier anywhere, one wave per workgroup;
 //   * both sequences sit in LDS (8-byte copies), the extension compares 8 bytes per trip;
-//   * the traceback bytes go to the slot's arena in the row layout the shared traceback reads (row_off / row_lo, mwf_device.h).
+//   * the traceback bytes go to the slot's arena as rows of 64 x chunks bytes that all start at the leftmost column: the shared
+//     traceback (mwf_device.h) finds a byte without reading a row table first — one memory round trip per step instead of two.
 // A pair whose window leaves the chunks, or that reaches the first shrink (penalty 256 - nH), comes back as ST_BAND_OVERFLOW and is
 // re-run on the packed band kernel (finalize(), mwf_engine.cpp).  Reference: wf_next_basic + wf_extend + the loop of mwf_wfa_core
 // (miniwfa.c:252-326, :380-430).
@@ -62,13 +63,14 @@ __device__ __forceinline__ int32_t lane_extend(const uint8_t *lt, const uint8_t 
 }
 
 template <bool TB, typename ArgsT>
-__device__ PassResult lane_pass(const ArgsT &A, const PairMem &M, int16_t *rows, const uint8_t *lt, const uint8_t *lq, bool trace_band)
+__device__ PassResult lane_pass(const ArgsT &A, PairMem &M, int16_t *rows, const uint8_t *lt, const uint8_t *lq, bool trace_band)
 {
 	const int32_t tl = M.tl, ql = M.ql, cmax = tl + ql + 1;
 	const int32_t lane = threadIdx.x;
 	const int32_t nH = A.pen.nH, lagx = A.pen.x, lag1 = A.pen.oe1, lag2 = A.pen.oe2, e1 = A.pen.e1, e2 = A.pen.e2, n1 = e1 + 1, n2 = e2 + 1;
-	const int32_t rows_slot = (int32_t)A.rows_slot, max_s = A.max_s, dbg_cap = A.dbg_cap;
-	const int64_t tb_slot_bytes = A.tb_slot_bytes, max_iter = A.max_iter;
+	const int32_t max_s = A.max_s, dbg_cap = A.dbg_cap;
+	const int64_t max_iter = A.max_iter;
+	const int32_t tb_slot_bytes = (int32_t)min(A.tb_slot_bytes, (int64_t)0x7fffffff);
 	const int32_t NC = A.lane_chunks, RL = row_ints(NC) * 2; // RL: int16 entries per row
 	const int32_t center = tl + 1, left = center - 32 * NC;   // entry 1 of a row is column `left`
 	int16_t *const Hr = rows, *const E1r = Hr + nH * RL, *const F1r = E1r + n1 * RL, *const E2r = F1r + n1 * RL, *const F2r = E2r + n2 * RL;
@@ -89,7 +91,9 @@ __device__ PassResult lane_pass(const ArgsT &A, const PairMem &M, int16_t *rows,
 
 	int32_t s = 0, wf_lo = tl + 1, wf_hi = tl + 1;
 	int32_t curH = 0, a1 = 0, a2 = 0; // H slot of penalty s; slots of the E1/F1 and E2/F2 rings penalty s wrote
-	int64_t cells = 0, tb_used = 0;
+	int64_t cells = 0;
+	int32_t tb_used = 0;
+	if (TB) M.tb_stride = 64 * NC, M.tb_left = left;
 	const int32_t s_shrink = 256 - nH; // the first penalty whose good bits a shrink would read (wf_stripe_shrink, miniwfa.c:144-171)
 	const int32_t cfin = ql + 1;       // the end cell (tl-1, ql-1) lies on diagonal ql-tl, i.e. this column
 	for (;;) {
@@ -103,13 +107,7 @@ __device__ PassResult lane_pass(const ArgsT &A, const PairMem &M, int16_t *rows,
 		const int32_t b1 = a1 + 1 == n1 ? 0 : a1 + 1, b2 = a2 + 1 == n2 ? 0 : a2 + 1;     // ring slots this penalty writes
 		int32_t r1 = b1 - e1; if (r1 < 0) r1 += n1;                                  // ... and reads: e1 (e2) penalties back
 		int32_t r2 = b2 - e2; if (r2 < 0) r2 += n2;
-		const int32_t origin = lo & ~3;
-		const int32_t row_bytes = (hi | 3) - origin + 1;
-		if (TB) {
-			if (s_new - 1 >= rows_slot) { R.status = ST_ROWS_OVERFLOW; break; }
-			if (tb_used + row_bytes > tb_slot_bytes) { R.status = ST_TB_OVERFLOW; break; }
-			if (lane == 0) M.row_off[s_new - 1] = tb_used, M.row_lo[s_new - 1] = origin;
-		}
+		if (TB && tb_used + 64 * NC > tb_slot_bytes) { R.status = ST_TB_OVERFLOW; break; }
 		if (trace_band && lane == 0 && s_new - 1 < dbg_cap) M.dbg[2 * (s_new - 1)] = lo, M.dbg[2 * (s_new - 1) + 1] = hi;
 		int32_t jx = newH - lagx; if (jx < 0) jx += nH;
 		int32_t j1 = newH - lag1; if (j1 < 0) j1 += nH;
@@ -133,7 +131,7 @@ __device__ PassResult lane_pass(const ArgsT &A, const PairMem &M, int16_t *rows,
 			const int32_t nmat = lane_extend(lt, lq, j, i, inm ? min(tl - j, ql - i) : 0);
 			const int32_t h = act ? max(v.h + nmat, kDead16) : kDead16;
 			Hr[newH * RL + idx] = (int16_t)h;
-			if (TB && act) M.tb[tb_used - origin + c] = (uint8_t)v.tb;
+			if (TB && act) M.tb[tb_used + (c - left)] = (uint8_t)v.tb;
 			// edge rule (miniwfa.c:325-326): H is the max of the five, so "any live" == "H live"
 			const uint32_t live = (uint32_t)(h >= -1);
 			// termination (miniwfa.c:405-409)
@@ -145,7 +143,7 @@ __device__ PassResult lane_pass(const ArgsT &A, const PairMem &M, int16_t *rows,
 		if (__ballot(flags & 2u)) wf_hi = hi;
 		const unsigned long long fm = __ballot(flags & 4u);
 		s = s_new, curH = newH, a1 = b1, a2 = b2;
-		if (TB) tb_used += row_bytes;
+		if (TB) tb_used += 64 * NC;
 		cells += hi - lo + 1;
 		if ((max_iter > 0 && cells > max_iter) || (max_s > 0 && s > max_s)) { // miniwfa.c:422-425
 			R.status = ST_STOPPED;
