@@ -21,7 +21,7 @@ Printed JSON (one line, rank 0): the driver contract fields plus
                  HBM fraction on the bytes the kernel itself must move and the VALU-issue fraction (what actually limits)
   cpu_baseline — the compiled reference (oracle/_ref, kind "reference") or our C restatement (kind "port")
                  on the host cores, bounded sample of the same batch (rank 0, N=1 only)
-  call_latency_us, long_pairs, peak_device_bytes, n_retries — extras (rank 0, N=1 only)
+  call_latency_us, short_reads, long_pairs, peak_device_bytes, n_retries — extras (rank 0, N=1 only)
 """
 from __future__ import annotations
 
@@ -108,6 +108,30 @@ def call_latency(mw, synth_pair, reps=40):
                     ref.align(t, q, ro)
                 rec["cpu_reference_us"] = (time.perf_counter() - t0) / n * 1e6
             out[f"{tl}bp_{label}"] = rec
+    return out
+
+
+def short_reads(mw, synth_pair, PackedBatch, reps=5):
+    """Batches of read-sized pairs at 5 % (score-only): Gbp/s from the library's HIP events around the kernels of one align call —
+    the one-wave-per-pair lane kernel (mwf_lane.hip); pairs whose window outgrows it are re-run on the band kernels (`re_run`,
+    outside the events)."""
+    out = {}
+    for n, tl in ((40000, 150), (20000, 250)):
+        pairs = [synth_pair(7000 + i, tl, 0.05) for i in range(n)]
+        bp = sum(len(t) + len(q) for t, q in pairs)
+        eng = mw.Engine(0)
+        b = eng.upload(PackedBatch(pairs))
+        o = mw.opt_init()
+        ms = []
+        for it in range(reps + 2):
+            b.align(o)
+            b.results()
+            if it >= 2:
+                ms.append(eng.stats().kernel_ms)
+        st = eng.stats()
+        out[f"{n}x{tl}bp"] = {"kernel_gbps": bp / (sum(ms) / len(ms)) / 1e6, "kernel_ms": sum(ms) / len(ms), "re_run": int(st.n_retries)}
+        b.free()
+        eng.close()
     return out
 
 
@@ -436,6 +460,10 @@ def main():
             out["call_latency_us"] = call_latency(mw, synth_pair)
         except Exception as e:  # never lose the headline line over the extras
             out["call_latency_us"] = {"error": repr(e)}
+        try:
+            out["short_reads"] = short_reads(mw, synth_pair, PackedBatch)
+        except Exception as e:
+            out["short_reads"] = {"error": repr(e)}
         if args.long_pairs and not strong:
             try:
                 out["long_pairs"] = long_pairs(mw, synth_pair, PackedBatch, cpu=args.cpu_sample > 0)
