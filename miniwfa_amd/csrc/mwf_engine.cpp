@@ -359,8 +359,10 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 		// pair re-run, 20 000 x 200 bp 0.52 / 0.61 with ten, 20 000 x 150 bp @ 10 % 0.75 / 0.93 with 499 (profiles/r03/lane_kernel_probe.txt).
 		const int chunks = g->lane_chunks > 0 ? g->lane_chunks : max_len <= 400 ? 3 : 4;
 		BandGeom lg{64, 1, 64 * chunks, lane_lds_bytes(P, chunks, max_seq_lds), 0, 1};
-		pl.kind = 2, pl.band = lg;
-		return;
+		if (lg.lds_bytes <= 60 * 1024) { // (deep rings — large gap-open costs — with a raised lane_max_len: the band classes below take the pairs)
+			pl.kind = 2, pl.band = lg;
+			return;
+		}
 	}
 	if (want_kind == 0 || low_mem || (!can_packed && !can_plain)) return;
 	const int64_t max_window = std::min<int64_t>(max_len + 1, 2 * max_bound + 3);

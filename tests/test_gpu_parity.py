@@ -686,6 +686,39 @@ def test_lane_kernel_short_pairs_fuzz_against_oracle(chunks, oracle):
     eng.close()
 
 
+def test_small_batches_share_the_pinned_result_page(oracle):
+    """Score-only batches of up to 64 pairs get their result arrays in ONE pinned host page per engine (no copy back); a second
+    batch alive on the same engine keeps its device arrays, a CIGAR-mode align of the owner moves it back to them, and uploads
+    that fit one pinned half are not waited for.  Whatever the placement, the results equal the oracle's."""
+    o = make_opt()
+    sets = [[synth_pair(900 + 10 * k + i, 120 + 37 * i, 0.05) for i in range(5)] for k in range(3)]
+    want = [[oracle.align(t, q, o)[:2] for t, q in ps] for ps in sets]
+    for host_results in (1, 0):
+        eng = mw.Engine(0)
+        eng.set("host_results", host_results)
+        bs = [eng.upload(PackedBatch(ps)) for ps in sets[:2]]       # two uploads back to back, neither waited for
+        for b in bs:
+            b.align(mw.opt_init())                                   # both enqueued before either is read
+        for b, w in zip(reversed(bs), reversed(want[:2])):           # read in the other order
+            s, it, _ = b.results()
+            assert [(int(x), int(y)) for x, y in zip(s, it)] == w
+        bs[0].align(mw.opt_init(flag=mw.MWF_F_CIGAR))                # the page's owner in CIGAR mode: back to its device arrays
+        s, it, nc = bs[0].results()
+        assert [(int(x), int(y)) for x, y in zip(s, it)] == want[0]
+        for i, (t, q) in enumerate(sets[0]):
+            assert bs[0].cigar(i, int(nc[i])).tolist() == oracle.align(t, q, make_opt(flag=1))[2]
+        bs[0].free()
+        b3 = eng.upload(PackedBatch(sets[2]))                        # the page is free again
+        for _ in range(2):
+            b3.align(mw.opt_init())
+            s, it, _ = b3.results()
+            assert [(int(x), int(y)) for x, y in zip(s, it)] == want[2]
+        bs[1].align(mw.opt_init())
+        s, it, _ = bs[1].results()
+        assert [(int(x), int(y)) for x, y in zip(s, it)] == want[1]
+        eng.close()
+
+
 def test_full_size_batch_properties(engine, oracle):
     """BASELINE config 3 at full size (1024 x 10 kb, 5 %): spot-check against the oracle, and check the
     size-independent properties on every pair: CIGAR re-scores to s and consumes both sequences."""
