@@ -9,7 +9,7 @@
 //     0-31 left, 32-63 right) — a window is symmetric around the main diagonal until the matrix clips it, so a narrow window costs
 //     one pass over the recurrence and a window of up to 64 x `lane_chunks` columns (2 by default: penalties up to ~78 with the
 //     default gap costs) is held;
-//   * the H ring (nH rows), the E1/F1 rings (e1 + 1 rows each) and the E2/F2 rings (e2 + 1 rows) are rows of int16 in LDS — offsets
+//   * the H ring (nH rows), the E1/F1 rings (e1 rows each) and the E2/F2 rings (e2 rows) are rows of int16 in LDS — offsets
 //     of pairs this short fit, a dead cell is stored as max(v, -32768) exactly as in the packed band kernel — with one pad column
 //     either side that always reads dead (reference pads, miniwfa.c:103-121); a lane reads its neighbours' columns straight from
 //     the rows, so any penalties are served (no template on e1/e2) and no cross-lane shuffles are needed;
@@ -67,7 +67,7 @@ __device__ PassResult lane_pass(const ArgsT &A, PairMem &M, int16_t *rows, const
 {
 	const int32_t tl = M.tl, ql = M.ql, cmax = tl + ql + 1;
 	const int32_t lane = threadIdx.x;
-	const int32_t nH = A.pen.nH, lagx = A.pen.x, lag1 = A.pen.oe1, lag2 = A.pen.oe2, e1 = A.pen.e1, e2 = A.pen.e2, n1 = e1 + 1, n2 = e2 + 1;
+	const int32_t nH = A.pen.nH, lagx = A.pen.x, lag1 = A.pen.oe1, lag2 = A.pen.oe2, e1 = A.pen.e1, e2 = A.pen.e2, n1 = e1, n2 = e2;
 	const int32_t max_s = A.max_s, dbg_cap = A.dbg_cap;
 	const int64_t max_iter = A.max_iter;
 	const int32_t tb_slot_bytes = (int32_t)min(A.tb_slot_bytes, (int64_t)0x7fffffff);
@@ -90,7 +90,7 @@ __device__ PassResult lane_pass(const ArgsT &A, PairMem &M, int16_t *rows, const
 	if (k0 == tl - 1 && k0 == ql - 1) return R;
 
 	int32_t s = 0, wf_lo = tl + 1, wf_hi = tl + 1;
-	int32_t curH = 0, a1 = 0, a2 = 0; // H slot of penalty s; slots of the E1/F1 and E2/F2 rings penalty s wrote
+	int32_t curH = 0, a1 = 0, a2 = 0; // H slot of penalty s; slots of the E1/F1 and E2/F2 rings the next penalty reads (e1, e2 penalties old) and then overwrites
 	int64_t cells = 0;
 	int32_t tb_used = 0;
 	if (TB) M.tb_stride = 64 * NC, M.tb_left = left;
@@ -104,9 +104,7 @@ __device__ PassResult lane_pass(const ArgsT &A, PairMem &M, int16_t *rows, const
 		const int32_t k_use = max(lo < center ? (center - 1 - lo) >> 5 : 0, hi > center ? (hi - center) >> 5 : 0);
 		if (k_use >= NC || s_new >= s_shrink) { R.status = ST_BAND_OVERFLOW; break; }
 		const int32_t newH = curH + 1 == nH ? 0 : curH + 1;
-		const int32_t b1 = a1 + 1 == n1 ? 0 : a1 + 1, b2 = a2 + 1 == n2 ? 0 : a2 + 1;     // ring slots this penalty writes
-		int32_t r1 = b1 - e1; if (r1 < 0) r1 += n1;                                  // ... and reads: e1 (e2) penalties back
-		int32_t r2 = b2 - e2; if (r2 < 0) r2 += n2;
+		const int32_t b1 = a1, b2 = a2, r1 = a1, r2 = a2; // a ring of exactly e1 (e2) rows: the row read is the row overwritten
 		if (TB && tb_used + 64 * NC > tb_slot_bytes) { R.status = ST_TB_OVERFLOW; break; }
 		if (trace_band && lane == 0 && s_new - 1 < dbg_cap) M.dbg[2 * (s_new - 1)] = lo, M.dbg[2 * (s_new - 1) + 1] = hi;
 		int32_t jx = newH - lagx; if (jx < 0) jx += nH;
@@ -114,13 +112,25 @@ __device__ PassResult lane_pass(const ArgsT &A, PairMem &M, int16_t *rows, const
 		int32_t j2 = newH - lag2; if (j2 < 0) j2 += nH;
 		uint32_t flags = 0;    // per lane, over its chunks: 1 = the lo column and live, 2 = the hi column and live, 4 = the end cell, reached
 		int32_t fin_info = 0;
+		// The E/F row a chunk overwrites is the row the next chunk still reads at the two columns where their blocks touch: the old F of
+		// this chunk's first column (lane 0) and the old E of its last (lane 63) travel to the next chunk in scalars.
+		int32_t cE1 = 0, cE2 = 0, cF1 = 0, cF2 = 0;
 		for (int32_t k = 0; k <= k_use; ++k) {
 			const int32_t c = lane < 32 ? center - 32 * (k + 1) + lane : center + 32 * k + lane - 32;
 			const int32_t d = c - center, idx = c - left + 1;
 			// sources (reference wf_next_prep, miniwfa.c:252-257)
 			const int16_t *hx_row = Hr + jx * RL + idx, *o1_row = Hr + j1 * RL + idx, *o2_row = Hr + j2 * RL + idx;
 			const int32_t hx = hx_row[0], o1m = o1_row[-1], o1p = o1_row[1], o2m = o2_row[-1], o2p = o2_row[1];
-			const int32_t g1m = E1r[r1 * RL + idx - 1], g1p = F1r[r1 * RL + idx + 1], g2m = E2r[r2 * RL + idx - 1], g2p = F2r[r2 * RL + idx + 1];
+			int32_t g1m = E1r[r1 * RL + idx - 1], g1p = F1r[r1 * RL + idx + 1], g2m = E2r[r2 * RL + idx - 1], g2p = F2r[r2 * RL + idx + 1];
+			if (k > 0) { // lane 31: the column left of the previous chunk's first; lane 32: the column right of its last
+				g1p = lane == 31 ? cF1 : g1p, g2p = lane == 31 ? cF2 : g2p;
+				g1m = lane == 32 ? cE1 : g1m, g2m = lane == 32 ? cE2 : g2m;
+			}
+			if (k < k_use) {
+				const int32_t oE1 = E1r[r1 * RL + idx], oF1 = F1r[r1 * RL + idx], oE2 = E2r[r2 * RL + idx], oF2 = F2r[r2 * RL + idx];
+				cE1 = __builtin_amdgcn_readlane(oE1, 63), cE2 = __builtin_amdgcn_readlane(oE2, 63);
+				cF1 = __builtin_amdgcn_readlane(oF1, 0), cF2 = __builtin_amdgcn_readlane(oF2, 0);
+			}
 			const bool act = c >= lo && c <= hi;
 			const Cell v = wf_cell<TB>(hx, o1m, g1m, o2m, g2m, o1p, g1p, o2p, g2p);
 			E1r[b1 * RL + idx] = (int16_t)(act ? max(v.e1, kDead16) : kDead16), F1r[b1 * RL + idx] = (int16_t)(act ? max(v.f1, kDead16) : kDead16);
@@ -142,7 +152,8 @@ __device__ PassResult lane_pass(const ArgsT &A, PairMem &M, int16_t *rows, const
 		if (__ballot(flags & 1u)) wf_lo = lo;
 		if (__ballot(flags & 2u)) wf_hi = hi;
 		const unsigned long long fm = __ballot(flags & 4u);
-		s = s_new, curH = newH, a1 = b1, a2 = b2;
+		s = s_new, curH = newH;
+		a1 = a1 + 1 == n1 ? 0 : a1 + 1, a2 = a2 + 1 == n2 ? 0 : a2 + 1;
 		if (TB) tb_used += 64 * NC;
 		cells += hi - lo + 1;
 		if ((max_iter > 0 && cells > max_iter) || (max_s > 0 && s > max_s)) { // miniwfa.c:422-425
@@ -161,7 +172,7 @@ __global__ __launch_bounds__(64) void wfa_lane_kernel(const BatchArgs)
 	// the arguments are read from the kernarg segment where they are used (mwf_device.h): nothing of them stays in SGPRs across the penalties
 	KArgs &A = kernel_args();
 	const int32_t lane = threadIdx.x;
-	const int32_t n_rows = A.pen.nH + 2 * (A.pen.e1 + 1) + 2 * (A.pen.e2 + 1);
+	const int32_t n_rows = A.pen.nH + 2 * A.pen.e1 + 2 * A.pen.e2;
 	int16_t *rows = (int16_t*)lds_lane;
 	uint8_t *lt = lds_lane + (n_rows * row_ints(A.lane_chunks) * 4 + 15) / 16 * 16;
 	for (;;) {
@@ -195,7 +206,7 @@ bool lane_supported(const Penalty &p)
 // needs (tl rounded up to 8) + 16 + (ql rounded up to 8) + 32 bytes)
 int lane_lds_bytes(const Penalty &p, int chunks, int64_t seq_bytes)
 {
-	const int64_t rings = ((int64_t)(p.nH + 2 * (p.e1 + 1) + 2 * (p.e2 + 1)) * (32 * chunks + 2) * 4 + 15) / 16 * 16;
+	const int64_t rings = ((int64_t)(p.nH + 2 * p.e1 + 2 * p.e2) * (32 * chunks + 2) * 4 + 15) / 16 * 16;
 	return (int)((rings + seq_bytes + 64 + 15) / 16 * 16);
 }
 
