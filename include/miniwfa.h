@@ -161,7 +161,7 @@ int32_t mwf_gpu_debug_band(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *op
  * form whose first pass stores none; 0 = a quarter of the device), "sys_p" (penalties per hand-off block: 4, 8, 16; default 8),
  * "sys_c" (columns per lane: 0 = chosen per pass from the expected window, 1, 4), "coop_grid" (at most this many workgroups; 0 = one
  * per CU), "coop_launch" (default 1: launched through hipLaunchCooperativeKernel; 0: plain launch),
- * "lane_max_len" (default 320: pairs whose longer sequence has at most this many bases try the one-wave-per-pair lane kernel first; 0: never), "lane_chunks" (its window in 64-column chunks,
+ * "lane_max_len" (default 400: pairs whose longer sequence has at most this many bases try the one-wave-per-pair lane kernel first; 0: never), "lane_chunks" (its window in 64-column chunks,
  * 1-4; default 0: by pair length), "host_results" (default 1: a score-only batch of up to 64 pairs gets its result arrays in pinned host memory — the mwf_gpu_batch_dev_*() pointers then
  * point there, still readable from device code; 0: always device memory)}; "trim" frees the engine's workspace pools (they grow back on demand). */
 int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value);

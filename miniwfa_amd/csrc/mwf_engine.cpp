@@ -70,7 +70,8 @@ struct mwf_gpu_s {
 	int force_kind = -1;
 	int res_pin_on = 1;        // small score-only batches: results written straight into pinned host memory (0: always copied back)
 	int lane_chunks = 0;       // its window: 64-column chunks of LDS rows (1-4; 0: three for pairs of up to 400 bases of target + query, else four); a penalty only passes over the chunks the window has reached
-	int lane_max_len = 320;    // pairs whose longer sequence has at most this many bases try the one-diagonal-per-lane kernel first (0: never)
+	int lane_max_len = 400;    // (measured: 20 000 x 400 bp @ 5 % 1.37 against 1.58 ms with 767 pairs re-run, x 500 bp @ 2 % 0.69 / 1.17, profiles/r03/lane_longer_pairs.txt)
+	                           // pairs whose longer sequence has at most this many bases try the one-diagonal-per-lane kernel first (0: never)
 	int band_pack = -1;        // int16-packed E/F registers in the band kernel: 0 never, otherwise whenever the value ranges allow
 	int ring16 = 1;            // generic kernel with E2/F2 in LDS: 16-bit ring rows in HBM while target length + penalty fits 16 bits (0: never)
 	int ring16_block = 0;      // its threads per workgroup (0: 512 score-only — two workgroups per CU with the 64 KB LDS copy —, 768 with traceback)
