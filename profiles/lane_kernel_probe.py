@@ -13,10 +13,10 @@ n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 rng = np.random.default_rng(5)
 bad = 0
 for seed in range(n_seeds):
-    pairs = fuzz_pairs(100 + seed, 150, 320)
+    pairs = fuzz_pairs(100 + seed, 150, 400 if seed % 2 else 320)
     pairs += [(b"", b""), (b"A", b""), (b"", b"ACGT"), (b"ACGT", b"ACGT"), (b"ACGTNNRYACGT" * 9, b"ACGTNNRYACGA" * 9), (b"A" * 300, b"A" * 290)]
     for _ in range(30):  # read-like: 5 % divergence, 100-300 bp
-        pairs.append(synth_pair(int(rng.integers(1 << 30)), int(rng.integers(100, 300)), 0.05))
+        pairs.append(synth_pair(int(rng.integers(1 << 30)), int(rng.integers(100, 400)), 0.05))
     pk = PackedBatch(pairs)
     for kw in (dict(), dict(flag=1), dict(flag=1, o2=4, e2=2), dict(x=2, o1=3, e1=1, o2=6, e2=1), dict(flag=1, x=6, o1=5, e1=3, o2=20, e2=2), dict(flag=1, max_s=20)):
         o = make_opt(**kw)
