@@ -3,7 +3,12 @@
 
     python bench.py --gpus N --steps K --warmup W                 # BASELINE configs[2]: 1024 x 10 kb per GPU, weak scaling
     python bench.py --config 5 --gpus N --steps K --warmup W      # BASELINE configs[4]: 10 000 x 50 kb in total, strong scaling
-    (N > 1: launched by  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1: one process per GPU.  Either launched by  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), or bare — `python bench.py --gpus N` without WORLD_SIZE
+    re-executes itself under torch.distributed.run on 127.0.0.1 with a free port (launcher_argv()).
+    MWF_BENCH_BACKEND=gloo: a DRY RUN of the N-rank plumbing on CPU (deal, per-rank step, ONE all_gather of the records, max-over-ranks
+    timing, the JSON line) on a tiny workload with the oracle standing in for the GPU; the line says "dry_run": true — it is a test of
+    the launcher and the gather (tests/test_bench_launch.py), never a measurement.
 
 Default workload (the batch BASELINE.json's metric is quoted on): per GPU, 1024 synthetic pairs, 10 kb target, query =
 target mutated at 5 % (60/20/20 sub/ins/del, geometric indels), score-only mwf_wfa_exact semantics, default
@@ -15,10 +20,11 @@ The host-buffers-in to host-results-out rate of the same batch (PCIe both ways, 
 printed beside it as `end_to_end_gbps`; it is never `value`.
 
 Printed JSON (one line, rank 0): the driver contract fields plus
-  roofline     — SURVEY.md §8(d)'s algorithmic bytes per (penalty, diagonal) cell (48 score-only: 7 int32 loads + 5
-                 stores of reference miniwfa.c:269-276) x cells per launch / HIP-event kernel time, against 8 TB/s; and,
-                 because the band kernel keeps four of the five wavefront arrays on chip, `binding`: the larger of the
-                 HBM fraction on the bytes the kernel itself must move and the VALU-issue fraction (what actually limits)
+  roofline     — ONE definition everywhere in the line (top level and long_pairs.*): achieved = HBM bytes per launch by the PMC
+                 counters (profiles/traffic.json: 2048 B x FETCH_SIZE + 1024 B x WRITE_SIZE, units calibrated on this device) /
+                 the kernel time measured live with HIP events on the launch stream; frac = achieved / 8 TB/s.  Named side fields:
+                 `own_bytes_frac` (the bytes the kernel itself must move per cell), `nominal_48B` (the reference's 48 /
+                 49 / 97 B per cell x cells / time — exceeds 1 for kernels that keep four of the five arrays on chip), issue fractions
   cpu_baseline — the compiled reference (oracle/_ref, kind "reference") or our C restatement (kind "port")
                  on the host cores, bounded sample of the same batch (rank 0, N=1 only)
   call_latency_us, short_reads, long_pairs, peak_device_bytes, n_retries — extras (rank 0, N=1 only)
@@ -28,7 +34,9 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
 import sys
+import threading
 import time
 
 import numpy as np
@@ -112,9 +120,9 @@ def call_latency(mw, synth_pair, reps=40):
 
 
 def short_reads(mw, synth_pair, PackedBatch, reps=5):
-    """Batches of read-sized pairs at 5 % (score-only): Gbp/s from the library's HIP events around the kernels of one align call —
-    the one-wave-per-pair lane kernel (mwf_lane.hip); pairs whose window outgrows it are re-run on the band kernels (`re_run`,
-    outside the events)."""
+    """Batches of read-sized pairs at 5 % (score-only) on the one-wave-per-pair lane kernel (mwf_lane.hip): `kernel_gbps` from the
+    library's HIP events around the kernels of one align call, `step_gbps` from the wall clock around align() + results() (what a
+    caller sees with the batch resident: host work, launches, the re-runs of pairs whose window outgrew the kernel, records back)."""
     out = {}
     for n, tl in ((40000, 150), (20000, 250)):
         pairs = [synth_pair(7000 + i, tl, 0.05) for i in range(n)]
@@ -122,23 +130,115 @@ def short_reads(mw, synth_pair, PackedBatch, reps=5):
         eng = mw.Engine(0)
         b = eng.upload(PackedBatch(pairs))
         o = mw.opt_init()
-        ms = []
+        ms, wall = [], []
         for it in range(reps + 2):
+            t0 = time.perf_counter()
             b.align(o)
             b.results()
+            t1 = time.perf_counter()
             if it >= 2:
                 ms.append(eng.stats().kernel_ms)
+                wall.append((t1 - t0) * 1e3)
         st = eng.stats()
-        out[f"{n}x{tl}bp"] = {"kernel_gbps": bp / (sum(ms) / len(ms)) / 1e6, "kernel_ms": sum(ms) / len(ms), "re_run": int(st.n_retries)}
+        # kernel_*: HIP events around the first launches of an align call (pairs re-run afterwards are outside them); step_*: wall clock of
+        # align() + results() with the batch resident — host classification, launches, every re-run, the records on the host
+        out[f"{n}x{tl}bp"] = {"kernel_gbps": bp / (sum(ms) / len(ms)) / 1e6, "kernel_ms": sum(ms) / len(ms), "step_gbps": bp / (sum(wall) / len(wall)) / 1e6,
+                              "step_ms": sum(wall) / len(wall), "re_run": int(st.n_retries)}
         b.free()
         eng.close()
     return out
 
 
-def long_pairs(mw, synth_pair, PackedBatch, cpu: bool):
+def long_batches(mw, synth_pair, PackedBatch, n=1250, tl=50000, div=0.03):
+    """One GPU's share of BASELINE configs[4] (10 000 x 50 kb @ 3 % over 8 GPUs = 1250 pairs), score-only, on the default kernel choice
+    (the generic kernel with 16-bit ring rows): one warm-up align, one timed."""
+    pairs = [synth_pair(60000 + i, tl, div) for i in range(n)]
+    pk = PackedBatch(pairs)
+    eng = mw.Engine(0)
+    b = eng.upload(pk)
+    o = mw.opt_init()
+    b.align(o); b.results()
+    t0 = time.perf_counter()
+    b.align(o)
+    s, it, _ = b.results()
+    wall = time.perf_counter() - t0
+    st = eng.stats()
+    cells = int(it.sum())
+    ks = st.kernel_ms * 1e-3
+    kb = 16 if st.packed == 16 else 32
+    rec = {"workload": f"{n} x {tl} bp @ {div:g}, score-only (one GPU's share of configs[4])", "kernel_ms": st.kernel_ms, "wall_ms": wall * 1e3,
+           "gbp_s": pk.bases / wall / 1e9, "gcells_per_s": cells / wall / 1e9, "cells": cells, "n_retries": int(st.n_retries), "mean_s": float(s.mean()),
+           "kernel_kind": int(st.kernel_kind), "block": int(st.block), "ring_bits": 16 if st.packed == 16 else 32,
+           "roofline": counter_roofline(ks, TRAFFIC.get(f"{n}x{tl}@{div:g}s", {}), float(kb) * cells, 48.0 * cells, "48 B x cells")}
+    b.free()
+    eng.close()
+    return rec
+
+
+LONG_SPECS = (("c4_like_150kb", 2001, 150000, 0.035, 0, 0,
+               (("score", {}, "c4-score"), ("cigar_highmem", {"flag": 1}, "c4-cigar"), ("cigar_lowmem_p5000", {"flag": 1, "step": 5000}, "c4-lowmem"))),
+              ("mhc_like_5Mb", 2002, 5000000, 0.008, 3, 15000,
+               (("cigar_lowmem_p5000", {"flag": 1, "step": 5000}, "mhc-lowmem"), ("score", {}, "mhc-score"))))
+
+
+def counter_roofline(kernel_s: float, prof: dict, own_bytes: float, nominal_bytes: float, nominal_label: str) -> dict:
+    """THE roofline block of this line, one definition for every kernel: achieved = HBM bytes per launch measured by the PMC counters
+    (profiles/traffic.json; 2048 B x FETCH_SIZE + 1024 B x WRITE_SIZE, the units calibrated by profiles/micro/fetch_calib.hip) / the kernel
+    time measured live with HIP events; frac = achieved / 8 TB/s.  Without a counter profile of the workload (non-default arguments) the
+    kernel's own bytes stand in and `frac_source` says so.  The other figures are named side fields, never `frac`."""
+    ks = max(kernel_s, 1e-12)
+    traffic = prof.get("hbm_bytes_per_launch")
+    used = traffic if traffic else own_bytes
+    rf = {"bound": "hbm", "achieved": used / ks / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": used / ks / 1e9 / HBM_PEAK_GBS,
+          "traffic": traffic,
+          "frac_source": ("PMC counter traffic per launch (profiles/traffic.json) / live HIP-event kernel time / 8 TB/s" if traffic else
+                          "no counter profile for this workload: the bytes the kernel itself must move / live kernel time / 8 TB/s"),
+          "traffic_source": prof.get("source"),
+          "kernel_s": ks,
+          "own_bytes": own_bytes, "own_bytes_frac": own_bytes / ks / 1e9 / HBM_PEAK_GBS,
+          "nominal_48B": {"what": nominal_label, "bytes": nominal_bytes, "gbs": nominal_bytes / ks / 1e9, "frac": nominal_bytes / ks / 1e9 / HBM_PEAK_GBS,
+                          "note": "SURVEY 8(d)'s byte model of the REFERENCE's loops; a kernel that keeps E1/F1/E2/F2 on chip and H in 16 bits moves a fraction "
+                                  "of it, so this figure can exceed 1 — it is not a roofline fraction"}}
+    if prof.get("valu_insts_per_launch"):
+        vi = prof["valu_insts_per_launch"]
+        rf["valu_issue_frac"] = vi / ks / 1e9 / VALU_PEAK_GINST
+        ai = vi + (prof.get("salu_insts_per_launch") or 0) + (prof.get("lds_insts_per_launch") or 0) + (prof.get("vmem_insts_per_launch") or 0)
+        rf["all_issue_frac"] = ai / ks / 1e9 / ISSUE_PEAK_GINST
+        rf["issue_source"] = prof.get("valu_source")
+    if prof.get("wait_any_over_wave_cycles") is not None:
+        rf["wait_any_over_wave_cycles"] = prof["wait_any_over_wave_cycles"]
+    return rf
+
+
+class BackgroundReference:
+    """The compiled reference (oracle/_ref) on ONE host thread beside the GPU work of this run — the same-run CPU baseline of the 5 Mb
+    pair (configs[3]; about four minutes of one core).  ctypes drops the GIL inside the call."""
+
+    def __init__(self, t, q, kw):
+        from oracle.pyoracle import Reference, make_opt
+        self.ref = Reference(arena=True)
+        self.t, self.q, self.opt = t, q, make_opt(**kw)
+        self.result, self.seconds, self.error = None, None, None
+        self.th = threading.Thread(target=self._run, daemon=True)
+        self.th.start()
+
+    def _run(self):
+        try:
+            t0 = time.perf_counter()
+            self.result = self.ref.align(self.t, self.q, self.opt)
+            self.seconds = time.perf_counter() - t0
+        except Exception as e:  # pragma: no cover
+            self.error = repr(e)
+
+    def join(self):
+        self.th.join()
+        return self
+
+
+def long_pairs(mw, synth_pair, PackedBatch, cpu: bool, mhc_cpu: bool):
     """BASELINE configs[1] and configs[3] (stand-ins): one pair on the whole device, each mode on a fresh
-    engine so that `peak_device_bytes` is that mode's own need; the compiled reference timed beside it where that takes
-    seconds (the 5 Mb pair's reference time — minutes — comes from the committed golden fixture)."""
+    engine so that `peak_device_bytes` is that mode's own need; the compiled reference timed beside it in the same run:
+    inline for the 150 kb pair (seconds), on a host thread that runs while the GPU legs do for the 5 Mb pair (minutes)."""
     lp = {}
     gold = {}
     try:
@@ -154,12 +254,13 @@ def long_pairs(mw, synth_pair, PackedBatch, cpu: bool):
             ref = Reference(arena=True) if Reference.available() else None
         except Exception:
             ref = None
-    specs = (("c4_like_150kb", 2001, 150000, 0.035, 0, 0,
-              (("score", {}, "c4-score"), ("cigar_highmem", {"flag": 1}, "c4-cigar"), ("cigar_lowmem_p5000", {"flag": 1, "step": 5000}, "c4-lowmem"))),
-             ("mhc_like_5Mb", 2002, 5000000, 0.008, 3, 15000,
-              (("cigar_lowmem_p5000", {"flag": 1, "step": 5000}, "mhc-lowmem"), ("score", {}, "mhc-score"))))
-    for name, seed, tl_, p_, nl, lm, modes in specs:
-        t_, q_ = synth_pair(seed, tl_, p_, nl, lm)
+    seqs = {name: synth_pair(seed, tl_, p_, nl, lm) for name, seed, tl_, p_, nl, lm, _ in LONG_SPECS}
+    bg = None
+    if ref is not None and mhc_cpu:   # configs[3]'s CPU baseline: started before the GPU legs, joined behind them
+        t_, q_ = seqs["mhc_like_5Mb"]
+        bg = BackgroundReference(t_, q_, {"flag": 1, "step": 5000})
+    for name, seed, tl_, p_, nl, lm, modes in LONG_SPECS:
+        t_, q_ = seqs[name]
         for label, kw, gid in modes:
             eng = mw.Engine(0)
             bb = eng.upload(PackedBatch([(t_, q_)]))
@@ -172,7 +273,8 @@ def long_pairs(mw, synth_pair, PackedBatch, cpu: bool):
             wall = time.perf_counter() - t0
             st_ = eng.stats()
             rec = {"s": int(s_[0]), "n_iter": int(it_[0]), "kernel_s": st_.kernel_ms * 1e-3, "wall_s": wall, "cells_pass1": int(st_.cells_pass1),
-                   "gbp_s": (len(t_) + len(q_)) / wall / 1e9, "peak_device_bytes": int(st_.dev_bytes_peak), "n_retries": int(st_.n_retries)}
+                   "gbp_s": (len(t_) + len(q_)) / wall / 1e9, "peak_device_bytes": int(st_.dev_bytes_peak), "n_retries": int(st_.n_retries),
+                   "lowmem_two_pass": int(st_.lowmem_two_pass)}
             # SURVEY 8(d) bytes: 48 per cell score-only, 49 with traceback, 97 in the low-memory first pass (+ 49 per cell of the second)
             if kw.get("step"):
                 nominal = 97 * int(st_.cells_pass1) + 49 * int(it_[0])
@@ -181,12 +283,10 @@ def long_pairs(mw, synth_pair, PackedBatch, cpu: bool):
                 nominal = (49 if kw.get("flag") else 48) * int(it_[0])
                 own = (16 + (1 if kw.get("flag") else 0)) * int(it_[0])
             ks = max(st_.kernel_ms * 1e-3, 1e-9)
-            prof = TRAFFIC.get(f"{name}:{label}", {})
-            rec["roofline"] = {"bound": "hbm", "achieved": nominal / ks / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nominal / ks / 1e9 / HBM_PEAK_GBS,
-                               "nominal_bytes": nominal, "kernel_own_bytes": own, "kernel_own_frac": own / ks / 1e9 / HBM_PEAK_GBS,
-                               "traffic": prof.get("hbm_bytes_per_launch"), "traffic_source": prof.get("source"),
-                               "us_per_penalty": ks / max(1, int(s_[0])) * 1e6 / (2 if kw.get("step") else 1),
-                               "binding": "per-penalty latency of ONE sequential chain of penalties (hand-off once per 8 penalties + single-wave issue), not bytes"}
+            rec["roofline"] = counter_roofline(ks, TRAFFIC.get(f"{name}:{label}", {}), own, nominal,
+                                               "97 B x first-pass cells + 49 B x second-pass cells" if kw.get("step") else ("49 B x cells" if kw.get("flag") else "48 B x cells"))
+            rec["roofline"]["us_per_penalty"] = ks / max(1, int(s_[0])) * 1e6 / (2 if kw.get("step") else 1)
+            rec["roofline"]["binding"] = "per-penalty latency of ONE sequential chain of penalties (hand-offs between chunk slots + single-wave issue), not bytes"
             if kw.get("flag"):
                 cg = bb.cigar(0, int(nc_[0])).tolist()
                 rec["cigar_rescored_ok"] = mw.cigar2score(mw.opt_init(), cg) == (int(s_[0]), len(t_), len(q_))
@@ -200,13 +300,40 @@ def long_pairs(mw, synth_pair, PackedBatch, cpu: bool):
                 rs = ref.align(t_, q_, ro)
                 rec["cpu_reference_s"] = time.perf_counter() - t0
                 rec["cpu_reference_matches"] = (rs[0], rs[1]) == (int(s_[0]), int(it_[0]))
+                rec["cpu_reference_how"] = "lh3/miniwfa (oracle/_ref), one host thread, same run, inline"
+            if bg is not None and name == "mhc_like_5Mb" and label == "cigar_lowmem_p5000":
+                rec["_gpu_answer"] = (int(s_[0]), int(it_[0]), cg)
             lp.setdefault(name, {"tl": len(t_), "ql": len(q_)})[label] = rec
             bb.free()
             eng.close()
+    if bg is not None:
+        bg.join()
+        rec = lp["mhc_like_5Mb"]["cigar_lowmem_p5000"]
+        gs, git, gcg = rec.pop("_gpu_answer")
+        if bg.error is None and bg.result is not None:
+            rec["cpu_reference_s"] = bg.seconds
+            rec["cpu_reference_matches"] = (bg.result[0], bg.result[1], bg.result[2]) == (gs, git, gcg)   # s, n_iter and every CIGAR word
+            rec["cpu_reference_how"] = ("lh3/miniwfa (oracle/_ref), one host thread, same run: started before the GPU legs of long_pairs and joined behind "
+                                        "them (it shares the host with the other legs' inline reference calls, each on its own core)")
+            rec["speedup_vs_cpu_reference_same_run"] = bg.seconds / max(rec["wall_s"], 1e-9)
+        else:
+            rec["cpu_reference_error"] = bg.error
     return lp
 
 
-def main():
+def launcher_argv(n: int, argv, port: int):
+    """The command a bare `python bench.py --gpus N` becomes: one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def free_port() -> int:
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
@@ -221,30 +348,119 @@ def main():
     ap.add_argument("--band-pack", type=int, default=-1, help="band kernel: 1 forces the int16-packed variants where the forced block has both")
     ap.add_argument("--cpu-sample", type=int, default=None, help="pairs in the cpu_baseline sample (0: skip)")
     ap.add_argument("--long-pairs", type=int, default=1, help="also time the single-pair configs (C4-like 150 kb, MHC-like 5 Mb) on rank 0 at N=1")
+    ap.add_argument("--mhc-cpu", type=int, default=1, help="1: time the compiled reference on the 5 Mb pair in this run (one host thread beside the GPU legs, ~4 min); 0: skip")
+    ap.add_argument("--long-batches", type=int, default=1, help="also time one GPU's share of configs[4] (1250 x 50 kb, score-only) on rank 0 at N=1")
     ap.add_argument("--extras", type=int, default=1, help="0: skip end_to_end / call latency / long pairs (profiling runs)")
     ap.add_argument("--seed", type=int, default=None)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    args.dry = os.environ.get("MWF_BENCH_BACKEND", "").lower() == "gloo"
     strong = args.config == 5
-    if strong:
+    if args.dry:     # the plumbing test: a few short pairs per rank
+        defaults = dict(pairs=40, tl=600, div=0.03, seed=60000, steps=2, warmup=1, cpu_sample=0) if strong else \
+                   dict(pairs=16, tl=300, div=0.05, seed=50000, steps=2, warmup=1, cpu_sample=0)
+    elif strong:
         defaults = dict(pairs=10000, tl=50000, div=0.03, seed=60000, steps=2, warmup=1, cpu_sample=32)
     else:
         defaults = dict(pairs=1024, tl=10000, div=0.05, seed=50000, steps=10, warmup=2, cpu_sample=1024)
     for k, v in defaults.items():
         if getattr(args, k) is None:
             setattr(args, k, v)
+    return args
+
+
+def dry_run(args, rank, world):
+    """MWF_BENCH_BACKEND=gloo: the multi-rank plumbing of this file on CPU — deal, per-rank step, ONE all_gather of the records, barrier +
+    max-over-ranks timing, the JSON line — with the oracle standing in for the GPU on a tiny workload.  Not a measurement."""
+    import torch
+    import torch.distributed as dist
+    from miniwfa_amd.synth import synth_pair
+    from miniwfa_amd.shard import gather_records, deal_pairs
+    from oracle.pyoracle import Oracle, make_opt
+    strong = args.config == 5
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    if strong:
+        n_total = args.pairs
+        deal = deal_pairs([2 * args.tl] * n_total, world)
+    else:
+        n_total = args.pairs * world
+        deal = [np.arange(r * args.pairs, (r + 1) * args.pairs) for r in range(world)]
+    pairs = [synth_pair(args.seed + int(i), args.tl, args.div) for i in deal[rank]]
+    orc, o = Oracle(), make_opt(flag=1 if args.cigar else 0)
+    bases = sum(len(t) + len(q) for t, q in pairs)
+    gathered = [None]
+
+    def step():
+        res = [orc.align(t, q, o) for t, q in pairs]
+        s_loc = torch.tensor([r[0] for r in res], dtype=torch.int32)
+        it_loc = torch.tensor([r[1] for r in res], dtype=torch.int64)
+        if world > 1:
+            gathered[0] = gather_records(dist, s_loc, it_loc, n_total, deal=deal)
+        else:
+            gathered[0] = (s_loc, it_loc)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    total_bases = bases
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        tot = torch.tensor([bases], dtype=torch.int64)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_bases = int(tot.item())
+    ok = True
+    if rank == 0:   # every pair's record arrived, in global order
+        s_all, it_all = gathered[0]
+        for i in range(n_total):
+            es, eit, _ = orc.align(*synth_pair(args.seed + i, args.tl, args.div), o)
+            ok = ok and (int(s_all[i]), int(it_all[i])) == (es, eit)
+        print(json.dumps({
+            "metric": "aligned Gbp/s (q+t)", "value": total_bases * args.steps / elapsed / 1e9, "unit": "Gbp/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "vs_baseline": None, "dtype": "int32", "data": "synthetic", "dry_run": True,
+            "config": {"workload": f"DRY RUN on CPU (MWF_BENCH_BACKEND=gloo): {n_total} pairs x {args.tl} bp dealt over {world} rank(s), the oracle standing in "
+                                   "for the GPU — exercises the launcher, the deal and the one all_gather of the records; NOT a measurement",
+                       "pairs_total": n_total, "pairs_this_rank": len(pairs)},
+            "roofline": None, "cpu_baseline": None, "gathered_records_match_oracle": ok}))
+    if world > 1:
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("dry run: gathered records differ from the oracle's")
+
+
+def main():
+    args = parse_args()
+    strong = args.config == 5
+    # ---- N > 1 without a launcher: become `python -m torch.distributed.run --nproc-per-node N ... bench.py <same arguments>`
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        cmd = launcher_argv(args.gpus, sys.argv[1:], free_port())
+        sys.stdout.flush()
+        os.execv(cmd[0], cmd)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node and --gpus must agree")
+    if args.dry:
+        return dry_run(args, rank, world)
 
     import torch
     import miniwfa_amd as mw
     from miniwfa_amd.synth import synth_pair, PackedBatch
     from miniwfa_amd.shard import gather_records, deal_pairs
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback (MWF_BENCH_BACKEND=gloo dry-runs the multi-rank plumbing on CPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -333,13 +549,26 @@ def main():
 
     k_ms = float(np.mean(kernel_ms))
     bytes_per_cell = 49 if args.cigar else ALGO_BYTES_PER_CELL
-    achieved = bytes_per_cell * cells / (k_ms * 1e-3) / 1e9
     mode = "score+CIGAR high-mem" if args.cigar else "score-only"
     if strong:
         workload = (f"{n_total} pairs in total x {args.tl} bp, {args.div:g} divergence, {mode} mwf_wfa_exact, default penalties, dealt over "
                     f"{world} GPU(s) (BASELINE configs[4])")
     else:
         workload = (f"{args.pairs} pairs/GPU x {args.tl} bp, {args.div:g} divergence, {mode} mwf_wfa_exact, default penalties (BASELINE configs[2])")
+    # What the kernel itself must move per cell (the floor of ITS traffic): the band kernels keep E1/F1/E2/F2 in registers,
+    # so only H crosses HBM (three loads + one store per cell: 16 bytes, 8 with the packed kernel's 16-bit rows), +1 traceback byte;
+    # the generic kernel with E2/F2 in LDS moves 32 of the 48, 16 with its 16-bit ring rows.
+    if st.kernel_kind == 2:
+        kb = (8 if st.packed else 16) + (1 if args.cigar else 0)
+    elif st.kernel_kind == 0:
+        kb = (16 if st.packed == 16 else 32) + (1 if args.cigar else 0)   # 16-bit ring rows: H (three loads, one store) + E1/F1 (load + store each) at 2 bytes
+    else:
+        kb = 16 + (1 if args.cigar else 0)
+    key = f"{pk.n}x{args.tl}@{args.div:g}{'c' if args.cigar else 's'}"
+    rf = counter_roofline(k_ms * 1e-3, TRAFFIC.get(key, {}), float(kb) * cells, float(bytes_per_cell) * cells, f"{bytes_per_cell} B x cells")
+    rf.update({"kernel_bytes_per_cell": kb, "cells_per_launch": cells, "kernel_ms": k_ms,
+               "note": "frac = counter traffic / kernel time / 8 TB/s (the same definition in long_pairs.*.roofline and long_batches.roofline). Nothing physical binds "
+                       "this kernel: what is left is per-penalty synchronisation (wait_any_over_wave_cycles) and single-wave issue latency (DESIGN.md section 4)."})
     out = {
         "metric": "aligned Gbp/s (q+t)",
         "value": total_bases * args.steps / elapsed / 1e9,
@@ -360,60 +589,8 @@ def main():
         "gcells_per_s": total_cells * args.steps / elapsed / 1e9,
         "kernel_gbps": pk.bases / (k_ms * 1e-3) / 1e9,
         "n_retries": timed_retries,
-        "roofline": {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None, "bytes_per_cell": bytes_per_cell, "cells_per_launch": cells, "kernel_ms": k_ms,
-        },
+        "roofline": rf,
     }
-    # What the kernel itself must move per cell (the floor of ITS traffic): the band kernels keep E1/F1/E2/F2 in registers,
-    # so only H crosses HBM (three loads + one store per cell: 16 bytes, 8 with the packed kernel's 16-bit rows), +1 traceback byte;
-    # the generic kernel with E2/F2 in LDS moves 32 of the 48, 16 with its 16-bit ring rows.
-    tr = TRAFFIC
-    key = f"{pk.n}x{args.tl}@{args.div:g}{'c' if args.cigar else 's'}"
-    prof = tr.get(key, {})
-    rf = out["roofline"]
-    if st.kernel_kind == 2:
-        kb = (8 if st.packed else 16) + (1 if args.cigar else 0)
-    elif st.kernel_kind == 0:
-        kb = (16 if st.packed == 16 else 32) + (1 if args.cigar else 0)   # 16-bit ring rows: H (three loads, one store) + E1/F1 (load + store each) at 2 bytes
-    else:
-        kb = 16 + (1 if args.cigar else 0)
-    rf["kernel_bytes_per_cell"] = kb
-    hbm_frac = kb * cells / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-    cands = [{"bound": "hbm (bytes this kernel must move)", "achieved": kb * cells / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac}]
-    if "hbm_bytes_per_launch" in prof:
-        rf["traffic"] = prof["hbm_bytes_per_launch"]
-        rf["traffic_gbs"] = prof["hbm_bytes_per_launch"] / (k_ms * 1e-3) / 1e9
-        rf["traffic_source"] = prof.get("source")
-    if "valu_insts_per_launch" in prof:
-        vi = prof["valu_insts_per_launch"]
-        cands.append({"bound": "valu issue", "achieved": vi / (k_ms * 1e-3) / 1e9, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
-                      "frac": vi / (k_ms * 1e-3) / 1e9 / VALU_PEAK_GINST, "valu_lane_ops_per_cell": vi * 64 / prof.get("cells_per_launch", cells),
-                      "source": prof.get("valu_source")})
-    if prof.get("valu_insts_per_launch") and prof.get("salu_insts_per_launch"):
-        # every instruction a SIMD issued, against what one SIMD issues with four ready waves (profiles/r02/valu_issue_rates_microbench.txt:
-        # 1.28 cycles per instruction, i.e. 0.78 per cycle and SIMD, for any mix of VALU / SALU) x 1024 SIMDs x 2.4 GHz
-        ai = prof["valu_insts_per_launch"] + prof["salu_insts_per_launch"] + (prof.get("lds_insts_per_launch") or 0) + (prof.get("vmem_insts_per_launch") or 0)
-        cands.append({"bound": "instruction issue (all types)", "achieved": ai / (k_ms * 1e-3) / 1e9, "peak": ISSUE_PEAK_GINST, "unit": "G wave-instructions/s",
-                      "frac": ai / (k_ms * 1e-3) / 1e9 / ISSUE_PEAK_GINST, "instructions_per_cell_lane": ai * 64 / prof.get("cells_per_launch", cells),
-                      "wait_any_over_wave_cycles": prof.get("wait_any_over_wave_cycles"), "source": prof.get("valu_source", "").replace("SQ_INSTS_VALU", "SQ_INSTS_VALU/SALU/LDS/VMEM_RD/VMEM_WR")})
-    # The top-level roofline is the BINDING one: the largest fraction among the rooflines of what this kernel really does (its own
-    # HBM bytes, counter-measured HBM traffic, VALU issue).  SURVEY 8(d)'s nominal figure (the reference's 48 B per cell) is kept
-    # beside it as `nominal_48B`: a kernel that keeps four of the five wavefront arrays on chip can exceed 1 by that definition.
-    nominal = {"bound": "hbm (SURVEY 8(d): the reference's algorithmic bytes per cell)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-               "frac": achieved / HBM_PEAK_GBS, "bytes_per_cell": bytes_per_cell}
-    if "traffic_gbs" in rf:
-        cands.append({"bound": "hbm (PMC traffic: 2 x FETCH_SIZE + WRITE_SIZE)", "achieved": rf["traffic_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                      "frac": rf["traffic_gbs"] / HBM_PEAK_GBS, "source": rf.get("traffic_source")})
-    best = max(cands, key=lambda c: c["frac"])
-    rf.update({"bound": "hbm" if best["bound"].startswith("hbm") else best["bound"], "bound_detail": best["bound"], "achieved": best["achieved"], "peak": best["peak"],
-               "unit": best["unit"], "frac": best["frac"]})
-    rf["nominal_48B"] = nominal
-    rf["hbm_measured"] = {"bytes_per_launch": rf.get("traffic"), "gbs": rf.get("traffic_gbs"), "frac": (rf["traffic_gbs"] / HBM_PEAK_GBS) if "traffic_gbs" in rf else None}
-    rf["candidates"] = cands
-    rf["note"] = ("bound/achieved/peak/frac: the largest fraction among the rooflines of what this kernel really does (candidates); nominal_48B: "
-                  "SURVEY 8(d)'s figure, cells x the reference's bytes per cell / kernel time; none binds — what is left is per-penalty "
-                  "synchronisation (wait_any_over_wave_cycles) and single-wave issue latency (DESIGN.md section 4).")
 
     if world == 1 and args.extras:
         out["peak_device_bytes"] = int(st.dev_bytes_peak)
@@ -464,9 +641,14 @@ def main():
             out["short_reads"] = short_reads(mw, synth_pair, PackedBatch)
         except Exception as e:
             out["short_reads"] = {"error": repr(e)}
+        if args.long_batches and not strong:
+            try:
+                out["long_batches"] = long_batches(mw, synth_pair, PackedBatch)
+            except Exception as e:
+                out["long_batches"] = {"error": repr(e)}
         if args.long_pairs and not strong:
             try:
-                out["long_pairs"] = long_pairs(mw, synth_pair, PackedBatch, cpu=args.cpu_sample > 0)
+                out["long_pairs"] = long_pairs(mw, synth_pair, PackedBatch, cpu=args.cpu_sample > 0, mhc_cpu=bool(args.mhc_cpu))
             except Exception as e:
                 out["long_pairs"] = {"error": repr(e)}
     print(json.dumps(out))
