@@ -11,7 +11,8 @@
  * (plain pointers and sizes only) that the Python/torch host side and bench.py drive.
  *
  * There is no CPU fallback anywhere behind this header: every alignment runs in the HIP
- * kernels of miniwfa_amd/csrc/mwf_kernels.hip, and every entry point aborts with a message
+ * kernels under miniwfa_amd/csrc/ (mwf_kernels.hip generic, mwf_band2.hip packed band,
+ * mwf_lane.hip short pairs, mwf_band.hip 32-bit band, mwf_sys.hip + mwf_coop.hip whole device), and every entry point aborts with a message
  * if no gfx950 device can be opened.
  */
 #ifndef MWF_HIP_MINIWFA_H
@@ -56,7 +57,8 @@ void mwf_opt_init(mwf_opt_t *opt);
 /* reference miniwfa.h:83 / miniwfa.c:603-615: optimal global alignment of ts[0,tl) vs qs[0,ql).
  * Sequences are length-delimited arbitrary bytes compared verbatim.  *r is fully overwritten.
  * Limits of this implementation (the reference has neither; both end in a message and abort(), like the reference's
- * own assert/panic paths): max(x, o1+e1, o2+e2) < 256 (ring slots kept in LDS tables), and tl+ql < 2^31-4 (columns
+ * own assert/panic paths): max(x, o1+e1, o2+e2) < 4096 (below 256 every kernel applies; from 256 on — gap-open costs in the
+ * hundreds — the pairs run on the generic kernel's big-ring form, one column per lane), and tl+ql < 2^31-4 (columns
  * are 32-bit).  x, e1, e2 >= 1 and o1, o2 >= 0, as the reference requires implicitly (miniwfa.c:390-392).
  * Device: MWF_DEVICE=<ordinal> (default 0).  Any number of host threads may call concurrently. */
 void mwf_wfa_exact(void *km, const mwf_opt_t *opt, int32_t tl, const char *ts, int32_t ql, const char *qs, mwf_rst_t *r);
@@ -141,7 +143,7 @@ typedef struct {
 	int32_t kernel_kind;   /* 0: one workgroup per pair (generic); 1: one pair across the whole device; 2: one workgroup per pair (band) */
 	int64_t dev_bytes;     /* device memory the engine holds now: workspace pools + recycled batch allocations (live batches hold their own) */
 	int64_t dev_bytes_peak;/* ... and the most it held since creation or the last mwf_gpu_set(g, "trim", 0) */
-	int32_t packed;        /* band kernel: 1 = the packed 16-bit variant (mwf_band2.hip); generic kernel: 16 = 16-bit ring rows */
+	int32_t packed;        /* band kernels: 1 = the packed 16-bit variant (mwf_band2.hip), 32 = the one-wave-per-pair lane kernel (mwf_lane.hip), 0 = 32-bit rows (mwf_band.hip); generic kernel: 16 = 16-bit ring rows */
 	int32_t lowmem_two_pass; /* low-memory mode: 1 = the first pass stored no traceback (provenance + snapshots), 0 = checkpoints walked off a full traceback */
 } mwf_gpu_stats_t;
 void mwf_gpu_get_stats(const mwf_gpu_t *g, mwf_gpu_stats_t *st);
@@ -158,7 +160,7 @@ int32_t mwf_gpu_debug_band(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *op
  * sequences in device memory; a pair that outgrows 16 bits or holds a byte outside A/C/G/T is re-run with 32-bit rows and byte probes;
  * 2: the same), "ring16_block" (0, 512, 768);
  * whole-device (systolic) kernel: "lowmem_budget_mb" (low-memory mode: a first-pass traceback above this many MB switches to the two-pass
- * form whose first pass stores none; 0 = a quarter of the device), "sys_p" (penalties per hand-off block: 4, 8, 16; default 8),
+ * form whose first pass stores none; 0 = a quarter of the device), "sys_p" (penalties per hand-off block: 8, the one the library is built with; 4 and 16 only in builds with -DMWF_SYS_ALL_P — any other value is refused),
  * "sys_c" (columns per lane: 0 = chosen per pass from the expected window, 1, 4), "coop_grid" (at most this many workgroups; 0 = one
  * per CU), "coop_launch" (default 1: launched through hipLaunchCooperativeKernel; 0: plain launch),
  * "lane_max_len" (default 400: pairs whose longer sequence has at most this many bases try the one-wave-per-pair lane kernel first; 0: never), "lane_chunks" (its window in 64-column chunks,

@@ -616,7 +616,7 @@ bool band_supported(const Penalty &p)
 {
 	const bool inst = (p.e1 == 2 && p.e2 == 1) || (p.e1 == 2 && p.e2 == 2);
 	// the prefetch reads H rows that are at least two penalties old
-	return inst && p.x >= 2 && p.oe1 >= 2 && p.oe2 >= 2;
+	return inst && p.x >= 2 && p.oe1 >= 2 && p.oe2 >= 2 && p.nH <= kMaxRing; // (the window table in LDS holds kMaxRing slices)
 }
 
 // (the int16-packed geometries live in mwf_band2.hip; here: long targets, whose offsets need 32 bits)

@@ -930,7 +930,7 @@ int occ_one(int lds_seq, bool seq2, bool tb)
 // the packed kernel: (e1,e2) instantiated, sequences fit LDS (the host checks), every H lag >= 1
 bool band2_supported(const Penalty &p)
 {
-	return (p.e1 == 2 && p.e2 == 1) || (p.e1 == 2 && p.e2 == 2) || (p.e1 == 1 && p.e2 == 1);
+	return ((p.e1 == 2 && p.e2 == 1) || (p.e1 == 2 && p.e2 == 2) || (p.e1 == 1 && p.e2 == 1)) && p.nH <= kMaxRing; // (window table in LDS; rows read as dead up to 256 columns beyond their window)
 }
 
 #ifdef MWF_BAND_DEV

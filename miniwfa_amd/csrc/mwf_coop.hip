@@ -172,11 +172,12 @@ __device__ __forceinline__ bool grid_sync(const BatchArgs &A, unsigned *sync, un
 				__builtin_amdgcn_s_sleep(1);
 				if (++spins > A.coop_spin_limit || ((spins & 255u) == 0 && ld_ag(abort_flag))) { ok = 0; break; }
 			}
-			__hip_atomic_store(&grp_gen[4 * grp], (seen & 0xffffffff00000000ull) | epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			// (a leader that gave up publishes a POISONED generation: its members leave the barrier knowing that it did not complete)
+			__hip_atomic_store(&grp_gen[4 * grp], (seen & 0xffffffff00000000ull) | (ok ? epoch : (epoch | 0x80000000u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		} else {
 			for (;;) {
 				seen = __hip_atomic_load(&grp_gen[4 * grp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				if ((unsigned)(seen & 0xffffffffu) >= epoch) break;
+				if ((unsigned)(seen & 0xffffffffu) >= epoch) { if (seen & 0x80000000ull) ok = 0; break; }
 				__builtin_amdgcn_s_sleep(1);
 				if (++spins > A.coop_spin_limit || ((spins & 255u) == 0 && ld_ag(abort_flag))) { ok = 0; break; }
 			}
@@ -928,7 +929,7 @@ int launch_pass(const BatchArgs &a, int grid, hipStream_t st)
 
 bool coop_supported(const Penalty &p)
 {
-	return (p.e1 == 2 && p.e2 == 1) || (p.e1 == 2 && p.e2 == 2) || (p.e1 == 1 && p.e2 == 1);
+	return ((p.e1 == 2 && p.e2 == 1) || (p.e1 == 2 && p.e2 == 2) || (p.e1 == 1 && p.e2 == 1)) && p.nH <= kMaxRing; // (per-slot window history in LDS)
 }
 
 int64_t coop_chunk_slots(int grid) { return (int64_t)grid * kNW * kK; }

@@ -1,5 +1,6 @@
-// mwf_device.h — device-side helpers shared by the two alignment kernels
-// (mwf_kernels.hip: generic ring-in-HBM kernel; mwf_band.hip: register-resident band kernel).
+// mwf_device.h — device-side helpers shared by every alignment kernel (mwf_kernels.hip generic, mwf_band.hip / mwf_band2.hip band,
+// mwf_lane.hip short pairs, mwf_coop.hip / mwf_sys.hip whole device): the recurrence and its
+// traceback byte, kernel-argument access, the shared traceback, per-pair memory views and outputs.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -8,13 +9,18 @@
 namespace mwf {
 namespace dev {
 
-struct Shared {
+template <int NR>
+struct SharedT {
 	int32_t flags[3][4];   // per penalty (mod 3): new lo edge live, new hi edge live, end cell reached, payload
 	int32_t red[2];        // shrink: first / last good column
 	int32_t item;          // work item broadcast
 	int32_t word[4];       // scratch broadcast
-	int32_t rng_lo[kMaxRing], rng_hi[kMaxRing]; // column window of the slice held by each H slot
+	int32_t rng_lo[NR], rng_hi[NR]; // column window of the slice held by each H slot
 };
+typedef SharedT<kMaxRing> Shared;
+// penalty sets with max(x, o1+e1, o2+e2) >= 256 (the reference takes any, miniwfa.c:390-393): the one-column-per-lane generic kernel with
+// a window table of kBigRing entries (32 KB of LDS), mwf_kernels.hip wfa_bigring_kernel
+typedef SharedT<kBigRing> SharedBig;
 
 struct PassResult {
 	int32_t status;

@@ -317,7 +317,7 @@ const char *validate(const mwf_opt_t &o)
 {
 	if (o.x < 1 || o.e1 < 1 || o.e2 < 1) return "x, e1 and e2 must be >= 1 (a zero lag would make a wavefront depend on itself)";
 	if (o.o1 < 0 || o.o2 < 0) return "gap-open penalties must be >= 0";
-	if (std::max(o.x, std::max(o.o1 + o.e1, o.o2 + o.e2)) + 1 > kMaxRing) return "max(x, o1+e1, o2+e2) must be < 256";
+	if (std::max<int64_t>(o.x, std::max<int64_t>((int64_t)o.o1 + o.e1, (int64_t)o.o2 + o.e2)) + 1 > kBigRing) return "max(x, o1+e1, o2+e2) must be < 4096";
 	if (o.step < 0) return "step must be >= 0";
 	return nullptr;
 }
@@ -432,11 +432,12 @@ int cached_occupancy(mwf_gpu_t *g, const Penalty &P, const Plan &pl, int lds_e2_
 	if (pl.kind == 2)
 		key = 1ull | (uint64_t)pl.band.block << 4 | (uint64_t)(pl.band.packed == 1) << 16 | (uint64_t)(pl.band.lds_bytes > 0) << 17 | (uint64_t)pl.cigar << 18 |
 		      (uint64_t)(pl.band.seq2 != 0) << 3 | (uint64_t)(pl.band.lane != 0) << 2 | (uint64_t)P.e1 << 20 | (uint64_t)P.e2 << 28 | (uint64_t)pl.band.lds_bytes << 36;
-	else key = 2ull | (uint64_t)pl.block << 4 | (uint64_t)stream_pass << 16 | (uint64_t)ring16 << 17 | (uint64_t)lds_e2_cols << 20;
+	else key = 2ull | (uint64_t)pl.block << 4 | (uint64_t)stream_pass << 16 | (uint64_t)ring16 << 17 | (uint64_t)(P.nH > kMaxRing) << 18 | (uint64_t)lds_e2_cols << 20;
 	auto it = g->occ_cache.find(key);
 	if (it != g->occ_cache.end()) return it->second;
 	const int per = pl.kind == 2 && pl.band.lane ? lane_kernel_occupancy(pl.band.lds_bytes, pl.cigar)
 	              : pl.kind == 2 ? (pl.band.packed ? band2_kernel_occupancy(P, pl.band, pl.cigar) : band_kernel_occupancy(P, pl.band, pl.cigar))
+	              : P.nH > kMaxRing ? bigring_kernel_occupancy()
 	                             : batch_kernel_occupancy(pl.block, stream_pass, lds_e2_cols, ring16);
 	g->occ_cache[key] = per;
 	return per;
@@ -480,7 +481,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 		per_cu = g->slots_per_cu > 0 ? g->slots_per_cu : cached_occupancy(g, P, pl, 0, false);
 	} else {
 		// wide windows (the 512-thread choice above), default gap extension: E2/F2 stay in LDS while the window fits 16 k columns
-		if (g->lds_e2 && pl.block == 512 && g->block == 0 && P.e2 == 1 && !g->scalar_generic && !pl.low_mem) {
+		if (g->lds_e2 && pl.block == 512 && g->block == 0 && P.e2 == 1 && !g->scalar_generic && !pl.low_mem && P.nH <= kMaxRing) {
 			lds_e2_cols = 16384;
 			// 16-bit ring rows halve the traffic of this HBM-bound kernel.  An offset is a target index (or runs past the matrix by
 			// at most one per penalty), so they hold while target length + penalty < 65530: taken optimistically for pairs whose
@@ -496,9 +497,16 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 			// 768 threads and one per CU (479 ms with 32-bit rows); with traceback the 512-thread copy spills too much: 768 (451 against 477 ms)
 			pl.block = ring16 ? (g->ring16_block ? g->ring16_block : (pl.cigar ? 768 : 512)) : 768;
 		}
+		if (P.nH > kMaxRing) pl.block = 256; // the big-ring form of the generic kernel (launch_batch): one column per lane, 256 threads
 		per_cu = g->slots_per_cu > 0 ? g->slots_per_cu : cached_occupancy(g, P, pl, lds_e2_cols, !g->scalar_generic, ring16);
 	}
 	slots = std::max(1, std::min(slots, g->n_cu * std::max(1, per_cu)));
+	if (P.nH > kMaxRing) {
+		// a deep ring is (nH + 2 n1 + 2 n2) rows of tl+ql columns per resident workgroup (times two in low-memory mode): fewer
+		// workgroups rather than a tenth of the device in rings
+		const int64_t per_slot = (int64_t)(P.nH + 2 * P.n1 + 2 * P.n2) * ((max_len + 3 + 255) / 256 * 256 + 512) * 4 * (pl.low_mem ? 2 : 1);
+		slots = (int)std::max<int64_t>(1, std::min<int64_t>(slots, (int64_t)(g->total_mem / 10) / std::max<int64_t>(per_slot, 1)));
+	}
 	if (getenv("MWF_DEBUG"))
 		fprintf(stderr, "[libmwf_hip] kernel kind %d: block %d packed %d lds %d B, %d workgroup(s) per CU, %d slots, %d pairs\n", pl.kind, pl.block,
 		        pl.band.packed, pl.band.lds_bytes, per_cu, slots, n_items);
@@ -1129,7 +1137,7 @@ int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value)
 	else if (!strcmp(name, "lowmem_budget_mb")) g->lowmem_budget_mb = std::max<int64_t>(0, value);
 	else if (!strcmp(name, "coop_grid")) g->coop_grid_cap = (int)std::max<int64_t>(0, value);
 	else if (!strcmp(name, "coop_launch")) g->coop_launch = value != 0;
-	else if (!strcmp(name, "sys_p") && (value == 4 || value == 8 || value == 16)) g->sys_p = (int)value;
+	else if (!strcmp(name, "sys_p") && sys_p_supported((int)value)) g->sys_p = (int)value; // (8; 4 and 16 only in builds with -DMWF_SYS_ALL_P)
 	else if (!strcmp(name, "sys_c") && (value == 0 || value == 1 || value == 4)) g->sys_c = (int)value;
 	else if (!strcmp(name, "trim")) { (void)hipSetDevice(g->device); trim(g); }
 	else return -1;

@@ -6,7 +6,8 @@
 namespace mwf {
 
 constexpr int32_t kNegInf = -0x40000000;   // reference miniwfa.c:67
-constexpr int32_t kMaxRing = 256;          // ring slots supported in LDS tables: max(x, o1+e1, o2+e2) + 1 <= 256
+constexpr int32_t kMaxRing = 256;          // ring slots the fast kernels' LDS tables hold: max(x, o1+e1, o2+e2) + 1 <= 256
+constexpr int32_t kBigRing = 4096;         // ... and the generic kernel's big-ring form (any penalties with max(x, o1+e1, o2+e2) < 4096)
 
 // per-pair status written by the kernels
 enum : int32_t {
@@ -124,6 +125,7 @@ struct BatchArgs {
 // launch wrappers implemented in mwf_kernels.hip (generic kernel: any penalties, any band, low-memory mode)
 int launch_reset(int32_t *status, int32_t *s, int32_t n, unsigned long long *cig_head, int32_t *queue, int32_t n_queue, void *stream);
 int launch_batch(const BatchArgs &a, int grid, int block, void *stream);
+int  bigring_kernel_occupancy();                      // ... of the big-ring form (penalty sets with max(x, o1+e1, o2+e2) >= 256)
 int  batch_kernel_occupancy(int block, bool stream_pass, int lds_e2_cols, bool ring16);   // resident workgroups per CU for that block size
 
 // launch wrappers implemented in mwf_band.hip (band kernel: E/F wavefronts live in registers)
@@ -145,6 +147,7 @@ int  launch_coop_trace(const BatchArgs &a, void *stream);                // chec
 // the provenance pass of the two-pass low-memory mode)
 int64_t sys_chunk_slots(int grid);                   // chunk slots a launch of `grid` workgroups holds
 int  sys_owned_cols(int p, int c);                   // columns a chunk slot owns: 64c - 2p
+bool sys_p_supported(int p);                         // block lengths (penalties per hand-off) the build has kernels for
 int64_t sys_box_ints(int p);                         // ints of one hand-off box
 int  sys_max_grid();                                 // co-resident workgroups the kernel may be launched with (one per CU)
 int  launch_sys_pass(const BatchArgs &a, int grid, void *stream);        // forward pass (score / traceback bytes / second pass with band resets)

@@ -52,8 +52,8 @@ __device__ __forceinline__ Penalty load_penalty(const ArgsT &A)
 	return P;
 }
 
-template <int T, typename ArgsT>
-__device__ bool take_snapshot(const ArgsT &A, const PairMem &M, Shared &sh, int32_t n_snap, int64_t &snap_used,
+template <int T, typename ArgsT, typename ShT>
+__device__ bool take_snapshot(const ArgsT &A, const PairMem &M, ShT &sh, int32_t n_snap, int64_t &snap_used,
                               int32_t s, int32_t curH, int32_t cur1, int32_t cur2)
 {
 	const Penalty P = load_penalty(A);
@@ -137,8 +137,8 @@ __device__ int32_t trace_checkpoints(const ArgsT &A, const PairMem &M, int32_t n
 // One forward pass over a pair.
 //   TB : store traceback bytes, honour checkpoints (core pass with MWF_F_CIGAR)
 //   SEG: low-memory first pass (shadow ring + snapshots, no traceback bytes, no stop rules, miniwfa.c:569-589)
-template <int T, bool TB, bool SEG, typename ArgsT>
-__device__ PassResult forward_pass(const ArgsT &A, const PairMem &M, Shared &sh, int32_t n_seg, bool trace_band)
+template <int T, bool TB, bool SEG, typename ArgsT, typename ShT>
+__device__ PassResult forward_pass(const ArgsT &A, const PairMem &M, ShT &sh, int32_t n_seg, bool trace_band)
 {
 	const Penalty P = load_penalty(A);
 	const int32_t tl = M.tl, ql = M.ql, cmax = tl + ql + 1; // columns 1..cmax hold diagonals -tl..ql
@@ -1144,6 +1144,50 @@ __global__ __launch_bounds__(T, (H16 && T == 512) ? 4 : 1) void wfa_batch_kernel
 	}
 }
 
+// Penalty sets whose ring is deeper than the fast kernels' LDS tables (max(x, o1+e1, o2+e2) >= 256; the reference takes any,
+// miniwfa.c:390-393): the one-column-per-lane passes with a window table of kBigRing entries.  Every mode: score, traceback,
+// low-memory two-pass.  Rare by nature (gap-open costs in the hundreds), so one plain form.
+template <int T>
+__global__ __launch_bounds__(T, 1) void wfa_bigring_kernel(const BatchArgs)
+{
+	__shared__ SharedBig sh;
+	KArgs &A0 = kernel_args();
+	for (;;) {
+		KArgs &A = fresh(A0);
+		if (threadIdx.x == 0) sh.item = (int32_t)atomicAdd(A.queue, 1);
+		__syncthreads();
+		const int32_t item = uni(sh.item);
+		__syncthreads();
+		if (item >= A.n_pairs) break;
+		const int32_t pair = A.order ? A.order[item] : item;
+		const int32_t slot = (int32_t)blockIdx.x;
+		PairMem M;
+		pair_mem(A, slot, pair, M);
+		const bool trace = A.dbg && pair == A.debug_pair;
+		int32_t n_seg = 0, status = ST_OK;
+		int64_t cells1 = 0;
+		PassResult R;
+		R.status = ST_OK, R.s = 0, R.info = 0, R.n_snap = 0, R.cells = 0;
+		if (A.step > 0 && A.want_cigar) { // low-memory first pass (reference mwf_wfa_exact, miniwfa.c:610-611)
+			const PassResult R1 = forward_pass<T, false, true>(A, M, sh, 0, false);
+			cells1 = R1.cells;
+			status = R1.status;
+			if (status == ST_OK) {
+				if (threadIdx.x == 0) sh.word[2] = trace_checkpoints(A, M, R1.n_snap, R1.info);
+				__syncthreads();
+				status = uni(sh.word[2]);
+				n_seg = R1.n_snap;
+			}
+			__syncthreads();
+		}
+		if (status == ST_OK) {
+			R = A.want_cigar ? forward_pass<T, true, false>(A, M, sh, n_seg, trace) : forward_pass<T, false, false>(A, M, sh, 0, trace);
+			status = R.status;
+		}
+		finish_pair(fresh(A), M, slot, pair, R, status, cells1);
+	}
+}
+
 } // namespace
 
 // Start of an align call: every pair "not run" (status -1, s -2: not final), CIGAR pool and work queue at zero.
@@ -1184,6 +1228,11 @@ static bool wants_lds2(const BatchArgs &a, int block) { return wants_stream(a) &
 
 int launch_batch(const BatchArgs &a, int grid, int block, void *stream)
 {
+	if (a.pen.nH > kMaxRing) { // a ring deeper than the LDS window tables of every other kernel
+		if (a.pen.nH > kBigRing) return -1;
+		hipLaunchKernelGGL(wfa_bigring_kernel<256>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+		return hipGetLastError() == hipSuccess ? 0 : -2;
+	}
 	if (wants_lds2(a, block)) {
 		const int lds = a.lds_e2_cols * 2 * (a.ring16 ? 2 : 4); // E2 and F2, as 16-bit codes with the 16-bit ring rows
 		const int lds_max = a.lds_e2_cols * 2 * 4;
@@ -1222,6 +1271,12 @@ static int occupancy_as(int block)
 	default: break;
 	}
 	return e == hipSuccess ? n : 0;
+}
+
+int bigring_kernel_occupancy()
+{
+	int n = 0;
+	return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_bigring_kernel<256>, 256, 0) == hipSuccess ? n : 0;
 }
 
 int batch_kernel_occupancy(int block, bool stream_pass, int lds_e2_cols, bool ring16)

@@ -7,8 +7,8 @@
 // plus its match extension, once per chunk the window has reached:
 //   * chunk 0 holds the 64 columns around the main diagonal; chunk k >= 1 the 32 columns beyond chunk k-1 on either side (lanes
 //     0-31 left, 32-63 right) — a window is symmetric around the main diagonal until the matrix clips it, so a narrow window costs
-//     one pass over the recurrence and a window of up to 64 x `lane_chunks` columns (2 by default: penalties up to ~78 with the
-//     default gap costs) is held;
+//     one pass over the recurrence and a window of up to 64 x `lane_chunks` columns (three chunks for pairs of up to 400 bases of
+//     target + query, else four: penalties up to ~110 / ~140 with the default gap costs) is held;
 //   * the H ring (nH rows), the E1/F1 rings (e1 rows each) and the E2/F2 rings (e2 rows) are rows of int16 in LDS — offsets
 //     of pairs this short fit, a dead cell is stored as max(v, -32768) exactly as in the packed band kernel — with one pad column
 //     either side that always reads dead (reference pads, miniwfa.c:103-121); a lane reads its neighbours' columns straight from
@@ -212,6 +212,13 @@ int lane_lds_bytes(const Penalty &p, int chunks, int64_t seq_bytes)
 
 int launch_lane(const BatchArgs &a, int grid, int lds, void *stream)
 {
+	// deep rings (large gap-open costs) or a raised lane_max_len: beyond 48 KB of dynamic LDS the runtime wants to be told (the attribute is
+	// per device and this may run on several host threads: set on every launch that needs it, as the band kernels do)
+	if (lds > 48 * 1024) {
+		(void)hipFuncSetAttribute(a.want_cigar ? reinterpret_cast<const void*>(&wfa_lane_kernel<true>) : reinterpret_cast<const void*>(&wfa_lane_kernel<false>),
+		                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+		(void)hipGetLastError();
+	}
 	if (a.want_cigar) hipLaunchKernelGGL(wfa_lane_kernel<true>, dim3(grid), dim3(64), lds, (hipStream_t)stream, a);
 	else hipLaunchKernelGGL(wfa_lane_kernel<false>, dim3(grid), dim3(64), lds, (hipStream_t)stream, a);
 	return hipGetLastError() == hipSuccess ? 0 : -2;

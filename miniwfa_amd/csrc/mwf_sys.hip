@@ -195,11 +195,12 @@ __device__ __forceinline__ bool sys_grid_sync(uint32_t spin_limit, unsigned *syn
 				if (spins < 32) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(100); // (idle workgroups wait here for a whole epoch: they must not hammer the fabric the hand-offs travel on)
 				if (++spins > spin_limit || ((spins & 255u) == 0 && ld_ag(abort_flag))) { ok = 0; break; }
 			}
-			__hip_atomic_store(&grp_gen[4 * grp], (unsigned long long)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			// (a leader that gave up publishes a POISONED generation: its members leave the barrier knowing that it did not complete)
+			__hip_atomic_store(&grp_gen[4 * grp], (unsigned long long)(ok ? epoch : (epoch | 0x80000000u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		} else {
 			for (;;) {
 				seen = __hip_atomic_load(&grp_gen[4 * grp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				if ((unsigned)(seen & 0xffffffffu) >= epoch) break;
+				if ((unsigned)(seen & 0xffffffffu) >= epoch) { if (seen & 0x80000000ull) ok = 0; break; }
 				if (spins < 32) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(100);
 				if (++spins > spin_limit || ((spins & 255u) == 0 && ld_ag(abort_flag))) { ok = 0; break; }
 			}
@@ -1083,7 +1084,7 @@ int launch_pass_c(const BatchArgs &a, int grid, hipStream_t st)
 	case 4:  hipLaunchKernelGGL((wfa_sys_kernel<E1, E2, 4, DEFER, TB, C>), dim3(grid), dim3(kT), 0, st, a); break;
 	case 16: hipLaunchKernelGGL((wfa_sys_kernel<E1, E2, 16, DEFER, TB, C>), dim3(grid), dim3(kT), 0, st, a); break;
 #endif
-	default: {
+	case 8: {
 		// The waits between workgroups rely on every workgroup being resident.  The grid is sized for that (one per CU, sys_max_grid) and
 		// the engine keeps this library's other kernels off the device meanwhile; a cooperative launch makes the runtime refuse a grid
 		// that could not be resident whatever else the process runs.  (A plain launch if the runtime refuses: the waits are bounded.)
@@ -1096,6 +1097,7 @@ int launch_pass_c(const BatchArgs &a, int grid, hipStream_t st)
 		hipLaunchKernelGGL((wfa_sys_kernel<E1, E2, 8, DEFER, TB, C>), dim3(grid), dim3(kT), 0, st, a);
 		break;
 	}
+	default: return -1; // no kernel for this block length: the host's layout (boxes, traceback rows) would not be the kernel's
 	}
 	return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -1122,6 +1124,14 @@ int launch_pass_d(const BatchArgs &a, int grid, hipStream_t st)
 
 int64_t sys_chunk_slots(int grid) { return (int64_t)grid * kNW * kK; }
 int sys_owned_cols(int p, int c) { return 64 * c - 2 * p; }
+bool sys_p_supported(int p)
+{
+#ifdef MWF_SYS_ALL_P
+	return p == 4 || p == 8 || p == 16;
+#else
+	return p == 8; // the product build instantiates one block length (P = 4 and 16 measured slower)
+#endif
+}
 int64_t sys_box_ints(int p) { return (2 * p * (p + 8) + 2 * p + 31) / 32 * 32; } // (whatever the columns per lane: 2 (p/c) lanes x (p + 8) c ints)
 
 int sys_max_grid()

@@ -1,13 +1,13 @@
-"""Fuzz of the 2-bit sequence copy against the byte-wise copy of the packed band kernel (and, with 'band3', of the balanced kernel):
+"""Fuzz of the 2-bit sequence copy against the byte-wise copy of the packed band kernel:
 random lengths (0 ... 3000), low-complexity and repetitive sequences (long exact runs: the per-lane and whole-wave run walkers),
-score and CIGAR, the three instantiated penalty sets.  Usage: python profiles/fuzz_seq2.py [band3] [seed]"""
+score and CIGAR, the three instantiated penalty sets.  Usage: python profiles/fuzz_seq2.py [seed]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import miniwfa_amd as mw
 from miniwfa_amd.synth import PackedBatch
 
-mode = "band3" if "band3" in sys.argv else "2bit"
+mode = "2bit"
 seed = int(sys.argv[-1]) if sys.argv[-1].isdigit() else 1
 rng = np.random.default_rng(seed)
 ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -38,7 +38,7 @@ pk = PackedBatch(pairs)
 
 def run(m, o):
     eng = mw.Engine(0)
-    eng.set("seq2bit", 0 if m == "bytes" else 1); eng.set("band3", 1 if m == "band3" else 0)
+    eng.set("seq2bit", 0 if m == "bytes" else 1)
     b = eng.upload(pk); b.align(o); s, it, nc = b.results()
     cig = [b.cigar(i, int(nc[i])).tolist() for i in range(pk.n)] if o.flag else None
     st = eng.stats(); b.free(); eng.close()

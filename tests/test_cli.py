@@ -54,3 +54,35 @@ def test_t3_output_matches_reference_format(cli, tmp_path):
     assert a[9] == "272" and a[10].strip() == "1X16=1X18=118I1=10I24="     # SURVEY Appendix B, -a
     e = subprocess.run([cli, "-ce", f1, f2], capture_output=True, text=True, check=True).stdout.split("\t")
     assert e[9] == "128"
+
+
+def test_reference_main_compiles_and_links_against_this_library(cli):
+    """The drop-in claim with the reference's OWN caller: /root/reference/main.c (main.c:19-92), unchanged and not copied, compiles
+    against include/miniwfa.h + include/kalloc.h and links with libmwf_hip.so (build container only: the sources do not travel)."""
+    if not os.path.exists("/root/reference/main.c"):
+        pytest.skip("reference sources not present (GPU box): the prebuilt binary is used by the GPU test below")
+    exe = b.build_ref_main()
+    assert exe and os.path.exists(exe)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 1 and "Usage: test-mwf" in r.stderr      # main.c:46-57
+    needed = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    assert "libmwf_hip.so" in needed and "libmwf_ref" not in needed  # every mwf_* / kalloc symbol comes from the HIP library
+
+
+@pytest.mark.gpu
+def test_reference_main_on_this_library_gives_the_reference_output(cli, tmp_path):
+    """... and run on the GPU it prints what tools/test-mwf prints and what the reference itself prints for its t3 fixture."""
+    exe = b.build_ref_main()
+    if not exe or not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref-main-on-libmwf_hip was not built (no reference sources where build() ran)")
+    t, q = golden_inputs(load_golden("exact_small.jsonl")[0])
+    f1 = _write(tmp_path, "t3-0.fa", ">1\n" + t.decode() + "\n")
+    f2 = _write(tmp_path, "t3-1.fa", ">2\n" + q.decode() + "\n")
+    exp = "1\t61\t0\t61\t+\t2\t189\t0\t189\t155"
+    for flags, tail in ((["-c"], "\t1X16=1X14=128I4=1X24="), ([], ""), (["-cp5"], "\t1X16=1X14=128I4=1X24="), (["-cu"], "\t1X16=1X18=128I1X24="),
+                        (["-ca"], None), (["-ce"], None), (["-cK"], "\t1X16=1X14=128I4=1X24=")):
+        ours = subprocess.run([cli, *flags, f1, f2], capture_output=True, text=True, check=True).stdout
+        theirs = subprocess.run([exe, *flags, f1, f2], capture_output=True, text=True, check=True).stdout
+        assert ours == theirs, (flags, ours, theirs)
+        if tail is not None:
+            assert theirs.strip() == exp + tail, (flags, theirs)

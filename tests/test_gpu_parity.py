@@ -88,6 +88,26 @@ def test_bench_shaped_golden_vectors(engine, oracle):
     run_vectors(engine, oracle, [v for v in load_golden("bench_shaped.jsonl") if v["entry"] == "exact"])
 
 
+def test_big_penalty_golden_vectors(engine, oracle):
+    """Penalty sets with max(x, o1+e1, o2+e2) >= 256 (gap opens of 254 ... 4000; the reference takes any, miniwfa.c:390-393) against
+    the reference's answers: s, n_iter, CIGAR in score, high-memory and low-memory (step 50 / 700) modes, stop rules.  From a ring
+    depth of 257 on the pairs run on the generic kernel's big-ring form; the set with o2+e2 = 255 still takes the fast kernels."""
+    vecs = load_golden("big_penalties.jsonl")
+    assert len(vecs) >= 200
+    run_vectors(engine, oracle, vecs)
+    # the same through the drop-in call
+    v = next(v for v in vecs if v["id"].startswith("big-t3#") and v["opt"]["flag"] and v["opt"]["o2"] == 300 and not v["opt"]["step"])
+    t, q = golden_inputs(v)
+    s, _, cig = mw.wfa_exact(t, q, gpu_opt(v["opt"]))
+    assert s == v["expect"]["s"] and ocig(cig) == v["expect"]["cigar"]
+    with pytest.raises(RuntimeError):   # beyond the limit stated in include/miniwfa.h: refused with a message, not computed wrongly
+        b = engine.upload(PackedBatch([(t, q)]))
+        try:
+            b.align(mw.opt_init(o2=5000))
+        finally:
+            b.free()
+
+
 def test_auto_exact_branch_matches_reference():
     for v in load_golden("exact_small.jsonl") + load_golden("bench_shaped.jsonl"):
         if v["entry"] != "auto":
@@ -1015,6 +1035,31 @@ def test_config5_default_kernel_at_full_pair_size(oracle):
     eng.close()
 
 
+def test_batch_multi_one_ranks_share_of_config5(oracle):
+    """BASELINE configs[4] through the drop-in batch entry point: one GPU's share of the 10 000 x 50 kb batch (1250 pairs @ 3 %,
+    score-only) in ONE mwf_wfa_batch_multi call with n_dev = 0 (every visible device; on the test box that is one).  The stored
+    reference answer of the cfg5 golden vector is reproduced inside the batch, three pairs equal the oracle, and the call agrees
+    pair by pair with the device-resident API (Engine/Batch) on the same inputs."""
+    gold = [v for v in load_golden("bench_shaped.jsonl") if v["id"].startswith("cfg5") and v["entry"] == "exact" and not v["opt"]["flag"]]
+    assert gold, "cfg5 golden vector missing"
+    pairs = [synth_pair(60000 + i, 50000, 0.03) for i in range(1250)]
+    pairs[777] = golden_inputs(gold[0])
+    got = mw.wfa_batch_multi(pairs, mw.opt_init(), n_dev=0)
+    assert len(got) == 1250 and all(r[0] > 0 and r[2] is None for r in got)
+    assert got[777][:2] == (gold[0]["expect"]["s"], gold[0]["expect"]["n_iter"])
+    for i in (0, 612, 1249):
+        assert got[i][:2] == oracle.align(pairs[i][0], pairs[i][1], make_opt())[:2], i
+    eng = mw.Engine(0)
+    b = eng.upload(PackedBatch(pairs))
+    b.align(mw.opt_init())
+    s, it, _ = b.results()
+    st = eng.stats()
+    assert (st.kernel_kind, st.packed) == (0, 16) and st.n_retries == 0
+    assert [r[0] for r in got] == s.tolist() and [r[1] for r in got] == it.tolist()
+    b.free()
+    eng.close()
+
+
 def test_two_threads_launch_the_large_lds_byte_wise_copy(oracle):
     """hipFuncAttributeMaxDynamicSharedMemorySize is per device and was once cached per process without a lock: two host
     threads (= two engines, as mwf_wfa_batch_multi has on a multi-GPU node) each launch a band kernel with a byte-wise sequence
@@ -1093,6 +1138,36 @@ def test_long_pair_and_batch_threads_share_the_device(oracle, capfd):
         t_.join()
     assert not errors, errors[:3]
     assert "gave up waiting" not in capfd.readouterr().err
+
+
+def test_whole_device_block_length_tunable_is_checked(oracle):
+    """"sys_p" (penalties per hand-off block of the whole-device kernel) sizes the hand-off boxes and the traceback layout on the host;
+    the product build has kernels for 8 only.  A value without a kernel must be refused when it is set — never laid out for and then
+    run on the P = 8 kernel — and 8 itself keeps working."""
+    eng = mw.Engine(0)
+    built_all = True
+    for p in (4, 16):
+        try:
+            eng.set("sys_p", p)
+        except ValueError:
+            built_all = False
+    for bad in (0, 2, 3, 12, 32):
+        with pytest.raises(ValueError):
+            eng.set("sys_p", bad)
+    t, q = synth_pair(99100, 12000, 0.06)
+    for p in ((4, 8, 16) if built_all else (8,)):     # (a -DMWF_SYS_ALL_P build: every block length against the oracle)
+        eng.set("sys_p", p)
+        eng.set("force_kind", 1)
+        for kw in (dict(), dict(flag=1), dict(flag=1, step=700)):
+            b = eng.upload(PackedBatch([(t, q)]))
+            b.align(mw.opt_init(**kw))
+            s, it, nc = b.results()
+            es, eit, ecig = oracle.align(t, q, make_opt(**kw))
+            assert (int(s[0]), int(it[0])) == (es, eit), (p, kw)
+            if ecig is not None:
+                assert b.cigar(0, int(nc[0])).tolist() == ecig, (p, kw)
+            b.free()
+    eng.close()
 
 
 def test_whole_device_kernel_columns_per_lane(oracle, capfd):

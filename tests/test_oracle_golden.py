@@ -38,6 +38,7 @@ def _check(oracle, v):
 
 SMALL = [v for v in load_golden("exact_small.jsonl") if v["entry"] != "chain"]
 BIG = [v for v in load_golden("bench_shaped.jsonl") if v["entry"] != "chain"]
+BIGPEN = load_golden("big_penalties.jsonl")   # max(x, o1+e1, o2+e2) >= 256: rings deeper than the fast kernels' tables (tests/golden/make_golden_bigpen.py)
 
 
 def test_struct_layout():
@@ -65,6 +66,13 @@ def test_t3_known_answer(oracle):
 @pytest.mark.parametrize("chunk", range(8))
 def test_small_golden(oracle, chunk):
     for v in SMALL[chunk::8]:
+        _check(oracle, v)
+
+
+@pytest.mark.parametrize("chunk", range(4))
+def test_big_penalty_golden(oracle, chunk):
+    assert len(BIGPEN) >= 200
+    for v in BIGPEN[chunk::4]:
         _check(oracle, v)
 
 
