@@ -72,6 +72,8 @@ struct mwf_gpu_s {
 	int lane_chunks = 0;       // its window: 64-column chunks of LDS rows (1-4; 0: three for pairs of up to 400 bases of target + query, else four); a penalty only passes over the chunks the window has reached
 	int lane_max_len = 400;    // (measured: 20 000 x 400 bp @ 5 % 1.37 against 1.58 ms with 767 pairs re-run, x 500 bp @ 2 % 0.69 / 1.17, profiles/r03/lane_longer_pairs.txt)
 	                           // pairs whose longer sequence has at most this many bases try the one-diagonal-per-lane kernel first (0: never)
+	int mid_max_pairs = -1;    // a batch of at most this many pairs may use the one-workgroup-per-pair, rings-in-LDS kernel (mwf_mid.hip) for its mid-size pairs (-1: one per CU; 0: never)
+	int mid_block = 0;         // its threads per workgroup: 0 by span (256 up to 512 columns, else 1024), 256, 1024
 	int band_pack = -1;        // int16-packed E/F registers in the band kernel: 0 never, otherwise whenever the value ranges allow
 	int ring16 = 1;            // generic kernel with E2/F2 in LDS: 16-bit ring rows in HBM while target length + penalty fits 16 bits (0: never)
 	int ring16_block = 0;      // its threads per workgroup (0: 512 score-only — two workgroups per CU with the 64 KB LDS copy —, 768 with traceback)
@@ -365,6 +367,19 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 			return;
 		}
 	}
+	if (geom_block == 33 && want_kind != 0 && !low_mem && mid_supported(P)) { // a few mid-size pairs: one workgroup per pair, every ring in LDS (mwf_mid.hip)
+		// the span: as many 64-column groups as the LDS holds beside the sequences (a window is about twice the final penalty wide: a 2 kb
+		// pair at 5 % needs ~1100 columns), never more than the widest possible window plus the dead margins
+		const int64_t want_cols = (std::min<int64_t>(max_len + 1, 2 * max_bound + 3) + 2 * P.nH + 63) / 64 * 64;
+		int groups = (int)std::min<int64_t>(want_cols / 64, 128);
+		while (groups > 1 && mid_lds_bytes(P, groups, max_seq_lds) > 158 * 1024) --groups;
+		const int lds = mid_lds_bytes(P, groups, max_seq_lds);
+		if (lds <= 158 * 1024) {
+			const int block = g->mid_block ? g->mid_block : (groups * 64 <= 512 ? 256 : 1024);
+			pl.kind = 2, pl.band = BandGeom{block, 1, 64 * groups, lds, 0, 2};
+			return;
+		}
+	}
 	if (want_kind == 0 || low_mem || (!can_packed && !can_plain)) return;
 	const int64_t max_window = std::min<int64_t>(max_len + 1, 2 * max_bound + 3);
 	BandGeom bg;
@@ -431,11 +446,12 @@ int cached_occupancy(mwf_gpu_t *g, const Penalty &P, const Plan &pl, int lds_e2_
 	uint64_t key;
 	if (pl.kind == 2)
 		key = 1ull | (uint64_t)pl.band.block << 4 | (uint64_t)(pl.band.packed == 1) << 16 | (uint64_t)(pl.band.lds_bytes > 0) << 17 | (uint64_t)pl.cigar << 18 |
-		      (uint64_t)(pl.band.seq2 != 0) << 3 | (uint64_t)(pl.band.lane != 0) << 2 | (uint64_t)P.e1 << 20 | (uint64_t)P.e2 << 28 | (uint64_t)pl.band.lds_bytes << 36;
+		      (uint64_t)(pl.band.seq2 != 0) << 3 | (uint64_t)(pl.band.lane == 1) << 2 | (uint64_t)(pl.band.lane == 2) << 19 | (uint64_t)P.e1 << 20 | (uint64_t)P.e2 << 28 | (uint64_t)pl.band.lds_bytes << 36;
 	else key = 2ull | (uint64_t)pl.block << 4 | (uint64_t)stream_pass << 16 | (uint64_t)ring16 << 17 | (uint64_t)(P.nH > kMaxRing) << 18 | (uint64_t)lds_e2_cols << 20;
 	auto it = g->occ_cache.find(key);
 	if (it != g->occ_cache.end()) return it->second;
-	const int per = pl.kind == 2 && pl.band.lane ? lane_kernel_occupancy(pl.band.lds_bytes, pl.cigar)
+	const int per = pl.kind == 2 && pl.band.lane == 2 ? 1 // (mwf_mid.hip: most of a CU's LDS per workgroup)
+	              : pl.kind == 2 && pl.band.lane ? lane_kernel_occupancy(pl.band.lds_bytes, pl.cigar)
 	              : pl.kind == 2 ? (pl.band.packed ? band2_kernel_occupancy(P, pl.band, pl.cigar) : band_kernel_occupancy(P, pl.band, pl.cigar))
 	              : P.nH > kMaxRing ? bigring_kernel_occupancy()
 	                             : batch_kernel_occupancy(pl.block, stream_pass, lds_e2_cols, ring16);
@@ -530,7 +546,8 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 			worst = std::min(worst, (max_bound + 1) * std::min<int64_t>(max_len + 1, 2 * (int64_t)(opt.step + 2 * P.nH) + 8));
 		}
 		worst += 8 * (max_bound + 2);
-		if (pl.kind == 2 && pl.band.lane) worst = (std::min<int64_t>(max_bound, 256) + 2) * pl.band.span; // its rows: the span wide, fewer than 256 of them
+		if (pl.kind == 2 && pl.band.lane == 1) worst = (std::min<int64_t>(max_bound, 256) + 2) * pl.band.span; // its rows: the span wide, fewer than 256 of them
+		if (pl.kind == 2 && pl.band.lane == 2) worst = (max_bound + 2) * pl.band.span;                          // rows of the span's width, one per penalty
 		// the device is only asked how much is free when the arena at hand cannot hold the worst case
 		int64_t per = worst;
 		if ((int64_t)g->tb.bytes < (int64_t)S * worst || g->tb_budget_mb > 0) per = std::min(per, std::max<int64_t>(tb_budget_bytes(g), (int64_t)g->tb.bytes) / (int64_t)S);
@@ -598,7 +615,8 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	// HIP events bracket the kernel only: every workspace allocation above is already done
 	if (timed) HIP_TRY(g, hipEventRecord(g->ev0, g->stream));
 	std::shared_lock<std::shared_mutex> gate(g_dev_gate[g->device % kMaxDevices]); // not while a whole-device kernel runs
-	const int lrc = pl.kind == 2 && pl.band.lane ? launch_lane(a, pl.grid, pl.band.lds_bytes, g->stream)
+	const int lrc = pl.kind == 2 && pl.band.lane == 2 ? launch_mid(a, pl.grid, pl.band.block, pl.band.lds_bytes, g->stream)
+	              : pl.kind == 2 && pl.band.lane ? launch_lane(a, pl.grid, pl.band.lds_bytes, g->stream)
 	              : pl.kind == 2 ? (pl.band.packed ? launch_band2(a, pl.grid, pl.band, g->stream) : launch_band(a, pl.grid, pl.band, g->stream))
 	                             : launch_batch(a, pl.grid, pl.block, g->stream);
 	gate.unlock();
@@ -613,7 +631,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	}
 	g->stats.n_launches += 1;
 	g->stats.grid = std::max(g->stats.grid, pl.grid), g->stats.block = pl.block, g->stats.kernel_kind = pl.kind;
-	g->stats.packed = pl.kind == 2 ? (pl.band.lane ? 32 : pl.band.packed) : (ring16 ? 16 : 0);
+	g->stats.packed = pl.kind == 2 ? (pl.band.lane == 2 ? 33 : pl.band.lane ? 32 : pl.band.packed) : (ring16 ? 16 : 0);
 	g->stats.lowmem_two_pass = pl.low_mem ? 1 : 0;
 	if (ran_kind) *ran_kind = pl.kind;
 	return 0;
@@ -1130,6 +1148,8 @@ int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value)
 	else if (!strcmp(name, "lane_chunks") && value >= 0 && value <= 4) g->lane_chunks = (int)value;
 	else if (!strcmp(name, "host_results")) g->res_pin_on = value != 0;
 	else if (!strcmp(name, "lane_max_len")) g->lane_max_len = (int)std::max<int64_t>(0, std::min<int64_t>(value, 8000));
+	else if (!strcmp(name, "mid_max_pairs")) g->mid_max_pairs = (int)std::max<int64_t>(-1, std::min<int64_t>(value, 1 << 20));
+	else if (!strcmp(name, "mid_block") && (value == 0 || value == 256 || value == 1024)) g->mid_block = (int)value;
 	else if (!strcmp(name, "lds_e2")) g->lds_e2 = value != 0;
 	else if (!strcmp(name, "scalar_generic")) g->scalar_generic = value != 0;
 	else if (!strcmp(name, "coop_spin_limit")) g->coop_spin_limit = std::max<int64_t>(0, std::min<int64_t>(value, 0x7fffffff));
@@ -1294,9 +1314,13 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	// groups 0-4: the size classes, 5: two-pass low-memory pairs, 6-9: classes 1-4 again for the pairs the host knows not to be
 	// plain A/C/G/T (byte-wise sequence copy from the start)
 	// 10: short pairs on the one-diagonal-per-lane kernel (mwf_lane.hip); what outgrows its 64 columns moves to the band classes
-	struct Group { std::vector<int32_t> ids; int64_t max_len = 0, max_bound = 0, max_bound1 = 0, max_tl = 0, max_seq_lds = 0; } grp[11];
+	// 11: mid-size pairs of a small batch on the one-workgroup-per-pair, rings-in-LDS kernel (mwf_mid.hip); what outgrows its span moves to the band classes
+	struct Group { std::vector<int32_t> ids; int64_t max_len = 0, max_bound = 0, max_bound1 = 0, max_tl = 0, max_seq_lds = 0; } grp[12];
 	const bool lane_ok = g->lane_max_len > 0 && lane_supported(P0);
+	const int mid_cap = g->mid_max_pairs < 0 ? g->n_cu : g->mid_max_pairs;
+	const bool mid_ok = g->force_kind < 0 && g->block == 0 && mid_cap > 0 && b->n <= mid_cap && mid_supported(P0);
 	const bool know_acgt = !b->h_acgt.empty() && g->seq2bit != 0;
+	auto window_of = [](int64_t len, int64_t bound) { return std::min<int64_t>(len + 1, 2 * bound + 3); };
 	for (int32_t i = 0; i < b->n; ++i) {
 		const int64_t len = (int64_t)b->h_tl[i] + b->h_ql[i], bound = penalty_bound(*opt, b->h_tl[i], b->h_ql[i], true);
 		const int64_t bound1 = penalty_bound(*opt, b->h_tl[i], b->h_ql[i], false);
@@ -1323,6 +1347,18 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		const bool to_lane = classes && lane_ok && c >= 1 && c <= 4 && std::max(b->h_tl[i], b->h_ql[i]) <= g->lane_max_len &&
 		                     std::abs(b->h_tl[i] - b->h_ql[i]) <= 24;
 		if (to_lane) c = 10, b->h_class[i] = 4;
+		// a few mid-size pairs: a workgroup each, rings in LDS (a penalty then costs a fraction of a microsecond instead of ~2).  Admitted
+		// when the span the LDS can hold beside the sequences covers the window of a pair at ~6 % divergence (about 0.3 (tl+ql)); 16-bit offsets.
+		if (mid_ok && !to_lane && c <= 4 && (!low_mem || step0) && (int64_t)b->h_tl[i] + bound < 32760) {
+			const int64_t seq_lds = (((int64_t)b->h_tl[i] + 7) & ~7LL) + 16 + (((int64_t)b->h_ql[i] + 7) & ~7LL) + 32;
+			const int64_t want = std::min<int64_t>(window_of(len, bound), len * 3 / 10 + 128) + 2 * P0.nH;
+			int groups = (int)std::min<int64_t>((std::min<int64_t>(len + 1, 2 * bound + 3) + 2 * P0.nH + 63) / 64, 128);
+			while (groups > 1 && mid_lds_bytes(P0, groups, seq_lds) > 158 * 1024) --groups;
+			if (mid_lds_bytes(P0, groups, seq_lds) <= 158 * 1024 && (int64_t)groups * 64 >= want && std::abs((int64_t)b->h_tl[i] - b->h_ql[i]) < groups * 32) {
+				b->h_class[i] = (int8_t)((c >= 1 && c <= 4) || (classes && (int64_t)b->h_tl[i] + bound < 32767 && g->band_pack != 0 && band2_supported(P0)) ? 2 : 0); // where an overflow goes: the wide packed band kernel, else generic
+				c = 11;
+			}
+		}
 		if (c >= 1 && c <= 4 && know_acgt && !b->h_acgt[i] && (int64_t)b->h_tl[i] + bound < 32767 && g->band_pack != 0 && band2_supported(P0)) c += 5;
 		Group &G = grp[c];
 		G.ids.push_back(i);
@@ -1331,7 +1367,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		G.max_tl = std::max<int64_t>(G.max_tl, b->h_tl[i]);
 		G.max_seq_lds = std::max<int64_t>(G.max_seq_lds, (((int64_t)b->h_tl[i] + 3) & ~3LL) + 8 + (((int64_t)b->h_ql[i] + 3) & ~3LL) + 16);
 	}
-	static const int run_order[11] = {5, 0, 1, 6, 2, 7, 3, 8, 4, 9, 10}; // largest workspace first
+	static const int run_order[12] = {5, 0, 1, 6, 2, 7, 3, 8, 4, 9, 11, 10}; // largest workspace first
 	std::vector<int32_t> order;
 	order.reserve((size_t)b->n);
 	for (int c : run_order) {
@@ -1355,11 +1391,11 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		if (G.ids.empty()) continue;
 		++done_groups;
 		int ran = 0;
-		const int cc = c == 10 ? 5 : c > 5 ? c - 5 : c;
+		const int cc = c == 11 ? 6 : c == 10 ? 5 : c > 5 ? c - 5 : c;
 		g->acgt_off_once = c > 5 && c < 10;
 		const int rc = run_batch_kernel(g, b, c == 5 ? *opt : opt_hi, b->d_order + at, (int32_t)G.ids.size(), slots, G.max_len, G.max_bound, G.max_bound1,
-		                                done_groups == 1, classes ? (c == 0 || c == 5 ? 0 : 2) : -1, G.max_tl, G.max_seq_lds, done_groups == n_groups,
-		                                cc == 5 ? 32 : cc == 4 ? 64 : cc == 3 ? 128 : cc == 2 ? 256 : 0, &ran);
+		                                done_groups == 1, (classes || c == 11) ? (c == 0 || c == 5 ? 0 : 2) : -1, G.max_tl, G.max_seq_lds, done_groups == n_groups,
+		                                cc == 6 ? 33 : cc == 5 ? 32 : cc == 4 ? 64 : cc == 3 ? 128 : cc == 2 ? 256 : 0, &ran);
 		g->acgt_off_once = false;
 		if (rc) return -1;
 		for (int32_t i : G.ids) b->h_kind[i] = (int8_t)ran;

@@ -118,7 +118,7 @@ struct BatchArgs {
 	int64_t sys_park_stride;   // ints between two groups' parking areas
 	int64_t *sys_ep;           // [group][epochs][2]: traceback layout per epoch of 256 penalties: base offset, first chunk | chunks << 32
 	int64_t sys_ep_stride;     // int64 words between two groups' tables
-	int32_t lane_chunks;       // one-diagonal-per-lane kernel (mwf_lane.hip): 64-column chunks of its LDS rows (1-4)
+	int32_t lane_chunks;       // one-diagonal-per-lane kernels: 64-column chunks of their LDS rows (mwf_lane.hip: 1-4; mwf_mid.hip: its span / 64)
 	int32_t sys_coop_launch;   // host side only: 1 = launch through hipLaunchCooperativeKernel (the runtime then guarantees that every workgroup is resident)
 };
 
@@ -135,7 +135,8 @@ struct BandGeom {
 	int span;         // columns the workgroup can hold: waves * chunks * 256 (balanced kernel: columns of its LDS state ring)
 	int lds_bytes;    // dynamic LDS for the sequence copy (0: read sequences from global memory)
 	int seq2;         // packed kernel: the sequence copy holds 2 bits per base (pairs of plain A/C/G/T; others come back as ST_ALPHABET)
-	int lane;         // 1: the one-wave, one-diagonal-per-lane kernel for short pairs (mwf_lane.hip): block 64, span 64, lds_bytes = rings + sequences
+	int lane;         // 1: the one-wave, one-diagonal-per-lane kernel for short pairs (mwf_lane.hip): block 64, span 64, lds_bytes = rings + sequences;
+	                  // 2: the one-workgroup, one-diagonal-per-lane kernel for a few mid-size pairs (mwf_mid.hip): span = columns of its LDS rows
 };
 // launch wrappers implemented in mwf_coop.hip (one pair across the whole device)
 bool coop_supported(const Penalty &p);
@@ -159,6 +160,11 @@ bool lane_supported(const Penalty &p);
 int  lane_lds_bytes(const Penalty &p, int chunks, int64_t seq_bytes); // seq_bytes >= tl + ql + 24 for every pair of the launch
 int  launch_lane(const BatchArgs &a, int grid, int lds, void *stream);
 int  lane_kernel_occupancy(int lds, bool cigar);
+
+// launch wrappers implemented in mwf_mid.hip (one workgroup per pair, one diagonal per lane, rings and sequences in LDS: a few mid-size pairs)
+bool mid_supported(const Penalty &p);
+int  mid_lds_bytes(const Penalty &p, int groups, int64_t seq_bytes); // seq_bytes >= (tl up to 8) + 16 + (ql up to 8) + 32 for every pair of the launch
+int  launch_mid(const BatchArgs &a, int grid, int block, int lds, void *stream);
 
 bool band_supported(const Penalty &p);                       // (e1,e2) instantiated and every H lag >= 2
 // launch wrappers implemented in mwf_band2.hip (packed band kernel: 16-bit offsets, sequences in LDS; BandGeom::packed)

@@ -155,6 +155,8 @@ __device__ PassResult forward_pass(const ArgsT &A, const PairMem &M, ShT &sh, in
 		const int32_t k0 = extend_run(M.ts, M.qs, tl, ql, -1, 0);
 		M.H[c0] = k0;
 		M.E1[c0] = M.F1[c0] = M.E2[c0] = M.F2[c0] = kNegInf;
+		// a ring deeper than 256 slices still holds the origin when the first shrink looks at it (miniwfa.c:144-171): its good bit
+		M.good[c0 >> 6] = in_matrix(0, k0, tl, ql) ? 1ull << (c0 & 63) : 0ull;
 		if (SEG) {
 			M.sH[c0] = -1;
 			M.sE1[c0] = M.sF1[c0] = M.sE2[c0] = M.sF2[c0] = kNegInf;

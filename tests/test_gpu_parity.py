@@ -706,6 +706,81 @@ def test_lane_kernel_short_pairs_fuzz_against_oracle(chunks, oracle):
     eng.close()
 
 
+def test_mid_kernel_fuzz_against_oracle(oracle):
+    """The one-workgroup-per-pair kernel with every ring in LDS (mwf_mid.hip) serves the mid-size pairs of SMALL batches — the single
+    pair of a drop-in call first of all.  Seeded fuzz: corner-case lengths, homopolymers and tandem repeats (long exact runs), unrelated
+    pairs whose window leaves the span (re-run on the band kernels), pairs past several band shrinks (s >> 256), unequal lengths, bytes
+    outside ACGT, five penalty sets (the kernel is not specialised on them; one the band kernels do not take at all), stop rules, both
+    workgroup sizes.  s, n_iter and CIGAR equal the oracle's."""
+    rng = np.random.default_rng(4141)
+    pairs = fuzz_pairs(57, 40, 3000)
+    pairs += [synth_pair(int(rng.integers(1 << 30)), int(rng.integers(401, 4000)), float(rng.choice([0.0, 0.01, 0.05, 0.1, 0.2]))) for _ in range(40)]
+    pairs += [synth_pair(5150, 2500, 0.04, 2, 300), synth_pair(5151, 1500, 0.05, 3, 700), (b"ACGTNNRYACGT" * 90, b"ACGTNNRYACGA" * 90),
+              (b"A" * 1500, b"A" * 1200), synth_pair(5152, 6000, 0.03), synth_pair(5153, 3000, 0.3)]
+    pk = PackedBatch(pairs)
+    for block, kw in ((0, dict()), (0, dict(flag=1)), (256, dict(flag=1, o2=4, e2=2)), (1024, dict(x=2, o1=3, e1=1, o2=6, e2=1)), (0, dict(flag=1, x=3, o1=5, e1=3, o2=20, e2=1)),
+                      (0, dict(flag=1, max_s=300)), (1024, dict(max_iter=150000))):
+        o = make_opt(**kw)
+        eng = mw.Engine(0)
+        eng.set("mid_block", block)
+        b = eng.upload(pk)
+        b.align(mw.opt_init(**kw))
+        s, it, nc = b.results()
+        for i, (t, q) in enumerate(pairs):
+            es, eit, ecig = oracle.align(t, q, o)
+            assert (int(s[i]), int(it[i])) == (es, eit), (block, kw, i, len(t), len(q))
+            if ecig is not None and es >= 0:
+                assert b.cigar(i, int(nc[i])).tolist() == ecig, (block, kw, i)
+        b.free()
+        eng.close()
+
+
+def test_mid_kernel_serves_single_calls(oracle):
+    """Which kernel a lone mid-size pair takes (stats.packed: 32 lane kernel, 33 mid kernel, 1 packed band kernel): a 2 kb pair runs on the
+    mid kernel, score and CIGAR, with no re-run; a 300 bp pair stays on the lane kernel; with "mid_max_pairs" 0, and in a batch
+    of more pairs than CUs, the band kernels take the 2 kb pairs.  Low-memory mode with a step the pair cannot reach is served as well."""
+    t, q = synth_pair(123, 2000, 0.05)
+    for kw in (dict(), dict(flag=1), dict(flag=1, step=5000)):
+        eng = mw.Engine(0)
+        b = eng.upload(PackedBatch([(t, q)]))
+        b.align(mw.opt_init(**kw))
+        st = eng.stats()
+        assert (st.kernel_kind, st.packed, st.block) == (2, 33, 1024), (kw, st.kernel_kind, st.packed, st.block)
+        s, it, nc = b.results()
+        assert eng.stats().n_retries == 0
+        es, eit, ecig = oracle.align(t, q, make_opt(**kw))
+        assert (int(s[0]), int(it[0])) == (es, eit), kw
+        if ecig is not None:
+            assert b.cigar(0, int(nc[0])).tolist() == ecig, kw
+        b.free()
+        eng.set("mid_max_pairs", 0)
+        b = eng.upload(PackedBatch([(t, q)]))
+        b.align(mw.opt_init(**kw))
+        assert eng.stats().packed == 1
+        s2, it2, _ = b.results()
+        assert (int(s2[0]), int(it2[0])) == (es, eit)
+        b.free()
+        eng.close()
+    eng = mw.Engine(0)
+    b = eng.upload(PackedBatch([synth_pair(124, 300, 0.05)]))
+    b.align(mw.opt_init())
+    assert eng.stats().packed == 32
+    b.results()
+    b.free()
+    many = [synth_pair(7000 + i, 1000, 0.05) for i in range(600)]
+    b = eng.upload(PackedBatch(many))
+    b.align(mw.opt_init())
+    assert eng.stats().packed == 1
+    s, it, _ = b.results()
+    for i in (0, 299, 599):
+        assert (int(s[i]), int(it[i])) == oracle.align(many[i][0], many[i][1], make_opt())[:2]
+    b.free()
+    eng.close()
+    # through the drop-in call
+    s, it, cig = mw.wfa_exact(t, q, mw.opt_init(flag=1))
+    assert (s, it, cig) == oracle.align(t, q, make_opt(flag=1))
+
+
 def test_small_batches_share_the_pinned_result_page(oracle):
     """Score-only batches of up to 64 pairs get their result arrays in ONE pinned host page per engine (no copy back); a second
     batch alive on the same engine keeps its device arrays, a CIGAR-mode align of the owner moves it back to them, and uploads
