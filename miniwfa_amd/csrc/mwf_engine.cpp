@@ -375,8 +375,11 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 		while (groups > 1 && mid_lds_bytes(P, groups, max_seq_lds) > 158 * 1024) --groups;
 		const int lds = mid_lds_bytes(P, groups, max_seq_lds);
 		if (lds <= 158 * 1024) {
-			const int block = g->mid_block ? g->mid_block : (groups * 64 <= 512 ? 256 : 1024);
-			pl.kind = 2, pl.band = BandGeom{block, 1, 64 * groups, lds, 0, 2};
+			// eight waves while the windows stay below ~700 columns (pairs of up to ~1.2 kb at 5 %), else sixteen (measured: 1 kb 0.255 against
+			// 0.314 ms, 2 kb 0.572 / 0.556, 4 kb 1.60 / 1.43; profiles/mid_kernel_probe.py)
+			const int block = g->mid_block ? g->mid_block : (max_len <= 2500 ? 512 : 1024);
+			const int seq2 = g->seq2bit != 0 && !g->acgt_off_once;
+			pl.kind = 2, pl.band = BandGeom{block, 1, 64 * groups, lds, seq2, 2};
 			return;
 		}
 	}
@@ -615,7 +618,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	// HIP events bracket the kernel only: every workspace allocation above is already done
 	if (timed) HIP_TRY(g, hipEventRecord(g->ev0, g->stream));
 	std::shared_lock<std::shared_mutex> gate(g_dev_gate[g->device % kMaxDevices]); // not while a whole-device kernel runs
-	const int lrc = pl.kind == 2 && pl.band.lane == 2 ? launch_mid(a, pl.grid, pl.band.block, pl.band.lds_bytes, g->stream)
+	const int lrc = pl.kind == 2 && pl.band.lane == 2 ? launch_mid(a, pl.grid, pl.band.block, pl.band.lds_bytes, pl.band.seq2 != 0, g->stream)
 	              : pl.kind == 2 && pl.band.lane ? launch_lane(a, pl.grid, pl.band.lds_bytes, g->stream)
 	              : pl.kind == 2 ? (pl.band.packed ? launch_band2(a, pl.grid, pl.band, g->stream) : launch_band(a, pl.grid, pl.band, g->stream))
 	                             : launch_batch(a, pl.grid, pl.block, g->stream);
@@ -1149,7 +1152,7 @@ int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value)
 	else if (!strcmp(name, "host_results")) g->res_pin_on = value != 0;
 	else if (!strcmp(name, "lane_max_len")) g->lane_max_len = (int)std::max<int64_t>(0, std::min<int64_t>(value, 8000));
 	else if (!strcmp(name, "mid_max_pairs")) g->mid_max_pairs = (int)std::max<int64_t>(-1, std::min<int64_t>(value, 1 << 20));
-	else if (!strcmp(name, "mid_block") && (value == 0 || value == 256 || value == 1024)) g->mid_block = (int)value;
+	else if (!strcmp(name, "mid_block") && (value == 0 || value == 256 || value == 512 || value == 1024)) g->mid_block = (int)value;
 	else if (!strcmp(name, "lds_e2")) g->lds_e2 = value != 0;
 	else if (!strcmp(name, "scalar_generic")) g->scalar_generic = value != 0;
 	else if (!strcmp(name, "coop_spin_limit")) g->coop_spin_limit = std::max<int64_t>(0, std::min<int64_t>(value, 0x7fffffff));
@@ -1318,6 +1321,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	struct Group { std::vector<int32_t> ids; int64_t max_len = 0, max_bound = 0, max_bound1 = 0, max_tl = 0, max_seq_lds = 0; } grp[12];
 	const bool lane_ok = g->lane_max_len > 0 && lane_supported(P0);
 	const int mid_cap = g->mid_max_pairs < 0 ? g->n_cu : g->mid_max_pairs;
+	bool mid_bytes = false;
 	const bool mid_ok = g->force_kind < 0 && g->block == 0 && mid_cap > 0 && b->n <= mid_cap && mid_supported(P0);
 	const bool know_acgt = !b->h_acgt.empty() && g->seq2bit != 0;
 	auto window_of = [](int64_t len, int64_t bound) { return std::min<int64_t>(len + 1, 2 * bound + 3); };
@@ -1357,6 +1361,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 			if (mid_lds_bytes(P0, groups, seq_lds) <= 158 * 1024 && (int64_t)groups * 64 >= want && std::abs((int64_t)b->h_tl[i] - b->h_ql[i]) < groups * 32) {
 				b->h_class[i] = (int8_t)((c >= 1 && c <= 4) || (classes && (int64_t)b->h_tl[i] + bound < 32767 && g->band_pack != 0 && band2_supported(P0)) ? 2 : 0); // where an overflow goes: the wide packed band kernel, else generic
 				c = 11;
+				mid_bytes |= know_acgt && !b->h_acgt[i]; // a pair the host knows not to be plain A/C/G/T: the (few) pairs of this class all take the byte-wise copy
 			}
 		}
 		if (c >= 1 && c <= 4 && know_acgt && !b->h_acgt[i] && (int64_t)b->h_tl[i] + bound < 32767 && g->band_pack != 0 && band2_supported(P0)) c += 5;
@@ -1392,7 +1397,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		++done_groups;
 		int ran = 0;
 		const int cc = c == 11 ? 6 : c == 10 ? 5 : c > 5 ? c - 5 : c;
-		g->acgt_off_once = c > 5 && c < 10;
+		g->acgt_off_once = (c > 5 && c < 10) || (c == 11 && mid_bytes);
 		const int rc = run_batch_kernel(g, b, c == 5 ? *opt : opt_hi, b->d_order + at, (int32_t)G.ids.size(), slots, G.max_len, G.max_bound, G.max_bound1,
 		                                done_groups == 1, (classes || c == 11) ? (c == 0 || c == 5 ? 0 : 2) : -1, G.max_tl, G.max_seq_lds, done_groups == n_groups,
 		                                cc == 6 ? 33 : cc == 5 ? 32 : cc == 4 ? 64 : cc == 3 ? 128 : cc == 2 ? 256 : 0, &ran);

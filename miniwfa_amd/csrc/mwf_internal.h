@@ -164,7 +164,7 @@ int  lane_kernel_occupancy(int lds, bool cigar);
 // launch wrappers implemented in mwf_mid.hip (one workgroup per pair, one diagonal per lane, rings and sequences in LDS: a few mid-size pairs)
 bool mid_supported(const Penalty &p);
 int  mid_lds_bytes(const Penalty &p, int groups, int64_t seq_bytes); // seq_bytes >= (tl up to 8) + 16 + (ql up to 8) + 32 for every pair of the launch
-int  launch_mid(const BatchArgs &a, int grid, int block, int lds, void *stream);
+int  launch_mid(const BatchArgs &a, int grid, int block, int lds, bool seq2, void *stream); // seq2: 2-bit sequence copies (a pair outside plain A/C/G/T comes back as ST_ALPHABET)
 
 bool band_supported(const Penalty &p);                       // (e1,e2) instantiated and every H lag >= 2
 // launch wrappers implemented in mwf_band2.hip (packed band kernel: 16-bit offsets, sequences in LDS; BandGeom::packed)

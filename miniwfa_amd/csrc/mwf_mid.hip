@@ -18,7 +18,8 @@
 //     for without any window test — a later window reaches at most nH columns beyond it, shrinks included;
 //   * the band shrink every 256 penalties (wf_stripe_shrink, miniwfa.c:144-171) works on ballot good bits kept in LDS per ring row and
 //     group, masked by each slice's own window;
-//   * both sequences sit in LDS as bytes (any alphabet); the extension compares 8 bytes per lane and trip, the wave walks together;
+//   * both sequences sit in LDS — at 2 bits per base for pairs of plain A/C/G/T (sixteen bases per trip of the extension, two LDS
+//     instructions), else as bytes (any alphabet, eight per trip); the wave walks the runs together;
 //   * traceback bytes go to the slot's arena as rows of C bytes that all start at the span's first column: the shared traceback
 //     (mwf_device.h) finds a byte without reading a row table first.
 // A pair whose window leaves the span comes back as ST_BAND_OVERFLOW and is re-run on the packed band kernel (finalize()).
@@ -66,6 +67,60 @@ __device__ __forceinline__ int32_t mid_extend(const uint8_t *lt, const uint8_t *
 	return max(min(n, room), 0);
 }
 
+// ---- 2-bit sequence copies (pairs of plain A/C/G/T): sixteen bases per dword, base j at bits 2*(j & 15) of dword j >> 4 — one
+// ds_read2_b32 and one v_alignbit per sequence give SIXTEEN bases from any position, so a trip of the extension is two LDS
+// instructions instead of six and a run must be twice as long before a second trip is needed (as in mwf_band2.hip).
+__device__ __forceinline__ uint32_t seq16(const uint8_t *b2, int32_t j)
+{
+	const uint32_t *p = (const uint32_t*)(b2 + ((j >> 4) << 2));
+	return __builtin_amdgcn_alignbit(p[1], p[0], (uint32_t)j << 1);
+}
+__device__ __forceinline__ int32_t mid_extend2(const uint8_t *lt, const uint8_t *lq, int32_t j, int32_t i, int32_t room)
+{
+	int32_t n = 0;
+	bool open = room > 0;
+	while (__ballot(open)) {
+		const uint32_t x = seq16(lt, j + n) ^ seq16(lq, i + n);
+		const int32_t adv = x ? (int32_t)(__builtin_ctz(x) >> 1) : 16;
+		n += open ? adv : 0;
+		open = open && x == 0 && n < room;
+	}
+	return max(min(n, room), 0);
+}
+// Bytes -> 2 bits per base into LDS at `dst` (two dwords of slack behind the last base).  Returns nonzero when a byte is not one of
+// A, C, G, T.  code = (byte >> 1) & 3: A 0, C 1, T 2, G 3.
+template <int T>
+__device__ __forceinline__ uint32_t mid_pack2bit(const uint8_t *src, int32_t len, uint8_t *dst)
+{
+	uint32_t bad = 0;
+	const int32_t n_dw = (len >> 4) + 2;
+	for (int32_t w = threadIdx.x; w < n_dw; w += T) {
+		uint32_t out = 0;
+		const int32_t b0 = w << 4;
+		if (b0 + 16 <= len) {
+			uint32_t q[4];
+			__builtin_memcpy(q, src + b0, 16);
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const uint32_t x = q[k], code = (x >> 1) & 0x03030303u;
+				const uint32_t lo1 = code & 0x01010101u, hi1 = (code >> 1) & 0x01010101u;
+				const uint32_t expect = 0x41414141u + (lo1 & ~hi1) * 0x02u + (hi1 & ~lo1) * 0x13u + (hi1 & lo1) * 0x06u; // 0 'A', 1 'C', 2 'T', 3 'G'
+				bad |= x ^ expect;
+				out |= ((code | code >> 6 | code >> 12 | code >> 18) & 0xffu) << (8 * k);
+			}
+		} else {
+#pragma unroll 1
+			for (int32_t k = 0; k < 16 && b0 + k < len; ++k) {
+				const uint32_t x = src[b0 + k], code = (x >> 1) & 3u;
+				bad |= x ^ ((0x47544341u >> (8 * code)) & 0xffu);
+				out |= code << (2 * k);
+			}
+		}
+		*(uint32_t*)(dst + 4 * w) = out;
+	}
+	return bad;
+}
+
 // bits of the 64-column group starting at column w0 that fall inside [lo,hi]
 __device__ __forceinline__ unsigned long long group_mask(int32_t w0, int32_t lo, int32_t hi)
 {
@@ -98,20 +153,26 @@ __host__ __device__ inline MidLayout mid_layout(int32_t nH, int32_t e1, int32_t 
 	return L;
 }
 
-template <int T, bool TB, typename ArgsT>
+template <int T, bool TB, bool S2, typename ArgsT>
 __device__ PassResult mid_pass(const ArgsT &A, PairMem &M, const MidLayout &L, const uint8_t *lt, const uint8_t *lq, bool trace_band)
 {
 	constexpr int NW = T / 64;
 	const int32_t tl = M.tl, ql = M.ql, cmax = tl + ql + 1;
 	const int32_t tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
-	const int32_t nH = A.pen.nH, lagx = A.pen.x, lag1 = A.pen.oe1, lag2 = A.pen.oe2, e1 = A.pen.e1, e2 = A.pen.e2, n1 = e1 + 1, n2 = e2 + 1;
-	const int32_t max_s = A.max_s, dbg_cap = A.dbg_cap;
-	const int64_t max_iter = A.max_iter;
+	const int32_t nH = A.pen.nH, n1 = A.pen.e1 + 1, n2 = A.pen.e2 + 1;
+	const int32_t dbg_cap = A.dbg_cap;
+	const int64_t iter_limit = A.max_iter > 0 ? A.max_iter : INT64_MAX;
+	const int32_t s_limit = A.max_s > 0 ? A.max_s : INT32_MAX;
 	const int64_t tb_slot_bytes = A.tb_slot_bytes;
 	const int32_t C = A.lane_chunks * 64, RL = L.RL, NG = C / 64;
 	// the span: C columns around the middle of the diagonals the alignment path runs between (0 and ql - tl); entry 1 of a row is column `left`
 	const int32_t center = tl + 1 + (ql - tl) / 2, left = center - C / 2, right = left + C - 1;
-	int16_t *const Hr = (int16_t*)lds_mid, *const E1r = Hr + nH * RL, *const F1r = E1r + n1 * RL, *const E2r = F1r + n1 * RL, *const F2r = E2r + n2 * RL;
+	// rows as byte offsets into the dynamic LDS: ring bases, ring sizes, and the rows of the coming penalty — carried from penalty to penalty
+	// (one add and one wrap each) instead of being derived from slot numbers (a dozen multiplies per penalty)
+	const int32_t RB = RL * 2;
+	const int32_t HB = nH * RB, B1 = n1 * RB, B2 = n2 * RB;
+	const int32_t bE1 = HB, bF1 = bE1 + B1, bE2 = bF1 + B1, bF2 = bE2 + B2;
+	char *const base = (char*)lds_mid;
 	unsigned long long *const good = (unsigned long long*)(lds_mid + L.good_off); // [nH][NG]
 	int2 *const win = (int2*)(lds_mid + L.win_off);                                 // [nH]: window of the slice each H slot holds
 	MidVars &V = *(MidVars*)(lds_mid + L.vars_off);
@@ -128,64 +189,61 @@ __device__ PassResult mid_pass(const ArgsT &A, PairMem &M, const MidLayout &L, c
 	}
 	__syncthreads();
 	const int32_t c00 = tl + 1;
-	if (c00 < left || c00 > right) { R.status = ST_BAND_OVERFLOW; return R; } // (cannot happen: the span is centred between the two end diagonals and at least 64 wide ... unless |ql - tl| > C)
+	if (c00 < left || c00 > right) { R.status = ST_BAND_OVERFLOW; return R; } // (|ql - tl| beyond the span)
 	int32_t k0 = 0;
 	if (wave == 0) {
-		k0 = mid_extend(lt, lq, 0, 0, min(tl, ql)) - 1;
-		if (lane == 0) Hr[c00 - left + 1] = (int16_t)k0, win[0] = make_int2(c00, c00), V.word = k0;
+		k0 = (S2 ? mid_extend2(lt, lq, 0, 0, min(tl, ql)) : mid_extend(lt, lq, 0, 0, min(tl, ql))) - 1;
+		if (lane == 0) *(int16_t*)(base + (c00 - left + 1) * 2) = (int16_t)k0, win[0] = make_int2(c00, c00), V.word = k0;
 	}
 	__syncthreads();
 	k0 = uni(V.word);
 	if (k0 == tl - 1 && k0 == ql - 1) return R;
 
 	int32_t s = 0, wf_lo = c00, wf_hi = c00;
-	int32_t curH = 0, cur1 = 0, cur2 = 0, par = 0;
+	int32_t curH = 0, par = 0;
+	// byte offsets (within their ring) of the rows penalty 1 writes and reads: H of penalties 1, 1-x, 1-(o1+e1), 1-(o2+e2); E/F of 1 and 1-e
+	int32_t oN = RB % HB, oX = ((nH + 1 - A.pen.x) % nH) * RB, oA = ((nH + 1 - A.pen.oe1) % nH) * RB, oB = ((nH + 1 - A.pen.oe2) % nH) * RB;
+	int32_t oN1 = RB, oR1 = (2 % n1) * RB, oN2 = RB, oR2 = (2 % n2) * RB;
 	int64_t cells = 0, tb_used = 0;
 	if (TB) M.tb_stride = C, M.tb_left = left;
 	const int32_t cfin = ql + 1; // the end cell (tl-1, ql-1) lies on diagonal ql-tl, i.e. this column
+	const int32_t vb = lane * 2;  // a lane's entry idx - 1 = 64 g + lane of a row, in bytes (+ 128 g): entries idx-1, idx, idx+1 at byte offsets 0, 2, 4
 	for (;;) {
 		const int32_t lo = wf_lo > 1 ? wf_lo - 1 : 1;       // miniwfa.c:417-418
 		const int32_t hi = wf_hi < cmax ? wf_hi + 1 : cmax;
 		const int32_t s_new = s + 1;
-		if (lo < left || hi > right) { R.status = ST_BAND_OVERFLOW; break; }
-		if (s_new + tl >= 32760) { R.status = ST_BAND_OVERFLOW; break; } // an offset (a target index, or past the matrix by one per penalty) must fit 16 bits
+		if (lo < left || hi > right || s_new + tl >= 32760) { R.status = ST_BAND_OVERFLOW; break; } // (an offset — a target index, or past the matrix by one per penalty — must fit 16 bits)
 		if (TB && tb_used + C > tb_slot_bytes) { R.status = ST_TB_OVERFLOW; break; }
 		const int32_t newH = curH + 1 == nH ? 0 : curH + 1;
-		const int32_t new1 = cur1 + 1 == n1 ? 0 : cur1 + 1, new2 = cur2 + 1 == n2 ? 0 : cur2 + 1;
 		const int32_t npar = par + 1 == 3 ? 0 : par + 1;
-		int32_t jx = newH - lagx; if (jx < 0) jx += nH;
-		int32_t j1 = newH - lag1; if (j1 < 0) j1 += nH;
-		int32_t j2 = newH - lag2; if (j2 < 0) j2 += nH;
-		const int32_t r1 = new1 + 1 == n1 ? 0 : new1 + 1, r2 = new2 + 1 == n2 ? 0 : new2 + 1; // rows of penalties s_new - e1, s_new - e2
 		const bool track_good = (((256 - (s_new & 255)) & 255) < nH); // a shrink can still see this slice
-		if (tid == 0) {
+		if (wave == 0) { // (the whole wave stores the same words: no exec mask to set up)
 			win[newH] = make_int2(lo, hi);
 			V.flags[npar + 1 == 3 ? 0 : npar + 1] = 0; // the flag word of the NEXT penalty (its last readers passed the previous barrier)
 			if (trace_band && s_new - 1 < dbg_cap) M.dbg[2 * (s_new - 1)] = lo, M.dbg[2 * (s_new - 1) + 1] = hi;
 		}
 		// columns written: the window and nH either side (dead), clamped to the span
-		const int32_t wlo = max(lo - nH, left), whi = min(hi + nH, right);
-		const int32_t g_first = (wlo - left) >> 6, g_last = (whi - left) >> 6;
-		const int16_t *const hx_base = Hr + jx * RL, *const o1_base = Hr + j1 * RL, *const o2_base = Hr + j2 * RL;
-		const int16_t *const e1_base = E1r + r1 * RL, *const f1_base = F1r + r1 * RL, *const e2_base = E2r + r2 * RL, *const f2_base = F2r + r2 * RL;
+		const int32_t g_first = (max(lo - nH, left) - left) >> 6, g_last = (min(hi + nH, right) - left) >> 6;
 		uint32_t flags = 0;
 		int32_t fin_info = 0;
-		for (int32_t g = g_first + (wave - g_first % NW + NW) % NW; g <= g_last; g += NW) {
-			const int32_t idx = 64 * g + lane + 1, c = left + 64 * g + lane;
+		for (int32_t g = g_first + ((wave - g_first) & (NW - 1)); g <= g_last; g += NW) {
+			const int32_t ga = vb + 128 * g, c = left + 64 * g + lane;
 			const int32_t d = c - 1 - tl;
 			// sources (reference wf_next_prep, miniwfa.c:252-257)
-			const int32_t hx = hx_base[idx], o1m = o1_base[idx - 1], o1p = o1_base[idx + 1], o2m = o2_base[idx - 1], o2p = o2_base[idx + 1];
-			const int32_t g1m = e1_base[idx - 1], g1p = f1_base[idx + 1], g2m = e2_base[idx - 1], g2p = f2_base[idx + 1];
+			const char *const pX = base + ga + oX, *const pA = base + ga + oA, *const pB = base + ga + oB;
+			const int32_t hx = *(const int16_t*)(pX + 2), o1m = *(const int16_t*)pA, o1p = *(const int16_t*)(pA + 4), o2m = *(const int16_t*)pB, o2p = *(const int16_t*)(pB + 4);
+			const int32_t g1m = *(const int16_t*)(base + ga + (bE1 + oR1)), g1p = *(const int16_t*)(base + ga + (bF1 + oR1) + 4);
+			const int32_t g2m = *(const int16_t*)(base + ga + (bE2 + oR2)), g2p = *(const int16_t*)(base + ga + (bF2 + oR2) + 4);
 			const bool act = c >= lo && c <= hi;
 			const Cell v = wf_cell<TB>(hx, o1m, g1m, o2m, g2m, o1p, g1p, o2p, g2p);
-			E1r[new1 * RL + idx] = (int16_t)(act ? max(v.e1, kDead16) : kDead16), F1r[new1 * RL + idx] = (int16_t)(act ? max(v.f1, kDead16) : kDead16);
-			E2r[new2 * RL + idx] = (int16_t)(act ? max(v.e2, kDead16) : kDead16), F2r[new2 * RL + idx] = (int16_t)(act ? max(v.f2, kDead16) : kDead16);
+			*(int16_t*)(base + ga + (bE1 + oN1) + 2) = (int16_t)(act ? max(v.e1, kDead16) : kDead16), *(int16_t*)(base + ga + (bF1 + oN1) + 2) = (int16_t)(act ? max(v.f1, kDead16) : kDead16);
+			*(int16_t*)(base + ga + (bE2 + oN2) + 2) = (int16_t)(act ? max(v.e2, kDead16) : kDead16), *(int16_t*)(base + ga + (bF2 + oN2) + 2) = (int16_t)(act ? max(v.f2, kDead16) : kDead16);
 			// match extension (reference wf_extend, miniwfa.c:400-411) of the cells inside the matrix
 			const bool inm = act && in_matrix(d, v.h, tl, ql);
 			const int32_t j = inm ? v.h + 1 : 0, i = inm ? d + j : 0;
-			const int32_t nmat = mid_extend(lt, lq, j, i, inm ? min(tl - j, ql - i) : 0);
+			const int32_t nmat = S2 ? mid_extend2(lt, lq, j, i, inm ? min(tl - j, ql - i) : 0) : mid_extend(lt, lq, j, i, inm ? min(tl - j, ql - i) : 0);
 			const int32_t h = act ? max(v.h + nmat, kDead16) : kDead16;
-			Hr[newH * RL + idx] = (int16_t)h;
+			*(int16_t*)(base + ga + oN + 2) = (int16_t)h;
 			if (TB && act) M.tb[tb_used + (c - left)] = (uint8_t)v.tb;
 			if (track_good) { // some array holds an in-matrix offset here (good_diag, miniwfa.c:139-142)
 				const bool gd = act && (inm || in_matrix(d, v.e1, tl, ql) || in_matrix(d, v.f1, tl, ql) || in_matrix(d, v.e2, tl, ql) || in_matrix(d, v.f2, tl, ql));
@@ -199,17 +257,20 @@ __device__ PassResult mid_pass(const ArgsT &A, PairMem &M, const MidLayout &L, c
 			flags |= (live & (uint32_t)(c == lo)) | ((live & (uint32_t)(c == hi)) << 1) | ((uint32_t)fin << 2);
 			fin_info = fin ? (nmat == 0 ? (int32_t)(v.tb & 7u) : 0) : fin_info;
 		}
-		{ // this wave's share of the three per-penalty flags: one LDS atomic per wave that has any
+		if (__ballot(flags != 0)) { // this wave's share of the three per-penalty flags: one LDS atomic per wave that has any
 			const unsigned long long fm = __ballot(flags & 4u);
 			uint32_t bits = (__ballot(flags & 1u) ? 1u : 0u) | (__ballot(flags & 2u) ? 2u : 0u);
 			if (fm) bits |= 4u | (uint32_t)__builtin_amdgcn_readlane(fin_info, (int32_t)__builtin_ctzll(fm)) << 4;
-			if (bits && lane == 0) atomicOr((unsigned int*)&V.flags[npar], bits);
+			if (lane == 0) atomicOr((unsigned int*)&V.flags[npar], bits);
 		}
+		// the rows of the coming penalty
+		oN = oN + RB == HB ? 0 : oN + RB, oX = oX + RB == HB ? 0 : oX + RB, oA = oA + RB == HB ? 0 : oA + RB, oB = oB + RB == HB ? 0 : oB + RB;
+		oN1 = oN1 + RB == B1 ? 0 : oN1 + RB, oR1 = oR1 + RB == B1 ? 0 : oR1 + RB, oN2 = oN2 + RB == B2 ? 0 : oN2 + RB, oR2 = oR2 + RB == B2 ? 0 : oR2 + RB;
 		__syncthreads();
 		const uint32_t fl = (uint32_t)uni(V.flags[npar]);
 		if (fl & 1u) wf_lo = lo;
 		if (fl & 2u) wf_hi = hi;
-		s = s_new, curH = newH, cur1 = new1, cur2 = new2, par = npar;
+		s = s_new, curH = newH, par = npar;
 		if (TB) tb_used += C;
 		if ((s & 0xff) == 0) { // shrink (reference wf_stripe_shrink, miniwfa.c:144-171) on the good bits of the slices still in the ring
 			if (tid == 0) V.red[0] = 0x7fffffff, V.red[1] = -1;
@@ -234,7 +295,7 @@ __device__ PassResult mid_pass(const ArgsT &A, PairMem &M, const MidLayout &L, c
 			wf_lo = glo, wf_hi = ghi;
 		}
 		cells += hi - lo + 1;
-		if ((max_iter > 0 && cells > max_iter) || (max_s > 0 && s > max_s)) { // miniwfa.c:422-425
+		if (cells > iter_limit || s > s_limit) { // miniwfa.c:422-425
 			R.status = ST_STOPPED;
 			break;
 		}
@@ -244,7 +305,7 @@ __device__ PassResult mid_pass(const ArgsT &A, PairMem &M, const MidLayout &L, c
 	return R;
 }
 
-template <int T, bool TB>
+template <int T, bool TB, bool S2>
 __global__ __launch_bounds__(T, 1) void wfa_mid_kernel(const BatchArgs)
 {
 	// the arguments are read from the kernarg segment where they are used (mwf_device.h): nothing of them stays in SGPRs across the penalties
@@ -254,7 +315,7 @@ __global__ __launch_bounds__(T, 1) void wfa_mid_kernel(const BatchArgs)
 	MidVars &V = *(MidVars*)(lds_mid + L.vars_off);
 	uint8_t *lt = lds_mid + L.seq_off;
 	for (;;) {
-		if (tid == 0) V.item = (int32_t)atomicAdd(A.queue, 1);
+		if (tid == 0) V.item = (int32_t)atomicAdd(A.queue, 1), V.word = 0;
 		__syncthreads();
 		const int32_t item = uni(V.item);
 		__syncthreads();
@@ -263,29 +324,44 @@ __global__ __launch_bounds__(T, 1) void wfa_mid_kernel(const BatchArgs)
 		PairMem M;
 		pair_mem(fresh(A), (int32_t)blockIdx.x, pair, M);
 		M.tl = uni(M.tl), M.ql = uni(M.ql);
-		uint8_t *lq = lt + ((M.tl + 7) & ~7) + 16;
-		// both sequences into LDS, eight bytes per thread and trip (the packed sequence buffer has 64 bytes of slack behind it)
-		for (int32_t j = 8 * tid; j < M.tl; j += 8 * T) *(uint64_t*)(lt + j) = ld8(M.ts + j);
-		for (int32_t j = 8 * tid; j < M.ql; j += 8 * T) *(uint64_t*)(lq + j) = ld8(M.qs + j);
-		__syncthreads();
+		uint8_t *lq = S2 ? lt + ((M.tl >> 4) + 2) * 4 : lt + ((M.tl + 7) & ~7) + 16;
+		PassResult R;
+		R.status = ST_OK, R.s = 0, R.info = 0, R.n_snap = 0, R.cells = 0;
+		if (S2) { // 2 bits per base; a base other than A/C/G/T: the host re-runs the pair on a byte-wise copy (ST_ALPHABET)
+			uint32_t bad = mid_pack2bit<T>(M.ts, M.tl, lt);
+			bad |= mid_pack2bit<T>(M.qs, M.ql, lq);
+			if (bad) V.word = 1;
+			__syncthreads();
+			if (uni(V.word)) R.status = ST_ALPHABET;
+			__syncthreads();
+		} else { // both sequences into LDS as they are, eight bytes per thread and trip (the packed sequence buffer has 64 bytes of slack behind it)
+			for (int32_t j = 8 * tid; j < M.tl; j += 8 * T) *(uint64_t*)(lt + j) = ld8(M.ts + j);
+			for (int32_t j = 8 * tid; j < M.ql; j += 8 * T) *(uint64_t*)(lq + j) = ld8(M.qs + j);
+			__syncthreads();
+		}
 		const bool trace = A.dbg && pair == A.debug_pair;
-		const PassResult R = mid_pass<T, TB>(fresh(A), M, L, lt, lq, trace);
+		if (R.status == ST_OK) R = mid_pass<T, TB, S2>(fresh(A), M, L, lt, lq, trace);
 		finish_pair(fresh(A), M, (int32_t)blockIdx.x, pair, R, R.status, 0);
 	}
 }
 
-template <int T>
-int launch_t(const BatchArgs &a, int grid, int lds, hipStream_t st)
+template <int T, bool TB, bool S2>
+int launch_v(const BatchArgs &a, int grid, int lds, hipStream_t st)
 {
 	// beyond 48 KB of dynamic LDS the runtime wants to be told (per device, and this may run on several host threads: on every launch)
 	if (lds > 48 * 1024) {
-		(void)hipFuncSetAttribute(a.want_cigar ? reinterpret_cast<const void*>(&wfa_mid_kernel<T, true>) : reinterpret_cast<const void*>(&wfa_mid_kernel<T, false>),
-		                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wfa_mid_kernel<T, TB, S2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 		(void)hipGetLastError();
 	}
-	if (a.want_cigar) hipLaunchKernelGGL((wfa_mid_kernel<T, true>), dim3(grid), dim3(T), lds, st, a);
-	else hipLaunchKernelGGL((wfa_mid_kernel<T, false>), dim3(grid), dim3(T), lds, st, a);
+	hipLaunchKernelGGL((wfa_mid_kernel<T, TB, S2>), dim3(grid), dim3(T), lds, st, a);
 	return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+template <int T>
+int launch_t(const BatchArgs &a, int grid, int lds, bool seq2, hipStream_t st)
+{
+	if (a.want_cigar) return seq2 ? launch_v<T, true, true>(a, grid, lds, st) : launch_v<T, true, false>(a, grid, lds, st);
+	return seq2 ? launch_v<T, false, true>(a, grid, lds, st) : launch_v<T, false, false>(a, grid, lds, st);
 }
 
 } // namespace
@@ -304,10 +380,11 @@ int mid_lds_bytes(const Penalty &p, int groups, int64_t seq_bytes)
 	return (int)(((int64_t)L.seq_off + seq_bytes + 64 + 15) / 16 * 16);
 }
 
-int launch_mid(const BatchArgs &a, int grid, int block, int lds, void *stream)
+int launch_mid(const BatchArgs &a, int grid, int block, int lds, bool seq2, void *stream)
 {
-	if (block == 256) return launch_t<256>(a, grid, lds, (hipStream_t)stream);
-	if (block == 1024) return launch_t<1024>(a, grid, lds, (hipStream_t)stream);
+	if (block == 256) return launch_t<256>(a, grid, lds, seq2, (hipStream_t)stream);
+	if (block == 512) return launch_t<512>(a, grid, lds, seq2, (hipStream_t)stream);
+	if (block == 1024) return launch_t<1024>(a, grid, lds, seq2, (hipStream_t)stream);
 	return -1;
 }
 

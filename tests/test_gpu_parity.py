@@ -264,8 +264,11 @@ def test_generic_kernel_takes_16_bit_rows_for_big_batches():
 
 def test_mixed_batch_runs_in_size_classes(oracle):
     """One batch with three very different pair sizes (what mwf_wfa_chain's gap fills look like): every size class goes
-    to its own kernel in its own launch, results identical to the oracle, in the caller's order."""
+    to its own kernel in its own launch, results identical to the oracle, in the caller's order.  (The mid kernel, which would take
+    the mid-size pairs of a batch this small, is switched off: this test is about the band classes; with it on the same batch is
+    checked below.)"""
     eng = mw.Engine(0)
+    eng.set("mid_max_pairs", 0)
     pairs, must = [], []
     for i in range(120):
         pairs.append(synth_pair(89000 + i, (40, 1500, 3500)[i % 3], (0.02, 0.1)[i % 2]))     # micro / tiny / small band kernel
@@ -287,6 +290,15 @@ def test_mixed_batch_runs_in_size_classes(oracle):
                 assert b.cigar(i, int(nc[i])).tolist() == ecig, i
         assert eng.stats().n_retries >= 2       # the two divergent 3500 bp pairs went small -> wide (-> generic)
         b.free()
+    eng.close()
+    eng = mw.Engine(0)                          # defaults: the 1.5 - 3.5 kb pairs of this small batch take the mid kernel (one more class)
+    b = eng.upload(PackedBatch(pairs))
+    b.align(mw.opt_init(flag=1))
+    s, it, nc = b.results()
+    for i, (t, q) in enumerate(pairs):
+        es, eit, ecig = oracle.align(t, q, make_opt(flag=1))
+        assert (int(s[i]), int(it[i])) == (es, eit) and b.cigar(i, int(nc[i])).tolist() == ecig, (i, len(t))
+    b.free()
     eng.close()
 
 
@@ -718,11 +730,12 @@ def test_mid_kernel_fuzz_against_oracle(oracle):
     pairs += [synth_pair(5150, 2500, 0.04, 2, 300), synth_pair(5151, 1500, 0.05, 3, 700), (b"ACGTNNRYACGT" * 90, b"ACGTNNRYACGA" * 90),
               (b"A" * 1500, b"A" * 1200), synth_pair(5152, 6000, 0.03), synth_pair(5153, 3000, 0.3)]
     pk = PackedBatch(pairs)
-    for block, kw in ((0, dict()), (0, dict(flag=1)), (256, dict(flag=1, o2=4, e2=2)), (1024, dict(x=2, o1=3, e1=1, o2=6, e2=1)), (0, dict(flag=1, x=3, o1=5, e1=3, o2=20, e2=1)),
-                      (0, dict(flag=1, max_s=300)), (1024, dict(max_iter=150000))):
+    for block, s2, kw in ((0, 1, dict()), (0, 1, dict(flag=1)), (256, 0, dict(flag=1, o2=4, e2=2)), (1024, 1, dict(x=2, o1=3, e1=1, o2=6, e2=1)), (512, 0, dict(flag=1, x=3, o1=5, e1=3, o2=20, e2=1)),
+                          (0, 1, dict(flag=1, max_s=300)), (1024, 0, dict(max_iter=150000))):
         o = make_opt(**kw)
         eng = mw.Engine(0)
         eng.set("mid_block", block)
+        eng.set("seq2bit", s2)      # 1: 2-bit sequence copies in LDS (pairs outside plain A/C/G/T take the byte-wise band classes); 0: byte copies, any alphabet
         b = eng.upload(pk)
         b.align(mw.opt_init(**kw))
         s, it, nc = b.results()
@@ -745,7 +758,7 @@ def test_mid_kernel_serves_single_calls(oracle):
         b = eng.upload(PackedBatch([(t, q)]))
         b.align(mw.opt_init(**kw))
         st = eng.stats()
-        assert (st.kernel_kind, st.packed, st.block) == (2, 33, 1024), (kw, st.kernel_kind, st.packed, st.block)
+        assert (st.kernel_kind, st.packed, st.block) == (2, 33, 1024), (kw, st.kernel_kind, st.packed, st.block)   # (4 kb of sequence: sixteen waves)
         s, it, nc = b.results()
         assert eng.stats().n_retries == 0
         es, eit, ecig = oracle.align(t, q, make_opt(**kw))
