@@ -124,6 +124,7 @@ struct mwf_gpu_batch_s {
 	int64_t max_tl = 0;        // longest target (offsets are target indices: bounds what a 16-bit offset must hold)
 	int32_t *d_order = nullptr;
 	std::vector<int32_t> h_order;   // what d_order holds: pair ids, grouped by size class, longest first inside a class
+	std::vector<int32_t> h_len_order; // pair ids, longest pair first (stable): what every grouping is dealt from
 	std::vector<int8_t> h_class;    // size class of every pair (0 generic, then band kernels: 1 wide, 2 small, 3 tiny, 4 micro)
 	std::vector<int8_t> h_kind;     // kernel that ran the pair last (0 generic, 1 whole-device, 2 band)
 	std::vector<int8_t> h_acgt;     // from the host's look at the bytes while a batch is built from host memory: 1 both sequences are plain
@@ -148,6 +149,20 @@ struct mwf_gpu_batch_s {
 	int64_t cig_used = 0;           // words of the pool in use (known after finalize)
 	std::vector<uint32_t> h_cig;    // host copy of the used part of the pool (fetch_cigars)
 	bool h_cig_valid = false;
+	// What the last align worked out from the pair lengths alone — size classes, processing order, per-class maxima — keyed by the
+	// options and tunables it depends on: lengths do not change between aligns of a batch, so the next align with the same key skips
+	// the per-pair pass (40 000 read pairs: ~2.5 ms of host work per align before, profiles/r04/short_reads.txt)
+	struct PlanCache {
+		bool valid = false;
+		int32_t opt_key[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+		int64_t tun_key[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+		int64_t max_len = 0, max_bound = 0;
+		bool has_groups = false, mid_bytes = false;
+		struct GI { int32_t n = 0; int64_t max_len = 0, max_bound = 0, max_bound1 = 0, max_tl = 0, max_seq_lds = 0; } gi[12];
+		std::vector<int8_t> cls0, flags0;
+	} plan;
+	std::vector<char> host_out;     // the fixed-size results as they came back (finalize)
+	size_t out_bytes_score = 0;     // leading part of the result region a score-only, high-memory align needs back: head, status, s, n_iter
 	// geometry and counters of the last align of THIS batch (finalize() must not read the engine's: another batch may have
 	// been aligned on the same engine in between)
 	int32_t last_grid = 0, n_retries = 0;
@@ -909,7 +924,7 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b);
 // out exactly as upload_segments() streams it.
 struct BlockLayout {
 	size_t order = 0, t_off = 0, q_off = 0, tl = 0, ql = 0, seqs = 0, in_end = 0;
-	size_t head = 0, status = 0, s = 0, ncig = 0, iter = 0, cigoff = 0, cells1 = 0, out_end = 0, dbg4 = 0, total = 0;
+	size_t head = 0, status = 0, s = 0, ncig = 0, iter = 0, cigoff = 0, cells1 = 0, score_end = 0, out_end = 0, dbg4 = 0, total = 0;
 };
 
 BlockLayout layout_block(size_t n, size_t seq_bytes, bool owned)
@@ -930,8 +945,9 @@ BlockLayout layout_block(size_t n, size_t seq_bytes, bool owned)
 	L.head = at, at += 64;
 	L.status = at, at += align_up(N * 4, 8);
 	L.s = at, at += align_up(N * 4, 8);
-	L.ncig = at, at += align_up(N * 4, 8);
 	L.iter = at, at += N * 8;
+	L.score_end = at; // a score-only, high-memory align needs nothing behind this back
+	L.ncig = at, at += align_up(N * 4, 8);
 	L.cigoff = at, at += N * 8;
 	L.cells1 = at, at += N * 8;
 	L.out_end = at;
@@ -964,13 +980,14 @@ mwf_gpu_batch_t *batch_common(mwf_gpu_t *g, int32_t n, const int32_t *h_tl, cons
 	b->d_status = (int32_t*)(base + L.status), b->d_s = (int32_t*)(base + L.s), b->d_ncig = (int32_t*)(base + L.ncig);
 	b->d_iter = (int64_t*)(base + L.iter), b->d_cigoff = (int64_t*)(base + L.cigoff), b->d_cells1 = (int64_t*)(base + L.cells1);
 	b->d_dbg4 = (int32_t*)(base + L.dbg4);
-	b->out_off = L.head, b->out_bytes = L.out_end - L.head;
+	b->out_off = L.head, b->out_bytes = L.out_end - L.head, b->out_bytes_score = L.score_end - L.head;
 	// longest pairs first, so the persistent workgroups finish together
 	b->h_order.resize((size_t)n);
 	std::iota(b->h_order.begin(), b->h_order.end(), 0);
 	std::stable_sort(b->h_order.begin(), b->h_order.end(), [&](int32_t x, int32_t y) {
 		return (int64_t)h_tl[x] + h_ql[x] > (int64_t)h_tl[y] + h_ql[y];
 	});
+	b->h_len_order = b->h_order;
 	b->h_class.assign((size_t)n, 0), b->h_kind.assign((size_t)n, 0), b->h_flags.assign((size_t)n, 0);
 	return b;
 }
@@ -1251,10 +1268,23 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		if (take_block(g, g->spare_cig, b->cig, (size_t)b->cig_pool_words * 4)) return -1;
 		b->d_cig_pool = (uint32_t*)b->cig.p;
 	}
+	// the plan of the last align applies when nothing it was derived from changed: the options that classify pairs and the tunables
+	mwf_gpu_batch_t::PlanCache &PC = b->plan;
+	{
+		const int32_t ok[8] = {opt->flag & MWF_F_CIGAR, opt->x, opt->o1, opt->e1, opt->o2, opt->e2, opt->step, opt->max_s};
+		const int64_t tk[14] = {g->force_kind, g->block, g->band_pack, g->ring16, g->lds_e2, g->scalar_generic, g->lane_max_len, g->seq2bit,
+		                        g->mid_max_pairs, g->coop_min_len, g->sys_p, g->coop_grid_cap, b->debug_pair, g->lane_chunks};
+		if (PC.valid && (memcmp(ok, PC.opt_key, sizeof(ok)) || memcmp(tk, PC.tun_key, sizeof(tk)))) PC.valid = false;
+		if (!PC.valid) memcpy(PC.opt_key, ok, sizeof(ok)), memcpy(PC.tun_key, tk, sizeof(tk)), PC.has_groups = false;
+	}
 	int64_t max_len = 0, max_bound = 0;
-	for (int32_t i = 0; i < b->n; ++i) {
-		max_len = std::max<int64_t>(max_len, (int64_t)b->h_tl[i] + b->h_ql[i]);
-		max_bound = std::max(max_bound, penalty_bound(*opt, b->h_tl[i], b->h_ql[i], true));
+	if (PC.valid) max_len = PC.max_len, max_bound = PC.max_bound;
+	else {
+		for (int32_t i = 0; i < b->n; ++i) {
+			max_len = std::max<int64_t>(max_len, (int64_t)b->h_tl[i] + b->h_ql[i]);
+			max_bound = std::max(max_bound, penalty_bound(*opt, b->h_tl[i], b->h_ql[i], true));
+		}
+		PC.max_len = max_len, PC.max_bound = max_bound, PC.valid = true;
 	}
 	if (max_len + 4 >= ((int64_t)1 << 31)) { g->err = "tl+ql must be below 2^31-4"; return -2; }
 	const int slots = 1 << 30; // as many as the chosen kernel can keep resident (run_batch_kernel bounds it)
@@ -1318,93 +1348,111 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	// plain A/C/G/T (byte-wise sequence copy from the start)
 	// 10: short pairs on the one-diagonal-per-lane kernel (mwf_lane.hip); what outgrows its 64 columns moves to the band classes
 	// 11: mid-size pairs of a small batch on the one-workgroup-per-pair, rings-in-LDS kernel (mwf_mid.hip); what outgrows its span moves to the band classes
-	struct Group { std::vector<int32_t> ids; int64_t max_len = 0, max_bound = 0, max_bound1 = 0, max_tl = 0, max_seq_lds = 0; } grp[12];
-	const bool lane_ok = g->lane_max_len > 0 && lane_supported(P0);
-	const int mid_cap = g->mid_max_pairs < 0 ? g->n_cu : g->mid_max_pairs;
+	typedef mwf_gpu_batch_t::PlanCache::GI GroupInfo;
+	GroupInfo gi[12];
 	bool mid_bytes = false;
-	const bool mid_ok = g->force_kind < 0 && g->block == 0 && mid_cap > 0 && b->n <= mid_cap && mid_supported(P0);
-	const bool know_acgt = !b->h_acgt.empty() && g->seq2bit != 0;
-	auto window_of = [](int64_t len, int64_t bound) { return std::min<int64_t>(len + 1, 2 * bound + 3); };
-	for (int32_t i = 0; i < b->n; ++i) {
-		const int64_t len = (int64_t)b->h_tl[i] + b->h_ql[i], bound = penalty_bound(*opt, b->h_tl[i], b->h_ql[i], true);
-		const int64_t bound1 = penalty_bound(*opt, b->h_tl[i], b->h_ql[i], false);
-		const bool step0 = low_mem && bound1 < opt->step;
-		int c = low_mem && !step0 ? 5 : 0;
-		if (classes && c == 0) {
-			const int64_t window = std::min<int64_t>(len + 1, 2 * bound + 3);
-			const bool packable = (int64_t)b->h_tl[i] + bound < 32767 && g->band_pack != 0 && band2_supported(P0);
-			const bool plain_ok = band_supported(P0);
-			// A window cannot outgrow min(tl+ql+1, 2 x penalty bound + 3); in practice it stays far below tl+ql (a quarter of
-			// it at 5 % divergence), so a pair is also given to a small kernel when it is merely short — if its window does
-			// outgrow that span, finalize() moves it to the wide band kernel, and from there to the generic one.
-			// (a pair too long for the packed band kernel goes to the generic kernel with 16-bit ring rows where those apply: faster than
-			// the unpacked band kernel and no window overflows to re-run, see choose_kernel)
-			if (!packable && g->ring16 != 0 && g->lds_e2 && !g->scalar_generic && P0.e2 == 1 && (int64_t)b->h_tl[i] + len / 8 < 65500) c = 0;
-			else if (packable && (window <= kBandMicroWindow || len + 1 <= 2 * (int64_t)(1 * 3 * 256))) c = 4;
-			else if (packable && (window <= kBandTinyWindow || len + 1 <= 3 * (int64_t)(2 * 3 * 256))) c = 3;
-			else if (packable ? (window <= kBandSmallWindow || len + 1 <= 3 * (int64_t)(4 * 3 * 256)) : (plain_ok && window <= 8 * 256 - 256 - 64)) c = 2;
-			else if ((packable || plain_ok) && len + 1 <= 4 * (int64_t)(8 * 3 * 256)) c = 1;
-		}
-		b->h_class[i] = (int8_t)(c == 5 ? 0 : c);
-		b->h_flags[i] = (int8_t)(step0 ? 1 : 0);
-		// short pairs: a window of 64 diagonals holds them while the penalty stays below ~45 (a 200 bp pair at 5 %)
-		const bool to_lane = classes && lane_ok && c >= 1 && c <= 4 && std::max(b->h_tl[i], b->h_ql[i]) <= g->lane_max_len &&
-		                     std::abs(b->h_tl[i] - b->h_ql[i]) <= 24;
-		if (to_lane) c = 10, b->h_class[i] = 4;
-		// a few mid-size pairs: a workgroup each, rings in LDS (a penalty then costs a fraction of a microsecond instead of ~2).  Admitted
-		// when the span the LDS can hold beside the sequences covers the window of a pair at ~6 % divergence (about 0.3 (tl+ql)); 16-bit offsets.
-		if (mid_ok && !to_lane && c <= 4 && (!low_mem || step0) && (int64_t)b->h_tl[i] + bound < 32760) {
-			const int64_t seq_lds = (((int64_t)b->h_tl[i] + 7) & ~7LL) + 16 + (((int64_t)b->h_ql[i] + 7) & ~7LL) + 32;
-			const int64_t want = std::min<int64_t>(window_of(len, bound), len * 3 / 10 + 128) + 2 * P0.nH;
-			int groups = (int)std::min<int64_t>((std::min<int64_t>(len + 1, 2 * bound + 3) + 2 * P0.nH + 63) / 64, 128);
-			while (groups > 1 && mid_lds_bytes(P0, groups, seq_lds) > 158 * 1024) --groups;
-			if (mid_lds_bytes(P0, groups, seq_lds) <= 158 * 1024 && (int64_t)groups * 64 >= want && std::abs((int64_t)b->h_tl[i] - b->h_ql[i]) < groups * 32) {
-				b->h_class[i] = (int8_t)((c >= 1 && c <= 4) || (classes && (int64_t)b->h_tl[i] + bound < 32767 && g->band_pack != 0 && band2_supported(P0)) ? 2 : 0); // where an overflow goes: the wide packed band kernel, else generic
-				c = 11;
-				mid_bytes |= know_acgt && !b->h_acgt[i]; // a pair the host knows not to be plain A/C/G/T: the (few) pairs of this class all take the byte-wise copy
-			}
-		}
-		if (c >= 1 && c <= 4 && know_acgt && !b->h_acgt[i] && (int64_t)b->h_tl[i] + bound < 32767 && g->band_pack != 0 && band2_supported(P0)) c += 5;
-		Group &G = grp[c];
-		G.ids.push_back(i);
-		G.max_len = std::max(G.max_len, len), G.max_bound = std::max(G.max_bound, bound);
-		G.max_bound1 = std::max(G.max_bound1, bound1);
-		G.max_tl = std::max<int64_t>(G.max_tl, b->h_tl[i]);
-		G.max_seq_lds = std::max<int64_t>(G.max_seq_lds, (((int64_t)b->h_tl[i] + 3) & ~3LL) + 8 + (((int64_t)b->h_ql[i] + 3) & ~3LL) + 16);
-	}
 	static const int run_order[12] = {5, 0, 1, 6, 2, 7, 3, 8, 4, 9, 11, 10}; // largest workspace first
-	std::vector<int32_t> order;
-	order.reserve((size_t)b->n);
-	for (int c : run_order) {
-		Group &G = grp[c];
-		std::stable_sort(G.ids.begin(), G.ids.end(), [&](int32_t x, int32_t y) { // longest first: the persistent workgroups finish together
-			return (int64_t)b->h_tl[x] + b->h_ql[x] > (int64_t)b->h_tl[y] + b->h_ql[y];
-		});
-		order.insert(order.end(), G.ids.begin(), G.ids.end());
-	}
-	if (order != b->h_order) {
-		b->h_order = order;
-		if (upload_segments(g, (char*)b->d_order, std::vector<Seg>{Seg{b->h_order.data(), order.size() * 4}})) return -1; // (waits for earlier work on the stream first)
+	if (PC.has_groups) { // same lengths, same options, same tunables as last time: classes, order (already on the device) and maxima as they were
+		b->h_class = PC.cls0, b->h_flags = PC.flags0;
+		for (int c = 0; c < 12; ++c) gi[c] = PC.gi[c];
+		mid_bytes = PC.mid_bytes;
+	} else {
+		const bool lane_ok = g->lane_max_len > 0 && lane_supported(P0);
+		const int mid_cap = g->mid_max_pairs < 0 ? g->n_cu : g->mid_max_pairs;
+		const bool mid_ok = g->force_kind < 0 && g->block == 0 && mid_cap > 0 && b->n <= mid_cap && mid_supported(P0);
+		const bool know_acgt = !b->h_acgt.empty() && g->seq2bit != 0;
+		const bool pack_pen = g->band_pack != 0 && band2_supported(P0), plain_ok = band_supported(P0);
+		const bool gen16 = g->ring16 != 0 && g->lds_e2 && !g->scalar_generic && P0.e2 == 1;
+		std::vector<int8_t> cls((size_t)b->n); // group of every pair
+		int32_t count[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+		for (int32_t i = 0; i < b->n; ++i) {
+			const int64_t tl = b->h_tl[i], ql = b->h_ql[i], len = tl + ql;
+			const int64_t bound1 = penalty_bound(*opt, tl, ql, false);
+			const int64_t bound = opt->max_s > 0 ? std::min<int64_t>(bound1, (int64_t)opt->max_s + 1) : bound1; // (= penalty_bound(..., true))
+			const bool step0 = low_mem && bound1 < opt->step;
+			int c = low_mem && !step0 ? 5 : 0;
+			const bool packable = tl + bound < 32767 && pack_pen;
+			if (classes && c == 0) {
+				const int64_t window = std::min<int64_t>(len + 1, 2 * bound + 3);
+				// A window cannot outgrow min(tl+ql+1, 2 x penalty bound + 3); in practice it stays far below tl+ql (a quarter of
+				// it at 5 % divergence), so a pair is also given to a small kernel when it is merely short — if its window does
+				// outgrow that span, finalize() moves it to the wide band kernel, and from there to the generic one.
+				// (a pair too long for the packed band kernel goes to the generic kernel with 16-bit ring rows where those apply: faster than
+				// the unpacked band kernel and no window overflows to re-run, see choose_kernel)
+				if (!packable && gen16 && tl + len / 8 < 65500) c = 0;
+				else if (packable && (window <= kBandMicroWindow || len + 1 <= 2 * (int64_t)(1 * 3 * 256))) c = 4;
+				else if (packable && (window <= kBandTinyWindow || len + 1 <= 3 * (int64_t)(2 * 3 * 256))) c = 3;
+				else if (packable ? (window <= kBandSmallWindow || len + 1 <= 3 * (int64_t)(4 * 3 * 256)) : (plain_ok && window <= 8 * 256 - 256 - 64)) c = 2;
+				else if ((packable || plain_ok) && len + 1 <= 4 * (int64_t)(8 * 3 * 256)) c = 1;
+			}
+			b->h_class[i] = (int8_t)(c == 5 ? 0 : c);
+			b->h_flags[i] = (int8_t)(step0 ? 1 : 0);
+			// short pairs: a window of 64 diagonals holds them while the penalty stays below ~45 (a 200 bp pair at 5 %)
+			const bool to_lane = classes && lane_ok && c >= 1 && c <= 4 && std::max(tl, ql) <= g->lane_max_len && std::abs(tl - ql) <= 24;
+			if (to_lane) c = 10, b->h_class[i] = 4;
+			// a few mid-size pairs: a workgroup each, rings in LDS (a penalty then costs a fraction of what it costs the band kernels).  Admitted
+			// when the span the LDS can hold beside the sequences covers the window of a pair at ~6 % divergence (about 0.3 (tl+ql)); 16-bit offsets.
+			if (mid_ok && !to_lane && c <= 4 && (!low_mem || step0) && tl + bound < 32760) {
+				const int64_t seq_lds = ((tl + 7) & ~7LL) + 16 + ((ql + 7) & ~7LL) + 32;
+				const int64_t window = std::min<int64_t>(len + 1, 2 * bound + 3);
+				const int64_t want = std::min<int64_t>(window, len * 3 / 10 + 128) + 2 * P0.nH;
+				int groups = (int)std::min<int64_t>((window + 2 * P0.nH + 63) / 64, 128);
+				while (groups > 1 && mid_lds_bytes(P0, groups, seq_lds) > 158 * 1024) --groups;
+				if (mid_lds_bytes(P0, groups, seq_lds) <= 158 * 1024 && (int64_t)groups * 64 >= want && std::abs(tl - ql) < groups * 32) {
+					b->h_class[i] = (int8_t)((c >= 1 && c <= 4) || (classes && packable) ? 2 : 0); // where an overflow goes: the wide packed band kernel, else generic
+					c = 11;
+					mid_bytes |= know_acgt && !b->h_acgt[i]; // a pair the host knows not to be plain A/C/G/T: the (few) pairs of this class all take the byte-wise copy
+				}
+			}
+			if (c >= 1 && c <= 4 && know_acgt && !b->h_acgt[i] && packable) c += 5;
+			GroupInfo &G = gi[c];
+			cls[i] = (int8_t)c, ++count[c];
+			G.max_len = std::max(G.max_len, len), G.max_bound = std::max(G.max_bound, bound);
+			G.max_bound1 = std::max(G.max_bound1, bound1);
+			G.max_tl = std::max<int64_t>(G.max_tl, tl);
+			G.max_seq_lds = std::max<int64_t>(G.max_seq_lds, ((tl + 3) & ~3LL) + 8 + ((ql + 3) & ~3LL) + 16);
+		}
+		// The processing order: groups in run order, longest first inside a group (the persistent workgroups finish together).  h_order is
+		// already sorted longest first (batch_common) and that order is stable: one pass over it deals the pairs to their groups.
+		std::vector<int32_t> start(12, 0), order((size_t)b->n);
+		{
+			int32_t at = 0;
+			for (int c : run_order) start[c] = at, at += count[c], gi[c].n = count[c];
+		}
+		if (b->h_len_order.empty()) {
+			b->h_len_order.resize((size_t)b->n);
+			std::iota(b->h_len_order.begin(), b->h_len_order.end(), 0);
+			std::stable_sort(b->h_len_order.begin(), b->h_len_order.end(), [&](int32_t x, int32_t y) {
+				return (int64_t)b->h_tl[x] + b->h_ql[x] > (int64_t)b->h_tl[y] + b->h_ql[y];
+			});
+		}
+		for (int32_t i : b->h_len_order) order[(size_t)start[cls[i]]++] = i;
+		if (order != b->h_order) {
+			b->h_order.swap(order);
+			if (upload_segments(g, (char*)b->d_order, std::vector<Seg>{Seg{b->h_order.data(), b->h_order.size() * 4}})) return -1; // (waits for earlier work on the stream first)
+		}
+		PC.cls0 = b->h_class, PC.flags0 = b->h_flags, PC.mid_bytes = mid_bytes, PC.has_groups = true;
+		for (int c = 0; c < 12; ++c) PC.gi[c] = gi[c];
 	}
 	int n_groups = 0, done_groups = 0;
-	for (const Group &G : grp) n_groups += !G.ids.empty();
+	for (const GroupInfo &G : gi) n_groups += G.n > 0;
 	mwf_opt_t opt_hi = *opt;
 	opt_hi.step = 0;
 	size_t at = 0;
 	for (int c : run_order) {
-		const Group &G = grp[c];
-		if (G.ids.empty()) continue;
+		const GroupInfo &G = gi[c];
+		if (G.n == 0) continue;
 		++done_groups;
 		int ran = 0;
 		const int cc = c == 11 ? 6 : c == 10 ? 5 : c > 5 ? c - 5 : c;
 		g->acgt_off_once = (c > 5 && c < 10) || (c == 11 && mid_bytes);
-		const int rc = run_batch_kernel(g, b, c == 5 ? *opt : opt_hi, b->d_order + at, (int32_t)G.ids.size(), slots, G.max_len, G.max_bound, G.max_bound1,
+		const int rc = run_batch_kernel(g, b, c == 5 ? *opt : opt_hi, b->d_order + at, G.n, slots, G.max_len, G.max_bound, G.max_bound1,
 		                                done_groups == 1, (classes || c == 11) ? (c == 0 || c == 5 ? 0 : 2) : -1, G.max_tl, G.max_seq_lds, done_groups == n_groups,
 		                                cc == 6 ? 33 : cc == 5 ? 32 : cc == 4 ? 64 : cc == 3 ? 128 : cc == 2 ? 256 : 0, &ran);
 		g->acgt_off_once = false;
 		if (rc) return -1;
-		for (int32_t i : G.ids) b->h_kind[i] = (int8_t)ran;
-		at += G.ids.size();
+		for (size_t j = at; j < at + (size_t)G.n; ++j) b->h_kind[b->h_order[j]] = (int8_t)ran;
+		at += (size_t)G.n;
 	}
 	b->aligned = true;
 	return 0;
@@ -1425,8 +1473,13 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 	if (!b->aligned) { g->err = "batch was not aligned"; return -1; }
 	const size_t n = (size_t)b->n;
 	b->h_s.resize(n), b->h_ncig.resize(n), b->h_status.resize(n), b->h_iter.resize(n), b->h_cigoff.resize(n), b->h_cells1.resize(n);
-	std::vector<char> host(b->out_bytes);
+	std::vector<char> &host = b->host_out;
+	if (host.size() < b->out_bytes) host.resize(b->out_bytes);
 	const BlockLayout L = layout_block(n, 0, false); // (only differences between result offsets are used)
+	// a score-only, high-memory align: n_cigar, CIGAR offsets and first-pass cells are zero by construction — only head, status, s and
+	// n_iter come back (16 of the 36 bytes per pair)
+	const bool lean = !(b->opt.flag & MWF_F_CIGAR);
+	const size_t need = lean ? b->out_bytes_score : b->out_bytes;
 	auto fetch = [&]() -> int {
 		if (n == 0) { HIP_TRY(g, hipStreamSynchronize(g->stream)); return 0; }
 		if (b->out_in_pin) { // the kernels wrote the engine's pinned result page (score-only: no CIGAR words)
@@ -1434,6 +1487,10 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 			memcpy(host.data(), g->res_pin, b->out_bytes);
 			memset(host.data(), 0, 8);
 			b->h_cig_valid = false;
+		} else if (lean) {
+			b->h_cig_valid = false;
+			if (download(g, host.data(), (const char*)b->block.p + b->out_off, need)) return -1;
+			memset(host.data() + need, 0, b->out_bytes - need);
 		} else {
 			// a small CIGAR-mode batch (the single pair of a drop-in call): the head of its CIGAR pool comes back with the results, one wait
 			// for both copies — when the pool's used part turns out to fit it, fetch_cigars() has nothing left to copy

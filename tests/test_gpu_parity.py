@@ -709,7 +709,8 @@ def test_lane_kernel_short_pairs_fuzz_against_oracle(chunks, oracle):
         b.free()
         eng.close()
     eng = mw.Engine(0)
-    eng.set("lane_max_len", 0)  # switched off: the band kernels take the short pairs
+    eng.set("lane_max_len", 0)  # switched off (and the mid kernel, which takes the pairs of a batch this small, as well): the band kernels take the short pairs
+    eng.set("mid_max_pairs", 0)
     b = eng.upload(pk)
     b.align(mw.opt_init(max_s=20))
     b.results()
