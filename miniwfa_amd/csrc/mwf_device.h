@@ -74,6 +74,84 @@ __device__ __forceinline__ int32_t extend_run(const uint8_t *ts, const uint8_t *
 	return k + min(n, room);
 }
 
+// ---- sequences held in LDS by the one-diagonal-per-lane kernels (mwf_lane.hip, mwf_mid.hip) ----------------------------------------
+// eight bytes at an arbitrary byte offset of an LDS array (three aligned dwords, two v_alignbyte)
+__device__ __forceinline__ uint64_t lds_ld8(const uint8_t *base, int32_t off)
+{
+	const uint32_t *p = (const uint32_t*)(base + (off & ~3));
+	const uint32_t a = p[0], b = p[1], c = p[2];
+	const uint32_t lo = __builtin_amdgcn_alignbyte(b, a, (uint32_t)off), hi = __builtin_amdgcn_alignbyte(c, b, (uint32_t)off);
+	return (uint64_t)hi << 32 | lo;
+}
+// Length of the exact-match run t[j..] == q[i..] on byte copies, at most `room` (<= 0: none; j and i must then still be readable
+// offsets).  The wave walks together, eight bytes per lane and trip, while any lane's run is open: straight-line trips under one
+// uniform branch (a divergent while loop costs ~25 mask instructions per trip).
+__device__ __forceinline__ int32_t lds_extend8(const uint8_t *lt, const uint8_t *lq, int32_t j, int32_t i, int32_t room)
+{
+	int32_t n = 0;
+	bool open = room > 0;
+	while (__ballot(open)) {
+		const uint64_t x = lds_ld8(lt, j + n) ^ lds_ld8(lq, i + n);
+		const int32_t adv = x ? (int32_t)(__builtin_ctzll(x) >> 3) : 8;
+		n += open ? adv : 0;
+		open = open && x == 0 && n < room;
+	}
+	return max(min(n, room), 0);
+}
+// 2-bit copies (pairs of plain A/C/G/T): sixteen bases per dword, base j at bits 2*(j & 15) of dword j >> 4 — one ds_read2_b32 and one
+// v_alignbit per sequence give SIXTEEN bases from any position: a trip is two LDS instructions instead of six, and a run must be
+// twice as long before a second trip is needed (as in mwf_band2.hip).
+__device__ __forceinline__ uint32_t lds_seq16(const uint8_t *b2, int32_t j)
+{
+	const uint32_t *p = (const uint32_t*)(b2 + ((j >> 4) << 2));
+	return __builtin_amdgcn_alignbit(p[1], p[0], (uint32_t)j << 1);
+}
+__device__ __forceinline__ int32_t lds_extend16(const uint8_t *lt, const uint8_t *lq, int32_t j, int32_t i, int32_t room)
+{
+	int32_t n = 0;
+	bool open = room > 0;
+	while (__ballot(open)) {
+		const uint32_t x = lds_seq16(lt, j + n) ^ lds_seq16(lq, i + n);
+		const int32_t adv = x ? (int32_t)(__builtin_ctz(x) >> 1) : 16;
+		n += open ? adv : 0;
+		open = open && x == 0 && n < room;
+	}
+	return max(min(n, room), 0);
+}
+// Bytes -> 2 bits per base into LDS at `dst` (two dwords of slack behind the last base), by T threads.  Returns nonzero when a byte
+// is not one of A, C, G, T.  code = (byte >> 1) & 3: A 0, C 1, T 2, G 3.
+template <int T>
+__device__ __forceinline__ uint32_t lds_pack2bit(const uint8_t *src, int32_t len, uint8_t *dst)
+{
+	uint32_t bad = 0;
+	const int32_t n_dw = (len >> 4) + 2;
+	for (int32_t w = threadIdx.x; w < n_dw; w += T) {
+		uint32_t out = 0;
+		const int32_t b0 = w << 4;
+		if (b0 + 16 <= len) {
+			uint32_t q[4];
+			__builtin_memcpy(q, src + b0, 16);
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const uint32_t x = q[k], code = (x >> 1) & 0x03030303u;
+				const uint32_t lo1 = code & 0x01010101u, hi1 = (code >> 1) & 0x01010101u;
+				const uint32_t expect = 0x41414141u + (lo1 & ~hi1) * 0x02u + (hi1 & ~lo1) * 0x13u + (hi1 & lo1) * 0x06u; // 0 'A', 1 'C', 2 'T', 3 'G'
+				bad |= x ^ expect;
+				out |= ((code | code >> 6 | code >> 12 | code >> 18) & 0xffu) << (8 * k);
+			}
+		} else {
+#pragma unroll 1
+			for (int32_t k = 0; k < 16 && b0 + k < len; ++k) {
+				const uint32_t x = src[b0 + k], code = (x >> 1) & 3u;
+				bad |= x ^ ((0x47544341u >> (8 * code)) & 0xffu);
+				out |= code << (2 * k);
+			}
+		}
+		*(uint32_t*)(dst + 4 * w) = out;
+	}
+	return bad;
+}
+
 // offset k on diagonal d is a cell of the DP matrix (reference good_diag, miniwfa.c:139-142)
 __device__ __forceinline__ bool in_matrix(int32_t d, int32_t k, int32_t tl, int32_t ql)
 {

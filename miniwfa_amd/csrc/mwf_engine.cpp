@@ -158,7 +158,7 @@ struct mwf_gpu_batch_s {
 		int64_t tun_key[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 		int64_t max_len = 0, max_bound = 0;
 		bool has_groups = false, mid_bytes = false;
-		struct GI { int32_t n = 0; int64_t max_len = 0, max_bound = 0, max_bound1 = 0, max_tl = 0, max_seq_lds = 0; } gi[12];
+		struct GI { int32_t n = 0; int64_t max_len = 0, max_bound = 0, max_bound1 = 0, max_tl = 0, max_seq_lds = 0; } gi[13];
 		std::vector<int8_t> cls0, flags0;
 	} plan;
 	std::vector<char> host_out;     // the fixed-size results as they came back (finalize)
@@ -376,7 +376,7 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 		// penalties: 14.5 KB, eleven waves; three: thirteen).  Three hold penalties up to ~110: 40 000 x 150 bp @ 5 % 0.68 against 0.79 ms with one
 		// pair re-run, 20 000 x 200 bp 0.52 / 0.61 with ten, 20 000 x 150 bp @ 10 % 0.75 / 0.93 with 499 (profiles/r03/lane_kernel_probe.txt).
 		const int chunks = g->lane_chunks > 0 ? g->lane_chunks : max_len <= 400 ? 3 : 4;
-		BandGeom lg{64, 1, 64 * chunks, lane_lds_bytes(P, chunks, max_seq_lds), 0, 1};
+		BandGeom lg{64, 1, 64 * chunks, lane_lds_bytes(P, chunks, max_seq_lds), (g->seq2bit != 0 && !g->acgt_off_once) ? 1 : 0, 1};
 		if (lg.lds_bytes <= 60 * 1024) { // (deep rings — large gap-open costs — with a raised lane_max_len: the band classes below take the pairs)
 			pl.kind = 2, pl.band = lg;
 			return;
@@ -634,7 +634,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	if (timed) HIP_TRY(g, hipEventRecord(g->ev0, g->stream));
 	std::shared_lock<std::shared_mutex> gate(g_dev_gate[g->device % kMaxDevices]); // not while a whole-device kernel runs
 	const int lrc = pl.kind == 2 && pl.band.lane == 2 ? launch_mid(a, pl.grid, pl.band.block, pl.band.lds_bytes, pl.band.seq2 != 0, g->stream)
-	              : pl.kind == 2 && pl.band.lane ? launch_lane(a, pl.grid, pl.band.lds_bytes, g->stream)
+	              : pl.kind == 2 && pl.band.lane ? launch_lane(a, pl.grid, pl.band.lds_bytes, pl.band.seq2 != 0, g->stream)
 	              : pl.kind == 2 ? (pl.band.packed ? launch_band2(a, pl.grid, pl.band, g->stream) : launch_band(a, pl.grid, pl.band, g->stream))
 	                             : launch_batch(a, pl.grid, pl.block, g->stream);
 	gate.unlock();
@@ -1349,12 +1349,13 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	// 10: short pairs on the one-diagonal-per-lane kernel (mwf_lane.hip); what outgrows its 64 columns moves to the band classes
 	// 11: mid-size pairs of a small batch on the one-workgroup-per-pair, rings-in-LDS kernel (mwf_mid.hip); what outgrows its span moves to the band classes
 	typedef mwf_gpu_batch_t::PlanCache::GI GroupInfo;
-	GroupInfo gi[12];
+	GroupInfo gi[13];
 	bool mid_bytes = false;
-	static const int run_order[12] = {5, 0, 1, 6, 2, 7, 3, 8, 4, 9, 11, 10}; // largest workspace first
+	// (12: the pairs of class 10 the host knows not to be plain A/C/G/T — reads with an N —: the lane kernel on byte-wise copies)
+	static const int run_order[13] = {5, 0, 1, 6, 2, 7, 3, 8, 4, 9, 11, 10, 12}; // largest workspace first
 	if (PC.has_groups) { // same lengths, same options, same tunables as last time: classes, order (already on the device) and maxima as they were
 		b->h_class = PC.cls0, b->h_flags = PC.flags0;
-		for (int c = 0; c < 12; ++c) gi[c] = PC.gi[c];
+		for (int c = 0; c < 13; ++c) gi[c] = PC.gi[c];
 		mid_bytes = PC.mid_bytes;
 	} else {
 		const bool lane_ok = g->lane_max_len > 0 && lane_supported(P0);
@@ -1364,7 +1365,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		const bool pack_pen = g->band_pack != 0 && band2_supported(P0), plain_ok = band_supported(P0);
 		const bool gen16 = g->ring16 != 0 && g->lds_e2 && !g->scalar_generic && P0.e2 == 1;
 		std::vector<int8_t> cls((size_t)b->n); // group of every pair
-		int32_t count[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+		int32_t count[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 		for (int32_t i = 0; i < b->n; ++i) {
 			const int64_t tl = b->h_tl[i], ql = b->h_ql[i], len = tl + ql;
 			const int64_t bound1 = penalty_bound(*opt, tl, ql, false);
@@ -1389,7 +1390,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 			b->h_flags[i] = (int8_t)(step0 ? 1 : 0);
 			// short pairs: a window of 64 diagonals holds them while the penalty stays below ~45 (a 200 bp pair at 5 %)
 			const bool to_lane = classes && lane_ok && c >= 1 && c <= 4 && std::max(tl, ql) <= g->lane_max_len && std::abs(tl - ql) <= 24;
-			if (to_lane) c = 10, b->h_class[i] = 4;
+			if (to_lane) c = (know_acgt && !b->h_acgt[i]) ? 12 : 10, b->h_class[i] = 4;
 			// a few mid-size pairs: a workgroup each, rings in LDS (a penalty then costs a fraction of what it costs the band kernels).  Admitted
 			// when the span the LDS can hold beside the sequences covers the window of a pair at ~6 % divergence (about 0.3 (tl+ql)); 16-bit offsets.
 			if (mid_ok && !to_lane && c <= 4 && (!low_mem || step0) && tl + bound < 32760) {
@@ -1414,7 +1415,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		}
 		// The processing order: groups in run order, longest first inside a group (the persistent workgroups finish together).  h_order is
 		// already sorted longest first (batch_common) and that order is stable: one pass over it deals the pairs to their groups.
-		std::vector<int32_t> start(12, 0), order((size_t)b->n);
+		std::vector<int32_t> start(13, 0), order((size_t)b->n);
 		{
 			int32_t at = 0;
 			for (int c : run_order) start[c] = at, at += count[c], gi[c].n = count[c];
@@ -1432,7 +1433,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 			if (upload_segments(g, (char*)b->d_order, std::vector<Seg>{Seg{b->h_order.data(), b->h_order.size() * 4}})) return -1; // (waits for earlier work on the stream first)
 		}
 		PC.cls0 = b->h_class, PC.flags0 = b->h_flags, PC.mid_bytes = mid_bytes, PC.has_groups = true;
-		for (int c = 0; c < 12; ++c) PC.gi[c] = gi[c];
+		for (int c = 0; c < 13; ++c) PC.gi[c] = gi[c];
 	}
 	int n_groups = 0, done_groups = 0;
 	for (const GroupInfo &G : gi) n_groups += G.n > 0;
@@ -1444,10 +1445,10 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		if (G.n == 0) continue;
 		++done_groups;
 		int ran = 0;
-		const int cc = c == 11 ? 6 : c == 10 ? 5 : c > 5 ? c - 5 : c;
-		g->acgt_off_once = (c > 5 && c < 10) || (c == 11 && mid_bytes);
+		const int cc = c == 11 ? 6 : (c == 10 || c == 12) ? 5 : c > 5 ? c - 5 : c;
+		g->acgt_off_once = (c > 5 && c < 10) || (c == 11 && mid_bytes) || c == 12;
 		const int rc = run_batch_kernel(g, b, c == 5 ? *opt : opt_hi, b->d_order + at, G.n, slots, G.max_len, G.max_bound, G.max_bound1,
-		                                done_groups == 1, (classes || c == 11) ? (c == 0 || c == 5 ? 0 : 2) : -1, G.max_tl, G.max_seq_lds, done_groups == n_groups,
+		                                done_groups == 1, (classes || c >= 11) ? (c == 0 || c == 5 ? 0 : 2) : -1, G.max_tl, G.max_seq_lds, done_groups == n_groups,
 		                                cc == 6 ? 33 : cc == 5 ? 32 : cc == 4 ? 64 : cc == 3 ? 128 : cc == 2 ? 256 : 0, &ran);
 		g->acgt_off_once = false;
 		if (rc) return -1;

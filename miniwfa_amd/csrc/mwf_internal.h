@@ -158,7 +158,7 @@ int  launch_sys_finish(const BatchArgs &a, void *stream);                // trac
 // launch wrappers implemented in mwf_lane.hip (one wave per pair, one diagonal per lane, rings and sequences in LDS: short pairs)
 bool lane_supported(const Penalty &p);
 int  lane_lds_bytes(const Penalty &p, int chunks, int64_t seq_bytes); // seq_bytes >= tl + ql + 24 for every pair of the launch
-int  launch_lane(const BatchArgs &a, int grid, int lds, void *stream);
+int  launch_lane(const BatchArgs &a, int grid, int lds, bool seq2, void *stream); // seq2: 2-bit sequence copies (a pair outside plain A/C/G/T comes back as ST_ALPHABET)
 int  lane_kernel_occupancy(int lds, bool cigar);
 
 // launch wrappers implemented in mwf_mid.hip (one workgroup per pair, one diagonal per lane, rings and sequences in LDS: a few mid-size pairs)

@@ -17,7 +17,8 @@
 //     rows read as dead beyond their window without window tests (windows only grow here: the kernel hands a pair back before the
 //     first band shrink);
 //   * a wave executes its LDS instructions in order and no other wave shares the rows: no barrier anywhere, one wave per workgroup;
-//   * both sequences sit in LDS (8-byte copies), the extension compares 8 bytes per trip;
+//   * both sequences sit in LDS — at 2 bits per base for pairs of plain A/C/G/T (sixteen bases per trip of the extension, two LDS
+//     instructions), else as bytes (eight per trip; a pair outside A/C/G/T comes back as ST_ALPHABET and is re-run byte-wise);
 //   * the traceback bytes go to the slot's arena as rows of 64 x chunks bytes that all start at the leftmost column: the shared
 //     traceback (mwf_device.h) finds a byte without reading a row table first — one memory round trip per step instead of two.
 // A pair whose window leaves the chunks, or that reaches the first shrink (penalty 256 - nH), comes back as ST_BAND_OVERFLOW and is
@@ -37,43 +38,23 @@ constexpr int32_t kDead16 = -32768;
 
 __device__ __forceinline__ int32_t row_ints(int nc) { return 32 * nc + 2; } // a row: pad, 64 x nc columns, pad as int16, rounded up to dwords
 
-// eight bytes at an arbitrary byte offset of an LDS array (three aligned dwords, two v_alignbyte)
-__device__ __forceinline__ uint64_t lds_ld8(const uint8_t *base, int32_t off)
-{
-	const uint32_t *p = (const uint32_t*)(base + (off & ~3));
-	const uint32_t a = p[0], b = p[1], c = p[2];
-	const uint32_t lo = __builtin_amdgcn_alignbyte(b, a, (uint32_t)off), hi = __builtin_amdgcn_alignbyte(c, b, (uint32_t)off);
-	return (uint64_t)hi << 32 | lo;
-}
-
-// Length of the exact-match run t[j..] == q[i..], at most `room` (<= 0: none; j and i must then still be readable offsets).  The
-// wave walks together, eight bytes per lane and trip, while any lane's run is open: straight-line trips under one uniform branch
-// (a divergent while loop costs ~25 mask instructions per trip).
-__device__ __forceinline__ int32_t lane_extend(const uint8_t *lt, const uint8_t *lq, int32_t j, int32_t i, int32_t room)
-{
-	int32_t n = 0;
-	bool open = room > 0;
-	while (__ballot(open)) {
-		const uint64_t x = lds_ld8(lt, j + n) ^ lds_ld8(lq, i + n);
-		const int32_t adv = x ? (int32_t)(__builtin_ctzll(x) >> 3) : 8;
-		n += open ? adv : 0;
-		open = open && x == 0 && n < room;
-	}
-	return max(min(n, room), 0);
-}
-
-template <bool TB, typename ArgsT>
+template <bool TB, bool S2, typename ArgsT>
 __device__ PassResult lane_pass(const ArgsT &A, PairMem &M, int16_t *rows, const uint8_t *lt, const uint8_t *lq, bool trace_band)
 {
 	const int32_t tl = M.tl, ql = M.ql, cmax = tl + ql + 1;
 	const int32_t lane = threadIdx.x;
-	const int32_t nH = A.pen.nH, lagx = A.pen.x, lag1 = A.pen.oe1, lag2 = A.pen.oe2, e1 = A.pen.e1, e2 = A.pen.e2, n1 = e1, n2 = e2;
-	const int32_t max_s = A.max_s, dbg_cap = A.dbg_cap;
-	const int64_t max_iter = A.max_iter;
+	const int32_t nH = A.pen.nH, n1 = A.pen.e1, n2 = A.pen.e2;
+	const int32_t dbg_cap = A.dbg_cap;
+	const int64_t iter_limit = A.max_iter > 0 ? A.max_iter : INT64_MAX;
+	const int32_t s_limit = A.max_s > 0 ? A.max_s : INT32_MAX;
 	const int32_t tb_slot_bytes = (int32_t)min(A.tb_slot_bytes, (int64_t)0x7fffffff);
 	const int32_t NC = A.lane_chunks, RL = row_ints(NC) * 2; // RL: int16 entries per row
 	const int32_t center = tl + 1, left = center - 32 * NC;   // entry 1 of a row is column `left`
-	int16_t *const Hr = rows, *const E1r = Hr + nH * RL, *const F1r = E1r + n1 * RL, *const E2r = F1r + n1 * RL, *const F2r = E2r + n2 * RL;
+	// rows as byte offsets: ring bases, ring sizes, and the rows of the coming penalty carried from penalty to penalty (one add and one
+	// wrap each) instead of being derived from slot numbers (a dozen multiplies per penalty)
+	const int32_t RB = RL * 2, HB = nH * RB, B1 = n1 * RB, B2 = n2 * RB;
+	const int32_t bE1 = HB, bF1 = bE1 + B1, bE2 = bF1 + B1, bF2 = bE2 + B2;
+	char *const base = (char*)rows;
 	const int32_t n_rows = nH + 2 * n1 + 2 * n2;
 	PassResult R;
 	R.status = ST_OK, R.s = 0, R.info = 0, R.n_snap = 0, R.cells = 0;
@@ -85,17 +66,24 @@ __device__ PassResult lane_pass(const ArgsT &A, PairMem &M, int16_t *rows, const
 		for (int32_t j = lane; j < (n_rows * RL * 2 + 15) / 16; j += 64) ((uint4*)rows)[j] = dead4;
 	}
 	__syncthreads(); // (one wave: for the compiler, the int16 accesses below are not reordered with the wide stores)
-	const int32_t k0 = lane_extend(lt, lq, 0, 0, min(tl, ql)) - 1;
-	if (lane == 0) Hr[center - left + 1] = (int16_t)k0;
+	const int32_t k0 = (S2 ? lds_extend16(lt, lq, 0, 0, min(tl, ql)) : lds_extend8(lt, lq, 0, 0, min(tl, ql))) - 1;
+	if (lane == 0) *(int16_t*)(base + (center - left + 1) * 2) = (int16_t)k0;
 	if (k0 == tl - 1 && k0 == ql - 1) return R;
 
 	int32_t s = 0, wf_lo = tl + 1, wf_hi = tl + 1;
-	int32_t curH = 0, a1 = 0, a2 = 0; // H slot of penalty s; slots of the E1/F1 and E2/F2 rings the next penalty reads (e1, e2 penalties old) and then overwrites
+	// byte offsets (within their ring) of the rows penalty 1 writes and reads: H of penalties 1, 1-x, 1-(o1+e1), 1-(o2+e2); the E/F rings
+	// have exactly e1 (e2) rows: the row read (e penalties old) is the row overwritten
+	int32_t oN = RB % HB, oX = ((nH + 1 - A.pen.x) % nH) * RB, oA = ((nH + 1 - A.pen.oe1) % nH) * RB, oB = ((nH + 1 - A.pen.oe2) % nH) * RB;
+	int32_t o1 = 0, o2 = 0;
 	int64_t cells = 0;
 	int32_t tb_used = 0;
 	if (TB) M.tb_stride = 64 * NC, M.tb_left = left;
 	const int32_t s_shrink = 256 - nH; // the first penalty whose good bits a shrink would read (wf_stripe_shrink, miniwfa.c:144-171)
 	const int32_t cfin = ql + 1;       // the end cell (tl-1, ql-1) lies on diagonal ql-tl, i.e. this column
+	// a lane's entry of chunk k: column c = center + lane + dk with dk = -32 (k + 1) (lanes 0-31) or 32 (k - 1) (lanes 32-63); entry
+	// idx = c - left + 1, so entry idx - 1 lies at byte 2 (32 NC + lane) + 2 dk of a row
+	const int32_t vb = 2 * (32 * NC + lane);
+	const bool lower = lane < 32;
 	for (;;) {
 		const int32_t lo = wf_lo > 1 ? wf_lo - 1 : 1;       // miniwfa.c:417-418
 		const int32_t hi = wf_hi < cmax ? wf_hi + 1 : cmax;
@@ -103,44 +91,41 @@ __device__ PassResult lane_pass(const ArgsT &A, PairMem &M, int16_t *rows, const
 		// chunks the window has reached: column c < center lies in chunk (center-1-c)/32, c >= center in chunk (c-center)/32
 		const int32_t k_use = max(lo < center ? (center - 1 - lo) >> 5 : 0, hi > center ? (hi - center) >> 5 : 0);
 		if (k_use >= NC || s_new >= s_shrink) { R.status = ST_BAND_OVERFLOW; break; }
-		const int32_t newH = curH + 1 == nH ? 0 : curH + 1;
-		const int32_t b1 = a1, b2 = a2, r1 = a1, r2 = a2; // a ring of exactly e1 (e2) rows: the row read is the row overwritten
 		if (TB && tb_used + 64 * NC > tb_slot_bytes) { R.status = ST_TB_OVERFLOW; break; }
 		if (trace_band && lane == 0 && s_new - 1 < dbg_cap) M.dbg[2 * (s_new - 1)] = lo, M.dbg[2 * (s_new - 1) + 1] = hi;
-		int32_t jx = newH - lagx; if (jx < 0) jx += nH;
-		int32_t j1 = newH - lag1; if (j1 < 0) j1 += nH;
-		int32_t j2 = newH - lag2; if (j2 < 0) j2 += nH;
 		uint32_t flags = 0;    // per lane, over its chunks: 1 = the lo column and live, 2 = the hi column and live, 4 = the end cell, reached
 		int32_t fin_info = 0;
 		// The E/F row a chunk overwrites is the row the next chunk still reads at the two columns where their blocks touch: the old F of
 		// this chunk's first column (lane 0) and the old E of its last (lane 63) travel to the next chunk in scalars.
 		int32_t cE1 = 0, cE2 = 0, cF1 = 0, cF2 = 0;
 		for (int32_t k = 0; k <= k_use; ++k) {
-			const int32_t c = lane < 32 ? center - 32 * (k + 1) + lane : center + 32 * k + lane - 32;
-			const int32_t d = c - center, idx = c - left + 1;
-			// sources (reference wf_next_prep, miniwfa.c:252-257)
-			const int16_t *hx_row = Hr + jx * RL + idx, *o1_row = Hr + j1 * RL + idx, *o2_row = Hr + j2 * RL + idx;
-			const int32_t hx = hx_row[0], o1m = o1_row[-1], o1p = o1_row[1], o2m = o2_row[-1], o2p = o2_row[1];
-			int32_t g1m = E1r[r1 * RL + idx - 1], g1p = F1r[r1 * RL + idx + 1], g2m = E2r[r2 * RL + idx - 1], g2p = F2r[r2 * RL + idx + 1];
+			const int32_t dk = lower ? -32 * (k + 1) : 32 * (k - 1);
+			const int32_t c = center + lane + dk, ga = vb + 2 * dk;
+			const int32_t d = c - center;
+			// sources (reference wf_next_prep, miniwfa.c:252-257): entries idx-1, idx, idx+1 at byte offsets 0, 2, 4 of `ga` in a row
+			const char *const pX = base + ga + oX, *const pA = base + ga + oA, *const pB = base + ga + oB;
+			const int32_t hx = *(const int16_t*)(pX + 2), o1m = *(const int16_t*)pA, o1p = *(const int16_t*)(pA + 4), o2m = *(const int16_t*)pB, o2p = *(const int16_t*)(pB + 4);
+			char *const pE1 = base + ga + (bE1 + o1), *const pF1 = base + ga + (bF1 + o1), *const pE2 = base + ga + (bE2 + o2), *const pF2 = base + ga + (bF2 + o2);
+			int32_t g1m = *(const int16_t*)pE1, g1p = *(const int16_t*)(pF1 + 4), g2m = *(const int16_t*)pE2, g2p = *(const int16_t*)(pF2 + 4);
 			if (k > 0) { // lane 31: the column left of the previous chunk's first; lane 32: the column right of its last
 				g1p = lane == 31 ? cF1 : g1p, g2p = lane == 31 ? cF2 : g2p;
 				g1m = lane == 32 ? cE1 : g1m, g2m = lane == 32 ? cE2 : g2m;
 			}
 			if (k < k_use) {
-				const int32_t oE1 = E1r[r1 * RL + idx], oF1 = F1r[r1 * RL + idx], oE2 = E2r[r2 * RL + idx], oF2 = F2r[r2 * RL + idx];
+				const int32_t oE1 = *(const int16_t*)(pE1 + 2), oF1 = *(const int16_t*)(pF1 + 2), oE2 = *(const int16_t*)(pE2 + 2), oF2 = *(const int16_t*)(pF2 + 2);
 				cE1 = __builtin_amdgcn_readlane(oE1, 63), cE2 = __builtin_amdgcn_readlane(oE2, 63);
 				cF1 = __builtin_amdgcn_readlane(oF1, 0), cF2 = __builtin_amdgcn_readlane(oF2, 0);
 			}
 			const bool act = c >= lo && c <= hi;
 			const Cell v = wf_cell<TB>(hx, o1m, g1m, o2m, g2m, o1p, g1p, o2p, g2p);
-			E1r[b1 * RL + idx] = (int16_t)(act ? max(v.e1, kDead16) : kDead16), F1r[b1 * RL + idx] = (int16_t)(act ? max(v.f1, kDead16) : kDead16);
-			E2r[b2 * RL + idx] = (int16_t)(act ? max(v.e2, kDead16) : kDead16), F2r[b2 * RL + idx] = (int16_t)(act ? max(v.f2, kDead16) : kDead16);
+			*(int16_t*)(pE1 + 2) = (int16_t)(act ? max(v.e1, kDead16) : kDead16), *(int16_t*)(pF1 + 2) = (int16_t)(act ? max(v.f1, kDead16) : kDead16);
+			*(int16_t*)(pE2 + 2) = (int16_t)(act ? max(v.e2, kDead16) : kDead16), *(int16_t*)(pF2 + 2) = (int16_t)(act ? max(v.f2, kDead16) : kDead16);
 			// match extension (reference wf_extend, miniwfa.c:208-246) of the cells inside the matrix
 			const bool inm = act && in_matrix(d, v.h, tl, ql);
 			const int32_t j = inm ? v.h + 1 : 0, i = inm ? d + j : 0;
-			const int32_t nmat = lane_extend(lt, lq, j, i, inm ? min(tl - j, ql - i) : 0);
+			const int32_t nmat = S2 ? lds_extend16(lt, lq, j, i, inm ? min(tl - j, ql - i) : 0) : lds_extend8(lt, lq, j, i, inm ? min(tl - j, ql - i) : 0);
 			const int32_t h = act ? max(v.h + nmat, kDead16) : kDead16;
-			Hr[newH * RL + idx] = (int16_t)h;
+			*(int16_t*)(base + ga + oN + 2) = (int16_t)h;
 			if (TB && act) M.tb[tb_used + (c - left)] = (uint8_t)v.tb;
 			// edge rule (miniwfa.c:325-326): H is the max of the five, so "any live" == "H live"
 			const uint32_t live = (uint32_t)(h >= -1);
@@ -152,11 +137,12 @@ __device__ PassResult lane_pass(const ArgsT &A, PairMem &M, int16_t *rows, const
 		if (__ballot(flags & 1u)) wf_lo = lo;
 		if (__ballot(flags & 2u)) wf_hi = hi;
 		const unsigned long long fm = __ballot(flags & 4u);
-		s = s_new, curH = newH;
-		a1 = a1 + 1 == n1 ? 0 : a1 + 1, a2 = a2 + 1 == n2 ? 0 : a2 + 1;
+		s = s_new;
+		oN = oN + RB == HB ? 0 : oN + RB, oX = oX + RB == HB ? 0 : oX + RB, oA = oA + RB == HB ? 0 : oA + RB, oB = oB + RB == HB ? 0 : oB + RB;
+		o1 = o1 + RB == B1 ? 0 : o1 + RB, o2 = o2 + RB == B2 ? 0 : o2 + RB;
 		if (TB) tb_used += 64 * NC;
 		cells += hi - lo + 1;
-		if ((max_iter > 0 && cells > max_iter) || (max_s > 0 && s > max_s)) { // miniwfa.c:422-425
+		if (cells > iter_limit || s > s_limit) { // miniwfa.c:422-425
 			R.status = ST_STOPPED;
 			break;
 		}
@@ -166,7 +152,7 @@ __device__ PassResult lane_pass(const ArgsT &A, PairMem &M, int16_t *rows, const
 	return R;
 }
 
-template <bool TB>
+template <bool TB, bool S2>
 __global__ __launch_bounds__(64) void wfa_lane_kernel(const BatchArgs)
 {
 	// the arguments are read from the kernarg segment where they are used (mwf_device.h): nothing of them stays in SGPRs across the penalties
@@ -184,13 +170,20 @@ __global__ __launch_bounds__(64) void wfa_lane_kernel(const BatchArgs)
 		PairMem M;
 		pair_mem(fresh(A), (int32_t)blockIdx.x, pair, M);
 		M.tl = uni(M.tl), M.ql = uni(M.ql);
-		uint8_t *lq = lt + ((M.tl + 7) & ~7) + 16;
-		// both sequences into LDS, eight bytes per lane and trip (the packed sequence buffer has 64 bytes of slack behind it)
-		for (int32_t j = 8 * lane; j < M.tl; j += 512) *(uint64_t*)(lt + j) = ld8(M.ts + j);
-		for (int32_t j = 8 * lane; j < M.ql; j += 512) *(uint64_t*)(lq + j) = ld8(M.qs + j);
+		uint8_t *lq = S2 ? lt + ((M.tl >> 4) + 2) * 4 : lt + ((M.tl + 7) & ~7) + 16;
+		PassResult R;
+		R.status = ST_OK, R.s = 0, R.info = 0, R.n_snap = 0, R.cells = 0;
+		if (S2) { // 2 bits per base; a base other than A/C/G/T: the host re-runs the pair on a byte-wise copy (ST_ALPHABET)
+			uint32_t bad = lds_pack2bit<64>(M.ts, M.tl, lt);
+			bad |= lds_pack2bit<64>(M.qs, M.ql, lq);
+			if (__ballot(bad != 0)) R.status = ST_ALPHABET;
+		} else { // both sequences into LDS as they are, eight bytes per lane and trip (the packed sequence buffer has 64 bytes of slack behind it)
+			for (int32_t j = 8 * lane; j < M.tl; j += 512) *(uint64_t*)(lt + j) = ld8(M.ts + j);
+			for (int32_t j = 8 * lane; j < M.ql; j += 512) *(uint64_t*)(lq + j) = ld8(M.qs + j);
+		}
 		__syncthreads(); // (one wave: orders the copies before the dword reads of the extension for the compiler)
 		const bool trace = A.dbg && pair == A.debug_pair;
-		const PassResult R = lane_pass<TB>(fresh(A), M, rows, lt, lq, trace);
+		if (R.status == ST_OK) R = lane_pass<TB, S2>(fresh(A), M, rows, lt, lq, trace);
 		finish_pair(fresh(A), M, (int32_t)blockIdx.x, pair, R, R.status, 0);
 	}
 }
@@ -210,25 +203,31 @@ int lane_lds_bytes(const Penalty &p, int chunks, int64_t seq_bytes)
 	return (int)((rings + seq_bytes + 64 + 15) / 16 * 16);
 }
 
-int launch_lane(const BatchArgs &a, int grid, int lds, void *stream)
+int launch_lane(const BatchArgs &a, int grid, int lds, bool seq2, void *stream)
 {
 	// deep rings (large gap-open costs) or a raised lane_max_len: beyond 48 KB of dynamic LDS the runtime wants to be told (the attribute is
 	// per device and this may run on several host threads: set on every launch that needs it, as the band kernels do)
+	const void *fn = a.want_cigar ? (seq2 ? reinterpret_cast<const void*>(&wfa_lane_kernel<true, true>) : reinterpret_cast<const void*>(&wfa_lane_kernel<true, false>))
+	                              : (seq2 ? reinterpret_cast<const void*>(&wfa_lane_kernel<false, true>) : reinterpret_cast<const void*>(&wfa_lane_kernel<false, false>));
 	if (lds > 48 * 1024) {
-		(void)hipFuncSetAttribute(a.want_cigar ? reinterpret_cast<const void*>(&wfa_lane_kernel<true>) : reinterpret_cast<const void*>(&wfa_lane_kernel<false>),
-		                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+		(void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 		(void)hipGetLastError();
 	}
-	if (a.want_cigar) hipLaunchKernelGGL(wfa_lane_kernel<true>, dim3(grid), dim3(64), lds, (hipStream_t)stream, a);
-	else hipLaunchKernelGGL(wfa_lane_kernel<false>, dim3(grid), dim3(64), lds, (hipStream_t)stream, a);
+	if (a.want_cigar) {
+		if (seq2) hipLaunchKernelGGL((wfa_lane_kernel<true, true>), dim3(grid), dim3(64), lds, (hipStream_t)stream, a);
+		else hipLaunchKernelGGL((wfa_lane_kernel<true, false>), dim3(grid), dim3(64), lds, (hipStream_t)stream, a);
+	} else {
+		if (seq2) hipLaunchKernelGGL((wfa_lane_kernel<false, true>), dim3(grid), dim3(64), lds, (hipStream_t)stream, a);
+		else hipLaunchKernelGGL((wfa_lane_kernel<false, false>), dim3(grid), dim3(64), lds, (hipStream_t)stream, a);
+	}
 	return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 int lane_kernel_occupancy(int lds, bool cigar)
 {
 	int n = 0;
-	const hipError_t e = cigar ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_lane_kernel<true>, 64, lds)
-	                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_lane_kernel<false>, 64, lds);
+	const hipError_t e = cigar ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_lane_kernel<true, true>, 64, lds)
+	                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_lane_kernel<false, true>, 64, lds);
 	return e == hipSuccess ? n : 0;
 }
 
