@@ -376,7 +376,9 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 		// penalties: 14.5 KB, eleven waves; three: thirteen).  Three hold penalties up to ~110: 40 000 x 150 bp @ 5 % 0.68 against 0.79 ms with one
 		// pair re-run, 20 000 x 200 bp 0.52 / 0.61 with ten, 20 000 x 150 bp @ 10 % 0.75 / 0.93 with 499 (profiles/r03/lane_kernel_probe.txt).
 		const int chunks = g->lane_chunks > 0 ? g->lane_chunks : max_len <= 400 ? 3 : 4;
-		BandGeom lg{64, 1, 64 * chunks, lane_lds_bytes(P, chunks, max_seq_lds), (g->seq2bit != 0 && !g->acgt_off_once) ? 1 : 0, 1};
+		// 2-bit sequence copies from ~450 bases of target + query on (measured: 20 000 x 250 bp 0.624 against 0.650 ms with byte copies, 40 000 x
+		// 150 bp 0.664 against 0.617 — packing costs more than the shorter extension trips save; profiles/r04/short_reads_step.txt)
+		BandGeom lg{64, 1, 64 * chunks, lane_lds_bytes(P, chunks, max_seq_lds), (g->seq2bit != 0 && !g->acgt_off_once && max_len >= 450) ? 1 : 0, 1};
 		if (lg.lds_bytes <= 60 * 1024) { // (deep rings — large gap-open costs — with a raised lane_max_len: the band classes below take the pairs)
 			pl.kind = 2, pl.band = lg;
 			return;

@@ -8,7 +8,8 @@ ragged batch does not leave one GPU with all the long pairs.  Every rank compute
 
 The only communication is the final gather of the fixed-size per-pair records: ONE `all_gather_into_tensor` of
 (s, n_iter) packed as two int64 per pair — RCCL over xGMI on GPUs (backend "nccl"), gloo in the CPU tests.  CIGARs,
-when wanted, are variable-length and travel as a second gather sized from the gathered n_cigar.
+when wanted, are variable-length: their lengths travel in one more fixed-record gather, the words as one broadcast per rank
+of exactly that rank's size (no padding to the largest payload).
 """
 from __future__ import annotations
 
@@ -71,7 +72,11 @@ def gather_records(dist, s_local, it_local, n_total: int, device=None, deal=None
 
 
 def gather_cigars(dist, cigars_local, n_total: int, device=None, deal=None):
-    """Variable-length payload: list (share order) of uint32 numpy arrays -> list for all n_total pairs on every rank."""
+    """Variable-length payload: list (share order) of uint32 numpy arrays -> list for all n_total pairs on every rank.
+
+    Two steps, neither padded to the largest payload: the per-pair lengths travel in ONE all_gather of fixed-size records (one int64
+    per pair, padded to the largest share like the (s, n_iter) records — a few bytes per pair), then every rank's CIGAR words travel
+    as ONE broadcast of exactly that rank's size (a rank with one long pair no longer makes every other rank ship that many words)."""
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
     if deal is None:
@@ -88,17 +93,19 @@ def gather_cigars(dist, cigars_local, n_total: int, device=None, deal=None):
     dist.all_gather_into_tensor(all_len, pad_len)
     all_len = all_len.view(world, cap).cpu().numpy()
     words = [int(all_len[r, :sizes[r]].sum()) for r in range(world)]
-    wcap = max(max(words) if words else 0, 1)
     flat = np.concatenate([np.asarray(c, dtype=np.uint32) for c in cigars_local]) if words[rank] else np.zeros(0, dtype=np.uint32)
-    pad = torch.zeros((wcap,), dtype=torch.int32, device=dev)
-    pad[:words[rank]] = torch.from_numpy(flat.view(np.int32).copy()).to(dev)
-    all_w = torch.empty((world * wcap,), dtype=torch.int32, device=dev)
-    dist.all_gather_into_tensor(all_w, pad)
-    all_w = all_w.view(world, wcap).cpu().numpy().view(np.uint32)
+    payload = []
+    for r in range(world):   # sized exchange: rank r's words, exactly, to everybody
+        if words[r] == 0:
+            payload.append(np.zeros(0, dtype=np.uint32))
+            continue
+        buf = torch.from_numpy(flat.view(np.int32).copy()).to(dev) if r == rank else torch.empty((words[r],), dtype=torch.int32, device=dev)
+        dist.broadcast(buf, src=r)
+        payload.append(buf.cpu().numpy().view(np.uint32))
     out: list = [None] * n_total
     for r in range(world):
         off = 0
         for j, ln in enumerate(all_len[r, :sizes[r]]):
-            out[int(ids[r][j])] = all_w[r, off:off + int(ln)].copy()
+            out[int(ids[r][j])] = payload[r][off:off + int(ln)].copy()
             off += int(ln)
     return out
