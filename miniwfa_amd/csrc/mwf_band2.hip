@@ -851,9 +851,10 @@ __global__ __launch_bounds__(T, T <= 512 ? ((TB && T < 512) ? 3 : 4) : 1) void w
 	LdsT *const L = (LdsT*)(lds2 + lds_seq);
 	Shared &sh = L->sh;
 	const int32_t edge_base = lds_seq + (int32_t)offsetof(LdsT, edge);
-	for (;;) {
+	for (int32_t round = 0;; ++round) {
 		KArgs &A = fresh(A0);
-		if (threadIdx.x == 0) sh.item = (int32_t)atomicAdd(A.queue, 1), sh.word[2] = 0;
+		// a work counter, or — queue == null: a launch of one workgroup per pair — pair blockIdx.x and nothing else (no counter to zero first)
+		if (threadIdx.x == 0) sh.item = A.queue ? (int32_t)atomicAdd(A.queue, 1) : (round == 0 ? (int32_t)blockIdx.x : A.n_pairs), sh.word[2] = 0;
 		__syncthreads();
 		const int32_t item = uni(sh.item);
 		__syncthreads();
@@ -878,6 +879,7 @@ __global__ __launch_bounds__(T, T <= 512 ? ((TB && T < 512) ? 3 : 4) : 1) void w
 		}
 		const bool trace = A.dbg && pair == A.debug_pair;
 		if (R.status == ST_OK) R = band2_pass<T, K, E1, E2, TB, S2>(A, M, sh, edge_base, qoff, trace);
+		if (S2) M.t2 = lds2, M.q2 = lds2 + qoff; // the traceback's back-match reads the 2-bit copies in LDS
 		finish_pair(fresh(A0), M, (int32_t)blockIdx.x, pair, R, R.status, 0);
 	}
 }

@@ -240,6 +240,9 @@ struct PairMem {
 	int32_t ep_ow, ep_p, ep_kw;
 	// rows of a fixed width that all start at the same column (mwf_lane.hip): byte of (row, col) at row * tb_stride + col - tb_left; 0: not this layout
 	int32_t tb_stride, tb_left;
+	// 2-bit copies of the two sequences in LDS (kernels that hold them: the traceback's back-match then stays on chip); null: compare
+	// the bytes at ts / qs (which may themselves point into LDS)
+	const uint8_t *t2, *q2;
 };
 
 // the traceback byte of (penalty row + 1, column col)
@@ -277,9 +280,25 @@ static __device__ int32_t traceback_wave(const ArgsT &A, const PairMem &M, uint3
 		}
 		run_op = op, run_len = len;
 	};
+	// The byte of the cell the walk stands on is requested as soon as the cell is known — before the back-match along its diagonal
+	// (which changes neither the row nor the column): the two round trips of a step travel together instead of one after the other.
+	uint32_t x_next = 0;
+	if (row >= 0 && i >= 0 && k >= 0) x_next = tb_byte(M, row, i - k + M.tl + 1);
 	while (i >= 0 && k >= 0 && !overflow) {
 		if (last == 0) { // greedy back-match, 64 bases per trip (miniwfa.c:335-341)
 			int32_t run = 0;
+			if (M.t2) { // 2-bit copies in LDS: one base per lane and trip
+				for (;;) {
+					const int32_t ii = i - run - lane, kk = k - run - lane;
+					bool eq = ii >= 0 && kk >= 0;
+					if (eq) eq = ((((const uint32_t*)M.q2)[ii >> 4] >> ((ii & 15) << 1)) & 3u) == ((((const uint32_t*)M.t2)[kk >> 4] >> ((kk & 15) << 1)) & 3u);
+					const unsigned long long m = __ballot(eq);
+					const int32_t n = m == ~0ull ? 64 : (int32_t)__builtin_ctzll(~m);
+					run += n;
+					if (n < 64) break;
+				}
+				goto matched;
+			}
 			// far from the start of both sequences: eight bases per lane, 512 per trip (a long pair is mostly exact matches, and a
 			// trip is a round trip to the sequences)
 			while (i - run >= 511 && k - run >= 511) {
@@ -306,8 +325,7 @@ static __device__ int32_t traceback_wave(const ArgsT &A, const PairMem &M, uint3
 			if (i < 0 || k < 0) break;
 		}
 		if (row < 0) { overflow = true; break; }
-		const int32_t col = i - k + M.tl + 1;
-		const uint32_t x = tb_byte(M, row, col);
+		const uint32_t x = x_next;
 		const int32_t state = last == 0 ? (int32_t)(x & 7u) : last;           // :346
 		const int32_t ext = state > 0 ? (int32_t)(x >> (state + 2)) & 1 : 0;  // :347
 		if (state == 0) { push(8, 1); --i, --k; row -= P.x; }
@@ -316,6 +334,7 @@ static __device__ int32_t traceback_wave(const ArgsT &A, const PairMem &M, uint3
 		else if (state == 2) { push(2, 1); --k; row -= ext ? P.e1 : P.oe1; }
 		else { push(2, 1); --k; row -= ext ? P.e2 : P.oe2; }
 		last = (state > 0 && ext) ? state : 0;                                // :365
+		if (row >= 0 && i >= 0 && k >= 0) x_next = tb_byte(M, row, i - k + M.tl + 1); // (the cell the path came from: its row holds it)
 	}
 	end_state[0] = row, end_state[1] = i, end_state[2] = k;
 	if (i >= 0) push(1, i + 1);          // :368-369
@@ -351,6 +370,7 @@ __device__ __forceinline__ void pair_mem(const ArgsT &A, int32_t slot, int32_t p
 	M.dbg = A.dbg;
 	M.ep = 0, M.ep_ow = 0, M.ep_p = 0, M.ep_kw = 0;
 	M.tb_stride = 0, M.tb_left = 0;
+	M.t2 = M.q2 = 0;
 }
 
 // After the forward pass(es): traceback on the first wave, CIGAR into the pool, per-pair outputs.

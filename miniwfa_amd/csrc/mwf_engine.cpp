@@ -93,6 +93,7 @@ struct mwf_gpu_s {
 	DevBuf sys_box, sys_prog, sys_log, sys_ep, sys_park, sys_ring, sys_good;
 	DevBuf spare_block, spare_cig; // allocations of freed batches, waiting for the next batch
 	int queue_next = 0;            // next unused work counter of the current align call
+	bool queue_clean = false;      // the work counters were zeroed by this align call's reset kernel (else a launch that needs one zeroes it itself)
 	// pinned staging
 	void *pin = nullptr;
 	size_t pin_half = 0;
@@ -138,6 +139,7 @@ struct mwf_gpu_batch_s {
 	int64_t *d_iter = nullptr, *d_cigoff = nullptr, *d_cells1 = nullptr;
 	size_t out_off = 0, out_bytes = 0;
 	bool out_in_pin = false;        // the result arrays lie in the engine's pinned result page (small score-only batches)
+	bool results_preinit = false;   // the device result arrays came up initialised with the batch's upload (status -1, s -2, CIGAR counter 0): its first align needs no reset kernel
 	DevBuf cig;                     // CIGAR pool (allocated by the first CIGAR-mode align)
 	uint32_t *d_cig_pool = nullptr;
 	int64_t cig_pool_words = 0;
@@ -599,8 +601,10 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	memset(&a, 0, sizeof(a));
 	a.seqs = b->d_seqs, a.t_off = b->d_t_off, a.q_off = b->d_q_off, a.tl = b->d_tl, a.ql = b->d_ql;
 	a.order = d_order, a.n_pairs = n_items;
-	// a fresh work counter: the first kQueueSlots launches of an align call use the ones its reset kernel zeroed
-	if (g->queue_next < kQueueSlots) a.queue = (int32_t*)g->queue.p + g->queue_next++;
+	// A launch of one workgroup per pair on the kernels that take it (lane, mid, packed band) needs no work counter: workgroup i aligns
+	// pair i.  Otherwise a fresh counter: the first kQueueSlots launches of an align call use the ones its reset kernel zeroed.
+	if (pl.kind == 2 && (pl.band.lane || pl.band.packed) && n_items <= pl.grid && !g->queue_clean) a.queue = nullptr;
+	else if (g->queue_clean && g->queue_next < kQueueSlots) a.queue = (int32_t*)g->queue.p + g->queue_next++;
 	else {
 		a.queue = (int32_t*)g->queue.p;
 		HIP_TRY(g, hipMemsetAsync(g->queue.p, 0, 4, g->stream)); // (stream order: the launch that used it last is complete by then)
@@ -1082,6 +1086,19 @@ mwf_gpu_batch_t *batch_from_host(mwf_gpu_t *g, int32_t n, const int32_t *tl, con
 		}
 	} else if (packed_bytes > 0) segs.push_back(Seg{packed, (size_t)packed_bytes});
 	segs.push_back(Seg{nullptr, 64});
+	// a small batch (the single pair of a drop-in call): its result arrays come up initialised with the same copy — every pair "not run",
+	// CIGAR counter at zero — so that its first align launches no reset kernel
+	static const int32_t kNotRun[64] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
+	                                    -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+	static const int32_t kNotFinal[64] = {-2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2,
+	                                      -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2};
+	if (n >= 1 && n <= 64) {
+		pad_to(L.in_end, L.head);
+		segs.push_back(Seg{nullptr, 64});                                   // head: the CIGAR pool's counter
+		segs.push_back(Seg{kNotRun, N * 4}), pad_to(L.status + N * 4, L.s);
+		segs.push_back(Seg{kNotFinal, N * 4});
+		b->results_preinit = true;
+	}
 	if (upload_segments(g, base, segs)) {
 		mwf_gpu_batch_free(b);
 		return nullptr;
@@ -1291,9 +1308,20 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	if (max_len + 4 >= ((int64_t)1 << 31)) { g->err = "tl+ql must be below 2^31-4"; return -2; }
 	const int slots = 1 << 30; // as many as the chosen kernel can keep resident (run_batch_kernel bounds it)
 	if (b->debug_pair >= 0 && ensure(g, g->dbg, (size_t)8 * (max_bound + 2))) return -1;
+	const bool was_busy = b->busy;
 	b->busy = true;
 	g->queue_next = 0;
-	if (launch_reset(b->d_status, b->d_s, b->n, b->d_cig_head, (int32_t*)g->queue.p, kQueueSlots, g->stream)) { g->err = "kernel launch failed (reset)"; return -1; }
+	// Every pair "not run", CIGAR pool and work counters at zero: one small kernel — unless the result arrays can be written from here
+	// (the pinned result page of a small score-only batch: the single pair of a drop-in call) or came up initialised with the batch
+	// (a small batch's first align); the kernels of such a call then run without a work counter where they can (run_batch_kernel).
+	bool preset = false;
+	if (b->out_in_pin && !was_busy) {
+		for (int32_t i = 0; i < b->n; ++i) b->d_status[i] = -1, b->d_s[i] = -2;
+		preset = true;
+	} else if (b->results_preinit) preset = true;
+	b->results_preinit = false;
+	g->queue_clean = !preset;
+	if (!preset && launch_reset(b->d_status, b->d_s, b->n, b->d_cig_head, (int32_t*)g->queue.p, kQueueSlots, g->stream)) { g->err = "kernel launch failed (reset)"; return -1; }
 	std::fill(b->h_flags.begin(), b->h_flags.end(), 0);
 	// a few long pairs: each one gets the whole device in turn
 	const Penalty P0 = make_penalty(*opt);

@@ -161,10 +161,13 @@ __global__ __launch_bounds__(64) void wfa_lane_kernel(const BatchArgs)
 	const int32_t n_rows = A.pen.nH + 2 * A.pen.e1 + 2 * A.pen.e2;
 	int16_t *rows = (int16_t*)lds_lane;
 	uint8_t *lt = lds_lane + (n_rows * row_ints(A.lane_chunks) * 4 + 15) / 16 * 16;
-	for (;;) {
+	for (int32_t round = 0;; ++round) {
+		// a work counter, or — queue == null: a launch of one workgroup per pair — pair blockIdx.x and nothing else (no counter to zero first)
 		int32_t item = 0;
-		if (lane == 0) item = (int32_t)atomicAdd(A.queue, 1);
-		item = uni(item);
+		if (A.queue) {
+			if (lane == 0) item = (int32_t)atomicAdd(A.queue, 1);
+			item = uni(item);
+		} else item = round == 0 ? (int32_t)blockIdx.x : A.n_pairs;
 		if (item >= A.n_pairs) break;
 		const int32_t pair = A.order ? A.order[item] : item;
 		PairMem M;
@@ -184,6 +187,7 @@ __global__ __launch_bounds__(64) void wfa_lane_kernel(const BatchArgs)
 		__syncthreads(); // (one wave: orders the copies before the dword reads of the extension for the compiler)
 		const bool trace = A.dbg && pair == A.debug_pair;
 		if (R.status == ST_OK) R = lane_pass<TB, S2>(fresh(A), M, rows, lt, lq, trace);
+		if (S2) M.t2 = lt, M.q2 = lq; // the traceback's back-match stays on chip
 		finish_pair(fresh(A), M, (int32_t)blockIdx.x, pair, R, R.status, 0);
 	}
 }

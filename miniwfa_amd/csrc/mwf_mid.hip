@@ -236,8 +236,9 @@ __global__ __launch_bounds__(T, 1) void wfa_mid_kernel(const BatchArgs)
 	const MidLayout L = mid_layout(A.pen.nH, A.pen.e1, A.pen.e2, A.lane_chunks * 64);
 	MidVars &V = *(MidVars*)(lds_mid + L.vars_off);
 	uint8_t *lt = lds_mid + L.seq_off;
-	for (;;) {
-		if (tid == 0) V.item = (int32_t)atomicAdd(A.queue, 1), V.word = 0;
+	for (int32_t round = 0;; ++round) {
+		// a work counter, or — queue == null: a launch of one workgroup per pair — pair blockIdx.x and nothing else (no counter to zero first)
+		if (tid == 0) V.item = A.queue ? (int32_t)atomicAdd(A.queue, 1) : (round == 0 ? (int32_t)blockIdx.x : A.n_pairs), V.word = 0;
 		__syncthreads();
 		const int32_t item = uni(V.item);
 		__syncthreads();
@@ -263,6 +264,7 @@ __global__ __launch_bounds__(T, 1) void wfa_mid_kernel(const BatchArgs)
 		}
 		const bool trace = A.dbg && pair == A.debug_pair;
 		if (R.status == ST_OK) R = mid_pass<T, TB, S2>(fresh(A), M, L, lt, lq, trace);
+		if (S2) M.t2 = lt, M.q2 = lq; // the traceback's back-match stays on chip
 		finish_pair(fresh(A), M, (int32_t)blockIdx.x, pair, R, R.status, 0);
 	}
 }
