@@ -327,6 +327,7 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 		for (int32_t j = 0; j < nH; ++j) sh.rng_lo[j] = 1, sh.rng_hi[j] = 0;
 		for (int32_t j = 0; j < 12; ++j) (&sh.flags[0][0])[j] = 0;
 		sh.rng_lo[0] = sh.rng_hi[0] = tl + 1;
+		sh.word[3] = -1; // furthest offset seen at a forecast penalty (dev::window_forecast)
 	}
 	__syncthreads(); // (orders the dead rows before the origin's store)
 	if (tid < 64) { // the origin's run, walked by the first wave
@@ -362,6 +363,7 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 		r.N1 = *(const int32_t*)(r1 + noff), r.N2 = *(const int32_t*)(r2 + noff);
 	};
 	int64_t cells = 0, tb_used = 0;
+	int32_t est_window = 0;
 	const int64_t iter_limit = A.max_iter > 0 ? A.max_iter : INT64_MAX;
 	const int32_t s_limit = A.max_s > 0 ? A.max_s : INT32_MAX;
 	const int64_t rows_slot = TB ? A.rows_slot : 0, tb_slot_bytes = TB ? A.tb_slot_bytes : 0;
@@ -418,6 +420,8 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 			if (k == 0 && wave == 0) *(int2*)(lds2 + wF + (NWK + 1) * 16 + 8) = make_int2(f1a, f2a);       // slot 0 is slot NWK-1's right neighbour
 		};
 		const int32_t ga = lo >> 8, gb = hi >> 8, gspan = gb - ga; // chunks [ga, gb] meet the window
+		const bool forecast = s_new == 64 || s_new == 256 || s_new == 1024; // uniform: look at how far the pair has come (dev::window_forecast)
+		int32_t far = kDeadPair;
 		const int32_t cfin = ql + 1; // the end cell (tl-1, ql-1) lies on diagonal ql-tl, i.e. in this column
 
 		if (wave == 0) { // (the whole wave stores the same words: no exec mask to set up)
@@ -703,6 +707,7 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 				nmA = pair_of(nmat[0], nmat[2]), nmB = pair_of(nmat[1], nmat[3]);
 			}
 			const int32_t hxA = pk_add(hA, nmA), hxB = pk_add(hB, nmB); // extended
+			if (forecast) far = pk_max(far, pk_max(hxA, hxB));
 			// ---- termination test of the extension sweep (miniwfa.c:405-409): only column ql+1 can hold the end cell
 			unsigned long long fm = 0;
 			int32_t done_info = 0;
@@ -736,6 +741,10 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 			if (bits && lane == 0) atomicOr((unsigned int*)&sh.flags[npar][0], bits);
 		}
 
+		if (forecast) {
+			const int32_t m = wave_max(max(lo16(far), hi16(far)));
+			if (lane == 0 && m >= 0) atomicMax(&sh.word[3], m);
+		}
 		// Everything older than this penalty's last operations must be complete before another wave may load it (vmcnt retires
 		// in issue order).  With every lag >= 3 the rows written now are first loaded two penalties from now: the youngest store
 		// may stay in flight across the barrier.
@@ -825,12 +834,16 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 			R.info = payload;
 			return true;
 		}
+		if (forecast) { // will the window outgrow the chunks this workgroup holds? then hand the pair back now, with the estimate
+			est_window = window_forecast(s, uni(sh.word[3]), tl, (NWK - 2) * kChunk);
+			if (est_window) { R.status = ST_BAND_OVERFLOW; return true; }
+		}
 		return false;
 	};
 	for (;;)
 		if (step()) break;
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	R.s = s, R.cells = cells;
+	R.s = s, R.cells = est_window ? -(int64_t)est_window : cells; // (a pair handed back early: the window it is expected to need, negated, for the host's choice of the next kernel)
 	return R;
 }
 

@@ -152,6 +152,26 @@ __device__ __forceinline__ uint32_t lds_pack2bit(const uint8_t *src, int32_t len
 	return bad;
 }
 
+// largest value of v over the lanes of the wave (rare paths only: six cross-lane steps)
+__device__ __forceinline__ int32_t wave_max(int32_t v)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+	return v;
+}
+// Early hand-back of a pair that will outgrow the span of the kernel it was given.  A window is about twice the penalty wide and the
+// penalty grows in proportion to the progress along the target, so once the furthest offset `kmax` reached at penalty s is known the
+// final window is about 2 s tl / (kmax + 1): beyond `cap` columns (with a safety factor that tightens as s grows) the pair goes back
+// to the host NOW — after s penalties instead of after cap / 2 — with the estimate, so that the re-run starts on a kernel that fits.
+// Returns 0 (carry on) or the estimated window.  A wrong guess costs a re-run on a wider kernel, never a wrong result.
+__device__ __forceinline__ int32_t window_forecast(int32_t s, int32_t kmax, int32_t tl, int32_t cap)
+{
+	if (kmax < 8 || tl < 64) return 0;
+	const int64_t need = 2 * (int64_t)s * tl / min(kmax + 1, tl) + 16;
+	const int32_t slack = s < 128 ? 13 : s < 512 ? 12 : 11; // tenths
+	return need * 10 > (int64_t)cap * slack ? (int32_t)min(need, (int64_t)0x3fffffff) : 0;
+}
+
 // offset k on diagonal d is a cell of the DP matrix (reference good_diag, miniwfa.c:139-142)
 __device__ __forceinline__ bool in_matrix(int32_t d, int32_t k, int32_t tl, int32_t ql)
 {

@@ -367,7 +367,7 @@ struct Plan {
 // Which kernel serves a set of pairs.  The band kernel keeps E/F in registers and therefore only holds windows up to
 // its span; it has no low-memory first pass.  kind: -1 automatic, 0 generic, 2 band.
 void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, int64_t max_len, int64_t max_bound,
-                   int64_t max_seq_lds, int64_t max_tl, int want_kind, Plan &pl, int geom_block = 0)
+                   int64_t max_seq_lds, int64_t max_tl, int want_kind, Plan &pl, int geom_block = 0, int64_t window_hint = 0)
 {
 	pl.kind = 0;
 	const bool low_mem = (opt.flag & MWF_F_CIGAR) && opt.step > 0;
@@ -403,7 +403,9 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 		}
 	}
 	if (want_kind == 0 || low_mem || (!can_packed && !can_plain)) return;
-	const int64_t max_window = std::min<int64_t>(max_len + 1, 2 * max_bound + 3);
+	// (window_hint: pairs a kernel handed back early come with the window they are expected to need, dev::window_forecast — the re-run
+	// takes the class that fits that, not the one that fits the worst case)
+	const int64_t max_window = window_hint > 0 ? std::min<int64_t>(std::min<int64_t>(max_len + 1, 2 * max_bound + 3), window_hint) : std::min<int64_t>(max_len + 1, 2 * max_bound + 3);
 	BandGeom bg;
 	bg.packed = 0, bg.seq2 = 0, bg.lane = 0;
 	// Packed variants (E/F registers as int16 pairs): valid when no offset (a target index, plus at most one per penalty for
@@ -501,7 +503,7 @@ std::shared_mutex g_dev_gate[kMaxDevices];
 // tb_total_budget < 0: the traceback budget is looked up here, and only when the arena has to grow.
 int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const int32_t *d_order, int32_t n_items,
                      int slots, int64_t max_len, int64_t max_bound, int64_t max_bound1, bool timed,
-                     int want_kind, int64_t max_tl, int64_t max_seq_lds, int timed_end, int geom_block, int *ran_kind)
+                     int want_kind, int64_t max_tl, int64_t max_seq_lds, int timed_end, int geom_block, int *ran_kind, int64_t window_hint = 0)
 {
 	const Penalty P = make_penalty(opt);
 	Plan pl;
@@ -509,7 +511,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	pl.low_mem = pl.cigar && opt.step > 0;
 	// generic kernel: four waves per pair, eight once the windows are wide (measured on 1250 x 50 kb: 708 ms against 782 ms)
 	pl.block = g->block > 0 && g->block != 768 ? g->block : (std::min<int64_t>(max_len + 1, 2 * max_bound + 3) >= 8192 ? 512 : 256);
-	choose_kernel(g, opt, P, max_len, max_bound, max_seq_lds, max_tl, want_kind >= 0 ? want_kind : g->force_kind, pl, geom_block);
+	choose_kernel(g, opt, P, max_len, max_bound, max_seq_lds, max_tl, want_kind >= 0 ? want_kind : g->force_kind, pl, geom_block, window_hint);
 	// `slots` is an upper bound from the caller (retries ask for fewer, larger slots); the chosen kernel's own residency
 	// bounds it as well
 	int per_cu, lds_e2_cols = 0;
@@ -1569,7 +1571,10 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 			} else if (st == ST_ALPHABET && kind == 2) {
 				to_band_bytes[step0].push_back((int32_t)i); // not plain ACGT: the byte-wise band kernel of the same class
 			} else if (st == ST_BAND_OVERFLOW && kind == 2) {
-				if (b->h_class[i] >= 2) b->h_class[i] = 1, to_band_wide[step0].push_back((int32_t)i);
+				// (a pair handed back EARLY carries the window it is expected to need, negated, where n_iter would be: one that no band class
+				// holds goes straight to the generic kernel)
+				const int64_t est = b->h_iter[i] < 0 ? -b->h_iter[i] : 0;
+				if (b->h_class[i] >= 2 && est <= (8 * 3 - 2) * 256) b->h_class[i] = 1, to_band_wide[step0].push_back((int32_t)i);
 				else b->h_class[i] = 0, to_generic[step0].push_back((int32_t)i);
 			} else if (kind == 1 && st == ST_INTERNAL && !(b->h_flags[i] & 8)) {
 				// a wait between workgroups of the whole-device kernel ran into its spin limit (they were not all resident, e.g.
@@ -1611,8 +1616,15 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 			if (run_coop_pair(g, b, b->opt, i, false, false)) return -1;
 		const bool shrink = !same_fewer[0][0].empty() || !same_fewer[0][1].empty() || !same_fewer[2][0].empty() || !same_fewer[2][1].empty();
 		if (shrink) tb_slots = std::max(1, tb_slots / 8);
-		auto rerun = [&](std::vector<int32_t> &ids, int step0, int want_kind, int slots) -> int {
+		auto rerun = [&](std::vector<int32_t> &ids, int step0, int want_kind, int slots, bool use_forecast = false) -> int {
 			if (ids.empty()) return 0;
+			int64_t hint = 0;
+			if (use_forecast) { // every pair of the re-run came back with a forecast: the class that holds the widest of them (+ 25 %)
+				for (int32_t i : ids) {
+					if (b->h_iter[i] >= 0) { hint = 0; break; }
+					hint = std::max<int64_t>(hint, -b->h_iter[i] * 5 / 4 + 64);
+				}
+			}
 			std::stable_sort(ids.begin(), ids.end(), [&](int32_t x, int32_t y) { return (int64_t)b->h_tl[x] + b->h_ql[x] > (int64_t)b->h_tl[y] + b->h_ql[y]; });
 			const mwf_opt_t &o = step0 ? opt_hi : b->opt;
 			int64_t max_len = 0, max_bound = 0, max_bound1 = 0, max_tl = 0, max_seq_lds = 0;
@@ -1628,7 +1640,7 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 			int rc = upload_segments(g, (char*)tmp.p, std::vector<Seg>{Seg{ids.data(), ids.size() * 4}});
 			int ran = 0;
 			if (rc == 0) rc = run_batch_kernel(g, b, o, (const int32_t*)tmp.p, (int32_t)ids.size(), slots, max_len, max_bound, max_bound1, false,
-			                                   want_kind, max_tl, max_seq_lds, 0, 0, &ran);
+			                                   want_kind, max_tl, max_seq_lds, 0, 0, &ran, hint);
 			if (rc == 0) rc = hipStreamSynchronize(g->stream) == hipSuccess ? 0 : -1;
 			release(g, tmp);
 			if (rc) return -1;
@@ -1642,7 +1654,7 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 			const int rc32 = rerun(to_generic32[z], z, 0, grid0);
 			g->ring16_off_once = false;
 			if (rc32) return -1;
-			if (rerun(to_band_wide[z], z, 2, wide)) return -1;
+			if (rerun(to_band_wide[z], z, 2, wide, true)) return -1;
 			g->acgt_off_once = true;
 			const int rc_bytes = rerun(to_band_bytes[z], z, 2, wide);
 			g->acgt_off_once = false;

@@ -41,6 +41,7 @@ struct MidVars {
 	int32_t flags[4];     // per penalty mod 3 (+1 spare): bit 0 new lo edge live, bit 1 new hi edge live, bit 2 end cell reached, bits 4.. payload
 	int32_t red[2];       // shrink: first / last good column
 	int32_t item, word;
+	int32_t far, pad[3];  // furthest offset seen at a forecast penalty (dev::window_forecast)
 };
 
 // bits of the 64-column group starting at column w0 that fall inside [lo,hi]
@@ -108,6 +109,7 @@ __device__ PassResult mid_pass(const ArgsT &A, PairMem &M, const MidLayout &L, c
 		for (int32_t j = tid; j < L.n_rows * RL * 2 / 16; j += T) ((uint4*)lds_mid)[j] = dead4;
 		for (int32_t j = tid; j < nH; j += T) win[j] = make_int2(1, 0);
 		if (tid < 4) V.flags[tid] = 0;
+		if (tid == 0) V.far = -1;
 	}
 	__syncthreads();
 	const int32_t c00 = tl + 1;
@@ -127,6 +129,7 @@ __device__ PassResult mid_pass(const ArgsT &A, PairMem &M, const MidLayout &L, c
 	int32_t oN = RB % HB, oX = ((nH + 1 - A.pen.x) % nH) * RB, oA = ((nH + 1 - A.pen.oe1) % nH) * RB, oB = ((nH + 1 - A.pen.oe2) % nH) * RB;
 	int32_t oN1 = RB, oR1 = (2 % n1) * RB, oN2 = RB, oR2 = (2 % n2) * RB;
 	int64_t cells = 0, tb_used = 0;
+	int32_t est_window = 0;
 	if (TB) M.tb_stride = C, M.tb_left = left;
 	const int32_t cfin = ql + 1; // the end cell (tl-1, ql-1) lies on diagonal ql-tl, i.e. this column
 	const int32_t vb = lane * 2;  // a lane's entry idx - 1 = 64 g + lane of a row, in bytes (+ 128 g): entries idx-1, idx, idx+1 at byte offsets 0, 2, 4
@@ -148,6 +151,8 @@ __device__ PassResult mid_pass(const ArgsT &A, PairMem &M, const MidLayout &L, c
 		const int32_t g_first = (max(lo - nH, left) - left) >> 6, g_last = (min(hi + nH, right) - left) >> 6;
 		uint32_t flags = 0;
 		int32_t fin_info = 0;
+		const bool forecast = s_new == 64 || s_new == 256 || s_new == 1024; // uniform: look at how far the pair has come (dev::window_forecast)
+		int32_t far = kDead16;
 		for (int32_t g = g_first + ((wave - g_first) & (NW - 1)); g <= g_last; g += NW) {
 			const int32_t ga = vb + 128 * g, c = left + 64 * g + lane;
 			const int32_t d = c - 1 - tl;
@@ -166,6 +171,7 @@ __device__ PassResult mid_pass(const ArgsT &A, PairMem &M, const MidLayout &L, c
 			const int32_t nmat = S2 ? lds_extend16(lt, lq, j, i, inm ? min(tl - j, ql - i) : 0) : lds_extend8(lt, lq, j, i, inm ? min(tl - j, ql - i) : 0);
 			const int32_t h = act ? max(v.h + nmat, kDead16) : kDead16;
 			*(int16_t*)(base + ga + oN + 2) = (int16_t)h;
+			far = max(far, h);
 			if (TB && act) M.tb[tb_used + (c - left)] = (uint8_t)v.tb;
 			if (track_good) { // some array holds an in-matrix offset here (good_diag, miniwfa.c:139-142)
 				const bool gd = act && (inm || in_matrix(d, v.e1, tl, ql) || in_matrix(d, v.f1, tl, ql) || in_matrix(d, v.e2, tl, ql) || in_matrix(d, v.f2, tl, ql));
@@ -184,6 +190,10 @@ __device__ PassResult mid_pass(const ArgsT &A, PairMem &M, const MidLayout &L, c
 			uint32_t bits = (__ballot(flags & 1u) ? 1u : 0u) | (__ballot(flags & 2u) ? 2u : 0u);
 			if (fm) bits |= 4u | (uint32_t)__builtin_amdgcn_readlane(fin_info, (int32_t)__builtin_ctzll(fm)) << 4;
 			if (lane == 0) atomicOr((unsigned int*)&V.flags[npar], bits);
+		}
+		if (forecast) {
+			const int32_t m = wave_max(far);
+			if (lane == 0 && m >= 0) atomicMax(&V.far, m);
 		}
 		// the rows of the coming penalty
 		oN = oN + RB == HB ? 0 : oN + RB, oX = oX + RB == HB ? 0 : oX + RB, oA = oA + RB == HB ? 0 : oA + RB, oB = oB + RB == HB ? 0 : oB + RB;
@@ -222,8 +232,12 @@ __device__ PassResult mid_pass(const ArgsT &A, PairMem &M, const MidLayout &L, c
 			break;
 		}
 		if (fl & 4u) { R.info = (int32_t)((fl >> 4) & 7u); break; }
+		if (forecast) { // will the window outgrow the span? then hand the pair back now, with the estimate
+			est_window = window_forecast(s, uni(V.far), tl, C - 2 * nH - 64);
+			if (est_window) { R.status = ST_BAND_OVERFLOW; break; }
+		}
 	}
-	R.s = s, R.cells = cells;
+	R.s = s, R.cells = est_window ? -(int64_t)est_window : cells;
 	return R;
 }
 
