@@ -1574,7 +1574,8 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 				// (a pair handed back EARLY carries the window it is expected to need, negated, where n_iter would be: one that no band class
 				// holds goes straight to the generic kernel)
 				const int64_t est = b->h_iter[i] < 0 ? -b->h_iter[i] : 0;
-				if (b->h_class[i] >= 2 && est <= (8 * 3 - 2) * 256) b->h_class[i] = 1, to_band_wide[step0].push_back((int32_t)i);
+				// (... only when the forecast is half again beyond the widest class: it is an estimate, and the generic kernel is several times slower)
+				if (b->h_class[i] >= 2 && est <= ((8 * 3 - 1) * 256 - 64) * 3 / 2) b->h_class[i] = 1, to_band_wide[step0].push_back((int32_t)i);
 				else b->h_class[i] = 0, to_generic[step0].push_back((int32_t)i);
 			} else if (kind == 1 && st == ST_INTERNAL && !(b->h_flags[i] & 8)) {
 				// a wait between workgroups of the whole-device kernel ran into its spin limit (they were not all resident, e.g.

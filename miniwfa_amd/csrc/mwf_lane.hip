@@ -76,7 +76,7 @@ __device__ PassResult lane_pass(const ArgsT &A, PairMem &M, int16_t *rows, const
 	int32_t oN = RB % HB, oX = ((nH + 1 - A.pen.x) % nH) * RB, oA = ((nH + 1 - A.pen.oe1) % nH) * RB, oB = ((nH + 1 - A.pen.oe2) % nH) * RB;
 	int32_t o1 = 0, o2 = 0;
 	int64_t cells = 0;
-	int32_t tb_used = 0, est_window = 0;
+	int32_t tb_used = 0;
 	if (TB) M.tb_stride = 64 * NC, M.tb_left = left;
 	const int32_t s_shrink = 256 - nH; // the first penalty whose good bits a shrink would read (wf_stripe_shrink, miniwfa.c:144-171)
 	const int32_t cfin = ql + 1;       // the end cell (tl-1, ql-1) lies on diagonal ql-tl, i.e. this column
@@ -95,8 +95,6 @@ __device__ PassResult lane_pass(const ArgsT &A, PairMem &M, int16_t *rows, const
 		if (trace_band && lane == 0 && s_new - 1 < dbg_cap) M.dbg[2 * (s_new - 1)] = lo, M.dbg[2 * (s_new - 1) + 1] = hi;
 		uint32_t flags = 0;    // per lane, over its chunks: 1 = the lo column and live, 2 = the hi column and live, 4 = the end cell, reached
 		int32_t fin_info = 0;
-		const bool forecast = s_new == 24 || s_new == 48; // uniform: look at how far the pair has come (dev::window_forecast)
-		int32_t far = kDead16;
 		// The E/F row a chunk overwrites is the row the next chunk still reads at the two columns where their blocks touch: the old F of
 		// this chunk's first column (lane 0) and the old E of its last (lane 63) travel to the next chunk in scalars.
 		int32_t cE1 = 0, cE2 = 0, cF1 = 0, cF2 = 0;
@@ -128,7 +126,6 @@ __device__ PassResult lane_pass(const ArgsT &A, PairMem &M, int16_t *rows, const
 			const int32_t nmat = S2 ? lds_extend16(lt, lq, j, i, inm ? min(tl - j, ql - i) : 0) : lds_extend8(lt, lq, j, i, inm ? min(tl - j, ql - i) : 0);
 			const int32_t h = act ? max(v.h + nmat, kDead16) : kDead16;
 			*(int16_t*)(base + ga + oN + 2) = (int16_t)h;
-			far = max(far, h);
 			if (TB && act) M.tb[tb_used + (c - left)] = (uint8_t)v.tb;
 			// edge rule (miniwfa.c:325-326): H is the max of the five, so "any live" == "H live"
 			const uint32_t live = (uint32_t)(h >= -1);
@@ -150,12 +147,8 @@ __device__ PassResult lane_pass(const ArgsT &A, PairMem &M, int16_t *rows, const
 			break;
 		}
 		if (fm) { R.info = __builtin_amdgcn_readlane(fin_info, (int32_t)__builtin_ctzll(fm)); break; }
-		if (forecast) { // will the window outgrow the chunks? then hand the pair back now, with the estimate (24 penalties spent instead of ~100)
-			est_window = window_forecast(s, wave_max(far), tl, 64 * NC - 16);
-			if (est_window) { R.status = ST_BAND_OVERFLOW; break; }
-		}
 	}
-	R.s = s, R.cells = est_window ? -(int64_t)est_window : cells;
+	R.s = s, R.cells = cells; // (no early hand-back here: a forecast after two dozen penalties is noise, and this kernel's whole run is ~100 penalties)
 	return R;
 }
 
