@@ -97,7 +97,7 @@ def call_latency(mw, synth_pair, reps=40):
         ref = Reference(arena=True) if Reference.available() else None
     except Exception:
         ref = None
-    for tl in (200, 2000, 10000):
+    for tl in (200, 1000, 2000, 10000):
         t, q = synth_pair(123, tl, 0.05)
         for label, flag in (("score", 0), ("cigar", 1)):
             o = mw.opt_init(flag=flag)

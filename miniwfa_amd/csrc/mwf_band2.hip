@@ -838,7 +838,7 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 			return true;
 		}
 		if (forecast) { // will the window outgrow the chunks this workgroup holds? then hand the pair back now, with the estimate
-			est_window = window_forecast(s, uni(sh.word[3]), tl, (NWK - 1) * kChunk - 64, NWK >= 24); // (the window this geometry is chosen for: kBand*Window in mwf_engine.cpp)
+			est_window = window_forecast(s, uni(sh.word[3]), tl, ql, (NWK - 1) * kChunk - 64, NWK >= 24); // (the window this geometry is chosen for: kBand*Window in mwf_engine.cpp)
 			if (est_window) { R.status = ST_BAND_OVERFLOW; return true; }
 		}
 		return false;

@@ -164,10 +164,10 @@ __device__ __forceinline__ int32_t wave_max(int32_t v)
 // final window is about 2 s tl / (kmax + 1): beyond `cap` columns (with a safety factor that tightens as s grows and the estimate's noise falls) the pair goes back
 // to the host NOW — after s penalties instead of after cap / 2 — with the estimate, so that the re-run starts on a kernel that fits.
 // Returns 0 (carry on) or the estimated window.  A wrong guess costs a re-run on a wider kernel, never a wrong result.
-__device__ __forceinline__ int32_t window_forecast(int32_t s, int32_t kmax, int32_t tl, int32_t cap, bool last_resort = false)
+__device__ __forceinline__ int32_t window_forecast(int32_t s, int32_t kmax, int32_t tl, int32_t ql, int32_t cap, bool last_resort = false)
 {
 	if (kmax < 8 || tl < 64) return 0;
-	const int64_t need = 2 * (int64_t)s * tl / min(kmax + 1, tl) + 16;
+	const int64_t need = min(2 * (int64_t)s * tl / min(kmax + 1, tl) + 16, (int64_t)tl + ql + 1); // (no window is wider than the matrix has diagonals)
 	// the progress after s penalties is that of ~s / 4.5 independent differences: relative noise ~ sqrt(4.5 / s), i.e. 0.27, 0.13 and 0.07 at
 	// penalties 64, 256 and 1024 — the factors leave five of those: a batch has thousands of pairs and a pair handed back by mistake is
 	// re-run on a slower kernel (factors of three sigma sent three pairs of the 1024 x 10 kb headline batch to the generic kernel per

@@ -1617,6 +1617,7 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 			if (run_coop_pair(g, b, b->opt, i, false, false)) return -1;
 		const bool shrink = !same_fewer[0][0].empty() || !same_fewer[0][1].empty() || !same_fewer[2][0].empty() || !same_fewer[2][1].empty();
 		if (shrink) tb_slots = std::max(1, tb_slots / 8);
+		auto pl_low_mem = [](const mwf_opt_t &o) { return (o.flag & MWF_F_CIGAR) && o.step > 0; };
 		auto rerun = [&](std::vector<int32_t> &ids, int step0, int want_kind, int slots, bool use_forecast = false) -> int {
 			if (ids.empty()) return 0;
 			int64_t hint = 0;
@@ -1640,8 +1641,15 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 			if (ensure(g, tmp, ids.size() * 4)) return -1;
 			int rc = upload_segments(g, (char*)tmp.p, std::vector<Seg>{Seg{ids.data(), ids.size() * 4}});
 			int ran = 0;
+			// a handful of short pairs that outgrew the lane kernel (one read in tens of thousands): the mid kernel, whose span holds the widest
+			// window such a pair can have at all, takes a fraction of what a lone workgroup of the band classes takes (one 150 bp pair: 0.18 ms
+			// of band kernel in every align of the 40 000-pair batch, profiles/r04/rocprof_lane_kernel_40000x150bp.txt)
+			const Penalty Pm = make_penalty(o);
+			const int mid_cap = g->mid_max_pairs < 0 ? g->n_cu : g->mid_max_pairs;
+			const bool to_mid = want_kind == 2 && use_forecast && g->force_kind < 0 && g->block == 0 && (int)ids.size() <= mid_cap && mid_supported(Pm) && max_len <= 1200 &&
+			                    max_tl + max_bound < 32760 && !(pl_low_mem(o));
 			if (rc == 0) rc = run_batch_kernel(g, b, o, (const int32_t*)tmp.p, (int32_t)ids.size(), slots, max_len, max_bound, max_bound1, false,
-			                                   want_kind, max_tl, max_seq_lds, 0, 0, &ran, hint);
+			                                   want_kind, max_tl, max_seq_lds, 0, to_mid ? 33 : 0, &ran, hint);
 			if (rc == 0) rc = hipStreamSynchronize(g->stream) == hipSuccess ? 0 : -1;
 			release(g, tmp);
 			if (rc) return -1;

@@ -233,7 +233,7 @@ __device__ PassResult mid_pass(const ArgsT &A, PairMem &M, const MidLayout &L, c
 		}
 		if (fl & 4u) { R.info = (int32_t)((fl >> 4) & 7u); break; }
 		if (forecast) { // will the window outgrow the span? then hand the pair back now, with the estimate
-			est_window = window_forecast(s, uni(V.far), tl, C - 2 * nH - 64);
+			est_window = window_forecast(s, uni(V.far), tl, ql, C - 2 * nH - 64);
 			if (est_window) { R.status = ST_BAND_OVERFLOW; break; }
 		}
 	}

@@ -1,18 +1,18 @@
 #!/usr/bin/env python3
-"""profiles/traffic.json (what bench.py's `roofline.traffic` / candidates quote) from the rocprofv3 summaries under profiles/r03/:
+"""profiles/traffic.json (what bench.py's `roofline.traffic` / candidates quote) from the rocprofv3 summaries under profiles/r04/:
 per-launch means of FETCH_SIZE / WRITE_SIZE (KiB) and of the instruction counters, per kernel and workload."""
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # key in traffic.json -> (summary file, kernel name prefix(es) the numbers are taken from, read width in bytes per lane)
 SRC = {
-    "1024x10000@0.05s": ("profiles/r03/rocprof_band2_kernel_1024x10kb_score.txt", ["wfa_band2_kernel<512, 3, 2, 1, false, true>"], 8),
-    "1024x10000@0.05c": ("profiles/r03/rocprof_band2_kernel_1024x10kb_cigar.txt", ["wfa_band2_kernel<512, 3, 2, 1, true, true>"], 8),
-    "1250x50000@0.03s": ("profiles/r03/rocprof_generic_stream16_kernel_1250x50kb.txt", ["wfa_batch_kernel<512, true, true, true, 0>"], 8),
-    "c4_like_150kb:score": ("profiles/r03/rocprof_sys_kernel_c4_score.txt", ["wfa_sys_kernel"], 4),
-    "c4_like_150kb:cigar_highmem": ("profiles/r03/rocprof_sys_kernel_c4_cigar.txt", ["wfa_sys_kernel"], 4),
-    "c4_like_150kb:cigar_lowmem_p5000": ("profiles/r03/rocprof_sys_kernel_c4_lowmem.txt", ["wfa_sys_kernel"], 4),
-    "mhc_like_5Mb:score": ("profiles/r03/rocprof_sys_kernel_mhc_score.txt", ["wfa_sys_kernel"], 16),
-    "mhc_like_5Mb:cigar_lowmem_p5000": ("profiles/r03/rocprof_sys_kernel_mhc_lowmem.txt", ["wfa_sys_kernel"], 16),
+    "1024x10000@0.05s": ("profiles/r04/rocprof_band2_kernel_1024x10kb_score.txt", ["wfa_band2_kernel<512, 3, 2, 1, false, true>"], 8),
+    "1024x10000@0.05c": ("profiles/r04/rocprof_band2_kernel_1024x10kb_cigar.txt", ["wfa_band2_kernel<512, 3, 2, 1, true, true>"], 8),
+    "1250x50000@0.03s": ("profiles/r04/rocprof_generic_stream16_kernel_1250x50kb.txt", ["wfa_batch_kernel<512, true, true, true, 0>"], 8),
+    "c4_like_150kb:score": ("profiles/r04/rocprof_sys_kernel_c4_score.txt", ["wfa_sys_kernel"], 4),
+    "c4_like_150kb:cigar_highmem": ("profiles/r04/rocprof_sys_kernel_c4_cigar.txt", ["wfa_sys_kernel"], 4),
+    "c4_like_150kb:cigar_lowmem_p5000": ("profiles/r04/rocprof_sys_kernel_c4_lowmem.txt", ["wfa_sys_kernel"], 4),
+    "mhc_like_5Mb:score": ("profiles/r04/rocprof_sys_kernel_mhc_score.txt", ["wfa_sys_kernel"], 16),
+    "mhc_like_5Mb:cigar_lowmem_p5000": ("profiles/r04/rocprof_sys_kernel_mhc_lowmem.txt", ["wfa_sys_kernel"], 16),
 }
 out = {}
 for key, (path, kerns, width) in SRC.items():
