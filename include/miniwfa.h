@@ -12,7 +12,7 @@
  *
  * There is no CPU fallback anywhere behind this header: every alignment runs in the HIP
  * kernels under miniwfa_amd/csrc/ (mwf_kernels.hip generic, mwf_band2.hip packed band,
- * mwf_lane.hip short pairs, mwf_band.hip 32-bit band, mwf_sys.hip + mwf_coop.hip whole device), and every entry point aborts with a message
+ * mwf_lane.hip short pairs, mwf_mid.hip the mid-size pairs of small batches, mwf_band.hip 32-bit band, mwf_sys.hip + mwf_coop.hip whole device), and every entry point aborts with a message
  * if no gfx950 device can be opened.
  */
 #ifndef MWF_HIP_MINIWFA_H
@@ -143,7 +143,7 @@ typedef struct {
 	int32_t kernel_kind;   /* 0: one workgroup per pair (generic); 1: one pair across the whole device; 2: one workgroup per pair (band) */
 	int64_t dev_bytes;     /* device memory the engine holds now: workspace pools + recycled batch allocations (live batches hold their own) */
 	int64_t dev_bytes_peak;/* ... and the most it held since creation or the last mwf_gpu_set(g, "trim", 0) */
-	int32_t packed;        /* band kernels: 1 = the packed 16-bit variant (mwf_band2.hip), 32 = the one-wave-per-pair lane kernel (mwf_lane.hip), 0 = 32-bit rows (mwf_band.hip); generic kernel: 16 = 16-bit ring rows */
+	int32_t packed;        /* band kernels: 1 = the packed 16-bit variant (mwf_band2.hip), 32 = the one-wave-per-pair lane kernel (mwf_lane.hip), 33 = the one-workgroup-per-pair mid kernel (mwf_mid.hip), 0 = 32-bit rows (mwf_band.hip); generic kernel: 16 = 16-bit ring rows */
 	int32_t lowmem_two_pass; /* low-memory mode: 1 = the first pass stored no traceback (provenance + snapshots), 0 = checkpoints walked off a full traceback */
 } mwf_gpu_stats_t;
 void mwf_gpu_get_stats(const mwf_gpu_t *g, mwf_gpu_stats_t *st);
@@ -163,6 +163,9 @@ int32_t mwf_gpu_debug_band(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *op
  * form whose first pass stores none; 0 = a quarter of the device), "sys_p" (penalties per hand-off block: 8, the one the library is built with; 4 and 16 only in builds with -DMWF_SYS_ALL_P — any other value is refused),
  * "sys_c" (columns per lane: 0 = chosen per pass from the expected window, 1, 4), "coop_grid" (at most this many workgroups; 0 = one
  * per CU), "coop_launch" (default 1: launched through hipLaunchCooperativeKernel; 0: plain launch),
+ * "mid_max_pairs" (a batch of at most this many pairs runs its mid-size pairs — beyond the lane kernel, up to ~9 kb of target + query — on the
+ * one-workgroup-per-pair kernel with every ring in LDS, mwf_mid.hip; default -1: one pair per CU; 0: never), "mid_block" (its threads per workgroup: 0 by pair
+ * length, 256, 512, 1024),
  * "lane_max_len" (default 400: pairs whose longer sequence has at most this many bases try the one-wave-per-pair lane kernel first; 0: never), "lane_chunks" (its window in 64-column chunks,
  * 1-4; default 0: by pair length), "host_results" (default 1: a score-only batch of up to 64 pairs gets its result arrays in pinned host memory — the mwf_gpu_batch_dev_*() pointers then
  * point there, still readable from device code; 0: always device memory)}; "trim" frees the engine's workspace pools (they grow back on demand). */
