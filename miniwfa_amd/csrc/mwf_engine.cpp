@@ -396,7 +396,7 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 		if (lds <= 158 * 1024) {
 			// eight waves while the windows stay below ~700 columns (pairs of up to ~1.2 kb at 5 %), else sixteen (measured: 1 kb 0.255 against
 			// 0.314 ms, 2 kb 0.572 / 0.556, 4 kb 1.60 / 1.43; profiles/mid_kernel_probe.py)
-			const int block = g->mid_block ? g->mid_block : (max_len <= 2500 ? 512 : 1024);
+			const int block = g->mid_block ? g->mid_block : (max_len <= 1000 ? 256 : max_len <= 2500 ? 512 : 1024); // (4 x 400 bp: 131 us on four waves, 145 on eight)
 			const int seq2 = g->seq2bit != 0 && !g->acgt_off_once;
 			pl.kind = 2, pl.band = BandGeom{block, 1, 64 * groups, lds, seq2, 2};
 			return;
@@ -1421,7 +1421,9 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 			b->h_class[i] = (int8_t)(c == 5 ? 0 : c);
 			b->h_flags[i] = (int8_t)(step0 ? 1 : 0);
 			// short pairs: a window of 64 diagonals holds them while the penalty stays below ~45 (a 200 bp pair at 5 %)
-			const bool to_lane = classes && lane_ok && c >= 1 && c <= 4 && std::max(tl, ql) <= g->lane_max_len && std::abs(tl - ql) <= 24;
+			// (in a batch small enough for the mid kernel the lane kernel keeps the pairs of up to 320 bases: 16 x 400 bp 0.31 ms on the lane
+			// kernel — pairs that outgrow its chunks are re-run — against 0.13 on the mid kernel, 1 x 300 bp 56 against 68 us; profiles/r04/lane_vs_mid.txt)
+			const bool to_lane = classes && lane_ok && c >= 1 && c <= 4 && std::max(tl, ql) <= (mid_ok ? std::min(g->lane_max_len, 320) : g->lane_max_len) && std::abs(tl - ql) <= 24;
 			if (to_lane) c = (know_acgt && !b->h_acgt[i]) ? 12 : 10, b->h_class[i] = 4;
 			// a few mid-size pairs: a workgroup each, rings in LDS (a penalty then costs a fraction of what it costs the band kernels).  Admitted
 			// when the span the LDS can hold beside the sequences covers the window of a pair at ~6 % divergence (about 0.3 (tl+ql)); 16-bit offsets.
