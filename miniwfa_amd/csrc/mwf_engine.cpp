@@ -761,7 +761,7 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 		// to one diagonal at every checkpoint, miniwfa.c:413-416); s is guessed as 3 % of tl+ql
 		if (two_pass) guess = std::min<int64_t>(guess, std::max<int64_t>((int64_t)64 << 20, (len * 3 / 100 + 1024) * std::min<int64_t>(len + 1, 2 * (int64_t)(opt.step + 2 * P.nH) + 8)) * (int64_t)NG);
 		// (the systolic kernel stores 256 bytes per penalty and chunk slot that takes part, a few slots beyond the window included)
-		const int64_t lay = (two_pass ? c_second : c_first) == 1 ? 12 : 9; // the pass whose traceback sets the size: 64-column slots own 48 (4/3 of the exact rows), 256-column ones 240 (the second pass of the low-memory mode is narrow: it fits whatever the first needed)
+		const int64_t lay = (two_pass ? c_second : c_first) == 1 ? 12 : (two_pass ? c_second : c_first) == 2 ? 10 : 9; // the pass whose traceback sets the size: 64-column slots own 48 (4/3 of the exact rows), 256-column ones 240 (the second pass of the low-memory mode is narrow: it fits whatever the first needed)
 		if (use_sys) guess = std::min<int64_t>(g->coop_tb_cap, guess / 8 * lay + (rows_slot / 256 + 2) * 8 * 65536 * (int64_t)NG);
 		int64_t want = std::min(use_sys ? worst / 8 * lay + (rows_slot / 256 + 2) * 8 * 65536 * (int64_t)NG : worst, g->tb_budget_mb > 0 ? (g->tb_budget_mb << 20) : guess * g->coop_tb_mult);
 		if ((int64_t)g->tb.bytes >= want) want = (int64_t)g->tb.bytes;
@@ -1199,7 +1199,7 @@ int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value)
 	else if (!strcmp(name, "coop_grid")) g->coop_grid_cap = (int)std::max<int64_t>(0, value);
 	else if (!strcmp(name, "coop_launch")) g->coop_launch = value != 0;
 	else if (!strcmp(name, "sys_p") && sys_p_supported((int)value)) g->sys_p = (int)value; // (8; 4 and 16 only in builds with -DMWF_SYS_ALL_P)
-	else if (!strcmp(name, "sys_c") && (value == 0 || value == 1 || value == 4)) g->sys_c = (int)value;
+	else if (!strcmp(name, "sys_c") && (value == 0 || value == 1 || value == 4 || (value == 2 && getenv("MWF_SYS_C2")))) g->sys_c = (int)value; // (2: builds with -DMWF_SYS_C2 only)
 	else if (!strcmp(name, "trim")) { (void)hipSetDevice(g->device); trim(g); }
 	else return -1;
 	return 0;

@@ -1106,6 +1106,9 @@ template <int E1, int E2, bool DEFER, bool TB>
 int launch_pass_p(const BatchArgs &a, int grid, hipStream_t st)
 {
 	if (a.sys_c == 1) return launch_pass_c<E1, E2, DEFER, TB, 1>(a, grid, st);
+#ifdef MWF_SYS_C2 // (experiment: 128-column slots that own 112)
+	if (a.sys_c == 2) return launch_pass_c<E1, E2, DEFER, TB, 2>(a, grid, st);
+#endif
 	return launch_pass_c<E1, E2, DEFER, TB, 4>(a, grid, st);
 }
 
