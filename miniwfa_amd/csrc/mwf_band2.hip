@@ -34,6 +34,9 @@ extern __shared__ __attribute__((aligned(16))) uint8_t lds2[];
 #define MWF_B2_WIDE_T 512 // threads x chunk slots per wave of the widest geometry (24 chunks): 512 x 3; experiments: 256 x 6, 384 x 4
 #define MWF_B2_WIDE_K 3
 #endif
+#ifndef MWF_B2_768_WAVES
+#define MWF_B2_768_WAVES 1 // waves per SIMD the 768-thread geometry is compiled for (1: one workgroup per CU, up to 168 VGPRs; experiment: 6 = two per CU at 80)
+#endif
 #ifndef MWF_B2_WIDE_WAVES
 #define MWF_B2_WIDE_WAVES 4 // waves per SIMD the widest geometry is compiled for (4: 128 VGPRs, two 512-thread workgroups per CU)
 #endif
@@ -853,7 +856,7 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 // Workgroups share a CU: 2 x 512, 4 x 256, 8 x 128 or 16 x 64 threads = 4 waves per SIMD, i.e. at most 128 VGPRs; with traceback
 // the smaller ones get 168 (3 per SIMD).  768 threads: one workgroup per CU.
 template <int T, int K, int E1, int E2, bool TB, bool S2>
-__global__ __launch_bounds__(T, T == MWF_B2_WIDE_T ? MWF_B2_WIDE_WAVES : T <= 512 ? ((TB && T < 512) ? 3 : 4) : 1) void wfa_band2_kernel(const BatchArgs)
+__global__ __launch_bounds__(T, T == MWF_B2_WIDE_T ? MWF_B2_WIDE_WAVES : T <= 512 ? ((TB && T < 512) ? 3 : 4) : MWF_B2_768_WAVES) void wfa_band2_kernel(const BatchArgs)
 {
 	constexpr int NWK = (T / 64) * K, D = (E1 > E2 ? E1 : E2) + 1;
 	// the arguments are read from the kernarg segment where they are used (dev::kernel_args / dev::fresh), never held for the kernel's lifetime
