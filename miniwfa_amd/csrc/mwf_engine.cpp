@@ -3,7 +3,7 @@
 //
 // Boundary: the reference's device-free API mwf_wfa_exact/auto/chain
 // (miniwfa.c:603-615, :850-908) is kept; a call ships its pair(s) to HBM, runs the kernels of
-// mwf_kernels.hip / mwf_band.hip / mwf_coop.hip and copies back (s, n_iter, n_cigar, CIGAR).  r->cigar is
+// mwf_kernels.hip / mwf_band2.hip / mwf_lane.hip / mwf_mid.hip / mwf_sys.hip (+ mwf_coop.hip) and copies back (s, n_iter, n_cigar, CIGAR).  r->cigar is
 // allocated from the caller's kalloc arena exactly as the reference does (miniwfa.c:434).  kalloc arenas for
 // scratch are replaced by device pools that only ever grow:
 //   * one workspace per engine (ring, traceback arena, row table, CIGAR scratch, snapshots);
@@ -371,8 +371,8 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 {
 	pl.kind = 0;
 	const bool low_mem = (opt.flag & MWF_F_CIGAR) && opt.step > 0;
-	// packed kernel (mwf_band2.hip): 16-bit offsets; unpacked kernel (mwf_band.hip): every H lag >= 2, long targets
-	const bool can_packed = band2_supported(P) && g->band_pack != 0, can_plain = band_supported(P);
+	// packed band kernel (mwf_band2.hip): 16-bit offsets
+	const bool can_packed = band2_supported(P) && g->band_pack != 0;
 	if (geom_block == 32 && want_kind != 0 && !low_mem && lane_supported(P)) { // the short-pair class: one wave per pair, one diagonal per lane
 		// The rows of all chunks are allocated whatever the window does, and LDS is what bounds the waves per CU (four chunks with the default
 		// penalties: 14.5 KB, eleven waves; three: thirteen).  Three hold penalties up to ~110: 40 000 x 150 bp @ 5 % 0.68 against 0.79 ms with one
@@ -402,7 +402,7 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 			return;
 		}
 	}
-	if (want_kind == 0 || low_mem || (!can_packed && !can_plain)) return;
+	if (want_kind == 0 || low_mem || !can_packed) return;
 	// (window_hint: pairs a kernel handed back early come with the window they are expected to need, dev::window_forecast — the re-run
 	// takes the class that fits that, not the one that fits the worst case)
 	const int64_t max_window = window_hint > 0 ? std::min<int64_t>(std::min<int64_t>(max_len + 1, 2 * max_bound + 3), window_hint) : std::min<int64_t>(max_len + 1, 2 * max_bound + 3);
@@ -416,51 +416,36 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 	//   window <= 2752: 256 threads x 3 chunks, four (three)
 	//   wider:          512 x 3, two per CU — with traceback too (35.4 ms on the 1024 x 10 kb batch with ~100 bytes of scratch per
 	//                   lane, against 43.4 ms for 768 x 2 with one workgroup per CU)
-	// Unpacked (long targets): 256 x 2 up to 1728 columns, 768 x 2 beyond.
-	// (measured alternatives on the 1024 x 10 kb batch: 1024 threads x 2 chunks spills and runs 50 ms, 512 x 3 unpacked 49 ms, 768 x 2 42 ms)
-	const bool range_ok = can_packed && max_tl + max_bound < 32767;
-	if (!range_ok && !can_plain) return;
-	// Pairs too long for 16-bit offsets in the band kernel: the generic kernel with 16-bit ring rows (packed recurrence on the codes,
-	// round 3) is faster than the unpacked band kernel even where that one's span would hold the window (512 x 20 kb @ 1 %: 5.4 against
-	// 8.0 ms, 512 x 50 kb @ 0.3 %: 4.2 / 5.9) and does not come back with window overflows (1024 x 12 kb @ 5 %: 42 ms against 101 ms
-	// for the band attempt plus the re-run of 925 pairs; profiles/r03/mid_pairs_kernels.txt).  The unpacked band kernel stays for what
-	// the 16-bit rows cannot hold, and for forced geometries.
-	if (!range_ok && want_kind != 2 && g->block == 0 && g->ring16 != 0 && g->lds_e2 && !g->scalar_generic && P.e2 == 1 &&
-	    max_tl + max_len / 8 < 65500) return;
-	const bool cigar = (opt.flag & MWF_F_CIGAR) != 0;
-	if (range_ok) {
-		bg.packed = 1;
-		bg.block = max_window <= kBandMicroWindow ? 64 : max_window <= kBandTinyWindow ? 128 : max_window <= kBandSmallWindow ? 256 : 512;
-	} else bg.block = max_window <= 8 * 256 - 256 - 64 ? 256 : 768;
-	// forced geometry (tests, tuning): 256 and 768 mean the unpacked variants unless packing is asked for as well
-	if ((g->block == 64 || g->block == 128) && range_ok) bg.block = g->block, bg.packed = 1;
-	if (g->block == 256) bg.block = 256, bg.packed = range_ok && g->band_pack == 1;
-	if (g->block == 768) bg.block = 768, bg.packed = range_ok && (cigar || g->band_pack == 1);
-	if (g->block == 512 && range_ok) bg.block = 512, bg.packed = 1;
+	// (measured alternatives on the 1024 x 10 kb batch: 1024 threads x 2 chunks spills and runs 50 ms, 768 x 2 42 ms; 768 x 2 at two
+	// workgroups per CU — 80 VGPRs, six spilled — 18.2 against 17.8 ms, round 4)
+	// Pairs whose offsets do not fit 16 bits take the generic kernel — with 16-bit ring rows where those apply, else 32-bit rows.  (The
+	// unpacked band kernel of round 1, mwf_band.hip, lost to it wherever both applied — 512 x 20 kb @ 1 %: 5.4 against 8.0 ms, 512 x 50 kb
+	// @ 0.3 %: 4.2 / 5.9, and 1024 x 12 kb @ 5 %: 42 against 101 ms with its window overflows re-run, profiles/r03/mid_pairs_kernels.txt —
+	// and was removed in round 4.)
+	const bool range_ok = max_tl + max_bound < 32767;
+	if (!range_ok) return;
+	bg.packed = 1;
+	bg.block = max_window <= kBandMicroWindow ? 64 : max_window <= kBandTinyWindow ? 128 : max_window <= kBandSmallWindow ? 256 : 512;
+	// forced geometry (tests, tuning)
+	if (g->block == 64 || g->block == 128 || g->block == 256 || g->block == 512 || g->block == 768) bg.block = g->block;
 	// geometry picked by the caller for a size class (pairs short enough that their window should stay inside a small span)
-	if (g->block == 0 && (geom_block == 64 || geom_block == 128) && range_ok) bg.block = geom_block, bg.packed = 1;
-	if (g->block == 0 && geom_block == 256) bg.block = 256, bg.packed = range_ok;
-	bg.span = bg.block / 64 * (bg.packed && bg.block != 768 ? 3 : 2) * 256;
+	if (g->block == 0 && (geom_block == 64 || geom_block == 128 || geom_block == 256)) bg.block = geom_block;
+	bg.span = bg.block / 64 * (bg.block != 768 ? 3 : 2) * 256;
 	if (want_kind != 2 && max_len + 1 > 4 * (int64_t)bg.span) return; // windows will mostly outgrow the span: go generic at once
 	const int64_t lds_cap = bg.block >= 768 ? 140 * 1024 : bg.block >= 512 ? 70 * 1024 : bg.block == 256 ? 36 * 1024 : bg.block == 128 ? 18 * 1024 : 9 * 1024;
 	// the packed kernel's sequence copy holds 2 bits per base unless that is switched off (or this is the re-run of pairs that
 	// are not plain ACGT): a quarter of the LDS, half the LDS instructions per probe
-	const bool seq2 = bg.packed && g->seq2bit != 0 && !g->acgt_off_once;
+	const bool seq2 = g->seq2bit != 0 && !g->acgt_off_once;
 	const int64_t need_lds = seq2 ? ((max_len >> 4) + 4) * 4 : max_seq_lds;
 	bg.lds_bytes = need_lds <= lds_cap ? (int)((need_lds + 15) / 16 * 16) : 0;
 	bg.seq2 = seq2 && bg.lds_bytes > 0;
 	// byte-wise copy (pairs outside plain ACGT) with wide windows: three slots of state plus six probe words per column do not fit the 128
 	// VGPRs two 512-thread workgroups per CU leave each wave (~500 bytes of scratch); 768 x 2 holds the same 24 chunks without spilling
-	if (bg.packed && !bg.seq2 && bg.block == 512 && g->block == 0 && max_seq_lds <= 140 * 1024) {
+	if (!bg.seq2 && bg.block == 512 && g->block == 0 && max_seq_lds <= 140 * 1024) {
 		bg.block = 768, bg.span = 768 / 64 * 2 * 256;
 		bg.lds_bytes = (int)((max_seq_lds + 15) / 16 * 16);
 	}
-	if (bg.packed && bg.lds_bytes == 0) { // the packed kernel keeps the sequences in LDS
-		bg.lds_bytes = max_seq_lds <= lds_cap ? (int)((max_seq_lds + 15) / 16 * 16) : 0; // (the unpacked kernel's copy is byte-wise)
-		if (!can_plain) return;
-		bg.packed = 0, bg.block = max_window <= 8 * 256 - 256 - 64 ? 256 : 768, bg.span = bg.block / 64 * 2 * 256;
-	}
-	if (!bg.packed && !can_plain) return;
+	if (bg.lds_bytes == 0) return; // the packed kernel keeps the sequences in LDS: what does not fit takes the generic kernel
 	pl.kind = 2, pl.band = bg;
 }
 
@@ -476,7 +461,7 @@ int cached_occupancy(mwf_gpu_t *g, const Penalty &P, const Plan &pl, int lds_e2_
 	if (it != g->occ_cache.end()) return it->second;
 	const int per = pl.kind == 2 && pl.band.lane == 2 ? 1 // (mwf_mid.hip: most of a CU's LDS per workgroup)
 	              : pl.kind == 2 && pl.band.lane ? lane_kernel_occupancy(pl.band.lds_bytes, pl.cigar)
-	              : pl.kind == 2 ? (pl.band.packed ? band2_kernel_occupancy(P, pl.band, pl.cigar) : band_kernel_occupancy(P, pl.band, pl.cigar))
+	              : pl.kind == 2 ? band2_kernel_occupancy(P, pl.band, pl.cigar)
 	              : P.nH > kMaxRing ? bigring_kernel_occupancy()
 	                             : batch_kernel_occupancy(pl.block, stream_pass, lds_e2_cols, ring16);
 	g->occ_cache[key] = per;
@@ -643,7 +628,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	std::shared_lock<std::shared_mutex> gate(g_dev_gate[g->device % kMaxDevices]); // not while a whole-device kernel runs
 	const int lrc = pl.kind == 2 && pl.band.lane == 2 ? launch_mid(a, pl.grid, pl.band.block, pl.band.lds_bytes, pl.band.seq2 != 0, g->stream)
 	              : pl.kind == 2 && pl.band.lane ? launch_lane(a, pl.grid, pl.band.lds_bytes, pl.band.seq2 != 0, g->stream)
-	              : pl.kind == 2 ? (pl.band.packed ? launch_band2(a, pl.grid, pl.band, g->stream) : launch_band(a, pl.grid, pl.band, g->stream))
+	              : pl.kind == 2 ? launch_band2(a, pl.grid, pl.band, g->stream)
 	                             : launch_batch(a, pl.grid, pl.block, g->stream);
 	gate.unlock();
 	if (lrc != 0) {
@@ -1375,7 +1360,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	// gap fills of mwf_wfa_auto's chain fallback, which inherit step = 5000) run in the classes as high-memory pairs; only
 	// genuinely long pairs go through the two-pass kernel (group 5).
 	const bool low_mem = cigar && opt->step > 0;
-	const bool classes = g->force_kind < 0 && g->block == 0 && (band_supported(P0) || (band2_supported(P0) && g->band_pack != 0));
+	const bool classes = g->force_kind < 0 && g->block == 0 && band2_supported(P0) && g->band_pack != 0;
 	// groups 0-4: the size classes, 5: two-pass low-memory pairs, 6-9: classes 1-4 again for the pairs the host knows not to be
 	// plain A/C/G/T (byte-wise sequence copy from the start)
 	// 10: short pairs on the one-diagonal-per-lane kernel (mwf_lane.hip); what outgrows its 64 columns moves to the band classes
@@ -1394,7 +1379,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		const int mid_cap = g->mid_max_pairs < 0 ? g->n_cu : g->mid_max_pairs;
 		const bool mid_ok = g->force_kind < 0 && g->block == 0 && mid_cap > 0 && b->n <= mid_cap && mid_supported(P0);
 		const bool know_acgt = !b->h_acgt.empty() && g->seq2bit != 0;
-		const bool pack_pen = g->band_pack != 0 && band2_supported(P0), plain_ok = band_supported(P0);
+		const bool pack_pen = g->band_pack != 0 && band2_supported(P0);
 		const bool gen16 = g->ring16 != 0 && g->lds_e2 && !g->scalar_generic && P0.e2 == 1;
 		std::vector<int8_t> cls((size_t)b->n); // group of every pair
 		int32_t count[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1415,8 +1400,8 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 				if (!packable && gen16 && tl + len / 8 < 65500) c = 0;
 				else if (packable && (window <= kBandMicroWindow || len + 1 <= 2 * (int64_t)(1 * 3 * 256))) c = 4;
 				else if (packable && (window <= kBandTinyWindow || len + 1 <= 3 * (int64_t)(2 * 3 * 256))) c = 3;
-				else if (packable ? (window <= kBandSmallWindow || len + 1 <= 3 * (int64_t)(4 * 3 * 256)) : (plain_ok && window <= 8 * 256 - 256 - 64)) c = 2;
-				else if ((packable || plain_ok) && len + 1 <= 4 * (int64_t)(8 * 3 * 256)) c = 1;
+				else if (packable && (window <= kBandSmallWindow || len + 1 <= 3 * (int64_t)(4 * 3 * 256))) c = 2;
+				else if (packable && len + 1 <= 4 * (int64_t)(8 * 3 * 256)) c = 1;
 			}
 			b->h_class[i] = (int8_t)(c == 5 ? 0 : c);
 			b->h_flags[i] = (int8_t)(step0 ? 1 : 0);

@@ -128,10 +128,10 @@ int launch_batch(const BatchArgs &a, int grid, int block, void *stream);
 int  bigring_kernel_occupancy();                      // ... of the big-ring form (penalty sets with max(x, o1+e1, o2+e2) >= 256)
 int  batch_kernel_occupancy(int block, bool stream_pass, int lds_e2_cols, bool ring16);   // resident workgroups per CU for that block size
 
-// launch wrappers implemented in mwf_band.hip (band kernel: E/F wavefronts live in registers)
+// geometry of a launch of the band family (mwf_band2.hip packed band kernel, mwf_lane.hip, mwf_mid.hip)
 struct BandGeom {
 	int block;        // threads per workgroup: 256 (x2 chunks), 768 (x2 chunks) or 512 (x3 chunks, packed state)
-	int packed;       // 1: E/F register state held as int16 pairs (mwf_band2.hip)
+	int packed;       // 1: the packed band kernel (mwf_band2.hip: E/F register state as int16 pairs, 16-bit H rows)
 	int span;         // columns the workgroup can hold: waves * chunks * 256 (balanced kernel: columns of its LDS state ring)
 	int lds_bytes;    // dynamic LDS for the sequence copy (0: read sequences from global memory)
 	int seq2;         // packed kernel: the sequence copy holds 2 bits per base (pairs of plain A/C/G/T; others come back as ST_ALPHABET)
@@ -166,12 +166,9 @@ bool mid_supported(const Penalty &p);
 int  mid_lds_bytes(const Penalty &p, int groups, int64_t seq_bytes); // seq_bytes >= (tl up to 8) + 16 + (ql up to 8) + 32 for every pair of the launch
 int  launch_mid(const BatchArgs &a, int grid, int block, int lds, bool seq2, void *stream); // seq2: 2-bit sequence copies (a pair outside plain A/C/G/T comes back as ST_ALPHABET)
 
-bool band_supported(const Penalty &p);                       // (e1,e2) instantiated and every H lag >= 2
 // launch wrappers implemented in mwf_band2.hip (packed band kernel: 16-bit offsets, sequences in LDS; BandGeom::packed)
 bool band2_supported(const Penalty &p);
 int  launch_band2(const BatchArgs &a, int grid, const BandGeom &g, void *stream);
 int  band2_kernel_occupancy(const Penalty &p, const BandGeom &g, bool cigar);
-int  launch_band(const BatchArgs &a, int grid, const BandGeom &g, void *stream);
-int  band_kernel_occupancy(const Penalty &p, const BandGeom &g, bool cigar);
 
 } // namespace mwf
