@@ -224,13 +224,15 @@ __device__ __forceinline__ int32_t run_wave2(int32_t j, int32_t aq, int32_t room
 	return min(n, room);
 }
 
-template <int D, int NWK>
+template <int DA, int NWK>
 struct alignas(16) Band2Lds {
 	Shared sh;
-	// per age and chunk slot r (entry r + 1): {E1, E2 of columns (c1,c3) of lane 63 | F1, F2 of columns (c0,c2) of lane 0}; entry 0 mirrors
-	// slot NWK-1 and entry NWK+1 slot 0, so that a slot finds its neighbours at fixed distances from its own entry
-	int32_t edge[D][NWK + 2][4];
-	int32_t dump[64 * 2 + (2 * NWK + 4) * 4]; // where the lanes that do not hold an outer column put theirs (no exec-mask games around the stores)
+	// per age and chunk slot r (entry r + 1), 8 ints: {E1, E2 of columns (c1,c3) of lane 63 | F1, F2 of columns (c0,c2) of lane 0 | E2 of columns
+	// (c0,c2) of lane 63, F2 of columns (c1,c3) of lane 0 (what the halo of a second penalty needs) | -, -}; entry 0 mirrors slot NWK-1 and
+	// entry NWK+1 slot 0, so that a slot finds its neighbours at fixed distances from its own entry.  DA ages: one more than the deepest
+	// history, because between two barriers a fast wave writes the entries of the second penalty while a slow one still reads for the first.
+	int32_t edge[DA][NWK + 2][8];
+	int32_t dump[64 * 2 + (2 * NWK + 8) * 8]; // where the lanes that do not hold an outer column put theirs (no exec-mask games around the stores)
 };
 
 // ---- packed 16-bit arithmetic: two columns per register, every operation one VOP3P instruction
@@ -277,13 +279,17 @@ __device__ __forceinline__ int32_t right_of_B(int32_t A, int32_t fill) { return 
 template <int T, int K, int E1, int E2, bool TB, bool S2, typename ArgsT>
 __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, const int32_t edge_base, const int32_t qoff, bool trace_band)
 {
-	constexpr int NW = T / 64, NWK = NW * K, D = (E1 > E2 ? E1 : E2) + 1;
+	constexpr int NW = T / 64, NWK = NW * K, D = (E1 > E2 ? E1 : E2) + 1, DA = D + 1;
 	constexpr int FULL = S2 ? 16 : 8; // bases the first probe of the match extension looks at
-	constexpr int kAge = (NWK + 2) * 16; // bytes of one age of the edge table
+	constexpr int kEnt = 32;             // bytes of one entry of the edge table
+	constexpr int kAge = (NWK + 2) * kEnt; // bytes of one age of the edge table
 	static_assert(D == 2 || D == 3, "edge-table ages");
 	const int32_t tl = M.tl, ql = M.ql, cmax = tl + ql + 1;
 	const int32_t tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
 	const int32_t W = A.W, nH = A.pen.nH, lagx = A.pen.x, lag1 = A.pen.oe1, lag2 = A.pen.oe2;
+	// The H ring has ONE ROW MORE than the deepest lag needs: between two barriers (two penalties, below) a fast wave writes the row of the
+	// second penalty while a slow wave still reads the oldest row for the first.
+	const int32_t nHr = nH + 1;
 	// H rows: W int16 per row, a quad of columns 4q..4q+3 stored as (c0, c2, c1, c3) — the two registers of a lane, one 8-byte load;
 	// 8 bytes of slack in front (lane 0 of chunk 0 looks one quad to the left; offsets are unsigned: the slack is part of `lane8`)
 	char *const Hb = (char*)M.H;
@@ -312,25 +318,25 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 	const int32_t T0 = both16(cmax), TLp = both16(tl), TL1 = both16(tl + 1);
 	// edge-table addresses: a slot's entry sits (k NW + 1) entries behind the wave's base.  Every lane stores its outer columns —
 	// lane 63 (E) and lane 0 (F) into the table, the others into a dump — so that no store needs an exec mask.
-	const int32_t ebase = edge_base + wave * 16, dump_base = edge_base + D * kAge + NW * 16; // (the mirror store reaches NW-1 entries back)
+	const int32_t ebase = edge_base + wave * kEnt, dump_base = edge_base + DA * kAge + NW * kEnt; // (the mirror store reaches NW-1 entries back)
 	const int32_t dump_lane = dump_base + lane * 8;
-	int32_t epos[D]; // byte offset of the table of age a + 1 (penalty s_new - a - 1); the oldest is overwritten and becomes age 1
+	int32_t epos[DA]; // byte offset of the table of age a + 1 (penalty s_new - a - 1); the oldest is overwritten and becomes age 1
 #pragma unroll
-	for (int a = 0; a < D; ++a) epos[a] = a * kAge;
+	for (int a = 0; a < DA; ++a) epos[a] = a * kAge;
 
 	// ---- every row read before it is written must read as dead around the origin: a slot that no penalty has written yet is only read
 	// during the first nH - 1 penalties, whose windows (and the columns next to them) stay within nH + 1 columns of the origin
 	{
 		const int32_t reach = nH + 1 + 8, g_a = max(tl + 1 - reach, 0) >> 8, n_g = ((tl + 1 + reach) >> 8) - g_a + 1, per_row = n_g * 64;
-		for (int32_t q = tid; q < nH * per_row; q += T) {
+		for (int32_t q = tid; q < nHr * per_row; q += T) {
 			const int32_t row = q / per_row, rem = q - row * per_row;
 			*(int2*)(Hb + (size_t)((uint32_t)row * RS + (uint32_t)(g_a * 512 + rem * 8 + 8))) = make_int2(kDeadPair, kDeadPair);
 		}
 	}
 	// ---- penalty 0 (reference wf_stripe_init, miniwfa.c:103-121) and its extension
-	for (int32_t j = tid; j < D * (NWK + 2) * 4; j += T) *(int32_t*)(lds2 + edge_base + 4 * j) = kDeadPair;
+	for (int32_t j = tid; j < DA * (NWK + 2) * 8; j += T) *(int32_t*)(lds2 + edge_base + 4 * j) = kDeadPair;
 	if (tid == 0) {
-		for (int32_t j = 0; j < nH; ++j) sh.rng_lo[j] = 1, sh.rng_hi[j] = 0;
+		for (int32_t j = 0; j < nHr; ++j) sh.rng_lo[j] = 1, sh.rng_hi[j] = 0;
 		for (int32_t j = 0; j < 12; ++j) (&sh.flags[0][0])[j] = 0;
 		sh.rng_lo[0] = sh.rng_hi[0] = tl + 1;
 		sh.word[3] = -1; // furthest offset seen at a forecast penalty (dev::window_forecast)
@@ -351,22 +357,19 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 	}
 
 	int32_t s = 0, wf_lo = tl + 1, wf_hi = tl + 1;
-	int32_t curH = 0, par = 0;
-	const uint32_t ring_bytes = (uint32_t)nH * RS;
+	int32_t curH = 0, par = 0; // par: the flag word of the last penalty computed (six words in turn: two penalties between barriers, see below)
+	const uint32_t ring_bytes = (uint32_t)nHr * RS;
 	// rows of the coming penalty and of its three lags, as byte offsets that advance by one row per penalty (penalty 1 first)
-	uint32_t bn = (uint32_t)(1 % nH) * RS, bx = (uint32_t)((nH - lagx + 1) % nH) * RS, b1 = (uint32_t)((nH - lag1 + 1) % nH) * RS, b2 = (uint32_t)((nH - lag2 + 1) % nH) * RS;
+	uint32_t bn = (uint32_t)(1 % nHr) * RS, bx = (uint32_t)((nHr - lagx + 1) % nHr) * RS, b1 = (uint32_t)((nHr - lag1 + 1) % nHr) * RS, b2 = (uint32_t)((nHr - lag2 + 1) % nHr) * RS;
 	// The rows of ONE chunk: H at the three lags (one 8-byte load each) and the word next to the chunk for the two gap-open rows.  These
-	// registers are where every chunk's rows land; at the end of a penalty they are loaded with the coming penalty's rows of the wave's
-	// first active chunk (`pre_g`), which travel while the wave waits at the barrier — every lag >= 2: those rows are final by then.
-	struct Rows { int2 HX, O1, O2; int32_t N1, N2; } pre;
-	pre.HX = pre.O1 = pre.O2 = make_int2(0, 0), pre.N1 = pre.N2 = 0;
-	int32_t pre_g = -1;
-	constexpr bool XPREF = MWF_B2_XPREF != 0; // (measured: +1 % on 1024 x 10 kb — the row loads are not what the critical wave waits for; off)
-	const bool xpref = XPREF && min_lag >= 2;
+	// registers are where every chunk's rows land.
+	// (of the o2 row the WHOLE neighbouring quad: its second column is what the halo of a second penalty is computed from)
+	struct Rows { int2 HX, O1, O2, N2q; int32_t N1; } pre;
+	pre.HX = pre.O1 = pre.O2 = pre.N2q = make_int2(0, 0), pre.N1 = 0;
 	auto load_rows = [&](Rows &r, const char *rx, const char *r1, const char *r2, uint32_t off) {
-		const uint32_t noff = off + (uint32_t)nd;
+		const uint32_t noff = off + (uint32_t)nd, qoff2 = off + (uint32_t)(lane == 0 ? -8 : 8);
 		r.HX = *(const int2*)(rx + off), r.O1 = *(const int2*)(r1 + off), r.O2 = *(const int2*)(r2 + off);
-		r.N1 = *(const int32_t*)(r1 + noff), r.N2 = *(const int32_t*)(r2 + noff);
+		r.N1 = *(const int32_t*)(r1 + noff), r.N2q = *(const int2*)(r2 + qoff2);
 	};
 	int64_t cells = 0, tb_used = 0;
 	int32_t est_window = 0;
@@ -388,57 +391,98 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 	remap(gl);
 	int32_t idle[K]; // penalties since the slot last held an active chunk (registers and edge-table entries start dead)
 #pragma unroll
-	for (int k = 0; k < K; ++k) idle[k] = D;
+	for (int k = 0; k < K; ++k) idle[k] = DA;
 
-	// One penalty; returns true when the pass ends.  A depth-2 history is two registers, [0] the newer: the penalty reads [1] for the last
-	// time, overwrites it, and the two trade places (v_swap_b32) — no copies, and a slot that is skipped leaves its registers alone.
+	// One STEP = one penalty, or — in the steady state — TWO penalties between a pair of barriers; returns true when the pass ends.
+	// A depth-2 history is two registers, [0] the newer: a penalty reads [1] for the last time, overwrites it, and the two trade places
+	// (v_swap_b32) — no copies, and a slot that is skipped leaves its registers alone.
+	//
+	// Two penalties per barrier (round 4).  What a wave needs of OTHER waves for penalty s+2 that they produce at s+1 is little:
+	//   * H rows: none — every H lag is >= 3 here, penalty s+2 reads rows of s-1 and older (written before the last barrier);
+	//   * E1/F1 (lag 2, the only depth-2 history that takes this path): the outer columns of s, in the edge table since the last barrier;
+	//   * E2/F2 with lag 1: the outer column of s+1 of the neighbouring chunk — recomputed HERE as a one-column halo: E2[s+1][cb-1] =
+	//     max(H[s+1-o2-e2][cb-2], E2[s][cb-2]) needs one more column of the o2 row (the whole neighbouring quad is loaded) and one more outer
+	//     column of the neighbour's E2 of penalty s (the edge table carries it), F2 alike on the right;
+	//   * the window of s+2 depends on the liveness of the edge cells of s+1 (miniwfa.c:325-326, :417-418): the wave that holds an edge chunk
+	//     computed that cell itself; every other wave assumes the window grew — which cannot matter to it, because the step is only doubled
+	//     while neither edge can cross a chunk boundary within it (a chunk strictly inside the window is computed the same whichever way the
+	//     edge went), and the true window — n_iter, the next step — is derived from both flag words behind the barrier;
+	//   * what is written between the barriers must not be what a slower wave still reads: one more H ring row, one more edge-table age,
+	//     six flag words in turn.
+	// Not doubled: good bits due (the nH penalties before a shrink), a forecast penalty, the first penalties of a pair and those behind a
+	// shrink (slots that left the window age out), windows of one chunk, an edge next to a chunk boundary, the band trace, e1 = 1.
+	const bool can_double = E1 == 2 && min_lag >= 3 && !trace_band && fresh(A).band2_double != 0;
+	int32_t haloE[K], haloF[K]; // E2 / F2 of the column next to a slot's chunk at the first penalty of a doubled step (in the half left_of_A / right_of_B take)
+#pragma unroll
+	for (int k = 0; k < K; ++k) haloE[k] = haloF[k] = kDeadPair;
 	auto step = [&]() __attribute__((always_inline)) -> bool {
 		constexpr int P1 = E1 - 1, P2 = E2 - 1;
-#ifdef MWF_B2_TIMING
-		const uint64_t tm0 = __builtin_readcyclecounter();
-#endif
-		const int32_t lo = wf_lo > 1 ? wf_lo - 1 : 1;       // miniwfa.c:417-418
-		const int32_t hi = wf_hi < cmax ? wf_hi + 1 : cmax;
-		const int32_t lo_p = lo, hi_p = hi;
-		const int32_t s_new = s + 1;
-		const int32_t newH = curH + 1 == nH ? 0 : curH + 1;
-		const int32_t npar = par + 1 == 3 ? 0 : par + 1;
-		const int32_t origin = lo & ~3;
-		const int32_t row_bytes = (hi | 3) - origin + 1;
+		const int32_t lo1 = wf_lo > 1 ? wf_lo - 1 : 1;       // miniwfa.c:417-418
+		const int32_t hi1 = wf_hi < cmax ? wf_hi + 1 : cmax;
+		const int32_t origin1 = lo1 & ~3, row_bytes1 = (hi1 | 3) - origin1 + 1;
 		if (TB) {
-			if (s_new - 1 >= rows_slot) { R.status = ST_ROWS_OVERFLOW; return true; }
-			if (tb_used + row_bytes > tb_slot_bytes) { R.status = ST_TB_OVERFLOW; return true; }
+			if (s >= rows_slot) { R.status = ST_ROWS_OVERFLOW; return true; }
+			if (tb_used + row_bytes1 > tb_slot_bytes) { R.status = ST_TB_OVERFLOW; return true; }
 		}
-		// the window of penalty s_new+1 lies inside [lo-1, hi+1] whatever the flags say; it must fit the register span
-		const int32_t gl_next = (lo > 1 ? lo - 1 : 1) >> 8;
-		if ((hi >> 8) - (lo >> 8) + 3 > NWK - 1) // (only then can the exact test fail)
-			if (((hi < cmax ? hi + 1 : cmax) >> 8) - gl_next + 1 > NWK - 1) { R.status = ST_BAND_OVERFLOW; return true; }
-		const char *const rowx = Hb + bx, *const row1 = Hb + b1, *const row2 = Hb + b2;
-		char *const rown = Hb + bn;
-		const bool track_good = (((256 - (s_new & 255)) & 255) < nH); // a shrink can still see this slice
-		// edge table: the ages to read (penalties s_new-E1 and s_new-E2) and the one to overwrite, as LDS addresses
-		const int32_t rE1 = ebase + epos[E1 - 1], rE2 = ebase + epos[E2 - 1];
-		const int32_t wE = lane == 63 ? ebase + epos[D - 1] : dump_lane, wF = lane == 0 ? ebase + epos[D - 1] : dump_lane;
-		auto put_edge = [&](int k, int32_t e1b, int32_t e2b, int32_t f1a, int32_t f2a) {
-			*(int2*)(lds2 + wE + (k * NW + 1) * 16) = make_int2(e1b, e2b);
-			*(int2*)(lds2 + wF + (k * NW + 1) * 16 + 8) = make_int2(f1a, f2a);
-			if (k == K - 1 && wave == NW - 1) *(int2*)(lds2 + wE - (NW - 1) * 16) = make_int2(e1b, e2b);  // slot NWK-1 is slot 0's left neighbour
-			if (k == 0 && wave == 0) *(int2*)(lds2 + wF + (NWK + 1) * 16 + 8) = make_int2(f1a, f2a);       // slot 0 is slot NWK-1's right neighbour
-		};
-		const int32_t ga = lo >> 8, gb = hi >> 8, gspan = gb - ga; // chunks [ga, gb] meet the window
-		// (not in the widest geometry: what it hands back goes to the generic kernel, several times slower — it would only do so at penalty 1024
-		// and beyond 1.5 x its span, and the bookkeeping costs the headline kernel 21 more spilled SGPRs)
-		const bool forecast = NWK < 24 && (s_new == 64 || s_new == 256 || s_new == 1024); // uniform: look at how far the pair has come (dev::window_forecast)
+		// the window of penalty s+2 lies inside [lo-1, hi+1] whatever the flags say; it must fit the register span
+		const int32_t gl_next = (lo1 > 1 ? lo1 - 1 : 1) >> 8;
+		if ((hi1 >> 8) - (lo1 >> 8) + 3 > NWK - 1) // (only then can the exact test fail)
+			if (((hi1 < cmax ? hi1 + 1 : cmax) >> 8) - gl_next + 1 > NWK - 1) { R.status = ST_BAND_OVERFLOW; return true; }
+		bool dbl = false;
+		if (can_double) { // uniform: every wave takes the same decision from the same numbers
+			const int32_t sa = s + 1, sb = s + 2, ph = s & 255;
+			const bool quiet = (((256 - (sa & 255)) & 255) >= nH) && (((256 - (sb & 255)) & 255) >= nH) && ph >= 8 && s >= 8 &&
+			                   sa != 64 && sb != 64 && sa != 256 && sb != 256 && sa != 1024 && sb != 1024;
+			// neither edge reaches another chunk by penalty s+3's possible window (what remap and the overflow test look at), and the window
+			// spans at least two chunks
+			const bool still = lo1 > 3 && ((lo1 - 3) >> 8) == (lo1 >> 8) && hi1 + 3 <= cmax && ((hi1 + 3) >> 8) == (hi1 >> 8) && (hi1 >> 8) > (lo1 >> 8) && gl_next == gl;
+			bool room = true;
+			if (TB) room = s + 1 < rows_slot && tb_used + row_bytes1 + ((((hi1 + 1) | 3) - ((lo1 - 1) & ~3)) + 1) <= tb_slot_bytes;
+			dbl = quiet && still && room;
+		}
+		int32_t lo_w = lo1, hi_w = hi1; // the window this wave computes the coming penalty with
+		int32_t w_lo0 = lo1, w_hi0 = hi1; // ... computed the step's first penalty with (the second's is derived from the flags)
+		uint32_t own = 0, mine = 0;        // edge chunks this wave holds (1: lo, 2: hi) and the liveness of their edge cells at the step's first penalty
+		int n_stores = 0;
+		bool track_good = false, forecast = false;
 		int32_t far = kDeadPair;
 		const int32_t cfin = ql + 1; // the end cell (tl-1, ql-1) lies on diagonal ql-tl, i.e. in this column
+#pragma unroll 1
+		for (int32_t p = 0;; ++p) {
+		const int32_t lo = lo_w, hi = hi_w;
+		const int32_t lo_p = lo, hi_p = hi;
+		const int32_t s_new = s + 1 + p;
+		const int32_t newH = curH + 1 == nHr ? 0 : curH + 1;
+		const int32_t npar = par + 1 == 6 ? 0 : par + 1;
+		const int32_t origin = lo & ~3;
+		const int32_t row_bytes = (hi | 3) - origin + 1;
+		const char *const rowx = Hb + bx, *const row1 = Hb + b1, *const row2 = Hb + b2;
+		char *const rown = Hb + bn;
+		track_good = (((256 - (s_new & 255)) & 255) < nH); // a shrink can still see this slice
+		// edge table: the ages to read (penalties s_new-E1 and s_new-E2) and the one to overwrite, as LDS addresses
+		const int32_t rE1 = ebase + epos[E1 - 1], rE2 = ebase + epos[E2 - 1];
+		const int32_t wE = lane == 63 ? ebase + epos[DA - 1] : dump_lane, wF = lane == 0 ? ebase + epos[DA - 1] : dump_lane;
+		auto put_edge = [&](int k, int32_t e1b, int32_t e2b, int32_t f1a, int32_t f2a, int32_t e2a, int32_t f2b) {
+			*(int2*)(lds2 + wE + (k * NW + 1) * kEnt) = make_int2(e1b, e2b);
+			*(int2*)(lds2 + wF + (k * NW + 1) * kEnt + 8) = make_int2(f1a, f2a);
+			*(int32_t*)(lds2 + wE + (k * NW + 1) * kEnt + 16) = e2a;
+			*(int32_t*)(lds2 + wF + (k * NW + 1) * kEnt + 20) = f2b;
+			if (k == K - 1 && wave == NW - 1) { // slot NWK-1 is slot 0's left neighbour
+				*(int2*)(lds2 + wE - (NW - 1) * kEnt) = make_int2(e1b, e2b);
+				*(int32_t*)(lds2 + wE - (NW - 1) * kEnt + 16) = e2a;
+			}
+			if (k == 0 && wave == 0) { // slot 0 is slot NWK-1's right neighbour
+				*(int2*)(lds2 + wF + (NWK + 1) * kEnt + 8) = make_int2(f1a, f2a);
+				*(int32_t*)(lds2 + wF + (NWK + 1) * kEnt + 20) = f2b;
+			}
+		};
+		const int32_t ga = lo >> 8, gb = hi >> 8, gspan = gb - ga; // chunks [ga, gb] meet the window
+		forecast = s_new == 64 || s_new == 256 || s_new == 1024; // uniform: look at how far the pair has come (dev::window_forecast); never in a doubled step
 
 		if (wave == 0) { // (the whole wave stores the same words: no exec mask to set up)
-			sh.rng_lo[newH] = lo, sh.rng_hi[newH] = hi;
-			sh.flags[npar + 1 == 3 ? 0 : npar + 1][0] = 0; // the flag word of the NEXT penalty (its last readers passed the previous barrier)
+			sh.rng_lo[newH] = lo, sh.rng_hi[newH] = hi; // (in a doubled step: this wave's view — only slices with good bits are ever looked at, and those are computed one per barrier)
 			if (TB) M.row_off[s_new - 1] = tb_used, M.row_lo[s_new - 1] = origin;
-#ifndef MWF_B2_TIMING // (the timing build keeps per-phase cycle counts in the trace buffer instead)
 			if (trace_band && s_new - 1 < fresh(A).dbg_cap) M.dbg[2 * (s_new - 1)] = lo, M.dbg[2 * (s_new - 1) + 1] = hi;
-#endif
 		}
 
 		bool act[K];
@@ -473,32 +517,19 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 #else
 		(void)busy;
 #endif
-#ifdef MWF_B2_TIMING
-		int n_act = 0;
-#pragma unroll
-		for (int k = 0; k < K; ++k) n_act += act[k] ? 1 : 0;
-#endif
 
-#ifdef MWF_B2_TIMING
-		const uint64_t tm1 = __builtin_readcyclecounter();
-#endif
-		int n_stores = 0;
 		// ---- every row must read as dead next to the chunks it was computed for (a later window reaches at most nH + 1 columns
 		// beyond this one: the reference's pads, miniwfa.c:96-99); the waves next to the window's ends hold the fewest chunks.  These
 		// stores go first: the store that may stay in flight across the barrier (relaxed_stores) is then a chunk's own.
 		if (ga >= 1 && wave == (ga - 1) % NW) *(int2*)(rown + ((uint32_t)((ga - 1) << 9) + lane8)) = make_int2(kDeadPair, kDeadPair);
 		if (wave == (gb + 1) % NW) *(int2*)(rown + ((uint32_t)((gb + 1) << 9) + lane8)) = make_int2(kDeadPair, kDeadPair);
-#if MWF_B2_TIMING == 2
-		bool chunk_timed = false;
-		uint32_t ct[4] = {0, 0, 0, 0};
-#endif
 #pragma unroll
 		for (int k = 0; k < K; ++k) {
 			// a chunk that left the window: its columns are not computed any more, i.e. their E/F are dead.  It runs through the ordinary
 			// code D more times (every column outside the window: masked dead — rare, a window edge crosses a chunk boundary inwards only
 			// at a shrink), which ages the slot's registers and edge-table entries; after that there is nothing left to do.
 			if (!act[k]) {
-				if (idle[k] >= D) continue; // uniform
+				if (idle[k] >= DA) continue; // uniform (DA times: every age of the edge table is rewritten dead)
 				++idle[k];
 			} else idle[k] = 0;
 			// (the window bounds are laundered per slot: what the chunk code derives from them stays inside this branch instead of being
@@ -507,20 +538,28 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 			asm volatile("" : "+s"(lo), "+s"(hi));
 			const int32_t g = gk[k], cb = g * kChunk, c0 = cb + 4 * lane;
 			// ---- rows: H at the three lags (one 8-byte load each) and the word next to the chunk for the two gap-open rows
-#if MWF_B2_TIMING == 2
-			uint64_t tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0, tc4 = 0;
-			const bool timed = !chunk_timed;
-			if (timed) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc0) :: "memory");
-#endif
 			const uint32_t off = (uint32_t)(cb << 1) + lane8;
-			if (!XPREF || g != pre_g) load_rows(pre, rowx, row1, row2, off); // uniform; (else they were requested before the last barrier)
-			if (XPREF) pre_g = -1;
+			load_rows(pre, rowx, row1, row2, off);
 			const int2 HX = pre.HX, O1 = pre.O1, O2 = pre.O2;
-			const int32_t N1 = pre.N1, N2 = pre.N2;
+			const int32_t N1 = pre.N1, N2 = lane == 0 ? pre.N2q.y : pre.N2q.x; // (lane 0: columns (c1,c3) of the quad to the left; lane 63: (c0,c2) of the quad to the right)
 			// gap-extension sources: E of column c-1, F of column c+1, e1 (e2) penalties ago; lane 0 / lane 63 take the neighbouring
 			// slot's outer columns from the edge table
-			const int32_t xE1 = *(const int32_t*)(lds2 + rE1 + k * NW * 16), xE2 = *(const int32_t*)(lds2 + rE2 + k * NW * 16 + 4);
-			const int32_t xF1 = *(const int32_t*)(lds2 + rE1 + (k * NW + 2) * 16 + 8), xF2 = *(const int32_t*)(lds2 + rE2 + (k * NW + 2) * 16 + 12);
+			const int32_t xE1 = *(const int32_t*)(lds2 + rE1 + k * NW * kEnt), xF1 = *(const int32_t*)(lds2 + rE1 + (k * NW + 2) * kEnt + 8);
+			int32_t xE2 = *(const int32_t*)(lds2 + rE2 + k * NW * kEnt + 4), xF2 = *(const int32_t*)(lds2 + rE2 + (k * NW + 2) * kEnt + 12);
+			if (E2 == 1 && dbl) { // uniform
+				if (p == 0) {
+					// The halo of the step's second penalty: E2 of the column left of this chunk and F2 of the column right of it AT THIS PENALTY, which
+					// the neighbouring slots compute as well but cannot hand over before the barrier — from the o2 row's neighbouring quad and the
+					// neighbours' second outer columns of the last penalty (miniwfa.c:271-276); dead outside this penalty's window, as they store it.
+					const int32_t e2n = *(const int32_t*)(lds2 + rE2 + k * NW * kEnt + 16);       // left neighbour, lane 63: E2 of (c0, c2): c2 = column cb - 2
+					const int32_t f2n = *(const int32_t*)(lds2 + rE2 + (k * NW + 2) * kEnt + 20); // right neighbour, lane 0: F2 of (c1, c3): c1 = column cb + 257
+					int32_t he = max(hi16(pre.N2q.x), hi16(e2n));            // lane 0: N2q.x = (c0, c2) of the quad to the left
+					int32_t hf = max(lo16(pre.N2q.y), lo16(f2n)) + 1;        // lane 63: N2q.y = (c1, c3) of the quad to the right
+					he = (cb - 1 >= lo && cb - 1 <= hi) ? he : -32768;
+					hf = (cb + kChunk >= lo && cb + kChunk <= hi) ? hf : -32768;
+					haloE[k] = (int32_t)((uint32_t)he << 16), haloF[k] = (int32_t)((uint32_t)hf & 0xffffu);
+				} else xE2 = haloE[k], xF2 = haloF[k];
+			}
 			const bool inside = cb >= lo && cb + kChunk - 1 <= hi; // uniform: every column of the chunk belongs to the window
 
 			// ---- recurrence (dev::wf_cell, miniwfa.c:267-278) on pairs of columns
@@ -537,9 +576,6 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 			const int32_t mA = pk_add(HX.x, ONE), mB = pk_add(HX.y, ONE);
 			int32_t hA = pk_max(pk_max(mA, pk_max(ne1A, ne2A)), pk_max(nf1A, nf2A));
 			int32_t hB = pk_max(pk_max(mB, pk_max(ne1B, ne2B)), pk_max(nf1B, nf2B));
-#if MWF_B2_TIMING == 2
-			if (timed) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc1) : "v"(hA), "v"(hB) : "memory");
-#endif
 			uint32_t tbw = 0;
 			if (TB) {
 				// The byte from the RESULTS (miniwfa.c:289-306): H is the maximum of m, e1, e2, f1, f2 and the reference's tie-breaking
@@ -610,11 +646,8 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 					asm volatile("v_swap_b32 %0, %1" : "+v"(f2h[0][k][i]), "+v"(f2h[1][k][i]));
 				}
 			}
-			put_edge(k, ne1B, ne2B, nf1A, nf2A);
+			put_edge(k, ne1B, ne2B, nf1A, nf2A, ne2A, nf2B);
 
-#if MWF_B2_TIMING == 2
-			if (timed) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc2) : "v"(hA), "v"(hB), "v"(rjA), "v"(dA) : "memory");
-#endif
 			// ---- match extension, first probe (FULL bases): j clamped to rj makes room = rj - j zero for dead and phantom offsets
 			const int32_t jA = pk_minu(pk_add(hA, ONE), rjA), jB = pk_minu(pk_add(hB, ONE), rjB);
 			const int32_t iqA = pk_add(jA, dA), iqB = pk_add(jB, dB);
@@ -663,9 +696,6 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 			typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
 			const int32_t cA = MWF_BC(int32_t, (us2_t)__builtin_amdgcn_cvt_pk_u16((uint32_t)cnt[0], (uint32_t)cnt[2])); // saturating
 			const int32_t cB = MWF_BC(int32_t, (us2_t)__builtin_amdgcn_cvt_pk_u16((uint32_t)cnt[1], (uint32_t)cnt[3]));
-#if MWF_B2_TIMING == 2
-			if (timed) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc3) : "v"(cA), "v"(cB) : "memory");
-#endif
 			const int32_t FULLp = both16(FULL);
 			const int32_t m9A = pk_minu(cA, pk_sub(rjA, jA)), m9B = pk_minu(cB, pk_sub(rjB, jB)); // > FULL: the whole probe matched, room left
 			int32_t nmA = pk_minu(m9A, FULLp), nmB = pk_minu(m9B, FULLp);
@@ -728,14 +758,6 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 			}
 			*(int2*)(rown + off) = make_int2(hxA, hxB);
 			++n_stores;
-#if MWF_B2_TIMING == 2
-			if (timed) {
-				asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc4) : "v"(hxA), "v"(hxB) : "memory");
-				chunk_timed = true;
-				ct[0] = (uint32_t)min(tc1 - tc0, (uint64_t)4095), ct[1] = (uint32_t)min(tc2 - tc1, (uint64_t)4095);
-				ct[2] = (uint32_t)min(tc3 - tc2, (uint64_t)4095), ct[3] = (uint32_t)min(tc4 - tc3, (uint64_t)4095);
-			}
-#endif
 			if (TB && c0 >= origin && c0 <= hi) *(uint32_t*)(M.tb + tb_used - origin + c0) = tbw;
 			if (track_good) {
 				unsigned long long *gword = M.good + (int64_t)newH * fresh(A).GW + g * 4;
@@ -746,82 +768,84 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 				}
 			}
 			if (fm) bits |= 4u | (uint32_t)__builtin_amdgcn_readlane(done_info, (int32_t)__builtin_ctzll(fm)) << 4;
-			if (bits && lane == 0) atomicOr((unsigned int*)&sh.flags[npar][0], bits);
+			if (bits && lane == 0) atomicOr((unsigned int*)(&sh.flags[0][0] + npar), bits);
+			if (p == 0) own |= (uint32_t)(g == ga) | (uint32_t)(g == gb) << 1, mine |= bits & 3u;
 		}
 
 		if (forecast) {
 			const int32_t m = wave_max(max(lo16(far), hi16(far)));
 			if (lane == 0 && m >= 0) atomicMax(&sh.word[3], m);
 		}
-		// Everything older than this penalty's last operations must be complete before another wave may load it (vmcnt retires
-		// in issue order).  With every lag >= 3 the rows written now are first loaded two penalties from now: the youngest store
-		// may stay in flight across the barrier.
-#ifdef MWF_B2_TIMING
-		const uint64_t tm2 = __builtin_readcyclecounter();
-#endif
-		// the coming penalty: its rows, and the request for the first active chunk's (five loads, younger than every store)
+		// the coming penalty: its rows, the ages of the edge table, the traceback row
 		bn = bn + RS == ring_bytes ? 0u : bn + RS, bx = bx + RS == ring_bytes ? 0u : bx + RS;
 		b1 = b1 + RS == ring_bytes ? 0u : b1 + RS, b2 = b2 + RS == ring_bytes ? 0u : b2 + RS;
-		bool requested = false;
-		const int32_t gf = !XPREF ? -1 : act[0] ? gk[0] : act[1] ? gk[1] : (K > 2 && act[K - 1]) ? gk[K - 1] : -1;
-		if (MWF_B2_XPREF == 1 && xpref && gf >= 0) { // variant 1: before the barrier
-			load_rows(pre, Hb + bx, Hb + b1, Hb + b2, (uint32_t)(gf << 9) + lane8);
-			pre_g = gf, requested = true;
-		}
-		const bool young_store = relaxed_stores && n_stores > 0 && !TB && !track_good;
-		if (requested) {
-			if (young_store) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-			else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
-		} else {
-			if (young_store) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
-			else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-		}
-#ifdef MWF_B2_TIMING
-		const uint64_t tm3 = __builtin_readcyclecounter();
-#endif
-		__builtin_amdgcn_s_barrier();
-		asm volatile("" ::: "memory");
-		if (MWF_B2_XPREF == 2 && gf >= 0) { // variant 2: straight behind the barrier, on the guess that the wave's first chunk stays what it was
-			load_rows(pre, Hb + bx, Hb + b1, Hb + b2, (uint32_t)(gf << 9) + lane8);
-			pre_g = gf;
-		}
-
-		// ---- bookkeeping, identical on every thread
-		const uint32_t fl = (uint32_t)uni(sh.flags[npar][0]);
-#ifdef MWF_B2_TIMING
-		if (trace_band && tid == (fresh(A).max_iter < 0 ? (int32_t)-fresh(A).max_iter : 0) && s_new - 1 < fresh(A).dbg_cap) { // cycles: header | chunks, drain | barrier+flags; chunks this wave ran in bits 28..
-			const uint64_t tm4 = __builtin_readcyclecounter();
-#if MWF_B2_TIMING == 2 // the first active chunk of the wave: rows + recurrence | masks, liveness, geometry, edge stores | first probe | walks, store
-			M.dbg[2 * (s_new - 1)] = (int32_t)(ct[0] | ct[1] << 12 | (uint32_t)n_act << 28);
-			M.dbg[2 * (s_new - 1) + 1] = (int32_t)(ct[2] | ct[3] << 12);
-			(void)tm4;
-#else
-			M.dbg[2 * (s_new - 1)] = (int32_t)(min((uint32_t)(tm1 - tm0), 65535u) | min((uint32_t)(tm2 - tm1), 65535u) << 16);
-			M.dbg[2 * (s_new - 1) + 1] = (int32_t)(min((uint32_t)(tm3 - tm2), 4095u) | min((uint32_t)(tm4 - tm3), 65535u) << 12 | (uint32_t)n_act << 28);
-#endif
-		}
-#endif
-		if (fl & 1u) wf_lo = lo;
-		if (fl & 2u) wf_hi = hi;
-		const int32_t done = (int32_t)((fl >> 2) & 1u), payload = (int32_t)((fl >> 4) & 7u);
-		s = s_new, curH = newH, par = npar;
 		{
-			const int32_t oldest = epos[D - 1];
+			const int32_t oldest = epos[DA - 1];
 #pragma unroll
-			for (int a = D - 1; a > 0; --a) epos[a] = epos[a - 1];
+			for (int a = DA - 1; a > 0; --a) epos[a] = epos[a - 1];
 			epos[0] = oldest;
 		}
-		if (gl_next != gl) gl = gl_next, remap(gl);
+		curH = newH, par = npar;
 		if (TB) tb_used += row_bytes;
-		if ((s & 0xff) == 0) { // shrink (reference wf_stripe_shrink, miniwfa.c:144-171) on the interleaved good bits
+		if (!dbl || p == 1) break;
+		// the second penalty's window as THIS wave must see it: the wave that holds an edge chunk knows whether the edge cell came out live
+		// (miniwfa.c:325-326: wf_lo becomes lo), every other wave assumes that it did
+		{
+			const int32_t wl = ((own & 1u) && !(mine & 1u)) ? wf_lo : lo, wh = ((own & 2u) && !(mine & 2u)) ? wf_hi : hi;
+			lo_w = wl > 1 ? wl - 1 : 1, hi_w = wh < cmax ? wh + 1 : cmax;
+		}
+		}
+
+		// the flag words of the next two penalties (their last readers passed a barrier long ago; this step's and the last step's are not among them)
+		if (wave == 0) {
+			const int32_t na = par + 1 >= 6 ? par - 5 : par + 1, nb = par + 2 >= 6 ? par - 4 : par + 2;
+			(&sh.flags[0][0])[na] = 0, (&sh.flags[0][0])[nb] = 0;
+		}
+		// Everything older than this step's last operations must be complete before another wave may load it (vmcnt retires
+		// in issue order).  With every lag >= 3 the rows written now are first loaded two penalties from now: the youngest store
+		// may stay in flight across the barrier.
+		const bool young_store = relaxed_stores && n_stores > 0 && !TB && !track_good;
+		if (young_store) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+		else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+		__builtin_amdgcn_s_barrier();
+		asm volatile("" ::: "memory");
+
+		// ---- bookkeeping, identical on every thread: the step's penalties in order
+		const int32_t n_pen = dbl ? 2 : 1;
+		const int32_t par_a = dbl ? (par == 0 ? 5 : par - 1) : par; // flag word of the step's first penalty
+		int32_t lo = w_lo0, hi = w_hi0;
+#pragma unroll 1
+		for (int32_t p = 0; p < n_pen; ++p) {
+			const uint32_t fl = (uint32_t)uni((&sh.flags[0][0])[p == 0 ? par_a : par]);
+			if (p == 1) lo = wf_lo > 1 ? wf_lo - 1 : 1, hi = wf_hi < cmax ? wf_hi + 1 : cmax; // the second penalty's TRUE window
+			if (fl & 1u) wf_lo = lo;
+			if (fl & 2u) wf_hi = hi;
+			const int32_t done = (int32_t)((fl >> 2) & 1u), payload = (int32_t)((fl >> 4) & 7u);
+			s = s + 1;
+			cells += hi - lo + 1;
+			if (cells > iter_limit || s > s_limit) { // miniwfa.c:422-425
+				R.status = ST_STOPPED;
+				return true;
+			}
+			if (done) {
+				R.info = payload;
+				return true;
+			}
+		}
+		{
+			const int32_t gn = (lo > 1 ? lo - 1 : 1) >> 8;
+			if (gn != gl) gl = gn, remap(gl);
+		}
+		if ((s & 0xff) == 0) { // shrink (reference wf_stripe_shrink, miniwfa.c:144-171) on the interleaved good bits (never behind a doubled step)
 			if (tid == 0) sh.red[0] = 0x7fffffff, sh.red[1] = -1;
 			__syncthreads();
 			const int32_t gfirst = wf_lo >> 8, n_words = ((wf_hi >> 8) - gfirst + 1) * 4, GWc = fresh(A).GW;
+			const int32_t stale = curH + 1 == nHr ? 0 : curH + 1; // the ring's spare row: a slice older than any the reference still holds
 			for (int32_t q = tid; q < n_words; q += T) {
 				const int32_t gg = gfirst + (q >> 2), kq = q & 3, base = gg * kChunk;
 				unsigned long long m = 0;
-				for (int32_t j = 0; j < nH; ++j)
-					if (sh.rng_lo[j] <= sh.rng_hi[j] && sh.rng_lo[j] <= base + kChunk - 1 && sh.rng_hi[j] >= base) m |= M.good[(int64_t)j * GWc + gg * 4 + kq];
+				for (int32_t j = 0; j < nHr; ++j)
+					if (j != stale && sh.rng_lo[j] <= sh.rng_hi[j] && sh.rng_lo[j] <= base + kChunk - 1 && sh.rng_hi[j] >= base) m |= M.good[(int64_t)j * GWc + gg * 4 + kq];
 				m &= lane_mask(base, kq, wf_lo, wf_hi);
 				if (m) {
 					atomicMin(&sh.red[0], base + 4 * (int32_t)__builtin_ctzll(m) + kq);
@@ -832,15 +856,6 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 			const int32_t glo = uni(sh.red[0]), ghi = uni(sh.red[1]);
 			if (ghi < 0) { R.status = ST_INTERNAL; return true; }
 			wf_lo = glo, wf_hi = ghi;
-		}
-		cells += hi - lo + 1;
-		if (cells > iter_limit || s > s_limit) { // miniwfa.c:422-425
-			R.status = ST_STOPPED;
-			return true;
-		}
-		if (done) {
-			R.info = payload;
-			return true;
 		}
 		if (forecast) { // will the window outgrow the chunks this workgroup holds? then hand the pair back now, with the estimate
 			est_window = window_forecast(s, uni(sh.word[3]), tl, ql, (NWK - 1) * kChunk - 64, NWK >= 24); // (the window this geometry is chosen for: kBand*Window in mwf_engine.cpp)
@@ -860,14 +875,14 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 template <int T, int K, int E1, int E2, bool TB, bool S2>
 __global__ __launch_bounds__(T, T == MWF_B2_WIDE_T ? MWF_B2_WIDE_WAVES : T <= 512 ? ((TB && T < 512) ? 3 : 4) : MWF_B2_768_WAVES) void wfa_band2_kernel(const BatchArgs)
 {
-	constexpr int NWK = (T / 64) * K, D = (E1 > E2 ? E1 : E2) + 1;
+	constexpr int NWK = (T / 64) * K, DA = (E1 > E2 ? E1 : E2) + 2;
 	// the arguments are read from the kernarg segment where they are used (dev::kernel_args / dev::fresh), never held for the kernel's lifetime
 	KArgs &A0 = kernel_args();
 	// the sequence copy starts at LDS offset 0 (the probes' inline-asm reads take LDS byte addresses): true while this kernel has no
 	// static LDS — trap rather than compute on the wrong bytes should that ever change
 	if ((uint32_t)(uintptr_t)lds2 != 0u) __builtin_trap();
 	// the bookkeeping words and the edge table sit behind the sequence copy
-	typedef Band2Lds<D, NWK> LdsT;
+	typedef Band2Lds<DA, NWK> LdsT;
 	const int32_t lds_seq = A0.band_lds_seq;
 	LdsT *const L = (LdsT*)(lds2 + lds_seq);
 	Shared &sh = L->sh;
@@ -883,6 +898,7 @@ __global__ __launch_bounds__(T, T == MWF_B2_WIDE_T ? MWF_B2_WIDE_WAVES : T <= 51
 		const int32_t pair = A.order ? A.order[item] : item;
 		PairMem M;
 		pair_mem(A, (int32_t)blockIdx.x, pair, M);
+		M.good = A.good + (int64_t)blockIdx.x * (A.pen.nH + 1) * A.GW; // (this kernel's H ring — and with it the good-bit rows — has one row more than nH)
 		const int32_t qoff = S2 ? ((M.tl >> 4) + 2) * 4 : ((M.tl + 3) & ~3) + 8; // both sequences start on a dword
 		PassResult R;
 		R.status = ST_OK, R.s = 0, R.info = 0, R.n_snap = 0, R.cells = 0;
@@ -906,7 +922,7 @@ __global__ __launch_bounds__(T, T == MWF_B2_WIDE_T ? MWF_B2_WIDE_WAVES : T <= 51
 }
 
 template <int T, int K, int E1, int E2>
-constexpr int lds_tail() { return (int)sizeof(Band2Lds<(E1 > E2 ? E1 : E2) + 1, (T / 64) * K>); }
+constexpr int lds_tail() { return (int)sizeof(Band2Lds<(E1 > E2 ? E1 : E2) + 2, (T / 64) * K>); }
 
 template <int T, int K, int E1, int E2, bool TB, bool S2>
 void launch_variant(const BatchArgs &a, int grid, int lds, hipStream_t st)
@@ -953,7 +969,7 @@ int occ_one(int lds_seq, bool seq2, bool tb)
 // the packed kernel: (e1,e2) instantiated, sequences fit LDS (the host checks), every H lag >= 1
 bool band2_supported(const Penalty &p)
 {
-	return ((p.e1 == 2 && p.e2 == 1) || (p.e1 == 2 && p.e2 == 2) || (p.e1 == 1 && p.e2 == 1)) && p.nH <= kMaxRing; // (window table in LDS; rows read as dead up to 256 columns beyond their window)
+	return ((p.e1 == 2 && p.e2 == 1) || (p.e1 == 2 && p.e2 == 2) || (p.e1 == 1 && p.e2 == 1)) && p.nH < kMaxRing; // (window table in LDS; rows read as dead up to 256 columns beyond their window)
 }
 
 #ifdef MWF_BAND_DEV
