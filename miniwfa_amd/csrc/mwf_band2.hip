@@ -37,6 +37,12 @@ extern __shared__ __attribute__((aligned(16))) uint8_t lds2[];
 #ifndef MWF_B2_768_WAVES
 #define MWF_B2_768_WAVES 1 // waves per SIMD the 768-thread geometry is compiled for (1: one workgroup per CU, up to 168 VGPRs; experiment: 6 = two per CU at 80)
 #endif
+#ifndef MWF_B2_SPAN_K
+// chunk slots per wave of the 1024-thread geometry (16 waves, one workgroup per CU): 80 chunks = windows of up to 20 224 columns.  Measured on
+// 1250 x 50 kb @ 3 % (windows of up to 16 900 columns): 4 slots 172 ms + 24 pairs re-run on the generic kernel = 240 ms, 5 slots (4 spilled VGPRs)
+// 174.6 ms and no re-run, 6 slots (12 spilled) 177.0; 256 x 50 kb: 36.2 (+ 9 re-runs: 104) / 38.7 / 39.6 ms; generic kernel 279 and 78 ms.
+#define MWF_B2_SPAN_K 5
+#endif
 #ifndef MWF_B2_WIDE_WAVES
 #define MWF_B2_WIDE_WAVES 4 // waves per SIMD the widest geometry is compiled for (4: 128 VGPRs, two 512-thread workgroups per CU)
 #endif
@@ -224,6 +230,20 @@ __device__ __forceinline__ int32_t run_wave2(int32_t j, int32_t aq, int32_t room
 	return min(n, room);
 }
 
+// ---- biased offsets (the 1024-thread geometry: targets of up to ~60 kb).  A 16-bit half holds  offset - B  with B = wide_bias(tl):
+// live offsets are >= -1, i.e. halves >= -1 - B, and everything below is dead.  Every place that reads an offset as a number adds B
+// back (the "+ 1" of j = k + 1 becomes "+ 1 + B": no instruction more); as unsigned 16-bit numbers the true values (up to 65 535)
+// fit where signed ones would not.  Two things move towards the ends of the 16 bits by at most one per penalty and are CHECKED at
+// every penalty that is a multiple of 256 (in the good-bit code of that penalty), with a margin of kBiasMargin > 2 x 256 + nH (what was
+// computed since the last check but one is still being read from the H ring):
+//   * dead values start at -32768 and a chain of them — F2 of the columns next to the lower window edge, which moves with the chain — gains
+//     one per penalty: no value may lie in [-1 - B - kBiasMargin, -1 - B);
+//   * offsets that ran past the end of the target (F of cells beyond the matrix keeps counting): no H above 32767 - kBiasMargin, i.e. more
+//     than kBiasOver - kBiasMargin beyond the target's end.
+// A pair that fails a check is handed back (ST_BAND_OVERFLOW: generic kernel).  With tl = 50 000 the dead side holds ~12 900 penalties.
+constexpr int32_t kBiasOver = 1500, kBiasMargin = 600;
+__device__ __forceinline__ int32_t wide_bias(int32_t tl) { return max(tl + kBiasOver - 32767, 0); }
+
 template <int D, int NWK>
 struct alignas(16) Band2Lds {
 	Shared sh;
@@ -278,12 +298,15 @@ template <int T, int K, int E1, int E2, bool TB, bool S2, typename ArgsT>
 __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, const int32_t edge_base, const int32_t qoff, bool trace_band)
 {
 	constexpr int NW = T / 64, NWK = NW * K, D = (E1 > E2 ? E1 : E2) + 1;
+	constexpr bool BI = T == 1024; // biased offsets (wide_bias)
 	constexpr int FULL = S2 ? 16 : 8; // bases the first probe of the match extension looks at
 	constexpr int kAge = (NWK + 2) * 16; // bytes of one age of the edge table
 	static_assert(D == 2 || D == 3, "edge-table ages");
 	const int32_t tl = M.tl, ql = M.ql, cmax = tl + ql + 1;
 	const int32_t tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
 	const int32_t W = A.W, nH = A.pen.nH, lagx = A.pen.x, lag1 = A.pen.oe1, lag2 = A.pen.oe2;
+	const int32_t B = BI ? wide_bias(tl) : 0;                   // a half holds offset - B
+	const int32_t ONEB = BI ? both16(1 + B) : 0x00010001;       // k -> j = k + 1 as a true (unsigned) number
 	// H rows: W int16 per row, a quad of columns 4q..4q+3 stored as (c0, c2, c1, c3) — the two registers of a lane, one 8-byte load;
 	// 8 bytes of slack in front (lane 0 of chunk 0 looks one quad to the left; offsets are unsigned: the slack is part of `lane8`)
 	char *const Hb = (char*)M.H;
@@ -340,7 +363,7 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 		const int32_t k0 = (S2 ? run_wave16(qoff, 0, 0, min(tl, ql), 0) : run_wave2(0, qoff, min(tl, ql), 0)) - 1;
 		if (tid == 0) {
 			const int32_t c = tl + 1, e = c & 3;
-			*(int16_t*)(Hb + 8 + (size_t)(uint32_t)(((c & ~3) + ((e & 1) << 1) + (e >> 1)) << 1)) = (int16_t)k0;
+			*(int16_t*)(Hb + 8 + (size_t)(uint32_t)(((c & ~3) + ((e & 1) << 1) + (e >> 1)) << 1)) = (int16_t)(k0 - B);
 			sh.word[1] = k0;
 		}
 	}
@@ -413,6 +436,8 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 		const int32_t gl_next = (lo > 1 ? lo - 1 : 1) >> 8;
 		if ((hi >> 8) - (lo >> 8) + 3 > NWK - 1) // (only then can the exact test fail)
 			if (((hi < cmax ? hi + 1 : cmax) >> 8) - gl_next + 1 > NWK - 1) { R.status = ST_BAND_OVERFLOW; return true; }
+		// (biased offsets, sequences beyond 32 kb: the room arithmetic holds ql - d in 16 unsigned bits)
+		if (BI && cmax - lo > 65535) { R.status = ST_BAND_OVERFLOW; return true; }
 		const char *const rowx = Hb + bx, *const row1 = Hb + b1, *const row2 = Hb + b2;
 		char *const rown = Hb + bn;
 		const bool track_good = (((256 - (s_new & 255)) & 255) < nH); // a shrink can still see this slice
@@ -428,7 +453,8 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 		const int32_t ga = lo >> 8, gb = hi >> 8, gspan = gb - ga; // chunks [ga, gb] meet the window
 		// (not in the widest geometry: what it hands back goes to the generic kernel, several times slower — it would only do so at penalty 1024
 		// and beyond 1.5 x its span, and the bookkeeping costs the headline kernel 21 more spilled SGPRs)
-		const bool forecast = NWK < 24 && (s_new == 64 || s_new == 256 || s_new == 1024); // uniform: look at how far the pair has come (dev::window_forecast)
+		// (the span geometry forecasts later: what it hands back goes to the generic kernel, twice as slow — no more)
+		const bool forecast = NWK < 24 ? (s_new == 64 || s_new == 256 || s_new == 1024) : NWK >= 64 ? (s_new == 1024 || s_new == 4096) : false; // uniform: look at how far the pair has come (dev::window_forecast)
 		int32_t far = kDeadPair;
 		const int32_t cfin = ql + 1; // the end cell (tl-1, ql-1) lies on diagonal ql-tl, i.e. in this column
 
@@ -575,12 +601,12 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 				if (g == ga) {
 					const int32_t rel = lo - cb;
 					const int32_t v = half_of(__builtin_amdgcn_readlane((rel & 1) ? hB : hA, rel >> 2), (rel >> 1) & 1);
-					bits |= v >= -1 ? 1u : 0u;
+					bits |= v >= -1 - B ? 1u : 0u;
 				}
 				if (g == gb) {
 					const int32_t rel = hi - cb;
 					const int32_t v = half_of(__builtin_amdgcn_readlane((rel & 1) ? hB : hA, rel >> 2), (rel >> 1) & 1);
-					bits |= v >= -1 ? 2u : 0u;
+					bits |= v >= -1 - B ? 2u : 0u;
 				}
 			}
 			// ---- lane geometry of the chunk: j = k + 1 may reach rj = min(tl, ql - d); query index = j + d, d = c - 1 - tl
@@ -591,10 +617,17 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 			// good bits: some array holds an in-matrix offset (miniwfa.c:139-142) <=> j <= rj for a live value (dead: j is huge)
 			uint32_t gbits = 0;
 			if (track_good) { // uniform
-				auto bad = [&](int32_t v, int32_t rj) { return pk_subsat(pk_add(v, ONE), rj); }; // zero iff good
+				auto bad = [&](int32_t v, int32_t rj) { return pk_subsat(pk_add(v, ONEB), rj); }; // zero iff good
 				const int32_t bA = pk_minu(pk_minu(bad(hA, rjA), pk_minu(bad(ne1A, rjA), bad(nf1A, rjA))), pk_minu(bad(ne2A, rjA), bad(nf2A, rjA))) | outA;
 				const int32_t bB = pk_minu(pk_minu(bad(hB, rjB), pk_minu(bad(ne1B, rjB), bad(nf1B, rjB))), pk_minu(bad(ne2B, rjB), bad(nf2B, rjB))) | outB;
 				gbits = (uint32_t)((bA & 0xffff) == 0) | (uint32_t)((bB & 0xffff) == 0) << 1 | (uint32_t)(((uint32_t)bA >> 16) == 0) << 2 | (uint32_t)(((uint32_t)bB >> 16) == 0) << 3;
+				if (BI && (s_new & 255) == 0) { // uniform: the range checks of wide_bias
+					const int32_t width = both16(kBiasMargin), from = both16(-1 - B - kBiasMargin), top = both16(32768 - kBiasMargin);
+					auto stray = [&](int32_t v, int32_t lo_end) { return pk_subsat(width, pk_sub(v, lo_end)); }; // nonzero iff lo_end <= v < lo_end + kBiasMargin
+					const int32_t any = stray(hA, from) | stray(hB, from) | stray(ne1A, from) | stray(ne1B, from) | stray(ne2A, from) | stray(ne2B, from) |
+					                    stray(nf1A, from) | stray(nf1B, from) | stray(nf2A, from) | stray(nf2B, from) | stray(hA, top) | stray(hB, top);
+					if (__ballot(any != 0)) bits |= 0x80u;
+				}
 			}
 			// ---- the new E/F are final: age the registers, publish this chunk's outer columns for the neighbouring slots
 			e1h[P1][k][0] = ne1A, e1h[P1][k][1] = ne1B, f1h[P1][k][0] = nf1A, f1h[P1][k][1] = nf1B;
@@ -616,7 +649,7 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 			if (timed) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc2) : "v"(hA), "v"(hB), "v"(rjA), "v"(dA) : "memory");
 #endif
 			// ---- match extension, first probe (FULL bases): j clamped to rj makes room = rj - j zero for dead and phantom offsets
-			const int32_t jA = pk_minu(pk_add(hA, ONE), rjA), jB = pk_minu(pk_add(hB, ONE), rjB);
+			const int32_t jA = pk_minu(pk_add(hA, ONEB), rjA), jB = pk_minu(pk_add(hB, ONEB), rjB);
 			const int32_t iqA = pk_add(jA, dA), iqB = pk_add(jB, dB);
 			int32_t cnt[4]; // columns c0 (A.lo), c1 (B.lo), c2 (A.hi), c3 (B.hi)
 			if (S2) {
@@ -639,7 +672,8 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 					const uint32_t J = (uint32_t)((u & 1) ? jB : jA), Q = (uint32_t)((u & 1) ? iqB : iqA);
 					// v_alignbit uses bits 4:0 of the shift.  Bit 15 of the LOW half must not leak into a high half's shift: j never has it (j <= rj <=
 					// tl < 32767), a query index can — column 0 (the pad column, lane 0 of chunk 0) clamps to index -1
-					const uint32_t tsh = (u & 2) ? J >> 15 : J << 1, qsh = (u & 2) ? (Q >> 15) & 30u : Q << 1;
+					// (biased offsets: targets beyond 32 kb — j has a bit 15 too)
+					const uint32_t tsh = (u & 2) ? (BI ? (J >> 15) & 30u : J >> 15) : J << 1, qsh = (u & 2) ? (Q >> 15) & 30u : Q << 1;
 					cnt[u] = lead_eq2(__builtin_amdgcn_alignbit((uint32_t)(tw[u] >> 32), (uint32_t)tw[u], tsh) ^ __builtin_amdgcn_alignbit((uint32_t)(qw[u] >> 32), (uint32_t)qw[u], qsh));
 				}
 			} else {
@@ -673,7 +707,7 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 			// ---- a run of >= FULL matches continues (the cells near the alignment path, and one first probe in 4^FULL by chance).  Each
 			// lane first walks its own runs, four trips at most; what is still open then the whole wave walks.
 			if (__ballot(pendp != 0)) {
-				int32_t hv[4] = {half_of(hA, 0), half_of(hB, 0), half_of(hA, 1), half_of(hB, 1)};
+				int32_t hv[4] = {half_of(hA, 0) + B, half_of(hB, 0) + B, half_of(hA, 1) + B, half_of(hB, 1) + B}; // true offsets
 				int32_t nmat[4] = {(int32_t)((uint32_t)nmA & 0xffffu), (int32_t)((uint32_t)nmB & 0xffffu), (int32_t)((uint32_t)nmA >> 16), (int32_t)((uint32_t)nmB >> 16)};
 				const uint32_t pend = (uint32_t)(((uint32_t)m9A & 0xffffu) > (uint32_t)FULL) | (uint32_t)(((uint32_t)m9B & 0xffffu) > (uint32_t)FULL) << 1 |
 				                      (uint32_t)(((uint32_t)m9A >> 16) > (uint32_t)FULL) << 2 | (uint32_t)(((uint32_t)m9B >> 16) > (uint32_t)FULL) << 3;
@@ -721,7 +755,7 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 			int32_t done_info = 0;
 			if ((uint32_t)(cfin - cb) < (uint32_t)kChunk && cfin >= lo && cfin <= hi) { // uniform
 				const int32_t rel = cfin - cb, hi_half = (rel >> 1) & 1;
-				const int32_t hv = half_of((rel & 1) ? hxB : hxA, hi_half), nm = (int32_t)((uint32_t)((rel & 1) ? nmB : nmA) >> (hi_half ? 16 : 0) & 0xffffu);
+				const int32_t hv = half_of((rel & 1) ? hxB : hxA, hi_half) + B, nm = (int32_t)((uint32_t)((rel & 1) ? nmB : nmA) >> (hi_half ? 16 : 0) & 0xffffu);
 				const uint32_t f = (uint32_t)(lane == (rel >> 2)) & (uint32_t)(hv == tl - 1) & inm_bit(ql - tl, hv - nm, tl, ql);
 				done_info = (f && nm == 0) ? (int32_t)((tbw >> (8 * (rel & 3))) & 7u) : 0;
 				fm = __ballot(f != 0);
@@ -750,7 +784,7 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 		}
 
 		if (forecast) {
-			const int32_t m = wave_max(max(lo16(far), hi16(far)));
+			const int32_t m = wave_max(max(lo16(far), hi16(far))) + B;
 			if (lane == 0 && m >= 0) atomicMax(&sh.word[3], m);
 		}
 		// Everything older than this penalty's last operations must be complete before another wave may load it (vmcnt retires
@@ -804,6 +838,7 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 		if (fl & 1u) wf_lo = lo;
 		if (fl & 2u) wf_hi = hi;
 		const int32_t done = (int32_t)((fl >> 2) & 1u), payload = (int32_t)((fl >> 4) & 7u);
+		if (BI && (fl & 0x80u)) { R.status = ST_BAND_OVERFLOW; return true; } // a value came near the end of its 16-bit range (wide_bias)
 		s = s_new, curH = newH, par = npar;
 		{
 			const int32_t oldest = epos[D - 1];
@@ -843,7 +878,7 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 			return true;
 		}
 		if (forecast) { // will the window outgrow the chunks this workgroup holds? then hand the pair back now, with the estimate
-			est_window = window_forecast(s, uni(sh.word[3]), tl, ql, (NWK - 1) * kChunk - 64, NWK >= 24); // (the window this geometry is chosen for: kBand*Window in mwf_engine.cpp)
+			est_window = window_forecast(s, uni(sh.word[3]), tl, ql, (NWK - 1) * kChunk - 64, NWK >= 24 && NWK < 64); // (the window this geometry is chosen for: kBand*Window in mwf_engine.cpp)
 			if (est_window) { R.status = ST_BAND_OVERFLOW; return true; }
 		}
 		return false;
@@ -858,7 +893,7 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 // Workgroups share a CU: 2 x 512, 4 x 256, 8 x 128 or 16 x 64 threads = 4 waves per SIMD, i.e. at most 128 VGPRs; with traceback
 // the smaller ones get 168 (3 per SIMD).  768 threads: one workgroup per CU.
 template <int T, int K, int E1, int E2, bool TB, bool S2>
-__global__ __launch_bounds__(T, T == MWF_B2_WIDE_T ? MWF_B2_WIDE_WAVES : T <= 512 ? ((TB && T < 512) ? 3 : 4) : MWF_B2_768_WAVES) void wfa_band2_kernel(const BatchArgs)
+__global__ __launch_bounds__(T, T == 1024 ? 4 : T == MWF_B2_WIDE_T ? MWF_B2_WIDE_WAVES : T <= 512 ? ((TB && T < 512) ? 3 : 4) : MWF_B2_768_WAVES) void wfa_band2_kernel(const BatchArgs)
 {
 	constexpr int NWK = (T / 64) * K, D = (E1 > E2 ? E1 : E2) + 1;
 	// the arguments are read from the kernarg segment where they are used (dev::kernel_args / dev::fresh), never held for the kernel's lifetime
@@ -925,7 +960,11 @@ int launch_one(const BatchArgs &a0, int grid, int lds_seq, bool seq2, hipStream_
 	BatchArgs a = a0;
 	a.band_lds_seq = lds_seq;
 	const int lds = lds_seq + lds_tail<T, K, E1, E2>();
-	if (a.want_cigar) {
+	if constexpr (T == 1024) { // the 1024-thread geometry exists on 2-bit sequence copies only (others: the generic kernel)
+		if (!seq2) return -1;
+		if (a.want_cigar) launch_variant<T, K, E1, E2, true, true>(a, grid, lds, st);
+		else launch_variant<T, K, E1, E2, false, true>(a, grid, lds, st);
+	} else if (a.want_cigar) {
 		if (seq2) launch_variant<T, K, E1, E2, true, true>(a, grid, lds, st);
 		else launch_variant<T, K, E1, E2, true, false>(a, grid, lds, st);
 	} else {
@@ -941,7 +980,11 @@ int occ_one(int lds_seq, bool seq2, bool tb)
 	const int lds = lds_seq + lds_tail<T, K, E1, E2>();
 	int n = 0;
 	hipError_t e;
-	if (tb) e = seq2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, true, true>, T, lds)
+	if constexpr (T == 1024) {
+		if (!seq2) return 0;
+		e = tb ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, true, true>, T, lds)
+		       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, false, true>, T, lds);
+	} else if (tb) e = seq2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, true, true>, T, lds)
 	                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, true, false>, T, lds);
 	else e = seq2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, false, true>, T, lds)
 	              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, false, false>, T, lds);
@@ -978,6 +1021,7 @@ bool band2_supported(const Penalty &p)
 	do {                                                                            \
 		if (g.block == 512) MWF_BAND2_PEN(FN, MWF_B2_WIDE_T, MWF_B2_WIDE_K, __VA_ARGS__) \
 		if (g.block == 768) MWF_BAND2_PEN(FN, 768, 2, __VA_ARGS__)                  \
+		if (g.block == 1024) MWF_BAND2_PEN(FN, 1024, MWF_B2_SPAN_K, __VA_ARGS__)    \
 		MWF_BAND2_REST(FN, __VA_ARGS__)                                             \
 	} while (0)
 
@@ -987,6 +1031,8 @@ int launch_band2(const BatchArgs &a, int grid, const BandGeom &g, void *stream)
 	MWF_BAND2_DISPATCH(launch_one, a, grid, g.lds_bytes, g.seq2 != 0, (hipStream_t)stream);
 	return -1;
 }
+
+int band2_span_chunks() { return 16 * MWF_B2_SPAN_K; }
 
 int band2_kernel_occupancy(const Penalty &p, const BandGeom &g, bool cigar)
 {

@@ -75,6 +75,7 @@ struct mwf_gpu_s {
 	int mid_max_pairs = -1;    // a batch of at most this many pairs may use the one-workgroup-per-pair, rings-in-LDS kernel (mwf_mid.hip) for its mid-size pairs (-1: one per CU; 0: never)
 	int mid_block = 0;         // its threads per workgroup: 0 by span (256 up to 512 columns, else 1024), 256, 1024
 	int band_pack = -1;        // int16-packed E/F registers in the band kernel: 0 never, otherwise whenever the value ranges allow
+	int band_span = 1;         // the 1024-thread geometry of the packed band kernel (80 chunks, biased offsets: pairs of up to ~60 kb whose windows stay below ~20 000 columns): 0 never, 2: every pair it can take (tests)
 	int ring16 = 1;            // generic kernel with E2/F2 in LDS: 16-bit ring rows in HBM while target length + penalty fits 16 bits (0: never)
 	int ring16_block = 0;      // its threads per workgroup (0: 512 score-only — two workgroups per CU with the 64 KB LDS copy —, 768 with traceback)
 	bool ring16_off_once = false; // set around the re-run of pairs whose offsets outgrew 16 bits
@@ -126,7 +127,7 @@ struct mwf_gpu_batch_s {
 	int32_t *d_order = nullptr;
 	std::vector<int32_t> h_order;   // what d_order holds: pair ids, grouped by size class, longest first inside a class
 	std::vector<int32_t> h_len_order; // pair ids, longest pair first (stable): what every grouping is dealt from
-	std::vector<int8_t> h_class;    // size class of every pair (0 generic, then band kernels: 1 wide, 2 small, 3 tiny, 4 micro)
+	std::vector<int8_t> h_class;    // size class of every pair (0 generic, then band kernels: 1 wide, 2 small, 3 tiny, 4 micro; 5: the 1024-thread span geometry)
 	std::vector<int8_t> h_kind;     // kernel that ran the pair last (0 generic, 1 whole-device, 2 band)
 	std::vector<int8_t> h_acgt;     // from the host's look at the bytes while a batch is built from host memory: 1 both sequences are plain
 	                                // A/C/G/T, 0 not (such a pair goes to the byte-wise sequence copy at once); empty: unknown (wrapped device
@@ -160,7 +161,7 @@ struct mwf_gpu_batch_s {
 		int64_t tun_key[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 		int64_t max_len = 0, max_bound = 0;
 		bool has_groups = false, mid_bytes = false;
-		struct GI { int32_t n = 0; int64_t max_len = 0, max_bound = 0, max_bound1 = 0, max_tl = 0, max_seq_lds = 0; } gi[13];
+		struct GI { int32_t n = 0; int64_t max_len = 0, max_bound = 0, max_bound1 = 0, max_tl = 0, max_seq_lds = 0; } gi[14];
 		std::vector<int8_t> cls0, flags0;
 	} plan;
 	std::vector<char> host_out;     // the fixed-size results as they came back (finalize)
@@ -353,6 +354,10 @@ int64_t penalty_bound(const mwf_opt_t &o, int64_t tl, int64_t ql, bool honour_ma
 
 // widest window the 64-, 128- and 256-thread packed band variants are chosen for: (waves x 3 chunks - 1) x 256 - 64 columns
 constexpr int64_t kBandMicroWindow = (1 * 3 - 1) * 256 - 64, kBandTinyWindow = (2 * 3 - 1) * 256 - 64, kBandSmallWindow = (4 * 3 - 1) * 256 - 64;
+constexpr int64_t kBandWideWindow = (8 * 3 - 1) * 256 - 64;
+// ... and the 1024-thread span geometry (16 waves x kBand2SpanK chunks, offsets biased by the target length: mwf_band2.hip wide_bias)
+constexpr int64_t kBandSpanMaxSeq = 62000;
+inline int64_t band_span_window() { return ((int64_t)band2_span_chunks() - 1) * 256 - 64; }
 
 struct Plan {
 	int kind = 0;              // 0: generic kernel, 2: band kernel
@@ -403,6 +408,12 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 		}
 	}
 	if (want_kind == 0 || low_mem || !can_packed) return;
+	if (geom_block == 1024) { // the span geometry (the caller checked the lengths of every pair: kBandSpanMaxSeq); 2-bit sequence copies only
+		const int64_t need_lds = ((max_len >> 4) + 4) * 4;
+		if (g->band_span == 0 || g->seq2bit == 0 || g->acgt_off_once || need_lds > 150 * 1024) return;
+		pl.kind = 2, pl.band = BandGeom{1024, 1, (int)band2_span_chunks() * 256, (int)((need_lds + 15) / 16 * 16), 1, 0};
+		return;
+	}
 	// (window_hint: pairs a kernel handed back early come with the window they are expected to need, dev::window_forecast — the re-run
 	// takes the class that fits that, not the one that fits the worst case)
 	const int64_t max_window = window_hint > 0 ? std::min<int64_t>(std::min<int64_t>(max_len + 1, 2 * max_bound + 3), window_hint) : std::min<int64_t>(max_len + 1, 2 * max_bound + 3);
@@ -1171,6 +1182,7 @@ int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value)
 	else if (!strcmp(name, "ring16")) g->ring16 = (int)value;
 	else if (!strcmp(name, "ring16_block") && (value == 0 || value == 512 || value == 768)) g->ring16_block = (int)value;
 	else if (!strcmp(name, "band_pack")) g->band_pack = (int)value;
+	else if (!strcmp(name, "band_span") && value >= 0 && value <= 2) g->band_span = (int)value;
 	else if (!strcmp(name, "lane_chunks") && value >= 0 && value <= 4) g->lane_chunks = (int)value;
 	else if (!strcmp(name, "host_results")) g->res_pin_on = value != 0;
 	else if (!strcmp(name, "lane_max_len")) g->lane_max_len = (int)std::max<int64_t>(0, std::min<int64_t>(value, 8000));
@@ -1278,7 +1290,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	mwf_gpu_batch_t::PlanCache &PC = b->plan;
 	{
 		const int32_t ok[8] = {opt->flag & MWF_F_CIGAR, opt->x, opt->o1, opt->e1, opt->o2, opt->e2, opt->step, opt->max_s};
-		const int64_t tk[14] = {g->force_kind, g->block, g->band_pack, g->ring16, g->lds_e2, g->scalar_generic, g->lane_max_len, g->seq2bit,
+		const int64_t tk[14] = {g->force_kind, g->block, g->band_pack + 4 * (int64_t)g->band_span, g->ring16, g->lds_e2, g->scalar_generic, g->lane_max_len, g->seq2bit,
 		                        g->mid_max_pairs, g->coop_min_len, g->sys_p, g->coop_grid_cap, b->debug_pair, g->lane_chunks};
 		if (PC.valid && (memcmp(ok, PC.opt_key, sizeof(ok)) || memcmp(tk, PC.tun_key, sizeof(tk)))) PC.valid = false;
 		if (!PC.valid) memcpy(PC.opt_key, ok, sizeof(ok)), memcpy(PC.tun_key, tk, sizeof(tk)), PC.has_groups = false;
@@ -1366,13 +1378,15 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	// 10: short pairs on the one-diagonal-per-lane kernel (mwf_lane.hip); what outgrows its 64 columns moves to the band classes
 	// 11: mid-size pairs of a small batch on the one-workgroup-per-pair, rings-in-LDS kernel (mwf_mid.hip); what outgrows its span moves to the band classes
 	typedef mwf_gpu_batch_t::PlanCache::GI GroupInfo;
-	GroupInfo gi[13];
+	GroupInfo gi[14];
 	bool mid_bytes = false;
 	// (12: the pairs of class 10 the host knows not to be plain A/C/G/T — reads with an N —: the lane kernel on byte-wise copies)
-	static const int run_order[13] = {5, 0, 1, 6, 2, 7, 3, 8, 4, 9, 11, 10, 12}; // largest workspace first
+	// 13: pairs too long (or with windows too wide) for the 512-thread packed geometry on its 1024-thread span geometry: targets of up to ~60 kb on biased
+	// 16-bit offsets, windows of up to ~16 000 columns; what outgrows it moves to the generic kernel
+	static const int run_order[14] = {5, 0, 13, 1, 6, 2, 7, 3, 8, 4, 9, 11, 10, 12}; // largest workspace first
 	if (PC.has_groups) { // same lengths, same options, same tunables as last time: classes, order (already on the device) and maxima as they were
 		b->h_class = PC.cls0, b->h_flags = PC.flags0;
-		for (int c = 0; c < 13; ++c) gi[c] = PC.gi[c];
+		for (int c = 0; c < 14; ++c) gi[c] = PC.gi[c];
 		mid_bytes = PC.mid_bytes;
 	} else {
 		const bool lane_ok = g->lane_max_len > 0 && lane_supported(P0);
@@ -1380,9 +1394,9 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		const bool mid_ok = g->force_kind < 0 && g->block == 0 && mid_cap > 0 && b->n <= mid_cap && mid_supported(P0);
 		const bool know_acgt = !b->h_acgt.empty() && g->seq2bit != 0;
 		const bool pack_pen = g->band_pack != 0 && band2_supported(P0);
-		const bool gen16 = g->ring16 != 0 && g->lds_e2 && !g->scalar_generic && P0.e2 == 1;
 		std::vector<int8_t> cls((size_t)b->n); // group of every pair
-		int32_t count[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+		int32_t count[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+		const bool span_pen = pack_pen && g->band_span != 0 && g->seq2bit != 0;
 		for (int32_t i = 0; i < b->n; ++i) {
 			const int64_t tl = b->h_tl[i], ql = b->h_ql[i], len = tl + ql;
 			const int64_t bound1 = penalty_bound(*opt, tl, ql, false);
@@ -1397,13 +1411,17 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 				// outgrow that span, finalize() moves it to the wide band kernel, and from there to the generic one.
 				// (a pair too long for the packed band kernel goes to the generic kernel with 16-bit ring rows where those apply: faster than
 				// the unpacked band kernel and no window overflows to re-run, see choose_kernel)
-				if (!packable && gen16 && tl + len / 8 < 65500) c = 0;
+				// (... unless the span geometry of the packed kernel takes it: windows of up to ~16 000 columns — a 50 kb pair at 3 % —, which is
+				// where the pairs whose windows will mostly fit are drawn: tl + ql below seven spans; bench.py long_batches)
+				const bool span_ok = span_pen && tl <= kBandSpanMaxSeq && ql <= kBandSpanMaxSeq && !(know_acgt && !b->h_acgt[i]);
+				if (span_ok && g->band_span == 2) c = 13;
 				else if (packable && (window <= kBandMicroWindow || len + 1 <= 2 * (int64_t)(1 * 3 * 256))) c = 4;
 				else if (packable && (window <= kBandTinyWindow || len + 1 <= 3 * (int64_t)(2 * 3 * 256))) c = 3;
 				else if (packable && (window <= kBandSmallWindow || len + 1 <= 3 * (int64_t)(4 * 3 * 256))) c = 2;
 				else if (packable && len + 1 <= 4 * (int64_t)(8 * 3 * 256)) c = 1;
+				else if (span_ok && len + 1 <= 7 * band2_span_chunks() * 256) c = 13;
 			}
-			b->h_class[i] = (int8_t)(c == 5 ? 0 : c);
+			b->h_class[i] = (int8_t)(c == 5 ? 0 : c == 13 ? 5 : c);
 			b->h_flags[i] = (int8_t)(step0 ? 1 : 0);
 			// short pairs: a window of 64 diagonals holds them while the penalty stays below ~45 (a 200 bp pair at 5 %)
 			// (in a batch small enough for the mid kernel the lane kernel keeps the pairs of up to 320 bases: 16 x 400 bp 0.31 ms on the lane
@@ -1434,7 +1452,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		}
 		// The processing order: groups in run order, longest first inside a group (the persistent workgroups finish together).  h_order is
 		// already sorted longest first (batch_common) and that order is stable: one pass over it deals the pairs to their groups.
-		std::vector<int32_t> start(13, 0), order((size_t)b->n);
+		std::vector<int32_t> start(14, 0), order((size_t)b->n);
 		{
 			int32_t at = 0;
 			for (int c : run_order) start[c] = at, at += count[c], gi[c].n = count[c];
@@ -1452,7 +1470,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 			if (upload_segments(g, (char*)b->d_order, std::vector<Seg>{Seg{b->h_order.data(), b->h_order.size() * 4}})) return -1; // (waits for earlier work on the stream first)
 		}
 		PC.cls0 = b->h_class, PC.flags0 = b->h_flags, PC.mid_bytes = mid_bytes, PC.has_groups = true;
-		for (int c = 0; c < 13; ++c) PC.gi[c] = gi[c];
+		for (int c = 0; c < 14; ++c) PC.gi[c] = gi[c];
 	}
 	int n_groups = 0, done_groups = 0;
 	for (const GroupInfo &G : gi) n_groups += G.n > 0;
@@ -1464,11 +1482,11 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		if (G.n == 0) continue;
 		++done_groups;
 		int ran = 0;
-		const int cc = c == 11 ? 6 : (c == 10 || c == 12) ? 5 : c > 5 ? c - 5 : c;
+		const int cc = c == 13 ? 7 : c == 11 ? 6 : (c == 10 || c == 12) ? 5 : c > 5 ? c - 5 : c;
 		g->acgt_off_once = (c > 5 && c < 10) || (c == 11 && mid_bytes) || c == 12;
 		const int rc = run_batch_kernel(g, b, c == 5 ? *opt : opt_hi, b->d_order + at, G.n, slots, G.max_len, G.max_bound, G.max_bound1,
 		                                done_groups == 1, (classes || c >= 11) ? (c == 0 || c == 5 ? 0 : 2) : -1, G.max_tl, G.max_seq_lds, done_groups == n_groups,
-		                                cc == 6 ? 33 : cc == 5 ? 32 : cc == 4 ? 64 : cc == 3 ? 128 : cc == 2 ? 256 : 0, &ran);
+		                                cc == 7 ? 1024 : cc == 6 ? 33 : cc == 5 ? 32 : cc == 4 ? 64 : cc == 3 ? 128 : cc == 2 ? 256 : 0, &ran);
 		g->acgt_off_once = false;
 		if (rc) return -1;
 		for (size_t j = at; j < at + (size_t)G.n; ++j) b->h_kind[b->h_order[j]] = (int8_t)ran;
@@ -1547,7 +1565,7 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 	const char *fail = nullptr;
 	for (int round = 0; round < 16 && !fail; ++round) {
 		// where every unfinished pair goes next: route = kind (0 generic, 1 whole-device alone, 2 band) and, for the band kernel, the class
-		std::vector<int32_t> to_generic[2], to_generic32[2], to_band_wide[2], to_band_bytes[2], same_fewer[3][2], coop_alone;
+		std::vector<int32_t> to_generic[2], to_generic32[2], to_band_wide[2], to_band_span[2], to_band_bytes[2], same_fewer[3][2], coop_alone;
 		bool grow_coop = false;
 		for (size_t i = 0; i < n; ++i) {
 			const int32_t st = b->h_status[i];
@@ -1555,6 +1573,8 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 			const int kind = b->h_kind[i], step0 = b->h_flags[i] & 1;
 			if (st == ST_BAND_OVERFLOW && kind == 0) {
 				to_generic32[step0].push_back((int32_t)i); // an offset outgrew the generic kernel's 16-bit ring rows: 32-bit rows
+			} else if (st == ST_ALPHABET && kind == 2 && b->h_class[i] == 5) {
+				b->h_class[i] = 0, to_generic[step0].push_back((int32_t)i); // (the span geometry has no byte-wise form)
 			} else if (st == ST_ALPHABET && kind == 2) {
 				to_band_bytes[step0].push_back((int32_t)i); // not plain ACGT: the byte-wise band kernel of the same class
 			} else if (st == ST_BAND_OVERFLOW && kind == 2) {
@@ -1562,7 +1582,11 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 				// holds goes straight to the generic kernel)
 				const int64_t est = b->h_iter[i] < 0 ? -b->h_iter[i] : 0;
 				// (... only when the forecast is half again beyond the widest class: it is an estimate, and the generic kernel is several times slower)
-				if (b->h_class[i] >= 2 && est <= ((8 * 3 - 1) * 256 - 64) * 3 / 2) b->h_class[i] = 1, to_band_wide[step0].push_back((int32_t)i);
+				// what outgrew (or is forecast to outgrow) the 512-thread geometry: the 1024-thread span geometry, if the pair fits that
+				const bool span_ok = b->h_class[i] >= 1 && b->h_class[i] <= 4 && g->band_span != 0 && g->seq2bit != 0 && g->force_kind < 0 && g->block == 0 &&
+				                     b->h_tl[i] <= kBandSpanMaxSeq && b->h_ql[i] <= kBandSpanMaxSeq && est <= band_span_window();
+				if (b->h_class[i] >= 2 && est <= kBandWideWindow * 3 / 2) b->h_class[i] = 1, to_band_wide[step0].push_back((int32_t)i);
+				else if (span_ok) b->h_class[i] = 5, to_band_span[step0].push_back((int32_t)i);
 				else b->h_class[i] = 0, to_generic[step0].push_back((int32_t)i);
 			} else if (kind == 1 && st == ST_INTERNAL && !(b->h_flags[i] & 8)) {
 				// a wait between workgroups of the whole-device kernel ran into its spin limit (they were not all resident, e.g.
@@ -1596,7 +1620,7 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 			}
 		}
 		size_t n_redo = coop_alone.size();
-		for (int z = 0; z < 2; ++z) n_redo += to_generic[z].size() + to_generic32[z].size() + to_band_wide[z].size() + to_band_bytes[z].size() + same_fewer[0][z].size() + same_fewer[2][z].size();
+		for (int z = 0; z < 2; ++z) n_redo += to_generic[z].size() + to_generic32[z].size() + to_band_wide[z].size() + to_band_span[z].size() + to_band_bytes[z].size() + same_fewer[0][z].size() + same_fewer[2][z].size();
 		if (n_redo == 0) break;
 		b->n_retries += (int32_t)n_redo;
 		if (grow_coop) g->coop_tb_mult *= 2;
@@ -1605,7 +1629,7 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 		const bool shrink = !same_fewer[0][0].empty() || !same_fewer[0][1].empty() || !same_fewer[2][0].empty() || !same_fewer[2][1].empty();
 		if (shrink) tb_slots = std::max(1, tb_slots / 8);
 		auto pl_low_mem = [](const mwf_opt_t &o) { return (o.flag & MWF_F_CIGAR) && o.step > 0; };
-		auto rerun = [&](std::vector<int32_t> &ids, int step0, int want_kind, int slots, bool use_forecast = false) -> int {
+		auto rerun = [&](std::vector<int32_t> &ids, int step0, int want_kind, int slots, bool use_forecast = false, int geom = 0) -> int {
 			if (ids.empty()) return 0;
 			int64_t hint = 0;
 			if (use_forecast) { // every pair of the re-run came back with a forecast: the class that holds the widest of them (+ 25 %)
@@ -1636,7 +1660,7 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 			const bool to_mid = want_kind == 2 && use_forecast && g->force_kind < 0 && g->block == 0 && (int)ids.size() <= mid_cap && mid_supported(Pm) && max_len <= 1200 &&
 			                    max_tl + max_bound < 32760 && !(pl_low_mem(o));
 			if (rc == 0) rc = run_batch_kernel(g, b, o, (const int32_t*)tmp.p, (int32_t)ids.size(), slots, max_len, max_bound, max_bound1, false,
-			                                   want_kind, max_tl, max_seq_lds, 0, to_mid ? 33 : 0, &ran, hint);
+			                                   want_kind, max_tl, max_seq_lds, 0, to_mid ? 33 : geom, &ran, hint);
 			if (rc == 0) rc = hipStreamSynchronize(g->stream) == hipSuccess ? 0 : -1;
 			release(g, tmp);
 			if (rc) return -1;
@@ -1651,12 +1675,15 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 			g->ring16_off_once = false;
 			if (rc32) return -1;
 			if (rerun(to_band_wide[z], z, 2, wide, true)) return -1;
+			if (rerun(to_band_span[z], z, 2, wide, false, 1024)) return -1;
 			g->acgt_off_once = true;
 			const int rc_bytes = rerun(to_band_bytes[z], z, 2, wide);
 			g->acgt_off_once = false;
 			if (rc_bytes) return -1;
 			if (rerun(same_fewer[0][z], z, 0, std::max(1, std::min<int>(tb_slots, (int)same_fewer[0][z].size())))) return -1;
-			if (rerun(same_fewer[2][z], z, 2, std::max(1, std::min<int>(tb_slots, (int)same_fewer[2][z].size())))) return -1;
+			bool all_span = !same_fewer[2][z].empty();
+			for (int32_t i : same_fewer[2][z]) all_span = all_span && b->h_class[i] == 5;
+			if (rerun(same_fewer[2][z], z, 2, std::max(1, std::min<int>(tb_slots, (int)same_fewer[2][z].size())), false, all_span ? 1024 : 0)) return -1;
 		}
 		if (fetch()) return -1;
 	}

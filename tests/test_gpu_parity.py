@@ -1087,11 +1087,14 @@ def test_two_threads_on_the_whole_device_kernel(oracle, capfd):
     assert "gave up waiting" not in capfd.readouterr().err
 
 
-def test_config5_default_kernel_at_full_pair_size(oracle):
+@pytest.mark.parametrize("span", [1, 0])
+def test_config5_default_kernel_at_full_pair_size(span, oracle):
     """BASELINE configs[4]'s pair shape on the kernel a rank's share of that batch really selects: >= 256 pairs x 50 kb @ 3 % on
-    DEFAULT settings go to the generic kernel with 16-bit ring rows (stats.kernel_kind == 0, stats.packed == 16).  Score-only and
-    CIGAR runs agree, every CIGAR re-scores, four pairs equal the oracle, the stored reference answer of cfg5#698 is reproduced
-    inside the batch, and one pair whose target + penalty exceeds 65 532 comes back through the 32-bit rows."""
+    DEFAULT settings go to the packed band kernel's 1024-thread span geometry (stats.kernel_kind == 2, stats.packed == 1, block 1024:
+    16-bit offsets biased by the target length), with "band_span" 0 to the generic kernel with 16-bit ring rows (kernel_kind 0,
+    packed 16).  Score-only and CIGAR runs agree, every CIGAR re-scores, four pairs equal the oracle, the stored reference answer of
+    cfg5#698 is reproduced inside the batch, and one pair whose window outgrows the span (handed back early, with a forecast) and whose
+    target + penalty exceeds 65 532 comes back through the generic kernel's 32-bit rows."""
     gold = [v for v in load_golden("bench_shaped.jsonl") if v["id"].startswith("cfg5") and v["entry"] == "exact" and not v["opt"]["flag"]]
     assert gold, "cfg5 golden vector missing"
     gt, gq = golden_inputs(gold[0])
@@ -1099,17 +1102,19 @@ def test_config5_default_kernel_at_full_pair_size(oracle):
     pairs.append((gt, gq))
     pairs.append(synth_pair(7200, 52000, 0.10))          # s ~ 15 k: target + penalty > 65 532
     eng = mw.Engine(0)
+    eng.set("band_span", span)
+    want = (2, 1, 1024) if span else (0, 16, 512)
     b = eng.upload(PackedBatch(pairs))
     b.align(mw.opt_init())
     st = eng.stats()
-    assert (st.kernel_kind, st.packed) == (0, 16), (st.kernel_kind, st.packed, st.block)
+    assert (st.kernel_kind, st.packed, st.block) == want, (st.kernel_kind, st.packed, st.block)
     s0, it0, _ = b.results()
-    assert eng.stats().n_retries == 1                    # the one pair that outgrew 16 bits
+    assert eng.stats().n_retries == (2 if span else 1)   # the one pair that outgrew the span (then the 16-bit rows) / the 16-bit rows
     assert (int(s0[254]), int(it0[254])) == (gold[0]["expect"]["s"], gold[0]["expect"]["n_iter"])
     assert int(s0[255]) + 52000 > 65532
     b.align(mw.opt_init(flag=mw.MWF_F_CIGAR))
     st = eng.stats()
-    assert (st.kernel_kind, st.packed) == (0, 16)
+    assert (st.kernel_kind, st.packed) == want[:2]
     s1, it1, nc = b.results()
     assert (s0 == s1).all() and (it0 == it1).all() and (s0 > 0).all()
     for i in (0, 85, 170, 253):
@@ -1121,6 +1126,79 @@ def test_config5_default_kernel_at_full_pair_size(oracle):
         assert mw.cigar2score(o, cig) == (int(s1[i]), len(pairs[i][0]), len(pairs[i][1])), i
     b.free()
     eng.close()
+
+
+def test_span_geometry_long_pairs_against_oracle(oracle):
+    """The packed band kernel's 1024-thread geometry (16 waves x 5 chunk slots, offsets biased by the target length so that targets of up
+    to ~60 kb fit 16 bits, mwf_band2.hip wide_bias): pairs of 20-60 kb whose windows stay below 20 000 columns, s, n_iter and CIGAR
+    against the oracle — default penalties, the (e1, e2) = (1, 1) and (2, 2) instantiations, a stop rule inside the pass."""
+    specs = [(50000, 0.03, 0, 0), (50000, 0.02, 0, 0), (40000, 0.035, 0, 0), (33000, 0.04, 0, 0), (20000, 0.06, 0, 0), (60000, 0.008, 0, 0),
+             (50000, 0.034, 0, 0), (25000, 0.05, 0, 0), (45000, 0.02, 3, 2500)]
+    pairs = [synth_pair(910 + i, tl, d, nl, lm) for i, (tl, d, nl, lm) in enumerate(specs)]
+    pk = PackedBatch(pairs)
+    for kw, sel in ((dict(), range(9)), (dict(flag=1), range(9)), (dict(flag=1, x=2, o1=3, e1=1, o2=6, e2=1), (1, 4)), (dict(x=6, o1=5, e1=2, o2=24, e2=2), (1, 5)),
+                    (dict(max_s=3000), (0, 5)), (dict(flag=1, max_iter=20000000), (0, 1))):
+        eng = mw.Engine(0)
+        eng.set("coop_min_len", 1 << 40)   # (a few long pairs alone would share the whole-device kernel)
+        b = eng.upload(pk)
+        b.align(mw.opt_init(**kw))
+        st = eng.stats()
+        assert (st.kernel_kind, st.packed, st.block) == (2, 1, 1024), (kw, st.kernel_kind, st.packed, st.block)
+        s, it, nc = b.results()
+        assert eng.stats().n_retries == 0, kw
+        o = make_opt(**kw)
+        for i in sel:
+            es, eit, ecig = oracle.align(pairs[i][0], pairs[i][1], o)
+            assert (int(s[i]), int(it[i])) == (es, eit), (kw, i)
+            if ecig is not None and es >= 0:
+                assert b.cigar(i, int(nc[i])).tolist() == ecig, (kw, i)
+        b.free()
+        eng.close()
+
+
+def test_span_geometry_hands_back_what_it_cannot_hold(oracle):
+    """What the span geometry cannot finish goes to the generic kernel and still equals the oracle: a window beyond its 80 chunks (handed
+    back early with a forecast), a 60 kb target whose dead values would drift into the live range of the biased offsets after ~3400
+    penalties (the range check at multiples of 256), two 62 kb sequences whose room arithmetic would leave 16 bits, bytes outside
+    A/C/G/T (the geometry exists on 2-bit sequence copies only)."""
+    t, q = synth_pair(77, 40000, 0.03)
+    pairs = [synth_pair(7301, 40000, 0.11), synth_pair(7302, 60000, 0.025), synth_pair(7303, 62000, 0.022), (t[:20000] + b"N" + t[20001:], q), synth_pair(7304, 30000, 0.03)]
+    eng = mw.Engine(0)
+    eng.set("coop_min_len", 1 << 40)
+    b = eng.upload(PackedBatch(pairs))
+    for kw in (dict(), dict(flag=1)):
+        b.align(mw.opt_init(**kw))
+        s, it, nc = b.results()
+        assert eng.stats().n_retries >= 3, eng.stats().n_retries
+        o = make_opt(**kw)
+        for i, (t_, q_) in enumerate(pairs):
+            es, eit, ecig = oracle.align(t_, q_, o)
+            assert (int(s[i]), int(it[i])) == (es, eit), (kw, i)
+            if ecig is not None:
+                assert b.cigar(i, int(nc[i])).tolist() == ecig, (kw, i)
+    b.free()
+    eng.close()
+
+
+def test_span_geometry_fuzz_on_short_pairs(oracle):
+    """"band_span" 2 sends every pair the span geometry can take to it, whatever its size: the fuzz set of the other band kernels (corner-case
+    lengths, empty sequences, homopolymers, tandem repeats, unrelated pairs, pairs past several shrinks) with a zero bias."""
+    pairs = fuzz_pairs(91, 60, 3000) + [synth_pair(8100 + i, 700 * (i + 1), 0.04 * (1 + i % 3)) for i in range(12)] + [(b"", b""), (b"ACGT", b""), (b"", b"AC")]
+    pk = PackedBatch(pairs)
+    for kw in (dict(), dict(flag=1), dict(flag=1, x=2, o1=3, e1=1, o2=6, e2=1), dict(max_s=200)):
+        eng = mw.Engine(0)
+        eng.set("band_span", 2)
+        b = eng.upload(pk)
+        b.align(mw.opt_init(**kw))
+        s, it, nc = b.results()
+        o = make_opt(**kw)
+        for i, (t, q) in enumerate(pairs):
+            es, eit, ecig = oracle.align(t, q, o)
+            assert (int(s[i]), int(it[i])) == (es, eit), (kw, i, len(t), len(q))
+            if ecig is not None and es >= 0:
+                assert b.cigar(i, int(nc[i])).tolist() == ecig, (kw, i)
+        b.free()
+        eng.close()
 
 
 def test_batch_multi_one_ranks_share_of_config5(oracle):
@@ -1142,7 +1220,7 @@ def test_batch_multi_one_ranks_share_of_config5(oracle):
     b.align(mw.opt_init())
     s, it, _ = b.results()
     st = eng.stats()
-    assert (st.kernel_kind, st.packed) == (0, 16) and st.n_retries == 0
+    assert (st.kernel_kind, st.packed, st.block) == (2, 1, 1024) and st.n_retries == 0   # the packed band kernel's span geometry
     assert [r[0] for r in got] == s.tolist() and [r[1] for r in got] == it.tolist()
     b.free()
     eng.close()
