@@ -151,7 +151,7 @@ def short_reads(mw, synth_pair, PackedBatch, reps=5):
 
 def long_batches(mw, synth_pair, PackedBatch, n=1250, tl=50000, div=0.03):
     """One GPU's share of BASELINE configs[4] (10 000 x 50 kb @ 3 % over 8 GPUs = 1250 pairs), score-only, on the default kernel choice
-    (the generic kernel with 16-bit ring rows): one warm-up align, one timed."""
+    (the packed band kernel's 1024-thread span geometry; round 3-4: the generic kernel with 16-bit ring rows): one warm-up align, one timed."""
     pairs = [synth_pair(60000 + i, tl, div) for i in range(n)]
     pk = PackedBatch(pairs)
     eng = mw.Engine(0)
@@ -165,10 +165,11 @@ def long_batches(mw, synth_pair, PackedBatch, n=1250, tl=50000, div=0.03):
     st = eng.stats()
     cells = int(it.sum())
     ks = st.kernel_ms * 1e-3
-    kb = 16 if st.packed == 16 else 32
+    kb = 8 if (st.kernel_kind == 2 and st.packed) else 16 if st.packed == 16 else 32   # packed band kernel: only the 16-bit H rows cross HBM (three loads + one store)
     rec = {"workload": f"{n} x {tl} bp @ {div:g}, score-only (one GPU's share of configs[4])", "kernel_ms": st.kernel_ms, "wall_ms": wall * 1e3,
            "gbp_s": pk.bases / wall / 1e9, "gcells_per_s": cells / wall / 1e9, "cells": cells, "n_retries": int(st.n_retries), "mean_s": float(s.mean()),
-           "kernel_kind": int(st.kernel_kind), "block": int(st.block), "ring_bits": 16 if st.packed == 16 else 32,
+           "kernel_kind": int(st.kernel_kind), "block": int(st.block), "ring_bits": 16 if (st.packed == 16 or st.kernel_kind == 2) else 32,
+           "kernel": KERNEL_NAMES.get(3 if (st.kernel_kind == 2 and st.packed) else st.kernel_kind, "?"), "kernel_bytes_per_cell": kb,
            "roofline": counter_roofline(ks, TRAFFIC.get(f"{n}x{tl}@{div:g}s", {}), float(kb) * cells, 48.0 * cells, "48 B x cells")}
     b.free()
     eng.close()

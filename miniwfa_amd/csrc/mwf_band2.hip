@@ -539,6 +539,7 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 			if (timed) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc0) :: "memory");
 #endif
 			const uint32_t off = (uint32_t)(cb << 1) + lane8;
+			// (measured and dropped, round 4: the rows of EVERY chunk the wave will run requested at the top of the penalty — 16 more VGPRs — 19.4 against 17.35 ms)
 			if (!XPREF || g != pre_g) load_rows(pre, rowx, row1, row2, off); // uniform; (else they were requested before the last barrier)
 			if (XPREF) pre_g = -1;
 			const int2 HX = pre.HX, O1 = pre.O1, O2 = pre.O2;

@@ -7,7 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = {
     "1024x10000@0.05s": ("profiles/r04/rocprof_band2_kernel_1024x10kb_score.txt", ["wfa_band2_kernel<512, 3, 2, 1, false, true>"], 8),
     "1024x10000@0.05c": ("profiles/r04/rocprof_band2_kernel_1024x10kb_cigar.txt", ["wfa_band2_kernel<512, 3, 2, 1, true, true>"], 8),
-    "1250x50000@0.03s": ("profiles/r04/rocprof_generic_stream16_kernel_1250x50kb.txt", ["wfa_batch_kernel<512, true, true, true, 0>"], 8),
+    "1250x50000@0.03s": ("profiles/r04/rocprof_band2_span_kernel_1250x50kb.txt", ["wfa_band2_kernel<1024, 5, 2, 1, false, true>"], 8),
+    "1250x50000@0.03s:generic16": ("profiles/r04/rocprof_generic_stream16_kernel_1250x50kb.txt", ["wfa_batch_kernel<512, true, true, true, 0>"], 8),
     "c4_like_150kb:score": ("profiles/r04/rocprof_sys_kernel_c4_score.txt", ["wfa_sys_kernel"], 4),
     "c4_like_150kb:cigar_highmem": ("profiles/r04/rocprof_sys_kernel_c4_cigar.txt", ["wfa_sys_kernel"], 4),
     "c4_like_150kb:cigar_lowmem_p5000": ("profiles/r04/rocprof_sys_kernel_c4_lowmem.txt", ["wfa_sys_kernel"], 4),

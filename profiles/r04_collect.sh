@@ -6,6 +6,7 @@ cpy() { [ -f "gpurun_out/$1/summary.txt" ] && cp "gpurun_out/$1/summary.txt" "pr
 cpy prof_r04_band2_score rocprof_band2_kernel_1024x10kb_score.txt
 cpy prof_r04_band2_cigar rocprof_band2_kernel_1024x10kb_cigar.txt
 cpy prof_r04_generic16 rocprof_generic_stream16_kernel_1250x50kb.txt
+cpy prof_r04_span rocprof_band2_span_kernel_1250x50kb.txt
 cpy pmcc_r04_lane rocprof_lane_kernel_40000x150bp.txt
 cpy pmcc_r04_mid1 rocprof_mid_kernel_1x2kb.txt
 cpy pmcc_r04_mid256 rocprof_mid_kernel_256x2kb.txt
