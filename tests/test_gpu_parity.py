@@ -250,6 +250,7 @@ def test_generic_kernel_takes_16_bit_rows_for_big_batches():
     for r16, n in ((0, 300), (1, 300), (1, 40)):
         eng = mw.Engine(0)
         eng.set("ring16", r16)
+        eng.set("band_span", 0)        # (by default pairs of this size take the packed band kernel's span geometry: this test is about the generic kernel)
         b = eng.upload(PackedBatch(pairs[:n]))
         b.align(mw.opt_init())
         s, it, nc = b.results()
