@@ -1,3 +1,8 @@
+// EXPERIMENT (round 4, not built): the mid kernel with a penalty in TWO STAGES on two sets of waves — the first half of the waves computes the recurrence of
+// penalty s and stores the row unextended, the second half extends the row of penalty s-1 in place meanwhile (every H lag >= 2).  Parity-green, but SLOWER:
+// one 500 bp pair 0.156-0.188 against 0.121-0.145 ms of kernel, 1 kb 0.30-0.36 against 0.23-0.29, 2 kb 0.73-0.78 against 0.51-0.53 (half the waves per stage =
+// twice the trips once the window passes 512 columns, and one more LDS word to read behind the barrier).
+
 // mwf_mid.hip — one workgroup per pair, one diagonal per lane, every wavefront ring in LDS: the kernel for a FEW mid-size pairs
 // (a single mwf_wfa_exact call on a pair of a few thousand bases — the reference's own usage, main.c:67-72 — or a handful of them).
 //
@@ -41,7 +46,10 @@ struct MidVars {
 	int32_t flags[4];     // per penalty mod 3 (+1 spare): bit 0 new lo edge live, bit 1 new hi edge live, bit 2 end cell reached, bits 4.. payload
 	int32_t red[2];       // shrink: first / last good column
 	int32_t item, word;
-	int32_t far, pad[3];  // furthest offset seen at a forecast penalty (dev::window_forecast)
+	int32_t far;          // furthest offset seen so far (dev::window_forecast)
+	int32_t fin;          // two-stage form: bit 0 the end cell was reached by the extension of the previous penalty's row, bits 4.. payload
+	int32_t fin_tb[3];    // ... the traceback byte of the end cell's column, per penalty mod 3
+	int32_t pad[3];
 };
 
 // bits of the 64-column group starting at column w0 that fall inside [lo,hi]
@@ -133,102 +141,120 @@ __device__ PassResult mid_pass(const ArgsT &A, PairMem &M, const MidLayout &L, c
 	if (TB) M.tb_stride = C, M.tb_left = left;
 	const int32_t cfin = ql + 1; // the end cell (tl-1, ql-1) lies on diagonal ql-tl, i.e. this column
 	const int32_t vb = lane * 2;  // a lane's entry idx - 1 = 64 g + lane of a row, in bytes (+ 128 g): entries idx-1, idx, idx+1 at byte offsets 0, 2, 4
+	// A penalty in TWO STAGES on two sets of waves (every H lag >= 2): the first half of the waves computes the recurrence of penalty s and
+	// stores the row UNEXTENDED, the second half extends the row of penalty s-1 in place meanwhile — nobody reads a row before the penalty after
+	// next.  What a lone pair pays per penalty is ONE trip of one wave plus the barrier (most waves idle anyway), and the recurrence trip
+	// without the match extension is a third of the whole.  Nothing but the extended offsets themselves depends on the extension: edge
+	// liveness (an extension adds >= 0 and only to live offsets), good bits (an extension stays inside the matrix) and the traceback byte
+	// are those of the unextended cell.  The end cell is seen one penalty late (V.fin): the penalty computed meanwhile is dropped.
+	const bool piped = min(A.pen.x, min(A.pen.oe1, A.pen.oe2)) >= 2 && NW >= 2;
+	const int32_t NR = piped ? NW / 2 : NW;      // waves of the recurrence stage
+	int32_t plo = c00, phi = c00, oP = 0;        // window and row of the previous penalty (what the extension stage works on)
+	if (tid == 0) V.fin = 0;
 	for (;;) {
-#ifdef MWF_MID_TIMING // cycles per penalty of one wave (max_iter = -thread): header | groups | flags .. barrier | bookkeeping; groups this wave ran in bits 28..
-		const uint64_t tm0 = __builtin_readcyclecounter();
-		int n_groups = 0;
-#endif
 		const int32_t lo = wf_lo > 1 ? wf_lo - 1 : 1;       // miniwfa.c:417-418
 		const int32_t hi = wf_hi < cmax ? wf_hi + 1 : cmax;
 		const int32_t s_new = s + 1;
-		if (lo < left || hi > right || s_new + tl >= 32760) { R.status = ST_BAND_OVERFLOW; break; } // (an offset — a target index, or past the matrix by one per penalty — must fit 16 bits)
-		if (TB && tb_used + C > tb_slot_bytes) { R.status = ST_TB_OVERFLOW; break; }
+		int32_t leave = ST_OK;
+		if (lo < left || hi > right || s_new + tl >= 32760) leave = ST_BAND_OVERFLOW; // (an offset — a target index, or past the matrix by one per penalty — must fit 16 bits)
+		else if (TB && tb_used + C > tb_slot_bytes) leave = ST_TB_OVERFLOW;
+		if (leave != ST_OK && !(piped && s > 0)) { R.status = leave; break; }
+		// (two stages: the row of penalty s is not extended yet — it may hold the end cell; only the extension runs in this last round)
 		const int32_t newH = curH + 1 == nH ? 0 : curH + 1;
 		const int32_t npar = par + 1 == 3 ? 0 : par + 1;
 		const bool track_good = (((256 - (s_new & 255)) & 255) < nH); // a shrink can still see this slice
-		if (wave == 0) { // (the whole wave stores the same words: no exec mask to set up)
+		if (wave == 0 && leave == ST_OK) { // (the whole wave stores the same words: no exec mask to set up)
 			win[newH] = make_int2(lo, hi);
 			V.flags[npar + 1 == 3 ? 0 : npar + 1] = 0; // the flag word of the NEXT penalty (its last readers passed the previous barrier)
-#ifndef MWF_MID_TIMING
 			if (trace_band && s_new - 1 < dbg_cap) M.dbg[2 * (s_new - 1)] = lo, M.dbg[2 * (s_new - 1) + 1] = hi;
-#endif
 		}
-		// columns written: the window and nH either side (dead), clamped to the span
-		const int32_t g_first = (max(lo - nH, left) - left) >> 6, g_last = (min(hi + nH, right) - left) >> 6;
 		uint32_t flags = 0;
 		int32_t fin_info = 0;
-		const bool forecast = s_new == 64 || s_new == 256 || s_new == 1024; // uniform: look at how far the pair has come (dev::window_forecast)
 		int32_t far = kDead16;
-#ifdef MWF_MID_TIMING
-		const uint64_t tm1 = __builtin_readcyclecounter();
-#endif
-		for (int32_t g = g_first + ((wave - g_first) & (NW - 1)); g <= g_last; g += NW) {
-#ifdef MWF_MID_TIMING
-			++n_groups;
-#endif
-			const int32_t ga = vb + 128 * g, c = left + 64 * g + lane;
-			const int32_t d = c - 1 - tl;
-			// sources (reference wf_next_prep, miniwfa.c:252-257)
-			const char *const pX = base + ga + oX, *const pA = base + ga + oA, *const pB = base + ga + oB;
-			const int32_t hx = *(const int16_t*)(pX + 2), o1m = *(const int16_t*)pA, o1p = *(const int16_t*)(pA + 4), o2m = *(const int16_t*)pB, o2p = *(const int16_t*)(pB + 4);
-			const int32_t g1m = *(const int16_t*)(base + ga + (bE1 + oR1)), g1p = *(const int16_t*)(base + ga + (bF1 + oR1) + 4);
-			const int32_t g2m = *(const int16_t*)(base + ga + (bE2 + oR2)), g2p = *(const int16_t*)(base + ga + (bF2 + oR2) + 4);
-			const bool act = c >= lo && c <= hi;
-			const Cell v = wf_cell<TB>(hx, o1m, g1m, o2m, g2m, o1p, g1p, o2p, g2p);
-			*(int16_t*)(base + ga + (bE1 + oN1) + 2) = (int16_t)(act ? max(v.e1, kDead16) : kDead16), *(int16_t*)(base + ga + (bF1 + oN1) + 2) = (int16_t)(act ? max(v.f1, kDead16) : kDead16);
-			*(int16_t*)(base + ga + (bE2 + oN2) + 2) = (int16_t)(act ? max(v.e2, kDead16) : kDead16), *(int16_t*)(base + ga + (bF2 + oN2) + 2) = (int16_t)(act ? max(v.f2, kDead16) : kDead16);
-			// match extension (reference wf_extend, miniwfa.c:400-411) of the cells inside the matrix
-			const bool inm = act && in_matrix(d, v.h, tl, ql);
-			const int32_t j = inm ? v.h + 1 : 0, i = inm ? d + j : 0;
-			const int32_t nmat = S2 ? lds_extend16(lt, lq, j, i, inm ? min(tl - j, ql - i) : 0) : lds_extend8(lt, lq, j, i, inm ? min(tl - j, ql - i) : 0);
-			const int32_t h = act ? max(v.h + nmat, kDead16) : kDead16;
-			*(int16_t*)(base + ga + oN + 2) = (int16_t)h;
-			far = max(far, h);
-			if (TB && act) M.tb[tb_used + (c - left)] = (uint8_t)v.tb;
-			if (track_good) { // some array holds an in-matrix offset here (good_diag, miniwfa.c:139-142)
-				const bool gd = act && (inm || in_matrix(d, v.e1, tl, ql) || in_matrix(d, v.f1, tl, ql) || in_matrix(d, v.e2, tl, ql) || in_matrix(d, v.f2, tl, ql));
-				const unsigned long long m = __ballot(gd);
-				if (lane == 0) good[newH * NG + g] = m;
+		const bool forecast = s_new == 64 || s_new == 256 || s_new == 1024; // uniform: look at how far the pair has come (dev::window_forecast)
+		if (leave != ST_OK ? false : wave < NR) {
+			// ---- stage 1: the recurrence.  Columns written: the window and nH either side (dead), clamped to the span
+			const int32_t g_first = (max(lo - nH, left) - left) >> 6, g_last = (min(hi + nH, right) - left) >> 6;
+			for (int32_t g = g_first + ((wave - g_first) & (NR - 1)); g <= g_last; g += NR) { // (NR is a power of two)
+				const int32_t ga = vb + 128 * g, c = left + 64 * g + lane;
+				const int32_t d = c - 1 - tl;
+				// sources (reference wf_next_prep, miniwfa.c:252-257)
+				const char *const pX = base + ga + oX, *const pA = base + ga + oA, *const pB = base + ga + oB;
+				const int32_t hx = *(const int16_t*)(pX + 2), o1m = *(const int16_t*)pA, o1p = *(const int16_t*)(pA + 4), o2m = *(const int16_t*)pB, o2p = *(const int16_t*)(pB + 4);
+				const int32_t g1m = *(const int16_t*)(base + ga + (bE1 + oR1)), g1p = *(const int16_t*)(base + ga + (bF1 + oR1) + 4);
+				const int32_t g2m = *(const int16_t*)(base + ga + (bE2 + oR2)), g2p = *(const int16_t*)(base + ga + (bF2 + oR2) + 4);
+				const bool act = c >= lo && c <= hi;
+				const Cell v = wf_cell<TB>(hx, o1m, g1m, o2m, g2m, o1p, g1p, o2p, g2p);
+				*(int16_t*)(base + ga + (bE1 + oN1) + 2) = (int16_t)(act ? max(v.e1, kDead16) : kDead16), *(int16_t*)(base + ga + (bF1 + oN1) + 2) = (int16_t)(act ? max(v.f1, kDead16) : kDead16);
+				*(int16_t*)(base + ga + (bE2 + oN2) + 2) = (int16_t)(act ? max(v.e2, kDead16) : kDead16), *(int16_t*)(base + ga + (bF2 + oN2) + 2) = (int16_t)(act ? max(v.f2, kDead16) : kDead16);
+				const bool inm = act && in_matrix(d, v.h, tl, ql);
+				int32_t nmat = 0;
+				if (!piped) { // match extension (reference wf_extend, miniwfa.c:400-411) of the cells inside the matrix, in line
+					const int32_t j = inm ? v.h + 1 : 0, i = inm ? d + j : 0;
+					nmat = S2 ? lds_extend16(lt, lq, j, i, inm ? min(tl - j, ql - i) : 0) : lds_extend8(lt, lq, j, i, inm ? min(tl - j, ql - i) : 0);
+				}
+				const int32_t h = act ? max(v.h + nmat, kDead16) : kDead16;
+				*(int16_t*)(base + ga + oN + 2) = (int16_t)h;
+				if (!piped) far = max(far, h);
+				if (TB && act) M.tb[tb_used + (c - left)] = (uint8_t)v.tb;
+				if (TB && piped && c == cfin) V.fin_tb[npar] = (int32_t)(v.tb & 7u);
+				if (track_good) { // some array holds an in-matrix offset here (good_diag, miniwfa.c:139-142)
+					const bool gd = act && (inm || in_matrix(d, v.e1, tl, ql) || in_matrix(d, v.f1, tl, ql) || in_matrix(d, v.e2, tl, ql) || in_matrix(d, v.f2, tl, ql));
+					const unsigned long long m = __ballot(gd);
+					if (lane == 0) good[newH * NG + g] = m;
+				}
+				// edge rule (miniwfa.c:325-326): H is the max of the five, so "any live" == "H live"
+				const uint32_t live = (uint32_t)(h >= -1);
+				// termination (miniwfa.c:405-409)
+				const bool fin = !piped && act && c == cfin && h == tl - 1 && in_matrix(ql - tl, h - nmat, tl, ql);
+				flags |= (live & (uint32_t)(c == lo)) | ((live & (uint32_t)(c == hi)) << 1) | ((uint32_t)fin << 2);
+				fin_info = fin ? (nmat == 0 ? (int32_t)(v.tb & 7u) : 0) : fin_info;
 			}
-			// edge rule (miniwfa.c:325-326): H is the max of the five, so "any live" == "H live"
-			const uint32_t live = (uint32_t)(h >= -1);
-			// termination (miniwfa.c:405-409)
-			const bool fin = act && c == cfin && h == tl - 1 && in_matrix(ql - tl, h - nmat, tl, ql);
-			flags |= (live & (uint32_t)(c == lo)) | ((live & (uint32_t)(c == hi)) << 1) | ((uint32_t)fin << 2);
-			fin_info = fin ? (nmat == 0 ? (int32_t)(v.tb & 7u) : 0) : fin_info;
+			if (__ballot(flags != 0)) { // this wave's share of the three per-penalty flags: one LDS atomic per wave that has any
+				const unsigned long long fm = __ballot(flags & 4u);
+				uint32_t bits = (__ballot(flags & 1u) ? 1u : 0u) | (__ballot(flags & 2u) ? 2u : 0u);
+				if (fm) bits |= 4u | (uint32_t)__builtin_amdgcn_readlane(fin_info, (int32_t)__builtin_ctzll(fm)) << 4;
+				if (lane == 0) atomicOr((unsigned int*)&V.flags[npar], bits);
+			}
+		} else if (s > 0 && wave >= NR) {
+			// ---- stage 2: the match extension of the row of penalty s (reference wf_extend, miniwfa.c:400-411), in place; its window is [plo, phi]
+			const int32_t NX = NW - NR, xw = wave - NR;
+			const int32_t g_first = (plo - left) >> 6, g_last = (phi - left) >> 6;
+			bool fin = false;
+			for (int32_t g = g_first + ((xw - g_first) & (NX - 1)); g <= g_last; g += NX) {
+				const int32_t ga = vb + 128 * g, c = left + 64 * g + lane;
+				const int32_t d = c - 1 - tl;
+				int16_t *const ph = (int16_t*)(base + ga + oP + 2);
+				const int32_t h0 = *ph;
+				const bool inm = c >= plo && c <= phi && in_matrix(d, h0, tl, ql);
+				const int32_t j = inm ? h0 + 1 : 0, i = inm ? d + j : 0;
+				const int32_t nmat = S2 ? lds_extend16(lt, lq, j, i, inm ? min(tl - j, ql - i) : 0) : lds_extend8(lt, lq, j, i, inm ? min(tl - j, ql - i) : 0);
+				if (nmat > 0) *ph = (int16_t)(h0 + nmat);
+				far = max(far, h0 + nmat);
+				if (c == cfin && inm && h0 + nmat == tl - 1 && in_matrix(ql - tl, h0, tl, ql)) fin = true, fin_info = nmat == 0 ? (TB ? V.fin_tb[par] : 0) : 0;
+			}
+			const unsigned long long fm = __ballot(fin);
+			if (fm && lane == (int32_t)__builtin_ctzll(fm)) V.fin = 1 | fin_info << 4;
 		}
-#ifdef MWF_MID_TIMING
-		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-		const uint64_t tm2 = __builtin_readcyclecounter();
-#endif
-		if (__ballot(flags != 0)) { // this wave's share of the three per-penalty flags: one LDS atomic per wave that has any
-			const unsigned long long fm = __ballot(flags & 4u);
-			uint32_t bits = (__ballot(flags & 1u) ? 1u : 0u) | (__ballot(flags & 2u) ? 2u : 0u);
-			if (fm) bits |= 4u | (uint32_t)__builtin_amdgcn_readlane(fin_info, (int32_t)__builtin_ctzll(fm)) << 4;
-			if (lane == 0) atomicOr((unsigned int*)&V.flags[npar], bits);
-		}
-		if (forecast) {
-			const int32_t m = wave_max(far);
-			if (lane == 0 && m >= 0) atomicMax(&V.far, m);
+		if (forecast && (piped ? wave >= NR : true)) { // the furthest offset of this row (two stages: of the row before), looked at by the forecast below
+			const int32_t mx = wave_max(far);
+			if (lane == 0 && mx >= 0) atomicMax(&V.far, mx);
 		}
 		// the rows of the coming penalty
+		oP = oN;
 		oN = oN + RB == HB ? 0 : oN + RB, oX = oX + RB == HB ? 0 : oX + RB, oA = oA + RB == HB ? 0 : oA + RB, oB = oB + RB == HB ? 0 : oB + RB;
 		oN1 = oN1 + RB == B1 ? 0 : oN1 + RB, oR1 = oR1 + RB == B1 ? 0 : oR1 + RB, oN2 = oN2 + RB == B2 ? 0 : oN2 + RB, oR2 = oR2 + RB == B2 ? 0 : oR2 + RB;
 		__syncthreads();
-#ifdef MWF_MID_TIMING
-		const uint64_t tm3 = __builtin_readcyclecounter();
-#endif
-		const uint32_t fl = (uint32_t)uni(V.flags[npar]);
-#ifdef MWF_MID_TIMING
-		if (trace_band && tid == (A.max_iter < 0 ? (int32_t)-A.max_iter : 0) && s_new - 1 < dbg_cap) {
-			const uint64_t tm4 = __builtin_readcyclecounter();
-			M.dbg[2 * (s_new - 1)] = (int32_t)(min((uint32_t)(tm1 - tm0), 65535u) | min((uint32_t)(tm2 - tm1), 65535u) << 16);
-			M.dbg[2 * (s_new - 1) + 1] = (int32_t)(min((uint32_t)(tm3 - tm2), 4095u) | min((uint32_t)(tm4 - tm3), 65535u) << 12 | (uint32_t)n_groups << 28);
+		if (piped) { // the row of penalty s turned out to hold the end cell: penalty s is the answer, what was computed of s + 1 meanwhile is dropped
+			const int32_t fw = uni(V.fin);
+			if (fw & 1) { R.info = (fw >> 4) & 7; break; }
 		}
-#endif
+		if (leave != ST_OK) { R.status = leave; break; }
+		const uint32_t fl = (uint32_t)uni(V.flags[npar]);
 		if (fl & 1u) wf_lo = lo;
 		if (fl & 2u) wf_hi = hi;
 		s = s_new, curH = newH, par = npar;
+		plo = lo, phi = hi;
 		if (TB) tb_used += C;
 		if ((s & 0xff) == 0) { // shrink (reference wf_stripe_shrink, miniwfa.c:144-171) on the good bits of the slices still in the ring
 			if (tid == 0) V.red[0] = 0x7fffffff, V.red[1] = -1;
@@ -257,8 +283,8 @@ __device__ PassResult mid_pass(const ArgsT &A, PairMem &M, const MidLayout &L, c
 			R.status = ST_STOPPED;
 			break;
 		}
-		if (fl & 4u) { R.info = (int32_t)((fl >> 4) & 7u); break; }
-		if (forecast) { // will the window outgrow the span? then hand the pair back now, with the estimate
+		if (!piped && (fl & 4u)) { R.info = (int32_t)((fl >> 4) & 7u); break; }
+		if (s == 64 || s == 256 || s == 1024) { // will the window outgrow the span? then hand the pair back now, with the estimate (dev::window_forecast)
 			est_window = window_forecast(s, uni(V.far), tl, ql, C - 2 * nH - 64);
 			if (est_window) { R.status = ST_BAND_OVERFLOW; break; }
 		}
