@@ -1587,6 +1587,9 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 				                     b->h_tl[i] <= kBandSpanMaxSeq && b->h_ql[i] <= kBandSpanMaxSeq && est <= band_span_window();
 				if (b->h_class[i] >= 2 && est <= kBandWideWindow * 3 / 2) b->h_class[i] = 1, to_band_wide[step0].push_back((int32_t)i);
 				else if (span_ok) b->h_class[i] = 5, to_band_span[step0].push_back((int32_t)i);
+				// (a forecast also says whether the generic kernel's 16-bit ring rows can hold the pair — offsets up to 65 532, i.e. target length
+				// + final penalty, about half the window: 50 kb pairs at 15 % ran them for nothing before taking the 32-bit rows)
+				else if (est > 0 && (int64_t)b->h_tl[i] + est / 2 + 64 > 65000) b->h_class[i] = 0, to_generic32[step0].push_back((int32_t)i);
 				else b->h_class[i] = 0, to_generic[step0].push_back((int32_t)i);
 			} else if (kind == 1 && st == ST_INTERNAL && !(b->h_flags[i] & 8)) {
 				// a wait between workgroups of the whole-device kernel ran into its spin limit (they were not all resident, e.g.
