@@ -49,6 +49,10 @@ struct DevBuf {
 
 constexpr size_t kPinHalfMax = (size_t)16 << 20; // pinned staging: two halves of at most this many bytes
 constexpr int kQueueSlots = 64;                  // work counters zeroed at the start of an align call, one per launch
+// The lane kernel's launches (tens of thousands of read pairs) take a SET of kLaneCounters work counters, each on a cache line of its own:
+// counter c deals the pairs c, c + 64, c + 128 ... of the order to the waves with blockIdx % 64 == c.  (One counter for all: 40 000 atomics on
+// one address, ~12.7 ns each — 0.51 of the kernel's 0.61 ms.)  kLaneSets sets per align call, behind the plain counters in the same buffer.
+constexpr int kLaneCounters = 64, kLaneStride = 32, kLaneSets = 4, kQueueInts = kQueueSlots + kLaneSets * kLaneCounters * kLaneStride;
 constexpr int kMaxDevices = 64;
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -94,6 +98,7 @@ struct mwf_gpu_s {
 	DevBuf sys_box, sys_prog, sys_log, sys_ep, sys_park, sys_ring, sys_good;
 	DevBuf spare_block, spare_cig; // allocations of freed batches, waiting for the next batch
 	int queue_next = 0;            // next unused work counter of the current align call
+	int lane_set_next = 0;         // ... and next unused set of lane-kernel counters
 	bool queue_clean = false;      // the work counters were zeroed by this align call's reset kernel (else a launch that needs one zeroes it itself)
 	// pinned staging
 	void *pin = nullptr;
@@ -601,7 +606,15 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	a.order = d_order, a.n_pairs = n_items;
 	// A launch of one workgroup per pair on the kernels that take it (lane, mid, packed band) needs no work counter: workgroup i aligns
 	// pair i.  Otherwise a fresh counter: the first kQueueSlots launches of an align call use the ones its reset kernel zeroed.
-	if (pl.kind == 2 && (pl.band.lane || pl.band.packed) && n_items <= pl.grid && !g->queue_clean) a.queue = nullptr;
+	// The lane kernel takes a set of 64 counters (kLaneCounters above).
+	if (pl.kind == 2 && pl.band.lane == 1 && n_items > pl.grid) {
+		if (g->queue_clean && g->lane_set_next < kLaneSets) a.queue = (int32_t*)g->queue.p + kQueueSlots + (g->lane_set_next++) * kLaneCounters * kLaneStride;
+		else {
+			a.queue = (int32_t*)g->queue.p + kQueueSlots;
+			HIP_TRY(g, hipMemsetAsync(a.queue, 0, (size_t)kLaneCounters * kLaneStride * 4, g->stream)); // (stream order: the launch that used it last is complete by then)
+		}
+	} else if (pl.kind == 2 && pl.band.lane == 1) a.queue = nullptr;
+	else if (pl.kind == 2 && (pl.band.lane || pl.band.packed) && n_items <= pl.grid && !g->queue_clean) a.queue = nullptr;
 	else if (g->queue_clean && g->queue_next < kQueueSlots) a.queue = (int32_t*)g->queue.p + g->queue_next++;
 	else {
 		a.queue = (int32_t*)g->queue.p;
@@ -1135,7 +1148,7 @@ mwf_gpu_t *mwf_gpu_create(int device, void *stream)
 	}
 	(void)hipEventCreate(&g->ev0);
 	(void)hipEventCreate(&g->ev1);
-	if (ensure(g, g->queue, kQueueSlots * 4) || hipMemsetAsync(g->queue.p, 0, kQueueSlots * 4, g->stream) != hipSuccess) {
+	if (ensure(g, g->queue, kQueueInts * 4) || hipMemsetAsync(g->queue.p, 0, kQueueInts * 4, g->stream) != hipSuccess) {
 		mwf_gpu_destroy(g);
 		return nullptr;
 	}
@@ -1309,7 +1322,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	if (b->debug_pair >= 0 && ensure(g, g->dbg, (size_t)8 * (max_bound + 2))) return -1;
 	const bool was_busy = b->busy;
 	b->busy = true;
-	g->queue_next = 0;
+	g->queue_next = 0, g->lane_set_next = 0;
 	// Every pair "not run", CIGAR pool and work counters at zero: one small kernel — unless the result arrays can be written from here
 	// (the pinned result page of a small score-only batch: the single pair of a drop-in call) or came up initialised with the batch
 	// (a small batch's first align); the kernels of such a call then run without a work counter where they can (run_batch_kernel).
@@ -1320,7 +1333,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	} else if (b->results_preinit) preset = true;
 	b->results_preinit = false;
 	g->queue_clean = !preset;
-	if (!preset && launch_reset(b->d_status, b->d_s, b->n, b->d_cig_head, (int32_t*)g->queue.p, kQueueSlots, g->stream)) { g->err = "kernel launch failed (reset)"; return -1; }
+	if (!preset && launch_reset(b->d_status, b->d_s, b->n, b->d_cig_head, (int32_t*)g->queue.p, kQueueInts, g->stream)) { g->err = "kernel launch failed (reset)"; return -1; }
 	std::fill(b->h_flags.begin(), b->h_flags.end(), 0);
 	// a few long pairs: each one gets the whole device in turn
 	const Penalty P0 = make_penalty(*opt);

@@ -1197,13 +1197,13 @@ __global__ void reset_kernel(int32_t *status, int32_t *s, int32_t n, unsigned lo
 {
 	const int32_t i = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
 	if (i < n) status[i] = -1, s[i] = -2;
-	if (i < n_queue) queue[i] = 0; // one work counter per launch of the align call (n_queue <= 256)
+	if (i < n_queue) queue[i] = 0; // the work counters of the align call's launches (the grid covers n_queue)
 	if (i == 0) *cig_head = 0ull;
 }
 
 int launch_reset(int32_t *status, int32_t *s, int32_t n, unsigned long long *cig_head, int32_t *queue, int32_t n_queue, void *stream)
 {
-	const int grid = n > 0 ? (n + 255) / 256 : 1;
+	const int grid = (std::max(n, n_queue) + 255) / 256 > 0 ? (std::max(n, n_queue) + 255) / 256 : 1;
 	hipLaunchKernelGGL(reset_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, status, s, n, cig_head, queue, n_queue);
 	return hipGetLastError() == hipSuccess ? 0 : -2;
 }

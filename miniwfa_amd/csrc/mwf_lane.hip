@@ -162,10 +162,15 @@ __global__ __launch_bounds__(64) void wfa_lane_kernel(const BatchArgs)
 	int16_t *rows = (int16_t*)lds_lane;
 	uint8_t *lt = lds_lane + (n_rows * row_ints(A.lane_chunks) * 4 + 15) / 16 * 16;
 	for (int32_t round = 0;; ++round) {
-		// a work counter, or — queue == null: a launch of one workgroup per pair — pair blockIdx.x and nothing else (no counter to zero first)
+		// Work counters — a set of 64, each on a cache line of its own: counter c deals the pairs c, c + 64, c + 128 ... of the order to the waves
+		// with blockIdx % 64 == c — or, queue == null: a launch of one wave per pair.  ONE global counter is what bounded this kernel through
+		// round 4: 40 000 read pairs are 40 000 atomics on one address, ~12.7 ns each — 0.51 of the 0.61 ms, whatever the reads (identical
+		// reads, which end at penalty 0: 0.508 ms); a static deal of the pairs to the waves removes the atomics but not the imbalance (reads at
+		// 2 %: 0.546 -> 0.321 ms, at 5 %: 0.603 -> 0.728; profiles/r04/lane_counter.txt).
 		int32_t item = 0;
 		if (A.queue) {
-			if (lane == 0) item = (int32_t)atomicAdd(A.queue, 1);
+			const int32_t nc = min(64, (int32_t)gridDim.x), c = (int32_t)blockIdx.x % nc; // (a launch of fewer than 64 waves: as many counters as waves)
+			if (lane == 0) item = c + nc * (int32_t)atomicAdd(A.queue + 32 * c, 1);
 			item = uni(item);
 		} else item = round == 0 ? (int32_t)blockIdx.x : A.n_pairs;
 		if (item >= A.n_pairs) break;
