@@ -908,6 +908,8 @@ __global__ __launch_bounds__(T, T == 1024 ? 4 : T == MWF_B2_WIDE_T ? MWF_B2_WIDE
 	LdsT *const L = (LdsT*)(lds2 + lds_seq);
 	Shared &sh = L->sh;
 	const int32_t edge_base = lds_seq + (int32_t)offsetof(LdsT, edge);
+	CigLocal cig_loc;
+	cig_loc.base = 0, cig_loc.left = 0;
 	for (int32_t round = 0;; ++round) {
 		KArgs &A = fresh(A0);
 		// a work counter, or — queue == null: a launch of one workgroup per pair — pair blockIdx.x and nothing else (no counter to zero first)
@@ -937,7 +939,7 @@ __global__ __launch_bounds__(T, T == 1024 ? 4 : T == MWF_B2_WIDE_T ? MWF_B2_WIDE
 		const bool trace = A.dbg && pair == A.debug_pair;
 		if (R.status == ST_OK) R = band2_pass<T, K, E1, E2, TB, S2>(A, M, sh, edge_base, qoff, trace);
 		if (S2) M.t2 = lds2, M.q2 = lds2 + qoff; // the traceback's back-match reads the 2-bit copies in LDS
-		finish_pair(fresh(A0), M, (int32_t)blockIdx.x, pair, R, R.status, 0);
+		finish_pair(fresh(A0), M, (int32_t)blockIdx.x, pair, R, R.status, 0, T <= 256 ? &cig_loc : nullptr); // (block mode: the geometries of the short pairs — thousands per launch)
 	}
 }
 

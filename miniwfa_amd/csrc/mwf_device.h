@@ -400,9 +400,12 @@ __device__ __forceinline__ void pair_mem(const ArgsT &A, int32_t slot, int32_t p
 }
 
 // After the forward pass(es): traceback on the first wave, CIGAR into the pool, per-pair outputs.
+// a workgroup's share of the CIGAR pool in block mode (BatchArgs::cig_block): where its next CIGAR goes and how many words are left there
+struct CigLocal { unsigned long long base; int32_t left; };
+
 template <typename ArgsT>
 __device__ __forceinline__ void finish_pair(const ArgsT &A, const PairMem &M, int32_t slot, int32_t pair,
-                                            const PassResult &R, int32_t status, int64_t cells1)
+                                            const PassResult &R, int32_t status, int64_t cells1, CigLocal *loc = nullptr)
 {
 	int32_t n_cigar = 0;
 	int64_t cig_off = 0;
@@ -415,8 +418,21 @@ __device__ __forceinline__ void finish_pair(const ArgsT &A, const PairMem &M, in
 			if (n_cigar < 0) status = ST_INTERNAL, n_cigar = 0;
 			else {
 				unsigned long long off = 0;
-				if (threadIdx.x == 0) off = atomicAdd(A.cig_head, (unsigned long long)n_cigar);
-				off = ((unsigned long long)(uint32_t)uni((int32_t)(off >> 32)) << 32) | (uint32_t)uni((int32_t)(off & 0xffffffffu));
+				const int32_t blk = loc ? A.cig_block : 0;
+				if (blk > 0 && n_cigar <= blk / 4) {
+					// block mode: from the workgroup's current block; one that cannot hold this CIGAR is abandoned (less than a quarter of it is lost: the host
+					// sized the pool for that) and the next one taken with ONE atomic for the dozen pairs it will hold
+					if (n_cigar > loc->left) {
+						unsigned long long nb = 0;
+						if (threadIdx.x == 0) nb = atomicAdd(A.cig_head, (unsigned long long)blk);
+						loc->base = ((unsigned long long)(uint32_t)uni((int32_t)(nb >> 32)) << 32) | (uint32_t)uni((int32_t)(nb & 0xffffffffu));
+						loc->left = blk;
+					}
+					off = loc->base, loc->base += (unsigned long long)n_cigar, loc->left -= n_cigar;
+				} else {
+					if (threadIdx.x == 0) off = atomicAdd(A.cig_head, (unsigned long long)n_cigar);
+					off = ((unsigned long long)(uint32_t)uni((int32_t)(off >> 32)) << 32) | (uint32_t)uni((int32_t)(off & 0xffffffffu));
+				}
 				if ((int64_t)off + n_cigar > A.cig_pool_words) status = ST_CIGAR_OVERFLOW, n_cigar = 0;
 				else {
 					cig_off = (int64_t)off;

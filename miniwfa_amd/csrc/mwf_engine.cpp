@@ -48,6 +48,7 @@ struct DevBuf {
 };
 
 constexpr size_t kPinHalfMax = (size_t)16 << 20; // pinned staging: two halves of at most this many bytes
+constexpr int kCigBlock = 256, kCigBlockGrid = 8192, kCigBlockPairs = 4096; // CIGAR pool in block mode (batch_common)
 constexpr int kQueueSlots = 64;                  // work counters zeroed at the start of an align call, one per launch
 // The lane kernel's launches (tens of thousands of read pairs) take a SET of kLaneCounters work counters, each on a cache line of its own:
 // counter c deals the pairs c, c + 64, c + 128 ... of the order to the waves with blockIdx % 64 == c.  (One counter for all: 40 000 atomics on
@@ -149,6 +150,7 @@ struct mwf_gpu_batch_s {
 	DevBuf cig;                     // CIGAR pool (allocated by the first CIGAR-mode align)
 	uint32_t *d_cig_pool = nullptr;
 	int64_t cig_pool_words = 0;
+	int32_t cig_block = 0;          // > 0: the pool is sized for workgroups that take it in blocks of this many words (batches of thousands of pairs)
 	// state of the last align
 	bool aligned = false, finalized = false, busy = false;
 	mwf_opt_t opt{};
@@ -639,6 +641,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	a.rows_slot = pl.rows_slot;
 	a.cig_scratch = pl.cigar ? (uint32_t*)g->cig_scratch.p : nullptr, a.cig_scratch_slot = pl.cig_scratch_slot;
 	a.cig_pool = b->d_cig_pool, a.cig_head = b->d_cig_head, a.cig_pool_words = b->cig_pool_words;
+	a.cig_block = pl.grid <= kCigBlockGrid ? b->cig_block : 0;
 	a.snap = pl.low_mem ? (int32_t*)g->snap.p : nullptr, a.snap_slot_ints = pl.snap_slot_ints;
 	a.snap_meta = pl.low_mem ? (int32_t*)g->snap_meta.p : nullptr, a.snap_meta_slot = pl.snap_meta_slot;
 	a.seg = pl.low_mem ? (int32_t*)g->seg.p : nullptr, a.seg_slot = pl.seg_slot;
@@ -986,6 +989,10 @@ mwf_gpu_batch_t *batch_common(mwf_gpu_t *g, int32_t n, const int32_t *h_tl, cons
 		b->max_seq_lds = std::max<int64_t>(b->max_seq_lds, (((int64_t)h_tl[i] + 3) & ~3LL) + 8 + (((int64_t)h_ql[i] + 3) & ~3LL) + 16);
 	}
 	b->cig_pool_words = std::max<int64_t>(words, 1);
+	// Thousands of pairs: one atomic on the pool's head per pair is ~12.7 ns on a single address (0.5 ms for 40 000 reads) — workgroups take the pool
+	// in blocks of kCigBlock words instead (dev::finish_pair).  A block is abandoned with less than a quarter of it unused and every workgroup leaves
+	// one partly used: 4/3 of the worst case plus a block per workgroup (at most kCigBlockGrid of them, run_batch_kernel) always holds.
+	if (n >= kCigBlockPairs) b->cig_block = kCigBlock, b->cig_pool_words = b->cig_pool_words / 3 * 4 + 4 + (int64_t)(kCigBlockGrid + 1) * kCigBlock;
 	L = layout_block((size_t)n, seq_bytes, owned);
 	if (take_block(g, g->spare_block, b->block, L.total)) {
 		delete b;

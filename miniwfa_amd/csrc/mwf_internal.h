@@ -118,6 +118,8 @@ struct BatchArgs {
 	int64_t sys_park_stride;   // ints between two groups' parking areas
 	int64_t *sys_ep;           // [group][epochs][2]: traceback layout per epoch of 256 penalties: base offset, first chunk | chunks << 32
 	int64_t sys_ep_stride;     // int64 words between two groups' tables
+	int32_t cig_block;         // > 0: workgroups take the CIGAR pool in blocks of this many words and place their pairs' CIGARs in them (batches of thousands of pairs:
+	                           // one atomic on cig_head per pair is ~12.7 ns on a single address); 0: one allocation per pair, no holes
 	int32_t lane_chunks;       // one-diagonal-per-lane kernels: 64-column chunks of their LDS rows (mwf_lane.hip: 1-4; mwf_mid.hip: its span / 64)
 	int32_t sys_coop_launch;   // host side only: 1 = launch through hipLaunchCooperativeKernel (the runtime then guarantees that every workgroup is resident)
 };

@@ -161,6 +161,8 @@ __global__ __launch_bounds__(64) void wfa_lane_kernel(const BatchArgs)
 	const int32_t n_rows = A.pen.nH + 2 * A.pen.e1 + 2 * A.pen.e2;
 	int16_t *rows = (int16_t*)lds_lane;
 	uint8_t *lt = lds_lane + (n_rows * row_ints(A.lane_chunks) * 4 + 15) / 16 * 16;
+	CigLocal cig_loc;
+	cig_loc.base = 0, cig_loc.left = 0;
 	for (int32_t round = 0;; ++round) {
 		// Work counters — a set of 64, each on a cache line of its own: counter c deals the pairs c, c + 64, c + 128 ... of the order to the waves
 		// with blockIdx % 64 == c — or, queue == null: a launch of one wave per pair.  ONE global counter is what bounded this kernel through
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(64) void wfa_lane_kernel(const BatchArgs)
 		const bool trace = A.dbg && pair == A.debug_pair;
 		if (R.status == ST_OK) R = lane_pass<TB, S2>(fresh(A), M, rows, lt, lq, trace);
 		if (S2) M.t2 = lt, M.q2 = lq; // the traceback's back-match stays on chip
-		finish_pair(fresh(A), M, (int32_t)blockIdx.x, pair, R, R.status, 0);
+		finish_pair(fresh(A), M, (int32_t)blockIdx.x, pair, R, R.status, 0, &cig_loc);
 	}
 }
 

@@ -1129,6 +1129,32 @@ def test_config5_default_kernel_at_full_pair_size(span, oracle):
     eng.close()
 
 
+def test_cigar_pool_in_block_mode_for_batches_of_thousands(oracle):
+    """A batch of thousands of pairs takes its CIGAR pool in blocks (one atomic on the pool's head per dozen pairs instead of one per pair —
+    40 000 of those on one address were half a millisecond; dev::finish_pair, BatchArgs::cig_block): 6000 read-length pairs on the lane kernel
+    and on the packed band kernel's short-pair geometries, every CIGAR re-scores to its s and consumes both sequences, a sample equals the
+    oracle's word for word — among them pairs whose CIGAR is longer than a quarter of a block (allocated on their own) and empty sequences."""
+    rng = np.random.default_rng(99)
+    pairs = [synth_pair(52000 + i, int(rng.integers(60, 260)), float(rng.choice([0.0, 0.02, 0.05, 0.1]))) for i in range(5900)]
+    pairs += [synth_pair(53000 + i, 700, 0.12) for i in range(60)] + [(b"", b"ACGT"), (b"ACGT", b""), (b"", b"")] + [synth_pair(53100 + i, 400, 0.3) for i in range(37)]
+    o = mw.opt_init(flag=mw.MWF_F_CIGAR)
+    for lane_max in (400, 0):          # 0: the lane kernel switched off — the same pairs on the band classes
+        eng = mw.Engine(0)
+        eng.set("lane_max_len", lane_max)
+        b = eng.upload(PackedBatch(pairs))
+        b.align(o)
+        s, it, nc = b.results()
+        b.fetch_cigars()
+        for i, (t, q) in enumerate(pairs):
+            cig = b.cigar(i, int(nc[i])).tolist()
+            assert mw.cigar2score(o, cig) == (int(s[i]), len(t), len(q)), (lane_max, i)
+        for i in list(range(0, 6000, 41)) + list(range(5900, 6000)):
+            es, eit, ecig = oracle.align(pairs[i][0], pairs[i][1], make_opt(flag=1))
+            assert (int(s[i]), int(it[i])) == (es, eit) and b.cigar(i, int(nc[i])).tolist() == (ecig or []), (lane_max, i)
+        b.free()
+        eng.close()
+
+
 def test_span_geometry_long_pairs_against_oracle(oracle):
     """The packed band kernel's 1024-thread geometry (16 waves x 5 chunk slots, offsets biased by the target length so that targets of up
     to ~60 kb fit 16 bits, mwf_band2.hip wide_bias): pairs of 20-60 kb whose windows stay below 20 000 columns, s, n_iter and CIGAR
