@@ -610,6 +610,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	// pair i.  Otherwise a fresh counter: the first kQueueSlots launches of an align call use the ones its reset kernel zeroed.
 	// The lane kernel takes a set of 64 counters (kLaneCounters above).
 	if (pl.kind == 2 && pl.band.lane == 1 && n_items > pl.grid) {
+		a.queue_parts = kLaneCounters;
 		if (g->queue_clean && g->lane_set_next < kLaneSets) a.queue = (int32_t*)g->queue.p + kQueueSlots + (g->lane_set_next++) * kLaneCounters * kLaneStride;
 		else {
 			a.queue = (int32_t*)g->queue.p + kQueueSlots;

@@ -45,6 +45,8 @@ struct BatchArgs {
 	const int32_t *order;      // optional processing order (longest first); may be null
 	int32_t n_pairs;
 	int32_t *queue;            // [0]: next position in `order`
+	int32_t queue_parts;       // > 0: `queue` is a set of that many counters, 32 ints apart; counter c deals positions c, c + parts, ... to the workgroups with
+	                           // blockIdx % parts == c (launches of thousands of short pairs: atomics on ONE address cost ~12.7 ns each)
 	// ---- options
 	Penalty pen;
 	int32_t want_cigar;        // MWF_F_CIGAR

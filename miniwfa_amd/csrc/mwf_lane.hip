@@ -171,7 +171,7 @@ __global__ __launch_bounds__(64) void wfa_lane_kernel(const BatchArgs)
 		// 2 %: 0.546 -> 0.321 ms, at 5 %: 0.603 -> 0.728; profiles/r04/lane_counter.txt).
 		int32_t item = 0;
 		if (A.queue) {
-			const int32_t nc = min(64, (int32_t)gridDim.x), c = (int32_t)blockIdx.x % nc; // (a launch of fewer than 64 waves: as many counters as waves)
+			const int32_t nc = min(A.queue_parts, (int32_t)gridDim.x), c = (int32_t)blockIdx.x % nc; // (a launch of fewer waves than counters: as many counters as waves)
 			if (lane == 0) item = c + nc * (int32_t)atomicAdd(A.queue + 32 * c, 1);
 			item = uni(item);
 		} else item = round == 0 ? (int32_t)blockIdx.x : A.n_pairs;
