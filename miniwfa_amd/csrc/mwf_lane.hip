@@ -84,7 +84,13 @@ __device__ PassResult lane_pass(const ArgsT &A, PairMem &M, int16_t *rows, const
 	// idx = c - left + 1, so entry idx - 1 lies at byte 2 (32 NC + lane) + 2 dk of a row
 	const int32_t vb = 2 * (32 * NC + lane);
 	const bool lower = lane < 32;
+	// (Measured and dropped, round 4: penalties nobody can score — with the default costs thirteen of the first 25, a third of what a 150 bp read at 5 % runs
+	// through — written dead without loads, recurrence or extension: which rows can hold a live cell follows from the penalties alone.  40 000 x 150 bp
+	// 0.555 against 0.535 ms, one 200 bp call 55.8 against 54.9 us: the scalar bookkeeping costs what the skipped vector work saves.)
 	for (;;) {
+#ifdef MWF_LANE_TIMING // cycles per penalty of the traced pair's wave: header | chunks | footer (+ chunks run, bit 31: a skipped penalty)
+		const uint64_t tm0 = __builtin_readcyclecounter();
+#endif
 		const int32_t lo = wf_lo > 1 ? wf_lo - 1 : 1;       // miniwfa.c:417-418
 		const int32_t hi = wf_hi < cmax ? wf_hi + 1 : cmax;
 		const int32_t s_new = s + 1;
@@ -92,9 +98,15 @@ __device__ PassResult lane_pass(const ArgsT &A, PairMem &M, int16_t *rows, const
 		const int32_t k_use = max(lo < center ? (center - 1 - lo) >> 5 : 0, hi > center ? (hi - center) >> 5 : 0);
 		if (k_use >= NC || s_new >= s_shrink) { R.status = ST_BAND_OVERFLOW; break; }
 		if (TB && tb_used + 64 * NC > tb_slot_bytes) { R.status = ST_TB_OVERFLOW; break; }
+#ifndef MWF_LANE_TIMING
 		if (trace_band && lane == 0 && s_new - 1 < dbg_cap) M.dbg[2 * (s_new - 1)] = lo, M.dbg[2 * (s_new - 1) + 1] = hi;
+#endif
 		uint32_t flags = 0;    // per lane, over its chunks: 1 = the lo column and live, 2 = the hi column and live, 4 = the end cell, reached
 		int32_t fin_info = 0;
+#ifdef MWF_LANE_TIMING
+		const uint64_t tm1 = __builtin_readcyclecounter();
+#endif
+		{
 		// The E/F row a chunk overwrites is the row the next chunk still reads at the two columns where their blocks touch: the old F of
 		// this chunk's first column (lane 0) and the old E of its last (lane 63) travel to the next chunk in scalars.
 		int32_t cE1 = 0, cE2 = 0, cF1 = 0, cF2 = 0;
@@ -134,6 +146,11 @@ __device__ PassResult lane_pass(const ArgsT &A, PairMem &M, int16_t *rows, const
 			flags |= (live & (uint32_t)(c == lo)) | ((live & (uint32_t)(c == hi)) << 1) | ((uint32_t)fin << 2);
 			fin_info = fin ? (nmat == 0 ? (int32_t)(v.tb & 7u) : 0) : fin_info;
 		}
+		}
+#ifdef MWF_LANE_TIMING
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		const uint64_t tm2 = __builtin_readcyclecounter();
+#endif
 		if (__ballot(flags & 1u)) wf_lo = lo;
 		if (__ballot(flags & 2u)) wf_hi = hi;
 		const unsigned long long fm = __ballot(flags & 4u);
@@ -146,6 +163,13 @@ __device__ PassResult lane_pass(const ArgsT &A, PairMem &M, int16_t *rows, const
 			R.status = ST_STOPPED;
 			break;
 		}
+#ifdef MWF_LANE_TIMING
+		if (trace_band && lane == 0 && s - 1 < dbg_cap) {
+			const uint64_t tm3 = __builtin_readcyclecounter();
+			M.dbg[2 * (s - 1)] = (int32_t)(min((uint32_t)(tm1 - tm0), 65535u) | min((uint32_t)(tm2 - tm1), 65535u) << 16);
+			M.dbg[2 * (s - 1) + 1] = (int32_t)(min((uint32_t)(tm3 - tm2), 65535u) | (uint32_t)(k_use + 1) << 16);
+		}
+#endif
 		if (fm) { R.info = __builtin_amdgcn_readlane(fin_info, (int32_t)__builtin_ctzll(fm)); break; }
 	}
 	R.s = s, R.cells = cells; // (no early hand-back here: a forecast after two dozen penalties is noise, and this kernel's whole run is ~100 penalties)
