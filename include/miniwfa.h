@@ -143,7 +143,7 @@ typedef struct {
 	int32_t kernel_kind;   /* 0: one workgroup per pair (generic); 1: one pair across the whole device; 2: one workgroup per pair (band) */
 	int64_t dev_bytes;     /* device memory the engine holds now: workspace pools + recycled batch allocations (live batches hold their own) */
 	int64_t dev_bytes_peak;/* ... and the most it held since creation or the last mwf_gpu_set(g, "trim", 0) */
-	int32_t packed;        /* band kernels: 1 = the packed 16-bit variant (mwf_band2.hip), 32 = the one-wave-per-pair lane kernel (mwf_lane.hip), 33 = the one-workgroup-per-pair mid kernel (mwf_mid.hip); generic kernel: 16 = 16-bit ring rows */
+	int32_t packed;        /* band kernels: 1 = the packed 16-bit variant (mwf_band2.hip; with block 1024: its span geometry for pairs of up to ~60 kb), 32 = the one-wave-per-pair lane kernel (mwf_lane.hip), 33 = the one-workgroup-per-pair mid kernel (mwf_mid.hip); generic kernel: 16 = 16-bit ring rows */
 	int32_t lowmem_two_pass; /* low-memory mode: 1 = the first pass stored no traceback (provenance + snapshots), 0 = checkpoints walked off a full traceback */
 } mwf_gpu_stats_t;
 void mwf_gpu_get_stats(const mwf_gpu_t *g, mwf_gpu_stats_t *st);
