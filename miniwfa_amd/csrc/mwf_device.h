@@ -310,7 +310,32 @@ static __device__ int32_t traceback_wave(const ArgsT &A, const PairMem &M, uint3
 	// (which changes neither the row nor the column): the two round trips of a step travel together instead of one after the other.
 	uint32_t x_next = 0;
 	if (row >= 0 && i >= 0 && k >= 0) x_next = tb_byte(M, row, i - k + M.tl + 1);
+	// A step is one DEPENDENT byte from a matrix written long ago: a round trip to HBM (~1 us) per CIGAR operation, which is what the traceback of
+	// a pair costs.  The path moves back by at most nH rows and one column per step, so every 40 rows the 64 lanes fetch the byte in the walk's
+	// current column of the next 64 rows — one round trip, together — and the steps through those rows find their cache lines in L2.
+#ifndef MWF_TB_NO_PREFETCH
+	const bool prefetch = A.tb_slot_bytes > 0;
+#else
+	const bool prefetch = false;
+#endif
+	int32_t pf_at = row;
 	while (i >= 0 && k >= 0 && !overflow) {
+		uint32_t pf = 0;
+		const bool pf_now = prefetch && row <= pf_at && row > 0;
+		if (pf_now) {
+			const int32_t r = row - 1 - lane, col = i - k + M.tl + 1;
+			if (r >= 0) {
+				int64_t at;
+				if (M.ep) { // (the whole-device kernel's layout: per epoch of 256 penalties and chunk slot)
+					const int64_t base = M.ep[2 * (r >> 8)], gn = M.ep[2 * (r >> 8) + 1];
+					const int32_t g = col / M.ep_ow;
+					at = base + ((int64_t)(r & 255) * (int32_t)(gn >> 32) + (g - (int32_t)(gn & 0xffffffff))) * M.ep_kw + (col - (g * M.ep_ow - M.ep_p));
+				} else at = M.tb_stride ? (int64_t)r * M.tb_stride + (col - M.tb_left) : M.row_off[r] + (col - M.row_lo[r]);
+				at = min(max(at, (int64_t)0), (int64_t)A.tb_slot_bytes - 1); // (an older row may not reach this column: any byte of the arena will do)
+				pf = M.tb[at];
+			}
+			pf_at = row - 40;
+		}
 		if (last == 0) { // greedy back-match, 64 bases per trip (miniwfa.c:335-341)
 			int32_t run = 0;
 			if (M.t2) { // 2-bit copies in LDS: one base per lane and trip
@@ -351,6 +376,7 @@ static __device__ int32_t traceback_wave(const ArgsT &A, const PairMem &M, uint3
 			if (i < 0 || k < 0) break;
 		}
 		if (row < 0) { overflow = true; break; }
+		if (pf_now) asm volatile("" :: "v"(pf)); // (the prefetched bytes have arrived — and stay in L2)
 		const uint32_t x = x_next;
 		const int32_t state = last == 0 ? (int32_t)(x & 7u) : last;           // :346
 		const int32_t ext = state > 0 ? (int32_t)(x >> (state + 2)) & 1 : 0;  // :347
