@@ -993,7 +993,8 @@ mwf_gpu_batch_t *batch_common(mwf_gpu_t *g, int32_t n, const int32_t *h_tl, cons
 	// Thousands of pairs: one atomic on the pool's head per pair is ~12.7 ns on a single address (0.5 ms for 40 000 reads) — workgroups take the pool
 	// in blocks of kCigBlock words instead (dev::finish_pair).  A block is abandoned with less than a quarter of it unused and every workgroup leaves
 	// one partly used: 4/3 of the worst case plus a block per workgroup (at most kCigBlockGrid of them, run_batch_kernel) always holds.
-	if (n >= kCigBlockPairs) b->cig_block = kCigBlock, b->cig_pool_words = b->cig_pool_words / 3 * 4 + 4 + (int64_t)(kCigBlockGrid + 1) * kCigBlock;
+	// (short pairs only: that is where thousands of CIGARs per millisecond are written — and where a third more pool is a few megabytes)
+	if (n >= kCigBlockPairs && words / n <= 2048) b->cig_block = kCigBlock, b->cig_pool_words = b->cig_pool_words / 3 * 4 + 4 + (int64_t)(kCigBlockGrid + 1) * kCigBlock;
 	L = layout_block((size_t)n, seq_bytes, owned);
 	if (take_block(g, g->spare_block, b->block, L.total)) {
 		delete b;
