@@ -1017,27 +1017,43 @@ __global__ __launch_bounds__(kT) void wfa_sys_kernel(const BatchArgs A)
 // reference miniwfa.c:495-549): the same walk over this kernel's traceback layout.
 __global__ void sys_walk_kernel(const BatchArgs A)
 {
-	if (threadIdx.x != 0) return;
+	// One wave, every lane walking the same chain (their loads are one broadcast): a step is one dependent byte of a matrix written long ago — a round trip
+	// to HBM.  Every 40 rows the 64 lanes fetch the byte in the walk's column of the next 64 rows together, so that the steps through them hit L2
+	// (dev::traceback_wave does the same).
+	const int32_t lane = (int32_t)threadIdx.x;
 	const int32_t grp = (int32_t)blockIdx.x; // one block per pair
 	int32_t *st = group_state(A, grp);
-	st[3] = 0;
+	if (lane == 0) st[3] = 0;
 	if (st[0] != ST_OK) return;
 	const Penalty &P = A.pen;
 	PairMem M;
 	sys_pair_mem(A, grp, group_pair(A, grp), M);
 	const int32_t s_final = st[1], step = A.step;
 	const int32_t n_seg = s_final / step;
-	if (n_seg > A.seg_slot) { st[0] = ST_SNAP_OVERFLOW; return; }
+	if (n_seg > A.seg_slot) { if (lane == 0) st[0] = ST_SNAP_OVERFLOW; return; }
 	int32_t arr = 0, s = s_final, col = M.ql + 1; // array 0=H 1=E1 2=F1 3=E2 4=F2; the end cell is on diagonal ql-tl
-	int32_t j = n_seg - 1;
+	int32_t j = n_seg - 1, pf_at = s_final;
 	while (j >= 0) {
 		const int32_t Sj = (j + 1) * step - 1;
 		if (s <= Sj) { // first cell of the chain that already existed at snapshot j
-			M.seg[2 * j] = s, M.seg[2 * j + 1] = col;
+			if (lane == 0) M.seg[2 * j] = s, M.seg[2 * j + 1] = col;
 			--j;
 			continue;
 		}
-		if (s <= 0) { st[0] = ST_INTERNAL; return; }
+		if (s <= 0) { if (lane == 0) st[0] = ST_INTERNAL; return; }
+		if (s <= pf_at && M.ep && A.tb_slot_bytes > 0) {
+			const int32_t r = s - 2 - lane;
+			uint32_t pf = 0;
+			if (r >= 0) {
+				const int64_t base = M.ep[2 * (r >> 8)], gn = M.ep[2 * (r >> 8) + 1];
+				const int32_t g = col / M.ep_ow;
+				int64_t at = base + ((int64_t)(r & 255) * (int32_t)(gn >> 32) + (g - (int32_t)(gn & 0xffffffff))) * M.ep_kw + (col - (g * M.ep_ow - M.ep_p));
+				at = min(max(at, (int64_t)0), (int64_t)A.tb_slot_bytes - 1); // (an older row may not reach this column: any byte of the arena will do)
+				pf = M.tb[at];
+			}
+			asm volatile("" :: "v"(pf));
+			pf_at = s - 40;
+		}
 		const uint32_t x = tb_byte(M, s - 1, col);
 		if (arr == 0) {
 			const uint32_t z = x & 7u;
@@ -1048,7 +1064,7 @@ __global__ void sys_walk_kernel(const BatchArgs A)
 		else if (arr == 3) { if (x & 0x20u) s -= P.e2; else s -= P.oe2, arr = 0; col -= 1; }
 		else { if (x & 0x40u) s -= P.e2; else s -= P.oe2, arr = 0; col += 1; }
 	}
-	st[3] = n_seg;
+	if (lane == 0) st[3] = n_seg;
 }
 
 __global__ __launch_bounds__(64) void sys_finish_kernel(const BatchArgs A)
