@@ -965,7 +965,7 @@ int launch_one(const BatchArgs &a0, int grid, int lds_seq, bool seq2, hipStream_
 	BatchArgs a = a0;
 	a.band_lds_seq = lds_seq;
 	const int lds = lds_seq + lds_tail<T, K, E1, E2>();
-	if constexpr (T == 1024) { // the 1024-thread geometry exists on 2-bit sequence copies only (others: the generic kernel)
+	if constexpr (T == 1024 || (T == 512 && K == 4)) { // the 1024-thread and the 512 x 4 geometries exist on 2-bit sequence copies only (the host knows)
 		if (!seq2) return -1;
 		if (a.want_cigar) launch_variant<T, K, E1, E2, true, true>(a, grid, lds, st);
 		else launch_variant<T, K, E1, E2, false, true>(a, grid, lds, st);
@@ -985,7 +985,7 @@ int occ_one(int lds_seq, bool seq2, bool tb)
 	const int lds = lds_seq + lds_tail<T, K, E1, E2>();
 	int n = 0;
 	hipError_t e;
-	if constexpr (T == 1024) {
+	if constexpr (T == 1024 || (T == 512 && K == 4)) {
 		if (!seq2) return 0;
 		e = tb ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, true, true>, T, lds)
 		       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, false, true>, T, lds);
@@ -1024,6 +1024,7 @@ bool band2_supported(const Penalty &p)
 #endif
 #define MWF_BAND2_DISPATCH(FN, ...)                                                 \
 	do {                                                                            \
+		if (g.block == 512 && g.span > 512 / 64 * 3 * 256) MWF_BAND2_PEN(FN, 512, 4, __VA_ARGS__) /* 32 chunks: windows of up to 7872 columns */ \
 		if (g.block == 512) MWF_BAND2_PEN(FN, MWF_B2_WIDE_T, MWF_B2_WIDE_K, __VA_ARGS__) \
 		if (g.block == 768) MWF_BAND2_PEN(FN, 768, 2, __VA_ARGS__)                  \
 		if (g.block == 1024) MWF_BAND2_PEN(FN, 1024, MWF_B2_SPAN_K, __VA_ARGS__)    \

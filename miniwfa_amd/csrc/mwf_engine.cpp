@@ -168,6 +168,7 @@ struct mwf_gpu_batch_s {
 		int64_t tun_key[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 		int64_t max_len = 0, max_bound = 0;
 		bool has_groups = false, mid_bytes = false;
+		bool four_slots = false;   // the last align of this batch saw a pair outgrow the 512-thread geometry's three chunk slots per wave late: four from now on
 		struct GI { int32_t n = 0; int64_t max_len = 0, max_bound = 0, max_bound1 = 0, max_tl = 0, max_seq_lds = 0; } gi[14];
 		std::vector<int8_t> cls0, flags0;
 	} plan;
@@ -362,6 +363,10 @@ int64_t penalty_bound(const mwf_opt_t &o, int64_t tl, int64_t ql, bool honour_ma
 // widest window the 64-, 128- and 256-thread packed band variants are chosen for: (waves x 3 chunks - 1) x 256 - 64 columns
 constexpr int64_t kBandMicroWindow = (1 * 3 - 1) * 256 - 64, kBandTinyWindow = (2 * 3 - 1) * 256 - 64, kBandSmallWindow = (4 * 3 - 1) * 256 - 64;
 constexpr int64_t kBandWideWindow = (8 * 3 - 1) * 256 - 64;
+// The 512-thread geometry with FOUR chunk slots per wave (32 chunks, 119 VGPRs, still two workgroups per CU; 2-bit sequence copies only): 2 % slower than
+// three slots on windows those hold (1024 x 10 kb @ 5 %: 17.7 against 17.4 ms) — and 17.7 against 24.8 ms on a batch in which ONE pair outgrows them
+// late and is re-run alone (three of four seeds of that batch shape, profiles/r04/wide4.txt).  Taken when a forecast or the batch's last align says so.
+constexpr int64_t kBandWide4Window = (8 * 4 - 1) * 256 - 64;
 // ... and the 1024-thread span geometry (16 waves x kBand2SpanK chunks, offsets biased by the target length: mwf_band2.hip wide_bias)
 constexpr int64_t kBandSpanMaxSeq = 62000;
 inline int64_t band_span_window() { return ((int64_t)band2_span_chunks() - 1) * 256 - 64; }
@@ -449,6 +454,8 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 	// geometry picked by the caller for a size class (pairs short enough that their window should stay inside a small span)
 	if (g->block == 0 && (geom_block == 64 || geom_block == 128 || geom_block == 256)) bg.block = geom_block;
 	bg.span = bg.block / 64 * (bg.block != 768 ? 3 : 2) * 256;
+	const bool four_slots = bg.block == 512 && g->block == 0 && window_hint > kBandWideWindow && window_hint <= kBandWide4Window;
+	if (four_slots) bg.span = 512 / 64 * 4 * 256;
 	if (want_kind != 2 && max_len + 1 > 4 * (int64_t)bg.span) return; // windows will mostly outgrow the span: go generic at once
 	const int64_t lds_cap = bg.block >= 768 ? 140 * 1024 : bg.block >= 512 ? 70 * 1024 : bg.block == 256 ? 36 * 1024 : bg.block == 128 ? 18 * 1024 : 9 * 1024;
 	// the packed kernel's sequence copy holds 2 bits per base unless that is switched off (or this is the re-run of pairs that
@@ -459,6 +466,7 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 	bg.seq2 = seq2 && bg.lds_bytes > 0;
 	// byte-wise copy (pairs outside plain ACGT) with wide windows: three slots of state plus six probe words per column do not fit the 128
 	// VGPRs two 512-thread workgroups per CU leave each wave (~500 bytes of scratch); 768 x 2 holds the same 24 chunks without spilling
+	if (!bg.seq2 && bg.block == 512 && four_slots) bg.span = 512 / 64 * 3 * 256; // (no byte-wise form of the four-slot geometry)
 	if (!bg.seq2 && bg.block == 512 && g->block == 0 && max_seq_lds <= 140 * 1024) {
 		bg.block = 768, bg.span = 768 / 64 * 2 * 256;
 		bg.lds_bytes = (int)((max_seq_lds + 15) / 16 * 16);
@@ -473,7 +481,7 @@ int cached_occupancy(mwf_gpu_t *g, const Penalty &P, const Plan &pl, int lds_e2_
 	uint64_t key;
 	if (pl.kind == 2)
 		key = 1ull | (uint64_t)pl.band.block << 4 | (uint64_t)(pl.band.packed == 1) << 16 | (uint64_t)(pl.band.lds_bytes > 0) << 17 | (uint64_t)pl.cigar << 18 |
-		      (uint64_t)(pl.band.seq2 != 0) << 3 | (uint64_t)(pl.band.lane == 1) << 2 | (uint64_t)(pl.band.lane == 2) << 19 | (uint64_t)P.e1 << 20 | (uint64_t)P.e2 << 28 | (uint64_t)pl.band.lds_bytes << 36;
+		      (uint64_t)(pl.band.seq2 != 0) << 3 | (uint64_t)(pl.band.lane == 1) << 2 | (uint64_t)(pl.band.block == 512 && pl.band.span > 6144) << 1 | (uint64_t)(pl.band.lane == 2) << 19 | (uint64_t)P.e1 << 20 | (uint64_t)P.e2 << 28 | (uint64_t)pl.band.lds_bytes << 36;
 	else key = 2ull | (uint64_t)pl.block << 4 | (uint64_t)stream_pass << 16 | (uint64_t)ring16 << 17 | (uint64_t)(P.nH > kMaxRing) << 18 | (uint64_t)lds_e2_cols << 20;
 	auto it = g->occ_cache.find(key);
 	if (it != g->occ_cache.end()) return it->second;
@@ -1315,7 +1323,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		const int64_t tk[14] = {g->force_kind, g->block, g->band_pack + 4 * (int64_t)g->band_span, g->ring16, g->lds_e2, g->scalar_generic, g->lane_max_len, g->seq2bit,
 		                        g->mid_max_pairs, g->coop_min_len, g->sys_p, g->coop_grid_cap, b->debug_pair, g->lane_chunks};
 		if (PC.valid && (memcmp(ok, PC.opt_key, sizeof(ok)) || memcmp(tk, PC.tun_key, sizeof(tk)))) PC.valid = false;
-		if (!PC.valid) memcpy(PC.opt_key, ok, sizeof(ok)), memcpy(PC.tun_key, tk, sizeof(tk)), PC.has_groups = false;
+		if (!PC.valid) memcpy(PC.opt_key, ok, sizeof(ok)), memcpy(PC.tun_key, tk, sizeof(tk)), PC.has_groups = false, PC.four_slots = false;
 	}
 	int64_t max_len = 0, max_bound = 0;
 	if (PC.valid) max_len = PC.max_len, max_bound = PC.max_bound;
@@ -1508,7 +1516,8 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		g->acgt_off_once = (c > 5 && c < 10) || (c == 11 && mid_bytes) || c == 12;
 		const int rc = run_batch_kernel(g, b, c == 5 ? *opt : opt_hi, b->d_order + at, G.n, slots, G.max_len, G.max_bound, G.max_bound1,
 		                                done_groups == 1, (classes || c >= 11) ? (c == 0 || c == 5 ? 0 : 2) : -1, G.max_tl, G.max_seq_lds, done_groups == n_groups,
-		                                cc == 7 ? 1024 : cc == 6 ? 33 : cc == 5 ? 32 : cc == 4 ? 64 : cc == 3 ? 128 : cc == 2 ? 256 : 0, &ran);
+		                                cc == 7 ? 1024 : cc == 6 ? 33 : cc == 5 ? 32 : cc == 4 ? 64 : cc == 3 ? 128 : cc == 2 ? 256 : 0, &ran,
+		                                (c == 1 && PC.four_slots) ? kBandWide4Window : 0);
 		g->acgt_off_once = false;
 		if (rc) return -1;
 		for (size_t j = at; j < at + (size_t)G.n; ++j) b->h_kind[b->h_order[j]] = (int8_t)ran;
@@ -1603,6 +1612,9 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 				// (a pair handed back EARLY carries the window it is expected to need, negated, where n_iter would be: one that no band class
 				// holds goes straight to the generic kernel)
 				const int64_t est = b->h_iter[i] < 0 ? -b->h_iter[i] : 0;
+				// (a pair of the wide class that outgrew its three chunk slots per wave LATE — that geometry carries no forecast — is re-run alone, ~7 ms for a
+				// 10 kb pair beside the batch's 17: the next align of this batch takes the four-slot geometry for the class)
+				if (b->h_class[i] == 1 && est == 0) b->plan.four_slots = true;
 				// (... only when the forecast is half again beyond the widest class: it is an estimate, and the generic kernel is several times slower)
 				// what outgrew (or is forecast to outgrow) the 512-thread geometry: the 1024-thread span geometry, if the pair fits that
 				const bool span_ok = b->h_class[i] >= 1 && b->h_class[i] <= 4 && g->band_span != 0 && g->seq2bit != 0 && g->force_kind < 0 && g->block == 0 &&

@@ -1,0 +1,15 @@
+"""1024 x 10 kb @ 5 % batches of four seeds, six aligns each (median of the last four): a pair that outgrows the 512-thread geometry late is re-run alone."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import miniwfa_amd as mw
+from miniwfa_amd.synth import synth_pair, PackedBatch
+for seed in (50000, 60000, 70000, 80000):
+    pk = PackedBatch([synth_pair(seed + i, 10000, 0.05) for i in range(1024)])
+    eng = mw.Engine(0); b = eng.upload(pk); o = mw.opt_init()
+    w = []
+    for _ in range(6):
+        t0 = time.perf_counter(); b.align(o); s, it, _ = b.results(); w.append((time.perf_counter() - t0) * 1e3)
+    st = eng.stats()
+    print(f"seed {seed}: step {np.median(w[2:]):.2f} ms, re-run {st.n_retries}, s max {int(s.max())}", flush=True)
+    b.free(); eng.close()

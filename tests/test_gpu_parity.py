@@ -1155,6 +1155,32 @@ def test_cigar_pool_in_block_mode_for_batches_of_thousands(oracle):
         eng.close()
 
 
+def test_wide_class_learns_four_chunk_slots_from_a_late_overflow(oracle):
+    """The 512-thread geometry holds 24 chunks (three per wave) and carries no forecast: a pair whose window outgrows them late is re-run alone
+    (on the span geometry).  The batch's plan remembers it — the next align of the same batch takes the four-slot form of the geometry for
+    the class and nothing is re-run; results are the same, and the pair in question equals the oracle."""
+    pairs = [synth_pair(60000 + i, 10000, 0.05) for i in range(1024)]
+    eng = mw.Engine(0)
+    b = eng.upload(PackedBatch(pairs))
+    b.align(mw.opt_init())
+    s0, it0, _ = b.results()
+    assert eng.stats().n_retries == 1, eng.stats().n_retries
+    b.align(mw.opt_init())
+    st = eng.stats()
+    assert (st.kernel_kind, st.packed, st.block) == (2, 1, 512)
+    s1, it1, _ = b.results()
+    assert eng.stats().n_retries == 0
+    assert (s0 == s1).all() and (it0 == it1).all()
+    i = int(np.argmax(s0))
+    assert (int(s1[i]), int(it1[i])) == oracle.align(pairs[i][0], pairs[i][1], make_opt())[:2]
+    b.align(mw.opt_init(flag=mw.MWF_F_CIGAR))     # (other options: a new plan, three slots again)
+    s2, it2, nc = b.results()
+    assert (s2 == s0).all() and (it2 == it0).all()
+    assert mw.cigar2score(mw.opt_init(), b.cigar(i, int(nc[i])).tolist()) == (int(s2[i]), len(pairs[i][0]), len(pairs[i][1]))
+    b.free()
+    eng.close()
+
+
 def test_span_geometry_long_pairs_against_oracle(oracle):
     """The packed band kernel's 1024-thread geometry (16 waves x 5 chunk slots, offsets biased by the target length so that targets of up
     to ~60 kb fit 16 bits, mwf_band2.hip wide_bias): pairs of 20-60 kb whose windows stay below 20 000 columns, s, n_iter and CIGAR
