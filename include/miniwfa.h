@@ -160,7 +160,9 @@ int32_t mwf_gpu_debug_band(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *op
  * sequences in device memory; a pair that outgrows 16 bits or holds a byte outside A/C/G/T is re-run with 32-bit rows and byte probes;
  * 2: the same), "ring16_block" (0, 512, 768), "band_span" (default 1: pairs too long or with windows too wide for the packed band kernel's
  * 512-thread geometry — up to 62 000 bases per sequence, windows of up to ~20 000 columns: 50 kb pairs at 3 % — run on its 1024-thread span
- * geometry, 16-bit offsets biased by the target length, instead of the generic kernel; 0: never; 2: every pair it can take (tests));
+ * geometry, 16-bit offsets biased by the target length, instead of the generic kernel; 0: never; 2: every pair it can take (tests)),
+ * "wide_slots" (chunk slots per wave of the packed band kernel's 512-thread geometry: 3 = 24 chunks, 4 = 32 chunks, 2 % slower where three suffice; default 0: four
+ * for a batch's first align under given options, three from then on if that align showed that they hold every pair);
  * whole-device (systolic) kernel: "lowmem_budget_mb" (low-memory mode: a first-pass traceback above this many MB switches to the two-pass
  * form whose first pass stores none; 0 = a quarter of the device), "sys_p" (penalties per hand-off block: 8, the one the library is built with; 4 and 16 only in builds with -DMWF_SYS_ALL_P — any other value is refused),
  * "sys_c" (columns per lane: 0 = chosen per pass from the expected window, 1, 4), "coop_grid" (at most this many workgroups; 0 = one

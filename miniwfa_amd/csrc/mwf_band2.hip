@@ -436,6 +436,9 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 		const int32_t gl_next = (lo > 1 ? lo - 1 : 1) >> 8;
 		if ((hi >> 8) - (lo >> 8) + 3 > NWK - 1) // (only then can the exact test fail)
 			if (((hi < cmax ? hi + 1 : cmax) >> 8) - gl_next + 1 > NWK - 1) { R.status = ST_BAND_OVERFLOW; return true; }
+		// (the four-slot form of the 512-thread geometry notes whether the three-slot form would have held the pair: the host's choice for the next align)
+		if (T == 512 && K == 4 && (hi >> 8) - (lo >> 8) + 3 > 23)
+			if (((hi < cmax ? hi + 1 : cmax) >> 8) - gl_next + 1 > 23) R.n_snap = 1;
 		// (biased offsets, sequences beyond 32 kb: the room arithmetic holds ql - d in 16 unsigned bits)
 		if (BI && cmax - lo > 65535) { R.status = ST_BAND_OVERFLOW; return true; }
 		const char *const rowx = Hb + bx, *const row1 = Hb + b1, *const row2 = Hb + b2;
@@ -940,6 +943,8 @@ __global__ __launch_bounds__(T, T == 1024 ? 4 : T == MWF_B2_WIDE_T ? MWF_B2_WIDE
 		}
 		const bool trace = A.dbg && pair == A.debug_pair;
 		if (R.status == ST_OK) R = band2_pass<T, K, E1, E2, TB, S2>(A, M, sh, edge_base, qoff, trace);
+		if (T == 512 && K == 4 && R.n_snap && threadIdx.x == 0) atomicOr((unsigned int*)(fresh(A0).cig_head + 1), 1u); // (mwf_engine.cpp: PlanCache::wide_state)
+		R.n_snap = 0;
 		if (S2) M.t2 = lds2, M.q2 = lds2 + qoff; // the traceback's back-match reads the 2-bit copies in LDS
 		finish_pair(fresh(A0), M, (int32_t)blockIdx.x, pair, R, R.status, 0, T <= 256 ? &cig_loc : nullptr); // (block mode: the geometries of the short pairs — thousands per launch)
 	}

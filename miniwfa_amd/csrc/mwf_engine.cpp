@@ -80,6 +80,7 @@ struct mwf_gpu_s {
 	int mid_max_pairs = -1;    // a batch of at most this many pairs may use the one-workgroup-per-pair, rings-in-LDS kernel (mwf_mid.hip) for its mid-size pairs (-1: one per CU; 0: never)
 	int mid_block = 0;         // its threads per workgroup: 0 by span (256 up to 512 columns, else 1024), 256, 1024
 	int band_pack = -1;        // int16-packed E/F registers in the band kernel: 0 never, otherwise whenever the value ranges allow
+	int wide_slots = 0;        // chunk slots per wave of the 512-thread packed geometry: 0 by batch (four until an align has shown that three hold every pair), 3, 4
 	int band_span = 1;         // the 1024-thread geometry of the packed band kernel (80 chunks, biased offsets: pairs of up to ~60 kb whose windows stay below ~20 000 columns): 0 never, 2: every pair it can take (tests)
 	int ring16 = 1;            // generic kernel with E2/F2 in LDS: 16-bit ring rows in HBM while target length + penalty fits 16 bits (0: never)
 	int ring16_block = 0;      // its threads per workgroup (0: 512 score-only — two workgroups per CU with the 64 KB LDS copy —, 768 with traceback)
@@ -168,7 +169,10 @@ struct mwf_gpu_batch_s {
 		int64_t tun_key[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 		int64_t max_len = 0, max_bound = 0;
 		bool has_groups = false, mid_bytes = false;
-		bool four_slots = false;   // the last align of this batch saw a pair outgrow the 512-thread geometry's three chunk slots per wave late: four from now on
+		// The wide class (512-thread geometry) holds 24 chunks with three slots per wave and 32 with four (2 % slower where three suffice).  0: not known yet —
+		// four slots, and the kernel reports whether three would have held every pair; 1: three hold this batch under these options; 2: four are needed.
+		int8_t wide_state = 0;
+		bool wide_measured = false; // this align's first launch of the class ran on four slots with the report word zeroed
 		struct GI { int32_t n = 0; int64_t max_len = 0, max_bound = 0, max_bound1 = 0, max_tl = 0, max_seq_lds = 0; } gi[14];
 		std::vector<int8_t> cls0, flags0;
 	} plan;
@@ -1213,6 +1217,7 @@ int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value)
 	else if (!strcmp(name, "ring16_block") && (value == 0 || value == 512 || value == 768)) g->ring16_block = (int)value;
 	else if (!strcmp(name, "band_pack")) g->band_pack = (int)value;
 	else if (!strcmp(name, "band_span") && value >= 0 && value <= 2) g->band_span = (int)value;
+	else if (!strcmp(name, "wide_slots") && (value == 0 || value == 3 || value == 4)) g->wide_slots = (int)value;
 	else if (!strcmp(name, "lane_chunks") && value >= 0 && value <= 4) g->lane_chunks = (int)value;
 	else if (!strcmp(name, "host_results")) g->res_pin_on = value != 0;
 	else if (!strcmp(name, "lane_max_len")) g->lane_max_len = (int)std::max<int64_t>(0, std::min<int64_t>(value, 8000));
@@ -1320,10 +1325,10 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	mwf_gpu_batch_t::PlanCache &PC = b->plan;
 	{
 		const int32_t ok[8] = {opt->flag & MWF_F_CIGAR, opt->x, opt->o1, opt->e1, opt->o2, opt->e2, opt->step, opt->max_s};
-		const int64_t tk[14] = {g->force_kind, g->block, g->band_pack + 4 * (int64_t)g->band_span, g->ring16, g->lds_e2, g->scalar_generic, g->lane_max_len, g->seq2bit,
+		const int64_t tk[14] = {g->force_kind, g->block, g->band_pack + 4 * (int64_t)g->band_span + 16 * (int64_t)g->wide_slots, g->ring16, g->lds_e2, g->scalar_generic, g->lane_max_len, g->seq2bit,
 		                        g->mid_max_pairs, g->coop_min_len, g->sys_p, g->coop_grid_cap, b->debug_pair, g->lane_chunks};
 		if (PC.valid && (memcmp(ok, PC.opt_key, sizeof(ok)) || memcmp(tk, PC.tun_key, sizeof(tk)))) PC.valid = false;
-		if (!PC.valid) memcpy(PC.opt_key, ok, sizeof(ok)), memcpy(PC.tun_key, tk, sizeof(tk)), PC.has_groups = false, PC.four_slots = false;
+		if (!PC.valid) memcpy(PC.opt_key, ok, sizeof(ok)), memcpy(PC.tun_key, tk, sizeof(tk)), PC.has_groups = false, PC.wide_state = 0;
 	}
 	int64_t max_len = 0, max_bound = 0;
 	if (PC.valid) max_len = PC.max_len, max_bound = PC.max_bound;
@@ -1339,6 +1344,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	if (b->debug_pair >= 0 && ensure(g, g->dbg, (size_t)8 * (max_bound + 2))) return -1;
 	const bool was_busy = b->busy;
 	b->busy = true;
+	PC.wide_measured = false;
 	g->queue_next = 0, g->lane_set_next = 0;
 	// Every pair "not run", CIGAR pool and work counters at zero: one small kernel — unless the result arrays can be written from here
 	// (the pinned result page of a small score-only batch: the single pair of a drop-in call) or came up initialised with the batch
@@ -1517,7 +1523,8 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		const int rc = run_batch_kernel(g, b, c == 5 ? *opt : opt_hi, b->d_order + at, G.n, slots, G.max_len, G.max_bound, G.max_bound1,
 		                                done_groups == 1, (classes || c >= 11) ? (c == 0 || c == 5 ? 0 : 2) : -1, G.max_tl, G.max_seq_lds, done_groups == n_groups,
 		                                cc == 7 ? 1024 : cc == 6 ? 33 : cc == 5 ? 32 : cc == 4 ? 64 : cc == 3 ? 128 : cc == 2 ? 256 : 0, &ran,
-		                                (c == 1 && PC.four_slots) ? kBandWide4Window : 0);
+		                                (c == 1 && (g->wide_slots == 4 || (g->wide_slots == 0 && PC.wide_state != 1 && g->queue_clean))) ? kBandWide4Window : 0);
+		if (c == 1 && g->wide_slots == 0 && PC.wide_state == 0 && g->queue_clean && ran == 2 && g->stats.block == 512) PC.wide_measured = true;
 		g->acgt_off_once = false;
 		if (rc) return -1;
 		for (size_t j = at; j < at + (size_t)G.n; ++j) b->h_kind[b->h_order[j]] = (int8_t)ran;
@@ -1587,6 +1594,12 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 		return 0;
 	};
 	if (fetch()) return -1;
+	if (b->plan.wide_measured) { // the four-slot kernels' report (reset to 0 by the align's reset kernel): did any pair need more than three slots hold?
+		uint32_t aux = 0;
+		memcpy(&aux, host.data() + 8, 4);
+		if (b->plan.wide_state == 0) b->plan.wide_state = (aux & 1u) ? 2 : 1;
+		b->plan.wide_measured = false;
+	}
 	b->busy = false;
 	mwf_opt_t opt_hi = b->opt;
 	opt_hi.step = 0;
@@ -1614,7 +1627,7 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 				const int64_t est = b->h_iter[i] < 0 ? -b->h_iter[i] : 0;
 				// (a pair of the wide class that outgrew its three chunk slots per wave LATE — that geometry carries no forecast — is re-run alone, ~7 ms for a
 				// 10 kb pair beside the batch's 17: the next align of this batch takes the four-slot geometry for the class)
-				if (b->h_class[i] == 1 && est == 0) b->plan.four_slots = true;
+				if (b->h_class[i] == 1 && est == 0) b->plan.wide_state = 2;
 				// (... only when the forecast is half again beyond the widest class: it is an estimate, and the generic kernel is several times slower)
 				// what outgrew (or is forecast to outgrow) the 512-thread geometry: the 1024-thread span geometry, if the pair fits that
 				const bool span_ok = b->h_class[i] >= 1 && b->h_class[i] <= 4 && g->band_span != 0 && g->seq2bit != 0 && g->force_kind < 0 && g->block == 0 &&

@@ -1155,28 +1155,48 @@ def test_cigar_pool_in_block_mode_for_batches_of_thousands(oracle):
         eng.close()
 
 
-def test_wide_class_learns_four_chunk_slots_from_a_late_overflow(oracle):
-    """The 512-thread geometry holds 24 chunks (three per wave) and carries no forecast: a pair whose window outgrows them late is re-run alone
-    (on the span geometry).  The batch's plan remembers it — the next align of the same batch takes the four-slot form of the geometry for
-    the class and nothing is re-run; results are the same, and the pair in question equals the oracle."""
+def test_wide_class_chunk_slots_follow_the_batch(oracle):
+    """The 512-thread geometry holds 24 chunks with three slots per wave and 32 with four (2 % slower where three suffice) and carries no forecast: with
+    three, a pair whose window outgrows them late is re-run alone on the span geometry ("wide_slots" 3: one such pair in this batch).  By default a batch's
+    first align under given options runs on four slots and reports whether three would have held every pair; later aligns follow that.  Same results
+    whatever the slots; the pair in question equals the oracle."""
     pairs = [synth_pair(60000 + i, 10000, 0.05) for i in range(1024)]
+    res = {}
+    for slots in (3, 4, 0):
+        eng = mw.Engine(0)
+        eng.set("wide_slots", slots)
+        b = eng.upload(PackedBatch(pairs))
+        for rep in range(3):
+            b.align(mw.opt_init())
+            st = eng.stats()
+            assert (st.kernel_kind, st.packed, st.block) == (2, 1, 512)
+            s, it, _ = b.results()
+            assert eng.stats().n_retries == (1 if slots == 3 else 0), (slots, rep, eng.stats().n_retries)
+            res[(slots, rep)] = (np.array(s), np.array(it))
+        if slots == 0:
+            b.align(mw.opt_init(flag=mw.MWF_F_CIGAR))     # (other options: a new plan)
+            s2, it2, nc = b.results()
+            assert eng.stats().n_retries == 0 and (s2 == res[(3, 0)][0]).all() and (it2 == res[(3, 0)][1]).all()
+            i = int(np.argmax(s2))
+            assert mw.cigar2score(mw.opt_init(), b.cigar(i, int(nc[i])).tolist()) == (int(s2[i]), len(pairs[i][0]), len(pairs[i][1]))
+        b.free()
+        eng.close()
+    for k, v in res.items():
+        assert (v[0] == res[(3, 0)][0]).all() and (v[1] == res[(3, 0)][1]).all(), k
+    i = int(np.argmax(res[(3, 0)][0]))
+    assert (int(res[(0, 2)][0][i]), int(res[(0, 2)][1][i])) == oracle.align(pairs[i][0], pairs[i][1], make_opt())[:2]
+    # a batch three slots hold: the first align measures (four slots), the others take three — nothing is ever re-run and the results stay
+    pairs = [synth_pair(50000 + i, 10000, 0.05) for i in range(256)]
     eng = mw.Engine(0)
     b = eng.upload(PackedBatch(pairs))
-    b.align(mw.opt_init())
-    s0, it0, _ = b.results()
-    assert eng.stats().n_retries == 1, eng.stats().n_retries
-    b.align(mw.opt_init())
-    st = eng.stats()
-    assert (st.kernel_kind, st.packed, st.block) == (2, 1, 512)
-    s1, it1, _ = b.results()
-    assert eng.stats().n_retries == 0
-    assert (s0 == s1).all() and (it0 == it1).all()
-    i = int(np.argmax(s0))
-    assert (int(s1[i]), int(it1[i])) == oracle.align(pairs[i][0], pairs[i][1], make_opt())[:2]
-    b.align(mw.opt_init(flag=mw.MWF_F_CIGAR))     # (other options: a new plan, three slots again)
-    s2, it2, nc = b.results()
-    assert (s2 == s0).all() and (it2 == it0).all()
-    assert mw.cigar2score(mw.opt_init(), b.cigar(i, int(nc[i])).tolist()) == (int(s2[i]), len(pairs[i][0]), len(pairs[i][1]))
+    got = []
+    for rep in range(3):
+        b.align(mw.opt_init())
+        s, it, _ = b.results()
+        assert eng.stats().n_retries == 0
+        got.append((np.array(s), np.array(it)))
+    assert all((g[0] == got[0][0]).all() and (g[1] == got[0][1]).all() for g in got)
+    assert (int(got[2][0][7]), int(got[2][1][7])) == oracle.align(pairs[7][0], pairs[7][1], make_opt())[:2]
     b.free()
     eng.close()
 
