@@ -294,11 +294,11 @@ __device__ __forceinline__ int32_t pair_of(int32_t lo, int32_t hi) { return (int
 __device__ __forceinline__ int32_t left_of_A(int32_t B, int32_t fill) { return __builtin_amdgcn_alignbit(B, from_left(B, fill), 16); }
 __device__ __forceinline__ int32_t right_of_B(int32_t A, int32_t fill) { return __builtin_amdgcn_alignbit(from_right(A, fill), A, 16); }
 
-template <int T, int K, int E1, int E2, bool TB, bool S2, typename ArgsT>
+template <int T, int K, int E1, int E2, bool TB, bool S2, bool BI4, typename ArgsT>
 __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, const int32_t edge_base, const int32_t qoff, bool trace_band)
 {
 	constexpr int NW = T / 64, NWK = NW * K, D = (E1 > E2 ? E1 : E2) + 1;
-	constexpr bool BI = T == 1024; // biased offsets (wide_bias)
+	constexpr bool BI = T == 1024 || BI4; // biased offsets with range checks (wide_bias): the span geometry and the four-slot 512-thread one's copy for long pairs
 	constexpr int FULL = S2 ? 16 : 8; // bases the first probe of the match extension looks at
 	constexpr int kAge = (NWK + 2) * 16; // bytes of one age of the edge table
 	static_assert(D == 2 || D == 3, "edge-table ages");
@@ -457,6 +457,8 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 		// (not in the widest geometry: what it hands back goes to the generic kernel, several times slower — it would only do so at penalty 1024
 		// and beyond 1.5 x its span, and the bookkeeping costs the headline kernel 21 more spilled SGPRs)
 		// (the span geometry forecasts later: what it hands back goes to the generic kernel, twice as slow — no more)
+		// (none in the four-slot 512-thread geometry either — measured: a tight one at penalty 1024 costs its batches 6 % in spilled SGPRs and hands back pairs that
+		// are then re-run alone, 1024 x 12 kb @ 5 % 34.2 against 24.7 ms)
 		const bool forecast = NWK < 24 ? (s_new == 64 || s_new == 256 || s_new == 1024) : NWK >= 64 ? (s_new == 1024 || s_new == 4096) : false; // uniform: look at how far the pair has come (dev::window_forecast)
 		int32_t far = kDeadPair;
 		const int32_t cfin = ql + 1; // the end cell (tl-1, ql-1) lies on diagonal ql-tl, i.e. in this column
@@ -896,7 +898,7 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 
 // Workgroups share a CU: 2 x 512, 4 x 256, 8 x 128 or 16 x 64 threads = 4 waves per SIMD, i.e. at most 128 VGPRs; with traceback
 // the smaller ones get 168 (3 per SIMD).  768 threads: one workgroup per CU.
-template <int T, int K, int E1, int E2, bool TB, bool S2>
+template <int T, int K, int E1, int E2, bool TB, bool S2, bool BI4 = false>
 __global__ __launch_bounds__(T, T == 1024 ? 4 : T == MWF_B2_WIDE_T ? MWF_B2_WIDE_WAVES : T <= 512 ? ((TB && T < 512) ? 3 : 4) : MWF_B2_768_WAVES) void wfa_band2_kernel(const BatchArgs)
 {
 	constexpr int NWK = (T / 64) * K, D = (E1 > E2 ? E1 : E2) + 1;
@@ -942,8 +944,8 @@ __global__ __launch_bounds__(T, T == 1024 ? 4 : T == MWF_B2_WIDE_T ? MWF_B2_WIDE
 			__syncthreads();
 		}
 		const bool trace = A.dbg && pair == A.debug_pair;
-		if (R.status == ST_OK) R = band2_pass<T, K, E1, E2, TB, S2>(A, M, sh, edge_base, qoff, trace);
-		if (T == 512 && K == 4 && R.n_snap && threadIdx.x == 0) atomicOr((unsigned int*)(fresh(A0).cig_head + 1), 1u); // (mwf_engine.cpp: PlanCache::wide_state)
+		if (R.status == ST_OK) R = band2_pass<T, K, E1, E2, TB, S2, BI4>(A, M, sh, edge_base, qoff, trace);
+		if (T == 512 && K == 4 && R.n_snap && threadIdx.x == 0 && fresh(A0).report_wide) atomicOr((unsigned int*)(fresh(A0).cig_head + 1), 1u); // (mwf_engine.cpp: PlanCache::wide_state)
 		R.n_snap = 0;
 		if (S2) M.t2 = lds2, M.q2 = lds2 + qoff; // the traceback's back-match reads the 2-bit copies in LDS
 		finish_pair(fresh(A0), M, (int32_t)blockIdx.x, pair, R, R.status, 0, T <= 256 ? &cig_loc : nullptr); // (block mode: the geometries of the short pairs — thousands per launch)
@@ -953,18 +955,18 @@ __global__ __launch_bounds__(T, T == 1024 ? 4 : T == MWF_B2_WIDE_T ? MWF_B2_WIDE
 template <int T, int K, int E1, int E2>
 constexpr int lds_tail() { return (int)sizeof(Band2Lds<(E1 > E2 ? E1 : E2) + 1, (T / 64) * K>); }
 
-template <int T, int K, int E1, int E2, bool TB, bool S2>
+template <int T, int K, int E1, int E2, bool TB, bool S2, bool BI4 = false>
 void launch_variant(const BatchArgs &a, int grid, int lds, hipStream_t st)
 {
 	// the attribute is per device and this may run on several host threads (mwf_wfa_batch_multi): set it on every launch that needs it
 	if (lds > 48 * 1024) {
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wfa_band2_kernel<T, K, E1, E2, TB, S2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wfa_band2_kernel<T, K, E1, E2, TB, S2, BI4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 		(void)hipGetLastError();
 	}
-	hipLaunchKernelGGL((wfa_band2_kernel<T, K, E1, E2, TB, S2>), dim3(grid), dim3(T), lds, st, a);
+	hipLaunchKernelGGL((wfa_band2_kernel<T, K, E1, E2, TB, S2, BI4>), dim3(grid), dim3(T), lds, st, a);
 }
 
-template <int T, int K, int E1, int E2>
+template <int T, int K, int E1, int E2, bool BI4 = false>
 int launch_one(const BatchArgs &a0, int grid, int lds_seq, bool seq2, hipStream_t st)
 {
 	BatchArgs a = a0;
@@ -972,8 +974,8 @@ int launch_one(const BatchArgs &a0, int grid, int lds_seq, bool seq2, hipStream_
 	const int lds = lds_seq + lds_tail<T, K, E1, E2>();
 	if constexpr (T == 1024 || (T == 512 && K == 4)) { // the 1024-thread and the 512 x 4 geometries exist on 2-bit sequence copies only (the host knows)
 		if (!seq2) return -1;
-		if (a.want_cigar) launch_variant<T, K, E1, E2, true, true>(a, grid, lds, st);
-		else launch_variant<T, K, E1, E2, false, true>(a, grid, lds, st);
+		if (a.want_cigar) launch_variant<T, K, E1, E2, true, true, BI4>(a, grid, lds, st);
+		else launch_variant<T, K, E1, E2, false, true, BI4>(a, grid, lds, st);
 	} else if (a.want_cigar) {
 		if (seq2) launch_variant<T, K, E1, E2, true, true>(a, grid, lds, st);
 		else launch_variant<T, K, E1, E2, true, false>(a, grid, lds, st);
@@ -984,7 +986,7 @@ int launch_one(const BatchArgs &a0, int grid, int lds_seq, bool seq2, hipStream_
 	return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-template <int T, int K, int E1, int E2>
+template <int T, int K, int E1, int E2, bool BI4 = false>
 int occ_one(int lds_seq, bool seq2, bool tb)
 {
 	const int lds = lds_seq + lds_tail<T, K, E1, E2>();
@@ -992,8 +994,8 @@ int occ_one(int lds_seq, bool seq2, bool tb)
 	hipError_t e;
 	if constexpr (T == 1024 || (T == 512 && K == 4)) {
 		if (!seq2) return 0;
-		e = tb ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, true, true>, T, lds)
-		       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, false, true>, T, lds);
+		e = tb ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, true, true, BI4>, T, lds)
+		       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, false, true, BI4>, T, lds);
 	} else if (tb) e = seq2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, true, true>, T, lds)
 	                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, true, false>, T, lds);
 	else e = seq2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, false, true>, T, lds)
@@ -1027,8 +1029,15 @@ bool band2_supported(const Penalty &p)
 		if (a_e1 == 1 && a_e2 == 1) return FN<T, K, 1, 1>(__VA_ARGS__);             \
 	}
 #endif
+#define MWF_BAND2_PEN4B(FN, ...)                                                    \
+	{                                                                               \
+		if (a_e1 == 2 && a_e2 == 1) return FN<512, 4, 2, 1, true>(__VA_ARGS__);     \
+		if (a_e1 == 2 && a_e2 == 2) return FN<512, 4, 2, 2, true>(__VA_ARGS__);     \
+		if (a_e1 == 1 && a_e2 == 1) return FN<512, 4, 1, 1, true>(__VA_ARGS__);     \
+	}
 #define MWF_BAND2_DISPATCH(FN, ...)                                                 \
 	do {                                                                            \
+		if (g.block == 512 && g.span > 512 / 64 * 3 * 256 && g.packed == 2) MWF_BAND2_PEN4B(FN, __VA_ARGS__) /* ... on biased offsets (pairs of up to ~14 kb) */ \
 		if (g.block == 512 && g.span > 512 / 64 * 3 * 256) MWF_BAND2_PEN(FN, 512, 4, __VA_ARGS__) /* 32 chunks: windows of up to 7872 columns */ \
 		if (g.block == 512) MWF_BAND2_PEN(FN, MWF_B2_WIDE_T, MWF_B2_WIDE_K, __VA_ARGS__) \
 		if (g.block == 768) MWF_BAND2_PEN(FN, 768, 2, __VA_ARGS__)                  \

@@ -173,7 +173,7 @@ struct mwf_gpu_batch_s {
 		// four slots, and the kernel reports whether three would have held every pair; 1: three hold this batch under these options; 2: four are needed.
 		int8_t wide_state = 0;
 		bool wide_measured = false; // this align's first launch of the class ran on four slots with the report word zeroed
-		struct GI { int32_t n = 0; int64_t max_len = 0, max_bound = 0, max_bound1 = 0, max_tl = 0, max_seq_lds = 0; } gi[14];
+		struct GI { int32_t n = 0; int64_t max_len = 0, max_bound = 0, max_bound1 = 0, max_tl = 0, max_seq_lds = 0; } gi[15];
 		std::vector<int8_t> cls0, flags0;
 	} plan;
 	std::vector<char> host_out;     // the fixed-size results as they came back (finalize)
@@ -424,6 +424,12 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 		}
 	}
 	if (want_kind == 0 || low_mem || !can_packed) return;
+	if (geom_block == 514) { // the 512-thread geometry with four chunk slots on biased offsets (the caller checked the lengths: kBandSpanMaxSeq); 2-bit copies only
+		const int64_t need_lds = ((max_len >> 4) + 4) * 4;
+		if (g->seq2bit == 0 || g->acgt_off_once || need_lds > 70 * 1024) return;
+		pl.kind = 2, pl.band = BandGeom{512, 2, 512 / 64 * 4 * 256, (int)((need_lds + 15) / 16 * 16), 1, 0}; // (packed 2: the copy that computes on biased offsets)
+		return;
+	}
 	if (geom_block == 1024) { // the span geometry (the caller checked the lengths of every pair: kBandSpanMaxSeq); 2-bit sequence copies only
 		const int64_t need_lds = ((max_len >> 4) + 4) * 4;
 		if (g->band_span == 0 || g->seq2bit == 0 || g->acgt_off_once || need_lds > 150 * 1024) return;
@@ -484,7 +490,7 @@ int cached_occupancy(mwf_gpu_t *g, const Penalty &P, const Plan &pl, int lds_e2_
 {
 	uint64_t key;
 	if (pl.kind == 2)
-		key = 1ull | (uint64_t)pl.band.block << 4 | (uint64_t)(pl.band.packed == 1) << 16 | (uint64_t)(pl.band.lds_bytes > 0) << 17 | (uint64_t)pl.cigar << 18 |
+		key = 1ull | (uint64_t)pl.band.block << 4 | (uint64_t)(pl.band.packed == 1) << 16 | (uint64_t)(pl.band.packed == 2) << 15 | (uint64_t)(pl.band.lds_bytes > 0) << 17 | (uint64_t)pl.cigar << 18 |
 		      (uint64_t)(pl.band.seq2 != 0) << 3 | (uint64_t)(pl.band.lane == 1) << 2 | (uint64_t)(pl.band.block == 512 && pl.band.span > 6144) << 1 | (uint64_t)(pl.band.lane == 2) << 19 | (uint64_t)P.e1 << 20 | (uint64_t)P.e2 << 28 | (uint64_t)pl.band.lds_bytes << 36;
 	else key = 2ull | (uint64_t)pl.block << 4 | (uint64_t)stream_pass << 16 | (uint64_t)ring16 << 17 | (uint64_t)(P.nH > kMaxRing) << 18 | (uint64_t)lds_e2_cols << 20;
 	auto it = g->occ_cache.find(key);
@@ -655,6 +661,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	a.cig_scratch = pl.cigar ? (uint32_t*)g->cig_scratch.p : nullptr, a.cig_scratch_slot = pl.cig_scratch_slot;
 	a.cig_pool = b->d_cig_pool, a.cig_head = b->d_cig_head, a.cig_pool_words = b->cig_pool_words;
 	a.cig_block = pl.grid <= kCigBlockGrid ? b->cig_block : 0;
+	a.report_wide = geom_block == 0 && window_hint == kBandWide4Window ? 1 : 0; // (the wide class's measuring align, mwf_gpu_batch_align)
 	a.snap = pl.low_mem ? (int32_t*)g->snap.p : nullptr, a.snap_slot_ints = pl.snap_slot_ints;
 	a.snap_meta = pl.low_mem ? (int32_t*)g->snap_meta.p : nullptr, a.snap_meta_slot = pl.snap_meta_slot;
 	a.seg = pl.low_mem ? (int32_t*)g->seg.p : nullptr, a.seg_slot = pl.seg_slot;
@@ -682,7 +689,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	}
 	g->stats.n_launches += 1;
 	g->stats.grid = std::max(g->stats.grid, pl.grid), g->stats.block = pl.block, g->stats.kernel_kind = pl.kind;
-	g->stats.packed = pl.kind == 2 ? (pl.band.lane == 2 ? 33 : pl.band.lane ? 32 : pl.band.packed) : (ring16 ? 16 : 0);
+	g->stats.packed = pl.kind == 2 ? (pl.band.lane == 2 ? 33 : pl.band.lane ? 32 : (pl.band.packed ? 1 : 0)) : (ring16 ? 16 : 0);
 	g->stats.lowmem_two_pass = pl.low_mem ? 1 : 0;
 	if (ran_kind) *ran_kind = pl.kind;
 	return 0;
@@ -1414,15 +1421,17 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	// 10: short pairs on the one-diagonal-per-lane kernel (mwf_lane.hip); what outgrows its 64 columns moves to the band classes
 	// 11: mid-size pairs of a small batch on the one-workgroup-per-pair, rings-in-LDS kernel (mwf_mid.hip); what outgrows its span moves to the band classes
 	typedef mwf_gpu_batch_t::PlanCache::GI GroupInfo;
-	GroupInfo gi[14];
+	GroupInfo gi[15];
 	bool mid_bytes = false;
 	// (12: the pairs of class 10 the host knows not to be plain A/C/G/T — reads with an N —: the lane kernel on byte-wise copies)
 	// 13: pairs too long (or with windows too wide) for the 512-thread packed geometry on its 1024-thread span geometry: targets of up to ~60 kb on biased
 	// 16-bit offsets, windows of up to ~16 000 columns; what outgrows it moves to the generic kernel
-	static const int run_order[14] = {5, 0, 13, 1, 6, 2, 7, 3, 8, 4, 9, 11, 10, 12}; // largest workspace first
+	// 14: pairs of up to ~16 kb per sequence whose worst-case penalty rules out plain 16-bit offsets: the 512-thread geometry with four chunk slots, which computes on
+	// biased offsets with range checks like the span geometry but keeps two pairs per CU (windows of up to 7872 columns; what outgrows them moves to the span geometry)
+	static const int run_order[15] = {5, 0, 13, 14, 1, 6, 2, 7, 3, 8, 4, 9, 11, 10, 12}; // largest workspace first
 	if (PC.has_groups) { // same lengths, same options, same tunables as last time: classes, order (already on the device) and maxima as they were
 		b->h_class = PC.cls0, b->h_flags = PC.flags0;
-		for (int c = 0; c < 14; ++c) gi[c] = PC.gi[c];
+		for (int c = 0; c < 15; ++c) gi[c] = PC.gi[c];
 		mid_bytes = PC.mid_bytes;
 	} else {
 		const bool lane_ok = g->lane_max_len > 0 && lane_supported(P0);
@@ -1431,7 +1440,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		const bool know_acgt = !b->h_acgt.empty() && g->seq2bit != 0;
 		const bool pack_pen = g->band_pack != 0 && band2_supported(P0);
 		std::vector<int8_t> cls((size_t)b->n); // group of every pair
-		int32_t count[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+		int32_t count[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 		const bool span_pen = pack_pen && g->band_span != 0 && g->seq2bit != 0;
 		for (int32_t i = 0; i < b->n; ++i) {
 			const int64_t tl = b->h_tl[i], ql = b->h_ql[i], len = tl + ql;
@@ -1455,9 +1464,12 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 				else if (packable && (window <= kBandTinyWindow || len + 1 <= 3 * (int64_t)(2 * 3 * 256))) c = 3;
 				else if (packable && (window <= kBandSmallWindow || len + 1 <= 3 * (int64_t)(4 * 3 * 256))) c = 2;
 				else if (packable && len + 1 <= 4 * (int64_t)(8 * 3 * 256)) c = 1;
+				// (tl + ql up to 3.5 of its spans: a 12 kb pair at 5 % needs ~6000 of the 7872 columns; 512 x 15 kb @ 5 % — windows of ~7500 — lost 44 pairs to late
+				// overflows, 30.7 against 24.9 ms on the span geometry from the start)
+				else if (span_ok && g->wide_slots != 3 && len + 1 <= 7 * (int64_t)(8 * 4 * 256) / 2) c = 14;
 				else if (span_ok && len + 1 <= 7 * band2_span_chunks() * 256) c = 13;
 			}
-			b->h_class[i] = (int8_t)(c == 5 ? 0 : c == 13 ? 5 : c);
+			b->h_class[i] = (int8_t)(c == 5 ? 0 : c == 13 ? 5 : c == 14 ? 1 : c);
 			b->h_flags[i] = (int8_t)(step0 ? 1 : 0);
 			// short pairs: a window of 64 diagonals holds them while the penalty stays below ~45 (a 200 bp pair at 5 %)
 			// (in a batch small enough for the mid kernel the lane kernel keeps the pairs of up to 320 bases: 16 x 400 bp 0.31 ms on the lane
@@ -1488,7 +1500,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		}
 		// The processing order: groups in run order, longest first inside a group (the persistent workgroups finish together).  h_order is
 		// already sorted longest first (batch_common) and that order is stable: one pass over it deals the pairs to their groups.
-		std::vector<int32_t> start(14, 0), order((size_t)b->n);
+		std::vector<int32_t> start(15, 0), order((size_t)b->n);
 		{
 			int32_t at = 0;
 			for (int c : run_order) start[c] = at, at += count[c], gi[c].n = count[c];
@@ -1506,7 +1518,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 			if (upload_segments(g, (char*)b->d_order, std::vector<Seg>{Seg{b->h_order.data(), b->h_order.size() * 4}})) return -1; // (waits for earlier work on the stream first)
 		}
 		PC.cls0 = b->h_class, PC.flags0 = b->h_flags, PC.mid_bytes = mid_bytes, PC.has_groups = true;
-		for (int c = 0; c < 14; ++c) PC.gi[c] = gi[c];
+		for (int c = 0; c < 15; ++c) PC.gi[c] = gi[c];
 	}
 	int n_groups = 0, done_groups = 0;
 	for (const GroupInfo &G : gi) n_groups += G.n > 0;
@@ -1518,11 +1530,11 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		if (G.n == 0) continue;
 		++done_groups;
 		int ran = 0;
-		const int cc = c == 13 ? 7 : c == 11 ? 6 : (c == 10 || c == 12) ? 5 : c > 5 ? c - 5 : c;
+		const int cc = c == 14 ? 8 : c == 13 ? 7 : c == 11 ? 6 : (c == 10 || c == 12) ? 5 : c > 5 ? c - 5 : c;
 		g->acgt_off_once = (c > 5 && c < 10) || (c == 11 && mid_bytes) || c == 12;
 		const int rc = run_batch_kernel(g, b, c == 5 ? *opt : opt_hi, b->d_order + at, G.n, slots, G.max_len, G.max_bound, G.max_bound1,
 		                                done_groups == 1, (classes || c >= 11) ? (c == 0 || c == 5 ? 0 : 2) : -1, G.max_tl, G.max_seq_lds, done_groups == n_groups,
-		                                cc == 7 ? 1024 : cc == 6 ? 33 : cc == 5 ? 32 : cc == 4 ? 64 : cc == 3 ? 128 : cc == 2 ? 256 : 0, &ran,
+		                                cc == 8 ? 514 : cc == 7 ? 1024 : cc == 6 ? 33 : cc == 5 ? 32 : cc == 4 ? 64 : cc == 3 ? 128 : cc == 2 ? 256 : 0, &ran,
 		                                (c == 1 && (g->wide_slots == 4 || (g->wide_slots == 0 && PC.wide_state != 1 && g->queue_clean))) ? kBandWide4Window : 0);
 		if (c == 1 && g->wide_slots == 0 && PC.wide_state == 0 && g->queue_clean && ran == 2 && g->stats.block == 512) PC.wide_measured = true;
 		g->acgt_off_once = false;

@@ -120,6 +120,7 @@ struct BatchArgs {
 	int64_t sys_park_stride;   // ints between two groups' parking areas
 	int64_t *sys_ep;           // [group][epochs][2]: traceback layout per epoch of 256 penalties: base offset, first chunk | chunks << 32
 	int64_t sys_ep_stride;     // int64 words between two groups' tables
+	int32_t report_wide;       // packed band kernel, 512 threads x 4 chunk slots: 1 = note in the word behind cig_head whether three slots would have held every pair
 	int32_t cig_block;         // > 0: workgroups take the CIGAR pool in blocks of this many words and place their pairs' CIGARs in them (batches of thousands of pairs:
 	                           // one atomic on cig_head per pair is ~12.7 ns on a single address); 0: one allocation per pair, no holes
 	int32_t lane_chunks;       // one-diagonal-per-lane kernels: 64-column chunks of their LDS rows (mwf_lane.hip: 1-4; mwf_mid.hip: its span / 64)
@@ -135,7 +136,7 @@ int  batch_kernel_occupancy(int block, bool stream_pass, int lds_e2_cols, bool r
 // geometry of a launch of the band family (mwf_band2.hip packed band kernel, mwf_lane.hip, mwf_mid.hip)
 struct BandGeom {
 	int block;        // threads per workgroup: 256 (x2 chunks), 768 (x2 chunks) or 512 (x3 chunks, packed state)
-	int packed;       // 1: the packed band kernel (mwf_band2.hip: E/F register state as int16 pairs, 16-bit H rows)
+	int packed;       // 1: the packed band kernel (mwf_band2.hip: E/F register state as int16 pairs, 16-bit H rows); 2: its 512 x 4 geometry's copy on biased offsets
 	int span;         // columns the workgroup can hold: waves * chunks * 256 (balanced kernel: columns of its LDS state ring)
 	int lds_bytes;    // dynamic LDS for the sequence copy (0: read sequences from global memory)
 	int seq2;         // packed kernel: the sequence copy holds 2 bits per base (pairs of plain A/C/G/T; others come back as ST_ALPHABET)

@@ -1201,6 +1201,36 @@ def test_wide_class_chunk_slots_follow_the_batch(oracle):
     eng.close()
 
 
+def test_four_slot_geometry_takes_pairs_of_12_kb_on_biased_offsets(oracle):
+    """Pairs of ~11-14 kb — too long for plain 16-bit offsets by the worst-case rule, short enough for windows of up to 7872 columns — run two per CU on the
+    512-thread geometry's four-slot copy that computes on biased offsets with range checks (class 14; before: the span geometry, one per CU).  Pairs whose
+    window outgrows its 32 chunks move on to the span geometry.  Score and CIGAR runs equal the generic kernel's on every pair and the oracle's on a sample."""
+    pairs = [synth_pair(71000 + i, 11000 + 97 * i, 0.05) for i in range(30)] + [synth_pair(71100 + i, 13500, 0.09) for i in range(3)] + [synth_pair(71200, 12000, 0.0), synth_pair(71201, 14000, 0.01)]
+    pk = PackedBatch(pairs)
+    ref = None
+    for kw in (dict(), dict(flag=1)):
+        eng = mw.Engine(0)
+        eng.set("force_kind", 0)
+        b = eng.upload(pk); b.align(mw.opt_init(**kw)); ref = [np.array(x) for x in b.results()]
+        b.free(); eng.close()
+        eng = mw.Engine(0)
+        b = eng.upload(pk)
+        b.align(mw.opt_init(**kw))
+        st = eng.stats()
+        assert (st.kernel_kind, st.packed, st.block) == (2, 1, 512), (st.kernel_kind, st.packed, st.block)
+        s, it, nc = b.results()
+        assert eng.stats().n_retries == 3            # the three pairs at 9 %: the span geometry
+        assert (s == ref[0]).all() and (it == ref[1]).all()
+        o = make_opt(**kw)
+        for i in (0, 17, 29, 31, 33, 34):
+            es, eit, ecig = oracle.align(pairs[i][0], pairs[i][1], o)
+            assert (int(s[i]), int(it[i])) == (es, eit), (kw, i)
+            if ecig is not None:
+                assert b.cigar(i, int(nc[i])).tolist() == ecig, (kw, i)
+        b.free()
+        eng.close()
+
+
 def test_span_geometry_long_pairs_against_oracle(oracle):
     """The packed band kernel's 1024-thread geometry (16 waves x 5 chunk slots, offsets biased by the target length so that targets of up
     to ~60 kb fit 16 bits, mwf_band2.hip wide_bias): pairs of 20-60 kb whose windows stay below 20 000 columns, s, n_iter and CIGAR
