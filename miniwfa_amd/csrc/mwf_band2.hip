@@ -43,6 +43,13 @@ extern __shared__ __attribute__((aligned(16))) uint8_t lds2[];
 // 174.6 ms and no re-run, 6 slots (12 spilled) 177.0; 256 x 50 kb: 36.2 (+ 9 re-runs: 104) / 38.7 / 39.6 ms; generic kernel 279 and 78 ms.
 #define MWF_B2_SPAN_K 5
 #endif
+#ifndef MWF_B2_W4K
+// Chunk slots per wave of the 512-thread geometry's copies on biased offsets (class 14 of mwf_engine.cpp: pairs of ~11-21 kb, two per CU instead of the span
+// geometry's one).  Measured (ms per align; span geometry | 4 | 5 | 6 slots): 1024 x 12 kb @ 5 % 34.9 | 24.6 | 24.8 | 27.7, 1024 x 15 kb @ 4 % 35.6 | - | 25.1 | 25.7,
+// 1024 x 17 kb @ 3 % 29.5 | - | 20.2 | 20.5, 512 x 18 kb @ 5 % 32.1 | - | - | 25.3, 1024 x 20 kb @ 3 % 37.3 | - | - | 26.9: five slots (40 chunks, 4 spilled VGPRs)
+// while target + query stay below 3.5 of their span, six (48 chunks) up to 3.5 of theirs.
+#define MWF_B2_W4K 5
+#endif
 #ifndef MWF_B2_WIDE_WAVES
 #define MWF_B2_WIDE_WAVES 4 // waves per SIMD the widest geometry is compiled for (4: 128 VGPRs, two 512-thread workgroups per CU)
 #endif
@@ -972,7 +979,7 @@ int launch_one(const BatchArgs &a0, int grid, int lds_seq, bool seq2, hipStream_
 	BatchArgs a = a0;
 	a.band_lds_seq = lds_seq;
 	const int lds = lds_seq + lds_tail<T, K, E1, E2>();
-	if constexpr (T == 1024 || (T == 512 && K == 4)) { // the 1024-thread and the 512 x 4 geometries exist on 2-bit sequence copies only (the host knows)
+	if constexpr (T == 1024 || (T == 512 && K >= 4)) { // the 1024-thread and the 512 x 4 geometries exist on 2-bit sequence copies only (the host knows)
 		if (!seq2) return -1;
 		if (a.want_cigar) launch_variant<T, K, E1, E2, true, true, BI4>(a, grid, lds, st);
 		else launch_variant<T, K, E1, E2, false, true, BI4>(a, grid, lds, st);
@@ -992,7 +999,7 @@ int occ_one(int lds_seq, bool seq2, bool tb)
 	const int lds = lds_seq + lds_tail<T, K, E1, E2>();
 	int n = 0;
 	hipError_t e;
-	if constexpr (T == 1024 || (T == 512 && K == 4)) {
+	if constexpr (T == 1024 || (T == 512 && K >= 4)) {
 		if (!seq2) return 0;
 		e = tb ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, true, true, BI4>, T, lds)
 		       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, false, true, BI4>, T, lds);
@@ -1031,13 +1038,20 @@ bool band2_supported(const Penalty &p)
 #endif
 #define MWF_BAND2_PEN4B(FN, ...)                                                    \
 	{                                                                               \
-		if (a_e1 == 2 && a_e2 == 1) return FN<512, 4, 2, 1, true>(__VA_ARGS__);     \
-		if (a_e1 == 2 && a_e2 == 2) return FN<512, 4, 2, 2, true>(__VA_ARGS__);     \
-		if (a_e1 == 1 && a_e2 == 1) return FN<512, 4, 1, 1, true>(__VA_ARGS__);     \
+		if (a_e1 == 2 && a_e2 == 1) return FN<512, MWF_B2_W4K, 2, 1, true>(__VA_ARGS__);     \
+		if (a_e1 == 2 && a_e2 == 2) return FN<512, MWF_B2_W4K, 2, 2, true>(__VA_ARGS__);     \
+		if (a_e1 == 1 && a_e2 == 1) return FN<512, MWF_B2_W4K, 1, 1, true>(__VA_ARGS__);     \
+	}
+#define MWF_BAND2_PEN4C(FN, ...)                                                    \
+	{                                                                               \
+		if (a_e1 == 2 && a_e2 == 1) return FN<512, MWF_B2_W4K + 1, 2, 1, true>(__VA_ARGS__); \
+		if (a_e1 == 2 && a_e2 == 2) return FN<512, MWF_B2_W4K + 1, 2, 2, true>(__VA_ARGS__); \
+		if (a_e1 == 1 && a_e2 == 1) return FN<512, MWF_B2_W4K + 1, 1, 1, true>(__VA_ARGS__); \
 	}
 #define MWF_BAND2_DISPATCH(FN, ...)                                                 \
 	do {                                                                            \
-		if (g.block == 512 && g.span > 512 / 64 * 3 * 256 && g.packed == 2) MWF_BAND2_PEN4B(FN, __VA_ARGS__) /* ... on biased offsets (pairs of up to ~14 kb) */ \
+		if (g.block == 512 && g.span > 8 * MWF_B2_W4K * 256 && g.packed == 2) MWF_BAND2_PEN4C(FN, __VA_ARGS__) /* ... six slots on biased offsets (pairs of up to ~21 kb) */ \
+		if (g.block == 512 && g.span > 512 / 64 * 3 * 256 && g.packed == 2) MWF_BAND2_PEN4B(FN, __VA_ARGS__) /* ... five slots on biased offsets (pairs of up to ~18 kb) */ \
 		if (g.block == 512 && g.span > 512 / 64 * 3 * 256) MWF_BAND2_PEN(FN, 512, 4, __VA_ARGS__) /* 32 chunks: windows of up to 7872 columns */ \
 		if (g.block == 512) MWF_BAND2_PEN(FN, MWF_B2_WIDE_T, MWF_B2_WIDE_K, __VA_ARGS__) \
 		if (g.block == 768) MWF_BAND2_PEN(FN, 768, 2, __VA_ARGS__)                  \
@@ -1053,6 +1067,7 @@ int launch_band2(const BatchArgs &a, int grid, const BandGeom &g, void *stream)
 }
 
 int band2_span_chunks() { return 16 * MWF_B2_SPAN_K; }
+int band2_biased512_chunks() { return 8 * MWF_B2_W4K; }
 
 int band2_kernel_occupancy(const Penalty &p, const BandGeom &g, bool cigar)
 {

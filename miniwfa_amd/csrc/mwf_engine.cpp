@@ -427,7 +427,9 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 	if (geom_block == 514) { // the 512-thread geometry with four chunk slots on biased offsets (the caller checked the lengths: kBandSpanMaxSeq); 2-bit copies only
 		const int64_t need_lds = ((max_len >> 4) + 4) * 4;
 		if (g->seq2bit == 0 || g->acgt_off_once || need_lds > 70 * 1024) return;
-		pl.kind = 2, pl.band = BandGeom{512, 2, 512 / 64 * 4 * 256, (int)((need_lds + 15) / 16 * 16), 1, 0}; // (packed 2: the copy that computes on biased offsets)
+		// (five chunk slots per wave while target + query stay below 3.5 of that span, else six)
+		const int chunks = band2_biased512_chunks() + (max_len + 1 <= 7 * (int64_t)(band2_biased512_chunks() * 256) / 2 ? 0 : 8);
+		pl.kind = 2, pl.band = BandGeom{512, 2, chunks * 256, (int)((need_lds + 15) / 16 * 16), 1, 0}; // (packed 2: the copy that computes on biased offsets)
 		return;
 	}
 	if (geom_block == 1024) { // the span geometry (the caller checked the lengths of every pair: kBandSpanMaxSeq); 2-bit sequence copies only
@@ -491,7 +493,7 @@ int cached_occupancy(mwf_gpu_t *g, const Penalty &P, const Plan &pl, int lds_e2_
 	uint64_t key;
 	if (pl.kind == 2)
 		key = 1ull | (uint64_t)pl.band.block << 4 | (uint64_t)(pl.band.packed == 1) << 16 | (uint64_t)(pl.band.packed == 2) << 15 | (uint64_t)(pl.band.lds_bytes > 0) << 17 | (uint64_t)pl.cigar << 18 |
-		      (uint64_t)(pl.band.seq2 != 0) << 3 | (uint64_t)(pl.band.lane == 1) << 2 | (uint64_t)(pl.band.block == 512 && pl.band.span > 6144) << 1 | (uint64_t)(pl.band.lane == 2) << 19 | (uint64_t)P.e1 << 20 | (uint64_t)P.e2 << 28 | (uint64_t)pl.band.lds_bytes << 36;
+		      (uint64_t)(pl.band.seq2 != 0) << 3 | (uint64_t)(pl.band.lane == 1) << 2 | (uint64_t)(pl.band.block == 512 && pl.band.span > 6144) << 1 | (uint64_t)(pl.band.block == 512 ? pl.band.span / 2048 : 0) << 56 | (uint64_t)(pl.band.lane == 2) << 19 | (uint64_t)P.e1 << 20 | (uint64_t)P.e2 << 28 | (uint64_t)pl.band.lds_bytes << 36;
 	else key = 2ull | (uint64_t)pl.block << 4 | (uint64_t)stream_pass << 16 | (uint64_t)ring16 << 17 | (uint64_t)(P.nH > kMaxRing) << 18 | (uint64_t)lds_e2_cols << 20;
 	auto it = g->occ_cache.find(key);
 	if (it != g->occ_cache.end()) return it->second;
@@ -1466,7 +1468,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 				else if (packable && len + 1 <= 4 * (int64_t)(8 * 3 * 256)) c = 1;
 				// (tl + ql up to 3.5 of its spans: a 12 kb pair at 5 % needs ~6000 of the 7872 columns; 512 x 15 kb @ 5 % — windows of ~7500 — lost 44 pairs to late
 				// overflows, 30.7 against 24.9 ms on the span geometry from the start)
-				else if (span_ok && g->wide_slots != 3 && len + 1 <= 7 * (int64_t)(8 * 4 * 256) / 2) c = 14;
+				else if (span_ok && g->wide_slots != 3 && len + 1 <= 7 * (int64_t)((band2_biased512_chunks() + 8) * 256) / 2) c = 14;
 				else if (span_ok && len + 1 <= 7 * band2_span_chunks() * 256) c = 13;
 			}
 			b->h_class[i] = (int8_t)(c == 5 ? 0 : c == 13 ? 5 : c == 14 ? 1 : c);

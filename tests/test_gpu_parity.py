@@ -1201,11 +1201,11 @@ def test_wide_class_chunk_slots_follow_the_batch(oracle):
     eng.close()
 
 
-def test_four_slot_geometry_takes_pairs_of_12_kb_on_biased_offsets(oracle):
-    """Pairs of ~11-14 kb — too long for plain 16-bit offsets by the worst-case rule, short enough for windows of up to 7872 columns — run two per CU on the
-    512-thread geometry's four-slot copy that computes on biased offsets with range checks (class 14; before: the span geometry, one per CU).  Pairs whose
-    window outgrows its 32 chunks move on to the span geometry.  Score and CIGAR runs equal the generic kernel's on every pair and the oracle's on a sample."""
-    pairs = [synth_pair(71000 + i, 11000 + 97 * i, 0.05) for i in range(30)] + [synth_pair(71100 + i, 13500, 0.09) for i in range(3)] + [synth_pair(71200, 12000, 0.0), synth_pair(71201, 14000, 0.01)]
+def test_512_thread_geometry_on_biased_offsets_takes_pairs_of_12_to_20_kb(oracle):
+    """Pairs of ~11-21 kb — too long for plain 16-bit offsets by the worst-case rule, short enough for windows of up to ~10 000 / ~12 000 columns — run two per CU on
+    the 512-thread geometry's five- and six-slot copies that compute on biased offsets with range checks (class 14; before: the span geometry, one per CU).  Pairs
+    whose window outgrows their chunks move on to the span geometry.  Score and CIGAR runs equal the generic kernel's on every pair and the oracle's on a sample."""
+    pairs = [synth_pair(71000 + i, 11000 + 97 * i, 0.05) for i in range(30)] + [synth_pair(71100 + i, 13500, 0.13) for i in range(3)] + [synth_pair(71200, 12000, 0.0), synth_pair(71201, 14000, 0.01)]
     pk = PackedBatch(pairs)
     ref = None
     for kw in (dict(), dict(flag=1)):
@@ -1219,7 +1219,7 @@ def test_four_slot_geometry_takes_pairs_of_12_kb_on_biased_offsets(oracle):
         st = eng.stats()
         assert (st.kernel_kind, st.packed, st.block) == (2, 1, 512), (st.kernel_kind, st.packed, st.block)
         s, it, nc = b.results()
-        assert eng.stats().n_retries == 3            # the three pairs at 9 %: the span geometry
+        assert eng.stats().n_retries == 3            # the three pairs at 13 %: the span geometry
         assert (s == ref[0]).all() and (it == ref[1]).all()
         o = make_opt(**kw)
         for i in (0, 17, 29, 31, 33, 34):
@@ -1229,6 +1229,21 @@ def test_four_slot_geometry_takes_pairs_of_12_kb_on_biased_offsets(oracle):
                 assert b.cigar(i, int(nc[i])).tolist() == ecig, (kw, i)
         b.free()
         eng.close()
+    # ... and the six-slot copy: 18-20 kb pairs
+    pairs = [synth_pair(72000 + i, 18000 + 150 * i, 0.04) for i in range(12)]
+    eng = mw.Engine(0)
+    eng.set("coop_min_len", 1 << 40)
+    b = eng.upload(PackedBatch(pairs))
+    b.align(mw.opt_init(flag=1))
+    st = eng.stats()
+    assert (st.kernel_kind, st.packed, st.block) == (2, 1, 512)
+    s, it, nc = b.results()
+    assert eng.stats().n_retries == 0
+    for i in (0, 11):
+        es, eit, ecig = oracle.align(pairs[i][0], pairs[i][1], make_opt(flag=1))
+        assert (int(s[i]), int(it[i])) == (es, eit) and b.cigar(i, int(nc[i])).tolist() == ecig, i
+    b.free()
+    eng.close()
 
 
 def test_span_geometry_long_pairs_against_oracle(oracle):
@@ -1243,6 +1258,7 @@ def test_span_geometry_long_pairs_against_oracle(oracle):
                     (dict(max_s=3000), (0, 5)), (dict(flag=1, max_iter=20000000), (0, 1))):
         eng = mw.Engine(0)
         eng.set("coop_min_len", 1 << 40)   # (a few long pairs alone would share the whole-device kernel)
+        eng.set("wide_slots", 3)           # (... and the pairs of up to ~21 kb would take the 512-thread geometry's copies on biased offsets: this test is about the span geometry)
         b = eng.upload(pk)
         b.align(mw.opt_init(**kw))
         st = eng.stats()
