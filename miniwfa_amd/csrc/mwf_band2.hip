@@ -50,6 +50,10 @@ extern __shared__ __attribute__((aligned(16))) uint8_t lds2[];
 // while target + query stay below 3.5 of their span, six (48 chunks) up to 3.5 of theirs.
 #define MWF_B2_W4K 5
 #endif
+#ifndef MWF_B2_SPAN_T
+#define MWF_B2_SPAN_T 1024 // threads of the span geometry (measured: 768 x 7 slots — twelve waves, 168 VGPRs, no spills — 187.6 against 178.7 ms on 1250 x 50 kb, 768 x 6 189.6)
+#endif
+#define MWF_IS_SPAN(T, K) ((T) == MWF_B2_SPAN_T && (K) == MWF_B2_SPAN_K)
 #ifndef MWF_B2_WIDE_WAVES
 #define MWF_B2_WIDE_WAVES 4 // waves per SIMD the widest geometry is compiled for (4: 128 VGPRs, two 512-thread workgroups per CU)
 #endif
@@ -305,7 +309,7 @@ template <int T, int K, int E1, int E2, bool TB, bool S2, bool BI4, typename Arg
 __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, const int32_t edge_base, const int32_t qoff, bool trace_band)
 {
 	constexpr int NW = T / 64, NWK = NW * K, D = (E1 > E2 ? E1 : E2) + 1;
-	constexpr bool BI = T == 1024 || BI4; // biased offsets with range checks (wide_bias): the span geometry and the four-slot 512-thread one's copy for long pairs
+	constexpr bool BI = MWF_IS_SPAN(T, K) || BI4; // biased offsets with range checks (wide_bias): the span geometry and the four-slot 512-thread one's copy for long pairs
 	constexpr int FULL = S2 ? 16 : 8; // bases the first probe of the match extension looks at
 	constexpr int kAge = (NWK + 2) * 16; // bytes of one age of the edge table
 	static_assert(D == 2 || D == 3, "edge-table ages");
@@ -906,7 +910,7 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 // Workgroups share a CU: 2 x 512, 4 x 256, 8 x 128 or 16 x 64 threads = 4 waves per SIMD, i.e. at most 128 VGPRs; with traceback
 // the smaller ones get 168 (3 per SIMD).  768 threads: one workgroup per CU.
 template <int T, int K, int E1, int E2, bool TB, bool S2, bool BI4 = false>
-__global__ __launch_bounds__(T, T == 1024 ? 4 : T == MWF_B2_WIDE_T ? MWF_B2_WIDE_WAVES : T <= 512 ? ((TB && T < 512) ? 3 : 4) : MWF_B2_768_WAVES) void wfa_band2_kernel(const BatchArgs)
+__global__ __launch_bounds__(T, MWF_IS_SPAN(T, K) ? (T == 1024 ? 4 : 3) : T == 1024 ? 4 : T == MWF_B2_WIDE_T ? MWF_B2_WIDE_WAVES : T <= 512 ? ((TB && T < 512) ? 3 : 4) : MWF_B2_768_WAVES) void wfa_band2_kernel(const BatchArgs)
 {
 	constexpr int NWK = (T / 64) * K, D = (E1 > E2 ? E1 : E2) + 1;
 	// the arguments are read from the kernarg segment where they are used (dev::kernel_args / dev::fresh), never held for the kernel's lifetime
@@ -979,7 +983,7 @@ int launch_one(const BatchArgs &a0, int grid, int lds_seq, bool seq2, hipStream_
 	BatchArgs a = a0;
 	a.band_lds_seq = lds_seq;
 	const int lds = lds_seq + lds_tail<T, K, E1, E2>();
-	if constexpr (T == 1024 || (T == 512 && K >= 4)) { // the 1024-thread and the 512 x 4 geometries exist on 2-bit sequence copies only (the host knows)
+	if constexpr (MWF_IS_SPAN(T, K) || (T == 512 && K >= 4)) { // the 1024-thread and the 512 x 4 geometries exist on 2-bit sequence copies only (the host knows)
 		if (!seq2) return -1;
 		if (a.want_cigar) launch_variant<T, K, E1, E2, true, true, BI4>(a, grid, lds, st);
 		else launch_variant<T, K, E1, E2, false, true, BI4>(a, grid, lds, st);
@@ -999,7 +1003,7 @@ int occ_one(int lds_seq, bool seq2, bool tb)
 	const int lds = lds_seq + lds_tail<T, K, E1, E2>();
 	int n = 0;
 	hipError_t e;
-	if constexpr (T == 1024 || (T == 512 && K >= 4)) {
+	if constexpr (MWF_IS_SPAN(T, K) || (T == 512 && K >= 4)) {
 		if (!seq2) return 0;
 		e = tb ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, true, true, BI4>, T, lds)
 		       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, false, true, BI4>, T, lds);
@@ -1055,7 +1059,7 @@ bool band2_supported(const Penalty &p)
 		if (g.block == 512 && g.span > 512 / 64 * 3 * 256) MWF_BAND2_PEN(FN, 512, 4, __VA_ARGS__) /* 32 chunks: windows of up to 7872 columns */ \
 		if (g.block == 512) MWF_BAND2_PEN(FN, MWF_B2_WIDE_T, MWF_B2_WIDE_K, __VA_ARGS__) \
 		if (g.block == 768) MWF_BAND2_PEN(FN, 768, 2, __VA_ARGS__)                  \
-		if (g.block == 1024) MWF_BAND2_PEN(FN, 1024, MWF_B2_SPAN_K, __VA_ARGS__)    \
+		if (g.block == 1024) MWF_BAND2_PEN(FN, MWF_B2_SPAN_T, MWF_B2_SPAN_K, __VA_ARGS__) \
 		MWF_BAND2_REST(FN, __VA_ARGS__)                                             \
 	} while (0)
 
@@ -1066,7 +1070,7 @@ int launch_band2(const BatchArgs &a, int grid, const BandGeom &g, void *stream)
 	return -1;
 }
 
-int band2_span_chunks() { return 16 * MWF_B2_SPAN_K; }
+int band2_span_chunks() { return MWF_B2_SPAN_T / 64 * MWF_B2_SPAN_K; }
 int band2_biased512_chunks() { return 8 * MWF_B2_W4K; }
 
 int band2_kernel_occupancy(const Penalty &p, const BandGeom &g, bool cigar)
