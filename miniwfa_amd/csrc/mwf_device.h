@@ -90,11 +90,13 @@ __device__ __forceinline__ int32_t lds_extend8(const uint8_t *lt, const uint8_t 
 {
 	int32_t n = 0;
 	bool open = room > 0;
-	while (__ballot(open)) {
-		const uint64_t x = lds_ld8(lt, j + n) ^ lds_ld8(lq, i + n);
-		const int32_t adv = x ? (int32_t)(__builtin_ctzll(x) >> 3) : 8;
-		n += open ? adv : 0;
-		open = open && x == 0 && n < room;
+	if (__ballot(open)) {
+		do { // (bottom-tested: one uniform branch per trip)
+			const uint64_t x = lds_ld8(lt, j + n) ^ lds_ld8(lq, i + n);
+			const int32_t adv = x ? (int32_t)(__builtin_ctzll(x) >> 3) : 8;
+			n += open ? adv : 0;
+			open = open && x == 0 && n < room;
+		} while (__ballot(open));
 	}
 	return max(min(n, room), 0);
 }
@@ -110,11 +112,13 @@ __device__ __forceinline__ int32_t lds_extend16(const uint8_t *lt, const uint8_t
 {
 	int32_t n = 0;
 	bool open = room > 0;
-	while (__ballot(open)) {
-		const uint32_t x = lds_seq16(lt, j + n) ^ lds_seq16(lq, i + n);
-		const int32_t adv = x ? (int32_t)(__builtin_ctz(x) >> 1) : 16;
-		n += open ? adv : 0;
-		open = open && x == 0 && n < room;
+	if (__ballot(open)) {
+		do {
+			const uint32_t x = lds_seq16(lt, j + n) ^ lds_seq16(lq, i + n);
+			const int32_t adv = x ? (int32_t)(__builtin_ctz(x) >> 1) : 16;
+			n += open ? adv : 0;
+			open = open && x == 0 && n < room;
+		} while (__ballot(open));
 	}
 	return max(min(n, room), 0);
 }
