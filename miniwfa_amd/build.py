@@ -85,39 +85,6 @@ def build_cli(force: bool = False) -> str:
     return CLI
 
 
-REF_MAIN = os.path.join(ROOT, "oracle", "_ref", "ref-main-on-libmwf_hip")
-
-
-def build_ref_main(ref: str = "/root/reference") -> str | None:
-    """TEST ARTEFACT (tests/test_cli.py): the reference's OWN, unchanged caller (main.c:19-92) compiled against this repo's headers
-    and linked with libmwf_hip.so — the drop-in claim with the reference's program rather than ours.  Only where the reference's
-    sources are present (the build container); nothing is copied: main.c, ketopt.h and kseq.h are reached through symlinks in a
-    scratch directory so that `#include "miniwfa.h"` / "kalloc.h" resolve to include/ instead of the reference's own headers.
-    The binary lands in oracle/_ref/ (git-ignored, travels to the GPU box like the compiled reference)."""
-    import shutil
-    import tempfile
-    need = [os.path.join(ref, f) for f in ("main.c", "ketopt.h", "kseq.h")]
-    if not all(os.path.exists(f) for f in need) or not os.path.exists("/usr/include/zlib.h"):
-        return REF_MAIN if os.path.exists(REF_MAIN) else None
-    if os.path.exists(REF_MAIN) and os.path.getmtime(REF_MAIN) >= max(os.path.getmtime(LIB), *(os.path.getmtime(f) for f in need)):
-        return REF_MAIN
-    os.makedirs(os.path.dirname(REF_MAIN), exist_ok=True)
-    tmp = tempfile.mkdtemp(prefix="mwf_refmain_")
-    try:
-        for f in need:
-            os.symlink(f, os.path.join(tmp, os.path.basename(f)))
-        cmd = ["gcc", "-O2", "-w", "-I", os.path.join(ROOT, "include"), os.path.join(tmp, "main.c"), "-o", REF_MAIN,
-               "-L", CSRC, "-lmwf_hip", "-Wl,-rpath,$ORIGIN/../../miniwfa_amd/csrc", "-lz"]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            sys.stderr.write(r.stdout + r.stderr)
-            raise RuntimeError("gcc failed building the reference's main.c against include/ + libmwf_hip.so")
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
-    return REF_MAIN
-
-
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_cli(force="--force" in sys.argv))
-    print(build_ref_main())

@@ -119,6 +119,16 @@ def synth_pair(seed: int, tl: int, p: float, n_long: int = 0, long_max: int = 0)
     return t, q
 
 
+def synth_diverged_block(seed: int, flank: int, block_t: int, block_q: int, p: float) -> tuple[bytes, bytes]:
+    """A pair whose middle does not align at all: shared flanks (mutated at rate p) around UNRELATED random blocks of
+    block_t / block_q bases.  With both blocks >= 10 kb this is the case chain mode bridges with one deletion + one
+    insertion instead of a gap fill (reference miniwfa.c:869, the `mwf_ksim < 0.02` branch)."""
+    a, b = random_seq(seed, flank), random_seq(seed + 1, flank)
+    t = a + random_seq(seed + 2, block_t) + b
+    q = mutate(a, seed + 4, p) + random_seq(seed + 3, block_q) + mutate(b, seed + 5, p)
+    return t, q
+
+
 def synth_batch(base_seed: int, n: int, tl: int, p: float) -> list[tuple[bytes, bytes]]:
     return [synth_pair(base_seed + i, tl, p) for i in range(n)]
 

@@ -104,3 +104,26 @@ def test_fresh_fuzz_against_reference(oracle):
         for o in (make_opt(), make_opt(flag=MWF_F_CIGAR), make_opt(flag=MWF_F_CIGAR, step=1 + j % 37),
                   make_opt(flag=MWF_F_CIGAR, x=2, o1=3, e1=1, o2=11, e2=2, step=(j % 3) * 20)):
             assert oracle.align(t, q, o) == ref.align(t, q, o), (j, tl, p, o.step)
+
+
+def test_chain_fixtures_are_reproducible():
+    """tests/golden/chain_fresh.jsonl (row f1, reference miniwfa.c:850-907): the generators still produce the inputs the stored
+    answers belong to; the chain's CIGAR consumes both sequences and its penalty is what the CIGAR costs; and — where the compiled
+    reference is present — a sample of the answers is what the reference says today."""
+    from miniwfa_amd.synth import synth_pair, synth_diverged_block
+    import re
+    vecs = load_golden("chain_fresh.jsonl")
+    assert len(vecs) >= 60
+    ref = Reference() if Reference.available() else None
+    for n, v in enumerate(vecs):
+        gen = v["gen"]
+        t, q = synth_pair(*gen["args"]) if gen["kind"] == "synth" else synth_diverged_block(*gen["args"])
+        assert (len(t), len(q)) == (v["tl"], v["ql"]), v["id"]
+        cig = v["expect"]["cigar"]
+        if cig is not None:
+            ops = [(int(a), b) for a, b in re.findall(r"(\d+)([=XID])", cig)]
+            assert sum(a for a, b in ops if b in "=XD") == len(t) and sum(a for a, b in ops if b in "=XI") == len(q), v["id"]
+        if ref is not None and n % 5 == 0 and v["tl"] <= 30000:
+            o = make_opt(**v["opt"])
+            s, it, c = (ref.chain if v["entry"] == "chain" else ref.auto)(t, q, o)
+            assert s == v["expect"]["s"] and (None if c is None else cigar_str(c)) == cig, v["id"]
