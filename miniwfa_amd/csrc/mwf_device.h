@@ -1,5 +1,5 @@
 // mwf_device.h — device-side helpers shared by every alignment kernel (mwf_kernels.hip generic, mwf_band2.hip packed band,
-// mwf_lane.hip short pairs, mwf_mid.hip mid-size pairs of small batches, mwf_coop.hip / mwf_sys.hip whole device): the recurrence and its
+// mwf_lane.hip short pairs, mwf_mid.hip mid-size pairs of small batches, mwf_sys.hip whole device): the recurrence and its
 // traceback byte, kernel-argument access, the shared traceback, per-pair memory views and outputs.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -3,7 +3,7 @@
 //
 // Boundary: the reference's device-free API mwf_wfa_exact/auto/chain
 // (miniwfa.c:603-615, :850-908) is kept; a call ships its pair(s) to HBM, runs the kernels of
-// mwf_kernels.hip / mwf_band2.hip / mwf_lane.hip / mwf_mid.hip / mwf_sys.hip (+ mwf_coop.hip) and copies back (s, n_iter, n_cigar, CIGAR).  r->cigar is
+// mwf_kernels.hip / mwf_band2.hip / mwf_lane.hip / mwf_mid.hip / mwf_sys.hip and copies back (s, n_iter, n_cigar, CIGAR).  r->cigar is
 // allocated from the caller's kalloc arena exactly as the reference does (miniwfa.c:434).  kalloc arenas for
 // scratch are replaced by device pools that only ever grow:
 //   * one workspace per engine (ring, traceback arena, row table, CIGAR scratch, snapshots);
@@ -69,6 +69,7 @@ struct mwf_gpu_s {
 	std::string err;
 	// tunables
 	int block = 0;              // 0: choose from the batch
+	int64_t tun_gen = 0;        // bumped by every successful mwf_gpu_set(): a cached plan of an align (PlanCache) is only replayed under the tunables it was made under
 	int slots_per_cu = 0;       // 0: occupancy of the kernel
 	int64_t coop_min_len = 0;
 	int64_t tb_budget_mb = 0;   // 0: automatic
@@ -97,7 +98,7 @@ struct mwf_gpu_s {
 	int sys_c = 0;             // its columns per lane: 0 automatic (1 while the window is expected to fit the slots that way, else 4), 1, 4
 	// workspace (per-stream pool)
 	DevBuf ring, sring, good, tb, row_off, row_lo, cig_scratch, snap, snap_meta, seg, queue, dbg, coop_edge, coop_misc;
-	DevBuf sys_box, sys_prog, sys_log, sys_ep, sys_park, sys_ring, sys_good;
+	DevBuf sys_box, sys_prog, sys_log, sys_ep, sys_park, sys_ring, sys_sring, sys_good;
 	DevBuf spare_block, spare_cig; // allocations of freed batches, waiting for the next batch
 	int queue_next = 0;            // next unused work counter of the current align call
 	int lane_set_next = 0;         // ... and next unused set of lane-kernel counters
@@ -158,6 +159,7 @@ struct mwf_gpu_batch_s {
 	std::vector<int32_t> h_s, h_ncig, h_status;
 	std::vector<int64_t> h_iter, h_cigoff, h_cells1;
 	int64_t cig_used = 0;           // words of the pool in use (known after finalize)
+	int32_t cig_block_left = 0;     // block mode: workgroups (= partly used blocks the pool has slack for) the launches of this align may still spend; reset by every align
 	std::vector<uint32_t> h_cig;    // host copy of the used part of the pool (fetch_cigars)
 	bool h_cig_valid = false;
 	// What the last align worked out from the pair lengths alone — size classes, processing order, per-class maxima — keyed by the
@@ -662,7 +664,10 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	a.rows_slot = pl.rows_slot;
 	a.cig_scratch = pl.cigar ? (uint32_t*)g->cig_scratch.p : nullptr, a.cig_scratch_slot = pl.cig_scratch_slot;
 	a.cig_pool = b->d_cig_pool, a.cig_head = b->d_cig_head, a.cig_pool_words = b->cig_pool_words;
-	a.cig_block = pl.grid <= kCigBlockGrid ? b->cig_block : 0;
+	// block mode leaves up to one partly used block per workgroup behind; the pool's slack (batch_common) covers kCigBlockGrid of them per align —
+	// one align can make several block-mode launches (size classes, byte-wise twins, re-runs): a launch the slack no longer covers takes words singly
+	a.cig_block = 0;
+	if (b->cig_block > 0 && pl.grid <= b->cig_block_left) a.cig_block = b->cig_block, b->cig_block_left -= pl.grid;
 	a.report_wide = geom_block == 0 && window_hint == kBandWide4Window ? 1 : 0; // (the wide class's measuring align, mwf_gpu_batch_align)
 	a.snap = pl.low_mem ? (int32_t*)g->snap.p : nullptr, a.snap_slot_ints = pl.snap_slot_ints;
 	a.snap_meta = pl.low_mem ? (int32_t*)g->snap_meta.p : nullptr, a.snap_meta_slot = pl.snap_meta_slot;
@@ -705,7 +710,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 
 int coop_grid_limit(mwf_gpu_t *g)
 {
-	if (g->coop_grid < 0) g->coop_grid = std::min(std::min(coop_max_grid(true), sys_max_grid()), g->n_cu);
+	if (g->coop_grid < 0) g->coop_grid = std::min(sys_max_grid(), g->n_cu);
 	return g->coop_grid_cap > 0 ? std::min(g->coop_grid, g->coop_grid_cap) : g->coop_grid;
 }
 
@@ -723,7 +728,7 @@ int coop_group_size(int n_cu, int64_t len, bool alone, int ow = 256)
 	return G;
 }
 
-// Up to n_cu / group size pairs side by side on the whole-device kernel, each on its own group of workgroups (mwf_coop.hip).
+// Up to n_cu / group size pairs side by side on the whole-device kernel, each on its own group of workgroups (mwf_sys.hip).
 // Everything is enqueued on the stream: first pass, and in low-memory mode the checkpoint walk over its traceback matrix
 // and the second pass, then traceback + outputs.
 int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const std::vector<int32_t> &pairs, int Gs, bool first, bool last)
@@ -758,8 +763,7 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 	const int64_t est2 = std::min<int64_t>(len + 1, 2 * ((int64_t)opt.step + 2 * P.nH) + 8);
 	const int c_first = g->sys_c ? g->sys_c : (!wide_again && est1 <= window_cap(1)) ? 1 : 4;
 	const int c_second = g->sys_c ? g->sys_c : (!wide_again && est2 <= window_cap(1)) ? 1 : 4;
-	if (ensure(g, g->ring, NG * (size_t)P.nH * W * 4 + 4096)) return -1;
-	if (ensure(g, g->good, NG * (size_t)P.nH * GW * 8)) return -1;
+	// (the systolic kernel has private H rings per chunk slot, sys_ring below: no ring of whole rows — 1 GB for the 5 Mb pair — is allocated here any more)
 	// Low-memory mode (opt.step > 0), two ways to the checkpoints:
 	//   walk     — the first pass stores its whole traceback (s^2 bytes: 55 GB for the 5 Mb pair) and the checkpoints are
 	//              read off it by walking the recorded choices back (fast while that fits the budget);
@@ -768,15 +772,16 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 	// Chosen by what the walk variant's arena would be against the budget ("lowmem_budget_mb", default 8 GB).
 	bool two_pass = false;
 	if (low_mem) {
-		// automatic: a quarter of the device (the 5 Mb pair's first-pass traceback, ~60 GB, fits a 288 GB device and the walk
-		// variant is several times faster than carrying provenance through the first pass)
-		const int64_t budget = g->lowmem_budget_mb > 0 ? g->lowmem_budget_mb << 20 : (int64_t)(g->total_mem / 4);
+		// automatic: 8 GB.  opt.step > 0 asks for the reference's low-memory mode (miniwfa.c:551-601; README.md:55-64: the 5 Mb MHC pair in 4 GB
+		// instead of 50): a first pass that would hold more traceback than that takes the two-pass form — provenance carried through the
+		// systolic kernel, snapshots of (nH + 2 e1 + 2 e2) array-slices every `step` penalties — and the device footprint stays within a few GB.
+		const int64_t budget = g->lowmem_budget_mb > 0 ? g->lowmem_budget_mb << 20 : (int64_t)8 << 30;
 		two_pass = std::max<int64_t>((int64_t)1 << 30, 6000 * len) * (int64_t)NG * g->coop_tb_mult * (c_first == 1 ? 12 : 9) / 8 > budget;
 	}
 	// granules crossing waves: [nH][TC][2 sides][4] x 8 bytes (twice for the two-pass mode: values and their provenance);
 	// misc: flags, barrier words, pass state, then the flag ring
-	const size_t gran_bytes = (size_t)P.nH * TC * 2 * 4 * 8 * (two_pass ? 2 : 1);
-	const size_t flag_ring_bytes = (size_t)64 * 32 * 128; // mwf_coop.hip: kFlagRing x kFlagCopies lines of 128 bytes
+	const size_t gran_bytes = 4096; // (the per-penalty granule exchange of mwf_coop.hip is gone: the field remains for the layout of the misc block)
+	const size_t flag_ring_bytes = 0; // (the flag ring of the removed per-penalty hand-off kernel)
 	const size_t misc_bytes = 4096 + flag_ring_bytes;
 	if (ensure(g, g->coop_edge, NG * gran_bytes)) return -1;
 	if (ensure(g, g->coop_misc, NG * misc_bytes + 4096)) return -1; // (+ the pair ids behind the last group)
@@ -796,7 +801,9 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 		if (two_pass) guess = std::min<int64_t>(guess, std::max<int64_t>((int64_t)64 << 20, (len * 3 / 100 + 1024) * std::min<int64_t>(len + 1, 2 * (int64_t)(opt.step + 2 * P.nH) + 8)) * (int64_t)NG);
 		// (the systolic kernel stores 256 bytes per penalty and chunk slot that takes part, a few slots beyond the window included)
 		const int64_t lay = (two_pass ? c_second : c_first) == 1 ? 12 : (two_pass ? c_second : c_first) == 2 ? 10 : 9; // the pass whose traceback sets the size: 64-column slots own 48 (4/3 of the exact rows), 256-column ones 240 (the second pass of the low-memory mode is narrow: it fits whatever the first needed)
-		if (use_sys) guess = std::min<int64_t>(g->coop_tb_cap, guess / 8 * lay + (rows_slot / 256 + 2) * 8 * 65536 * (int64_t)NG);
+		// (+ a few slots of margin per epoch of 256 penalties; epochs by the guessed penalty, not by the worst case — 10 M penalties for the 5 Mb pair, 20 GB of margin)
+		const int64_t ep_guess = (len * 3 / 100 + 1024) / 256 + 2;
+		if (use_sys) guess = std::min<int64_t>(g->coop_tb_cap, guess / 8 * lay + ep_guess * 8 * 65536 * (int64_t)NG);
 		int64_t want = std::min(use_sys ? worst / 8 * lay + (rows_slot / 256 + 2) * 8 * 65536 * (int64_t)NG : worst, g->tb_budget_mb > 0 ? (g->tb_budget_mb << 20) : guess * g->coop_tb_mult);
 		if ((int64_t)g->tb.bytes >= want) want = (int64_t)g->tb.bytes;
 		else {
@@ -818,11 +825,14 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 	if (two_pass) {
 		// shadow H rows; snapshots: (nH + 2 e1 + 2 e2) array-slices x the window at every `step` penalties, windows about as
 		// wide as the penalty: ~ NS * s^2 / step ints with s guessed as 3 % of tl+ql (doubled with the arena after an overflow)
-		const int64_t NS = P.nH + 2 * P.e1 + 2 * P.e2, s_guess = len * 3 / 100 + 1024;
-		snap_meta_slot = (bound1 / opt.step + 2) * 8;
-		snap_slot_ints = std::min<int64_t>(std::max<int64_t>((int64_t)4 << 20, NS * (s_guess / opt.step + 2) * std::min<int64_t>(len + 1, s_guess)) * g->coop_tb_mult,
-		                                   ((int64_t)48 << 30) / 4);
-		if (ensure(g, g->sring, NG * (size_t)P.nH * W * 4 + 4096)) return -1;
+		// (systolic layout: a snapshot holds NS array-slices of every owned column of the chunks that take part in its epoch — the window plus
+		// 2 x 265 columns and a chunk; the window at snapshot j is about 2 j step wide; s is guessed as 3 % of tl+ql, doubled with the arena after an overflow)
+		const int64_t NS = P.nH + 2 * P.e1 + 2 * P.e2, s_guess = len * 3 / 100 + 1024, n_guess = s_guess / opt.step + 2;
+		int64_t cols = 0;
+		for (int64_t j = 1; j <= n_guess; ++j) cols += std::min<int64_t>(len + 1, 2 * j * opt.step) + 1100;
+		snap_meta_slot = (bound1 / opt.step + 256 / opt.step + 4) * 8; // (+ the snapshots of the last epoch's surplus penalties)
+		snap_slot_ints = std::min<int64_t>(std::max<int64_t>((int64_t)4 << 20, NS * cols) * g->coop_tb_mult, ((int64_t)48 << 30) / 4) / 4 * 4;
+		if (ensure(g, g->sys_sring, NG * (size_t)TC * P.nH * 256 * 4)) return -1;
 		if (ensure(g, g->snap, NG * (size_t)snap_slot_ints * 4)) return -1;
 		if (ensure(g, g->snap_meta, NG * (size_t)snap_meta_slot * 4)) return -1;
 	}
@@ -832,7 +842,7 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 	}
 
 	const int64_t sys_rows = std::max(bound, bound1) + 2, sys_log_ints = 2 * (sys_rows + 256 + 8), sys_ep_words = 2 * (sys_rows / 256 + 3);
-	const int64_t sys_box_group = TC * 2 * sys_box_ints(sysP), sys_park_group = TC * 8 * 64 * 4;
+	const int64_t sys_box_group = TC * 2 * sys_box_ints(sysP, two_pass), sys_park_group = TC * (two_pass ? 16 : 8) * 64 * 4;
 	if (use_sys) {
 		if (ensure(g, g->sys_ring, NG * (size_t)TC * P.nH * 256 * 4)) return -1;
 		if (ensure(g, g->sys_good, NG * (size_t)P.nH * TC * 4 * 8)) return -1;
@@ -858,7 +868,7 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 	a.cig_scratch = cigar ? (uint32_t*)g->cig_scratch.p : nullptr, a.cig_scratch_slot = cig_scratch;
 	a.cig_pool = b->d_cig_pool, a.cig_head = b->d_cig_head, a.cig_pool_words = b->cig_pool_words;
 	a.seg = low_mem ? (int32_t*)g->seg.p : nullptr, a.seg_slot = seg_slot;
-	a.sring = two_pass ? (int32_t*)g->sring.p : nullptr;
+	a.sring = two_pass ? (int32_t*)g->sys_sring.p : nullptr; // (provenance of the systolic kernel's private H rings: the same shape, set_cols())
 	a.snap = two_pass ? (int32_t*)g->snap.p : nullptr, a.snap_slot_ints = snap_slot_ints;
 	a.snap_meta = two_pass ? (int32_t*)g->snap_meta.p : nullptr, a.snap_meta_slot = snap_meta_slot;
 	a.out_s = b->d_s, a.out_iter = b->d_iter, a.out_ncig = b->d_ncig, a.out_cigoff = b->d_cigoff;
@@ -877,16 +887,6 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 	HIP_TRY(g, hipMemcpyAsync(d_ids, pairs.data(), NG * 4, hipMemcpyHostToDevice, g->stream));
 	a.coop_pair_ids = d_ids;
 
-	auto reset_sync = [&](bool all) -> int { // granule tags and the flag ring start out as "no penalty" (-1), counters at zero
-		for (size_t q = 0; q < NG; ++q) {
-			char *m = (char*)g->coop_misc.p + q * misc_bytes;
-			if (all) { HIP_TRY(g, hipMemsetAsync(m, 0, 4096, g->stream)); }
-			else HIP_TRY(g, hipMemsetAsync(m + 1024, 0, 1024, g->stream));
-			HIP_TRY(g, hipMemsetAsync(m + 4096, 0xff, flag_ring_bytes, g->stream));
-		}
-		HIP_TRY(g, hipMemsetAsync(g->coop_edge.p, 0xff, NG * gran_bytes, g->stream));
-		return 0;
-	};
 	// the same launch on the systolic kernel: a private H ring per chunk slot, its own good-bit rows, hand-off boxes, edge log
 	BatchArgs as = a;
 	if (use_sys) {
@@ -912,17 +912,16 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 	};
 	std::unique_lock<std::shared_mutex> lock(g_dev_gate[g->device % kMaxDevices]);
 	HIP_TRY(g, hipDeviceSynchronize()); // kernels of other engines (other host threads) on this device: let them drain first
-	const bool sys_first = use_sys && !two_pass; // the provenance pass of the two-pass mode stays on mwf_coop.hip
-	if (sys_first ? reset_sys(true) : reset_sync(true)) return -1;
+	if (reset_sys(true)) return -1;
 	if (first) HIP_TRY(g, hipEventRecord(g->ev0, g->stream));
 	auto set_cols = [&](int c) { as.sys_c = c, as.ring_slot_ints = TC * P.nH * 64 * c, as.GW = (int32_t)(TC * c); };
 	set_cols(c_first);
 	a.coop_pass = as.coop_pass = two_pass ? 3 : low_mem ? 1 : 0;
 	g->stats.lowmem_two_pass = two_pass ? 1 : 0;
-	if (sys_first ? launch_sys_pass(as, Gs * n_groups, g->stream) : launch_coop_pass(a, Gs * n_groups, g->stream)) { g->err = "kernel launch failed (whole-device pass)"; return -1; }
+	if (launch_sys_pass(as, Gs * n_groups, g->stream)) { g->err = "kernel launch failed (whole-device pass)"; return -1; }
 	g->stats.n_launches += 1;
 	if (low_mem) {
-		if (two_pass ? launch_coop_trace(a, g->stream) : launch_sys_walk(as, g->stream)) { g->err = "kernel launch failed (checkpoints)"; return -1; }
+		if (two_pass ? launch_sys_trace(as, g->stream) : launch_sys_walk(as, g->stream)) { g->err = "kernel launch failed (checkpoints)"; return -1; }
 		if (reset_sys(false)) return -1; // barrier counters and progress words of the second pass
 		a.coop_pass = as.coop_pass = 2;
 		set_cols(c_second);
@@ -1189,7 +1188,7 @@ static void trim(mwf_gpu_t *g)
 {
 	(void)hipStreamSynchronize(g->stream);
 	for (DevBuf *b : {&g->ring, &g->sring, &g->good, &g->tb, &g->row_off, &g->row_lo, &g->cig_scratch, &g->snap, &g->snap_meta, &g->seg, &g->dbg,
-	                  &g->coop_edge, &g->coop_misc, &g->sys_box, &g->sys_prog, &g->sys_log, &g->sys_ep, &g->sys_park, &g->sys_ring, &g->sys_good,
+	                  &g->coop_edge, &g->coop_misc, &g->sys_box, &g->sys_prog, &g->sys_log, &g->sys_ep, &g->sys_park, &g->sys_ring, &g->sys_sring, &g->sys_good,
 	                  &g->spare_block, &g->spare_cig})
 		release(g, *b);
 	g->dev_bytes_peak = g->dev_bytes;
@@ -1240,9 +1239,10 @@ int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value)
 	else if (!strcmp(name, "coop_grid")) g->coop_grid_cap = (int)std::max<int64_t>(0, value);
 	else if (!strcmp(name, "coop_launch")) g->coop_launch = value != 0;
 	else if (!strcmp(name, "sys_p") && sys_p_supported((int)value)) g->sys_p = (int)value; // (8; 4 and 16 only in builds with -DMWF_SYS_ALL_P)
-	else if (!strcmp(name, "sys_c") && (value == 0 || value == 1 || value == 4 || (value == 2 && getenv("MWF_SYS_C2")))) g->sys_c = (int)value; // (2: builds with -DMWF_SYS_C2 only)
+	else if (!strcmp(name, "sys_c") && (value == 0 || sys_c_supported((int)value))) g->sys_c = (int)value; // (2: builds with -DMWF_SYS_C2 only — the host's box / traceback layout must be the launched kernel's)
 	else if (!strcmp(name, "trim")) { (void)hipSetDevice(g->device); trim(g); }
 	else return -1;
+	++g->tun_gen; // (whatever the tunable: no hand-kept list of "the ones that classify" to forget an entry of)
 	return 0;
 }
 
@@ -1334,8 +1334,8 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	mwf_gpu_batch_t::PlanCache &PC = b->plan;
 	{
 		const int32_t ok[8] = {opt->flag & MWF_F_CIGAR, opt->x, opt->o1, opt->e1, opt->o2, opt->e2, opt->step, opt->max_s};
-		const int64_t tk[14] = {g->force_kind, g->block, g->band_pack + 4 * (int64_t)g->band_span + 16 * (int64_t)g->wide_slots, g->ring16, g->lds_e2, g->scalar_generic, g->lane_max_len, g->seq2bit,
-		                        g->mid_max_pairs, g->coop_min_len, g->sys_p, g->coop_grid_cap, b->debug_pair, g->lane_chunks};
+		// the tunables as a generation count (every mwf_gpu_set() bumps it) + the engine the plan was made on + the traced pair
+		const int64_t tk[14] = {g->tun_gen, (int64_t)(intptr_t)g, b->debug_pair, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 		if (PC.valid && (memcmp(ok, PC.opt_key, sizeof(ok)) || memcmp(tk, PC.tun_key, sizeof(tk)))) PC.valid = false;
 		if (!PC.valid) memcpy(PC.opt_key, ok, sizeof(ok)), memcpy(PC.tun_key, tk, sizeof(tk)), PC.has_groups = false, PC.wide_state = 0;
 	}
@@ -1365,6 +1365,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	} else if (b->results_preinit) preset = true;
 	b->results_preinit = false;
 	g->queue_clean = !preset;
+	b->cig_block_left = kCigBlockGrid;
 	if (!preset && launch_reset(b->d_status, b->d_s, b->n, b->d_cig_head, (int32_t*)g->queue.p, kQueueInts, g->stream)) { g->err = "kernel launch failed (reset)"; return -1; }
 	std::fill(b->h_flags.begin(), b->h_flags.end(), 0);
 	// a few long pairs: each one gets the whole device in turn
@@ -1541,7 +1542,12 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		if (c == 1 && g->wide_slots == 0 && PC.wide_state == 0 && g->queue_clean && ran == 2 && g->stats.block == 512) PC.wide_measured = true;
 		g->acgt_off_once = false;
 		if (rc) return -1;
-		for (size_t j = at; j < at + (size_t)G.n; ++j) b->h_kind[b->h_order[j]] = (int8_t)ran;
+		// (bit 64: the pair ran on the plain three-slot 512-thread geometry — the only one whose LATE overflow says "this batch's wide class needs four slots")
+		const bool three_slots = c == 1 && ran == 2 && g->stats.block == 512 && !(g->wide_slots == 4 || (g->wide_slots == 0 && PC.wide_state != 1 && g->queue_clean));
+		for (size_t j = at; j < at + (size_t)G.n; ++j) {
+			const int32_t i = b->h_order[j];
+			b->h_kind[i] = (int8_t)ran, b->h_flags[i] = (int8_t)((b->h_flags[i] & ~64) | (three_slots ? 64 : 0));
+		}
 		at += (size_t)G.n;
 	}
 	b->aligned = true;
@@ -1603,6 +1609,7 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 		}
 		const char *o = host.data() - L.head;
 		memcpy(&b->cig_used, o + L.head, 8);
+		b->cig_used = std::min<int64_t>(b->cig_used, b->cig_pool_words); // (the head advances in whole blocks: its last step may point past the pool)
 		memcpy(b->h_status.data(), o + L.status, n * 4), memcpy(b->h_s.data(), o + L.s, n * 4), memcpy(b->h_ncig.data(), o + L.ncig, n * 4);
 		memcpy(b->h_iter.data(), o + L.iter, n * 8), memcpy(b->h_cigoff.data(), o + L.cigoff, n * 8), memcpy(b->h_cells1.data(), o + L.cells1, n * 8);
 		return 0;
@@ -1641,12 +1648,16 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 				const int64_t est = b->h_iter[i] < 0 ? -b->h_iter[i] : 0;
 				// (a pair of the wide class that outgrew its three chunk slots per wave LATE — that geometry carries no forecast — is re-run alone, ~7 ms for a
 				// 10 kb pair beside the batch's 17: the next align of this batch takes the four-slot geometry for the class)
-				if (b->h_class[i] == 1 && est == 0) b->plan.wide_state = 2;
+				// (only a pair that really ran on that geometry says so: class-14 pairs on biased offsets and re-runs of mid / lane pairs carry class 1 as well)
+				if ((b->h_flags[i] & 64) && est == 0) b->plan.wide_state = 2;
+				b->h_flags[i] &= ~64;
 				// (... only when the forecast is half again beyond the widest class: it is an estimate, and the generic kernel is several times slower)
 				// what outgrew (or is forecast to outgrow) the 512-thread geometry: the 1024-thread span geometry, if the pair fits that
 				const bool span_ok = b->h_class[i] >= 1 && b->h_class[i] <= 4 && g->band_span != 0 && g->seq2bit != 0 && g->force_kind < 0 && g->block == 0 &&
 				                     b->h_tl[i] <= kBandSpanMaxSeq && b->h_ql[i] <= kBandSpanMaxSeq && est <= band_span_window();
-				if (b->h_class[i] >= 2 && est <= kBandWideWindow * 3 / 2) b->h_class[i] = 1, to_band_wide[step0].push_back((int32_t)i);
+				// (a forecast the four-slot 512-thread geometry holds — the re-run takes four slots for it, see rerun(); beyond it the span geometry at once:
+				// round 4 sent forecasts of up to 1.5 x the THREE-slot window here and re-ran them on three slots, which by their own forecast could not hold them)
+				if (b->h_class[i] >= 2 && est <= kBandWide4Window) b->h_class[i] = 1, to_band_wide[step0].push_back((int32_t)i);
 				else if (span_ok) b->h_class[i] = 5, to_band_span[step0].push_back((int32_t)i);
 				// (a forecast also says whether the generic kernel's 16-bit ring rows can hold the pair — offsets up to 65 532, i.e. target length
 				// + final penalty, about half the window: 50 kb pairs at 15 % ran them for nothing before taking the 32-bit rows)
@@ -1701,6 +1712,8 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 					if (b->h_iter[i] >= 0) { hint = 0; break; }
 					hint = std::max<int64_t>(hint, -b->h_iter[i] * 5 / 4 + 64);
 				}
+				// (every forecast of this re-run is at most kBandWide4Window: the margin must not push the hint past the four-slot geometry, back onto three slots)
+				if (hint > kBandWide4Window && want_kind == 2 && geom == 0) hint = kBandWide4Window;
 			}
 			std::stable_sort(ids.begin(), ids.end(), [&](int32_t x, int32_t y) { return (int64_t)b->h_tl[x] + b->h_ql[x] > (int64_t)b->h_tl[y] + b->h_ql[y]; });
 			const mwf_opt_t &o = step0 ? opt_hi : b->opt;

@@ -143,21 +143,19 @@ struct BandGeom {
 	int lane;         // 1: the one-wave, one-diagonal-per-lane kernel for short pairs (mwf_lane.hip): block 64, span 64, lds_bytes = rings + sequences;
 	                  // 2: the one-workgroup, one-diagonal-per-lane kernel for a few mid-size pairs (mwf_mid.hip): span = columns of its LDS rows
 };
-// launch wrappers implemented in mwf_coop.hip (one pair across the whole device)
+// one pair (or a few) across the whole device: mwf_sys.hip (the per-penalty hand-off kernel of rounds 1-2, mwf_coop.hip, was removed in round 5)
 bool coop_supported(const Penalty &p);
-int  coop_max_grid(bool cigar);
 int64_t coop_chunk_slots(int grid);                  // 256-column chunks a launch of `grid` workgroups holds (window capacity + 1)                      // co-resident workgroups the kernel may be launched with
-int  launch_coop_pass(const BatchArgs &a, int grid, void *stream);       // the provenance pass of the two-pass low-memory mode (coop_pass == 3)
-int  launch_coop_trace(const BatchArgs &a, void *stream);                // checkpoints from the snapshots of a provenance pass
-// launch wrappers implemented in mwf_sys.hip (the systolic whole-device kernel: same penalties as mwf_coop.hip, every pass but
-// the provenance pass of the two-pass low-memory mode)
+// launch wrappers implemented in mwf_sys.hip (the systolic whole-device kernel: every pass, the provenance pass of the two-pass low-memory mode included)
 int64_t sys_chunk_slots(int grid);                   // chunk slots a launch of `grid` workgroups holds
 int  sys_owned_cols(int p, int c);                   // columns a chunk slot owns: 64c - 2p
+bool sys_c_supported(int c);                         // columns per lane the build has kernels for (1 and 4; 2 only with -DMWF_SYS_C2)
 bool sys_p_supported(int p);                         // block lengths (penalties per hand-off) the build has kernels for
-int64_t sys_box_ints(int p);                         // ints of one hand-off box
+int64_t sys_box_ints(int p, bool seg = false);                         // ints of one hand-off box
 int  sys_max_grid();                                 // co-resident workgroups the kernel may be launched with (one per CU)
 int  launch_sys_pass(const BatchArgs &a, int grid, void *stream);        // forward pass (score / traceback bytes / second pass with band resets)
-int  launch_sys_walk(const BatchArgs &a, void *stream);                  // checkpoints from the traceback matrix of a first pass
+int  launch_sys_walk(const BatchArgs &a, void *stream);
+int  launch_sys_trace(const BatchArgs &a, void *stream);                 // checkpoints from the snapshots of the systolic kernel's provenance pass                  // checkpoints from the traceback matrix of a first pass
 int  launch_sys_finish(const BatchArgs &a, void *stream);                // traceback + per-pair outputs
 
 // launch wrappers implemented in mwf_lane.hip (one wave per pair, one diagonal per lane, rings and sequences in LDS: short pairs)

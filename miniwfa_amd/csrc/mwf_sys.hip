@@ -1,7 +1,7 @@
 // mwf_sys.hip — one sequence pair across the whole device, systolic form (BASELINE configs 2 and 4: a 150 kb pair, a 5 Mb pair).
 //
 // A single pair is a strictly sequential chain of penalties (reference miniwfa.c:397-426); the only parallelism is across the
-// diagonals of one wavefront, and the only dependence of lag 1 is E2/F2 of the neighbouring diagonal.  mwf_coop.hip exchanged
+// diagonals of one wavefront, and the only dependence of lag 1 is E2/F2 of the neighbouring diagonal.  Rounds 1-2 (mwf_coop.hip, removed) exchanged
 // the outer columns of every 256-column chunk between neighbouring waves at EVERY penalty and polled the fate of the two edge
 // columns at every penalty: 5-6 us per penalty, whatever the window, because a penalty costs two dependent cross-CU round trips.
 // Here the exchange happens once per block of P penalties (P = 8):
@@ -24,7 +24,8 @@
 //     (from the edge log), the traceback layout.
 // Traceback bytes are laid out per epoch and slot (256 bytes per slot and penalty, dev::tb_byte); the second pass of the
 // low-memory mode collapses the window at its checkpoints exactly as the reference does (miniwfa.c:413-416) — every slot
-// knows the checkpoints in advance.  The provenance pass of the two-pass low-memory mode stays in mwf_coop.hip.
+// knows the checkpoints in advance.  The provenance pass of the two-pass low-memory mode (SEG, round 5) runs here as well: shadow
+// registers, a shadow H ring and shadow halves of the hand-off boxes; snapshots need nothing global (see sys_pass).
 // Results are bit-identical to the other kernels (tests/test_gpu_parity.py, tests/test_long_pairs.py).
 #include "mwf_device.h"
 
@@ -169,7 +170,7 @@ struct SysLds {
 };
 
 // Device-wide barrier of this pair's group of workgroups, with a release/acquire pair for data written with ordinary
-// stores (counters on two levels: workgroups with the same index mod 8 share a word; see mwf_coop.hip grid_sync).
+// stores (counters on two levels: workgroups with the same index mod 8 share a word).
 __device__ __forceinline__ bool sys_grid_sync(uint32_t spin_limit, unsigned *sync, int32_t *abort_flag, unsigned lb, SysLds &L, unsigned &epoch, unsigned n_wg)
 {
 	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -227,14 +228,22 @@ __device__ __forceinline__ int32_t seg_effective(const int32_t *seg, int32_t n_s
 __device__ __forceinline__ int32_t floordiv(int32_t a, int32_t b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
 
 // grp / lb / G: this pair's group of workgroups, this workgroup's index in it, the group's size
-template <int E1, int E2, bool TB, int P, bool DEFER, int C>
+// SEG (round 5): the first pass of the true low-memory mode (reference mwf_wfa_seg, miniwfa.c:551-601) — no traceback byte is stored; every
+// wavefront value carries the index of the cell its predecessor chain went through at the last snapshot (shadow registers, a shadow H ring,
+// shadow halves of the hand-off boxes: moved by the choices the traceback byte records, miniwfa.c:495-526), and whenever (s + 1) % step == 0
+// every slot flattens the provenance of its owned columns into the snapshot and renumbers all its columns (miniwfa.c:451-474).  Nothing global
+// is needed for that: the index of a cell is a function of its array-slice, its column and the epoch's chunk range alone.
+template <int E1, int E2, bool TB, int P, bool DEFER, int C, bool SEG = false>
 __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, int32_t n_seg, int32_t grp, int32_t lb, int32_t G)
 {
 	constexpr int kW = 64 * C;                // columns a slot computes
 	constexpr int PL = P / C;                 // halo lanes per side
 	constexpr int OW = kW - 2 * P;            // columns a slot owns
 	constexpr int NEF = 2 * E1 + 2 * E2;      // E/F register arrays per column
-	constexpr int LANE_INTS = (P + NEF) * C;  // ints one outer lane publishes per block
+	constexpr bool WTB = TB || SEG;           // the recurrence yields the traceback byte
+	static_assert(!(TB && SEG), "the first pass of the low-memory mode stores no traceback");
+	constexpr int SH_OFF = (P + NEF) * C;     // SEG: a lane's provenance values sit behind its wavefront values
+	constexpr int LANE_INTS = (P + NEF) * C * (SEG ? 2 : 1);  // ints one outer lane publishes per block
 	constexpr int WIN_OFF = 2 * PL * LANE_INTS; // ints in front of a box's window views
 	static_assert(P % C == 0 && (C == 1 || C == 2 || C == 4), "columns per lane");
 	constexpr int BOX_INTS = (WIN_OFF + 2 * P + 31) / 32 * 32;
@@ -254,7 +263,8 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 	int32_t *const box = A.sys_box + (int64_t)grp * A.sys_box_stride;
 	u64 *const prog = A.sys_prog + (int64_t)grp * A.sys_prog_stride;
 	int32_t *const logL = A.sys_log + (int64_t)grp * A.sys_log_stride, *const logH = logL + A.sys_log_stride / 2;
-	int32_t *const park = A.sys_park + (int64_t)grp * A.sys_park_stride;    // [slot][NEF][64 lanes][4]
+	int32_t *const park = A.sys_park + (int64_t)grp * A.sys_park_stride;    // [slot][NEF (SEG: 2 NEF)][64 lanes][4]
+	int32_t *const sring = SEG ? M.sH : nullptr;                            // [slot][nH][256]: provenance of the H ring
 	PassResult R;
 	R.status = ST_OK, R.s = 0, R.info = 0, R.n_snap = 0, R.cells = 0;
 	unsigned epoch = 0; // the host zeroes the barrier words before every pass
@@ -262,20 +272,23 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 	// E/F wavefronts of the RESIDENT slot (four columns per lane; age 0 is the previous penalty) and its prefetched H rows
 	int32_t e1h[E1][C], f1h[E1][C], e2h[E2][C], f2h[E2][C];
 	int32_t phx[C], po1[C], po2[C];
+	// SEG: their provenance (dead code otherwise); the origin's is -1, where the chain through the snapshots ends (miniwfa.c:119, :542)
+	int32_t se1h[E1][C], sf1h[E1][C], se2h[E2][C], sf2h[E2][C];
+	int32_t sphx[C], spo1[C], spo2[C];
 	int32_t res = -1; // slot of this wave whose E/F are in the registers
 	auto set_dead = [&]() {
 #pragma unroll
 		for (int i = 0; i < C; ++i) {
 #pragma unroll
-			for (int a = 0; a < E1; ++a) e1h[a][i] = f1h[a][i] = kNegInf;
+			for (int a = 0; a < E1; ++a) e1h[a][i] = f1h[a][i] = kNegInf, se1h[a][i] = sf1h[a][i] = -1;
 #pragma unroll
-			for (int a = 0; a < E2; ++a) e2h[a][i] = f2h[a][i] = kNegInf;
+			for (int a = 0; a < E2; ++a) e2h[a][i] = f2h[a][i] = kNegInf, se2h[a][i] = sf2h[a][i] = -1;
 		}
 	};
 	set_dead();
 	// A wave holds up to kK slots but works on one at a time, a whole block of penalties each: the other slot's registers rest
 	// in HBM (six 16-byte words per lane; only waves whose two slots are both inside the window ever swap)
-	auto park_ptr = [&](int32_t r, int32_t a) -> int32_t* { return park + (((int64_t)r * NEF + a) * 64 + lane) * C; };
+	auto park_ptr = [&](int32_t r, int32_t a) -> int32_t* { return park + (((int64_t)r * (SEG ? 2 * NEF : NEF) + a) * 64 + lane) * C; };
 	auto make_resident = [&](int32_t k) {
 		if (res == k) return;
 		if (res >= 0 && uni(L.sv[wv * kK + res].part)) {
@@ -289,6 +302,16 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 			for (int q = 0; q < E2; ++q, ++a) st_cols<C>(park_ptr(r, a), e2h[q]);
 #pragma unroll
 			for (int q = 0; q < E2; ++q, ++a) st_cols<C>(park_ptr(r, a), f2h[q]);
+			if (SEG) {
+#pragma unroll
+				for (int q = 0; q < E1; ++q, ++a) st_cols<C>(park_ptr(r, a), se1h[q]);
+#pragma unroll
+				for (int q = 0; q < E1; ++q, ++a) st_cols<C>(park_ptr(r, a), sf1h[q]);
+#pragma unroll
+				for (int q = 0; q < E2; ++q, ++a) st_cols<C>(park_ptr(r, a), se2h[q]);
+#pragma unroll
+				for (int q = 0; q < E2; ++q, ++a) st_cols<C>(park_ptr(r, a), sf2h[q]);
+			}
 		}
 		res = k;
 		if (uni(L.sv[wv * kK + k].fresh)) {
@@ -306,6 +329,16 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 		for (int q = 0; q < E2; ++q, ++a) ld_cols<C>(park_ptr(r, a), e2h[q]);
 #pragma unroll
 		for (int q = 0; q < E2; ++q, ++a) ld_cols<C>(park_ptr(r, a), f2h[q]);
+		if (SEG) {
+#pragma unroll
+			for (int q = 0; q < E1; ++q, ++a) ld_cols<C>(park_ptr(r, a), se1h[q]);
+#pragma unroll
+			for (int q = 0; q < E1; ++q, ++a) ld_cols<C>(park_ptr(r, a), sf1h[q]);
+#pragma unroll
+			for (int q = 0; q < E2; ++q, ++a) ld_cols<C>(park_ptr(r, a), se2h[q]);
+#pragma unroll
+			for (int q = 0; q < E2; ++q, ++a) ld_cols<C>(park_ptr(r, a), sf2h[q]);
+		}
 	};
 
 	// ---- penalty 0: origin and its extension (the first wave of workgroup 0 walks it cooperatively)
@@ -328,11 +361,16 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 	int32_t sid = 0, sid_blk = 0;
 	int32_t seg_s = TB && n_seg > 0 ? uni(M.seg[0]) : -1, seg_c = TB && n_seg > 0 ? uni(M.seg[1]) : 0; // the next checkpoint
 	int64_t cells = 0, tb_used = 0;
+	// SEG: the next snapshot is due when `snap_next` penalties are done, i.e. (s + 1) % step == 0 (miniwfa.c:585-586); it will be the snap_idx-th;
+	// snap_used ints of the arena lie in front of this epoch's snapshots.  Every wave keeps the same count (idle ones included).
+	int32_t snap_next_blk = SEG ? A.step - 1 : 0x7fffffff, snap_idx_blk = 0;
+	int64_t snap_used = 0;
 	int32_t pgA = 1, pgB = 0; // chunks that took part in the previous epoch
 	const int32_t cfin = ql + 1; // the end cell (tl-1, ql-1) lies on diagonal ql-tl, i.e. in this column
 	const int32_t gmax = cmax / OW;
 
 	auto row_ptr = [&](int32_t r, int32_t j) -> int32_t* { return ring + (((int64_t)r * nH + j) * kW + C * lane); };
+	auto srow_ptr = [&](int32_t r, int32_t j) -> int32_t* { return sring + (((int64_t)r * nH + j) * kW + C * lane); };
 	auto prefetch = [&](int32_t r, int32_t slotH) { // the three H rows the penalty that writes ring row slotH reads
 		int32_t jx = slotH - lagx; if (jx < 0) jx += nH;
 		int32_t j1 = slotH - lag1; if (j1 < 0) j1 += nH;
@@ -340,6 +378,7 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 		ld_cols<C>(row_ptr(r, jx), phx);
 		ld_cols<C>(row_ptr(r, j1), po1);
 		ld_cols<C>(row_ptr(r, j2), po2);
+		if (SEG) ld_cols<C>(srow_ptr(r, jx), sphx), ld_cols<C>(srow_ptr(r, j1), spo1), ld_cols<C>(srow_ptr(r, j2), spo2);
 	};
 
 #ifdef MWF_SYS_TIMING
@@ -359,6 +398,21 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 		if (n_ep > TC - 1) { R.status = ST_BAND_OVERFLOW; break; }
 		if (s + 1 > A.rows_slot) { R.status = ST_ROWS_OVERFLOW; break; } // (the log and the epoch table hold rows_slot + 256 penalties)
 		const int64_t ep_base = tb_used;
+		// SEG: the snapshots that fall into this epoch (penalties done s .. s+255), laid out for its chunk range: one array-slice = n_ep x OW ints
+		const int32_t ep_snap_first = snap_next_blk, ep_snap_idx0 = snap_idx_blk;
+		const int32_t snap_per = SEG ? n_ep * OW : 0;
+		const int64_t snap_total = (int64_t)(nH + NEF) * snap_per;
+		int32_t n_snap_ep = 0;
+		if (SEG) {
+			n_snap_ep = ep_snap_first <= s + kEpoch - 1 ? (s + kEpoch - 1 - ep_snap_first) / A.step + 1 : 0;
+			if ((int64_t)(ep_snap_idx0 + n_snap_ep) * 8 > A.snap_meta_slot || snap_used + n_snap_ep * snap_total > A.snap_slot_ints || snap_total > 0x7fffffffLL) { R.status = ST_SNAP_OVERFLOW; break; }
+			if (lb == 0 && tid < n_snap_ep) { // (at most 256 per epoch: step >= 1)
+				int32_t *meta = M.snap_meta + (int64_t)(ep_snap_idx0 + tid) * 8;
+				const int64_t base = snap_used + tid * snap_total;
+				const int32_t S = ep_snap_first + tid * A.step;
+				meta[0] = (int32_t)(base & 0xffffffff), meta[1] = (int32_t)(base >> 32), meta[2] = S, meta[3] = S % nH, meta[4] = gA, meta[5] = n_ep, meta[6] = OW, meta[7] = 0;
+			}
+		}
 		if (TB) {
 			if (tb_used + (int64_t)kEpoch * n_ep * kW > A.tb_slot_bytes) { R.status = ST_TB_OVERFLOW; break; }
 			if (lead) {
@@ -385,7 +439,10 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 				if (s == 0) { // the origin (reference wf_stripe_init, miniwfa.c:103-121)
 					const int32_t c0 = tl + 1;
 					if (lane == 0) L.hist[sl][0] = make_int2(min(max(c0, cb), cb + kW), max(min(c0, cb + kW - 1), cb - 1));
-					if ((uint32_t)(c0 - cb) < (uint32_t)kW && lane == (c0 - cb) / C) ring[((int64_t)r * nH + 0) * kW + (c0 - cb)] = k0;
+					if ((uint32_t)(c0 - cb) < (uint32_t)kW && lane == (c0 - cb) / C) {
+						ring[((int64_t)r * nH + 0) * kW + (c0 - cb)] = k0;
+						if (SEG) sring[((int64_t)r * nH + 0) * kW + (c0 - cb)] = -1;
+					}
 				}
 			}
 			if (!now && res == k) res = -1;
@@ -473,6 +530,26 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 						for (int a = 0; a < E2; ++a, q += C) ld_box<C>(q, e2h[a]);
 #pragma unroll
 						for (int a = 0; a < E2; ++a, q += C) ld_box<C>(q, f2h[a]);
+						if (SEG) { // the provenance of the same values
+							int32_t v[P][C];
+#pragma unroll
+							for (int t = 0; t < P; ++t) ld_box<C>(src + SH_OFF + t * C, v[t]);
+							int32_t j = (s0 - P + 1) % nH;
+#pragma unroll
+							for (int t = 0; t < P; ++t) {
+								st_cols<C>(srow_ptr(r, j), v[t]);
+								j = j + 1 == nH ? 0 : j + 1;
+							}
+							q = src + SH_OFF + P * C;
+#pragma unroll
+							for (int a = 0; a < E1; ++a, q += C) ld_box<C>(q, se1h[a]);
+#pragma unroll
+							for (int a = 0; a < E1; ++a, q += C) ld_box<C>(q, sf1h[a]);
+#pragma unroll
+							for (int a = 0; a < E2; ++a, q += C) ld_box<C>(q, se2h[a]);
+#pragma unroll
+							for (int a = 0; a < E2; ++a, q += C) ld_box<C>(q, sf2h[a]);
+						}
 					} else if ((hal || har) && me) {
 						// no neighbour on that side (it does not take part, or has just joined): nothing there was ever inside the window
 						// (its H rows are masked by the window views below: the window never reached those columns)
@@ -531,6 +608,7 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 				// DEFER stage 2 runs one penalty late, behind the next stage 1: the sequence bytes travel while the wave computes.
 				int32_t curHk = curH;
 				sid = sid0, seg_s = seg_s0, seg_c = seg_c0; // (every slot of the wave walks the same penalties)
+				int32_t snap_next = snap_next_blk, snap_idx = snap_idx_blk;
 				if (!lag_one) prefetch(r, curHk + 1 == nH ? 0 : curHk + 1);
 				const int32_t par = (int32_t)(B & 1);
 				const bool own_fin = (uint32_t)(cfin - (cb + P)) < (uint32_t)OW; // this slot owns the end diagonal
@@ -547,12 +625,12 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 #pragma unroll
 				for (int i = 0; i < C; ++i) rj[i] = max(min(tl, ql - (c0 + i - 1 - tl)), 0);
 				// what stage 2 needs of a penalty
-				int32_t x_hv[C] = {}, x_snew = 0, x_newH = 0, x_t = 0;
+				int32_t x_hv[C] = {}, x_shv[C] = {}, x_snew = 0, x_newH = 0, x_t = 0;
 				uint64_t x_t8[C] = {}, x_q8[C] = {};
 				uint32_t x_tbw = 0;
 #pragma unroll 1
 				for (int t = 0; t < P + (DEFER ? 1 : 0); ++t) {
-					int32_t c_hv[C], c_snew = 0, c_newH = 0;
+					int32_t c_hv[C], c_shv[C] = {}, c_snew = 0, c_newH = 0;
 					uint64_t c_t8[C], c_q8[C];
 					uint32_t c_tbw = 0;
 					// what stage 2a leaves for stage 2b
@@ -604,6 +682,45 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 					MWF_T(ts_1);
 					if (!DEFER || t < P) {
 					const int32_t sc = s0 + t; // penalties done so far
+					if (SEG && sc == snap_next) {
+						// ---- snapshot (reference wf_snapshot1, miniwfa.c:451-474): flatten the provenance of this slot's owned columns, renumber every
+						// column of the slot (halo included: a cell's index is a function of its array-slice and column) and what the slot has already
+						// published of this block's rows.  Index = (slice * n_ep + owner chunk - gA) * OW + column - owner chunk * OW; slices: the H ring
+						// by age (0 = the penalty just done), then E1, F1, E2, F2 by age.
+						int32_t *const x = M.snap + (snap_used + (int64_t)(snap_idx - ep_snap_idx0) * snap_total);
+						const int32_t gc = lane < PL ? g - 1 : lane >= 64 - PL ? g + 1 : g;
+						const int32_t rel = (gc - gA) * OW + (c0 - gc * OW);
+						const bool own = lane >= PL && lane < 64 - PL;
+						const bool ol = lane >= PL && lane < 2 * PL, orr = lane >= 64 - 2 * PL && lane < 64 - PL;
+						int32_t *const bxl = box + ((int64_t)r * 2 + par) * BOX_INTS + ((orr ? PL : 0) + (ol ? lane - PL : lane - (64 - 2 * PL))) * LANE_INTS + SH_OFF;
+						for (int32_t j = 0; j < nH; ++j) {
+							int32_t age = curHk - j;
+							if (age < 0) age += nH;
+							if (age > sc) continue; // uniform: that ring row has not been written yet
+							int32_t v[C];
+							ld_cols<C>(srow_ptr(r, j), v);
+							const int32_t f0 = age * snap_per + rel;
+							if (own) st_cols<C>(x + f0, v);
+#pragma unroll
+							for (int i = 0; i < C; ++i) v[i] = f0 + i;
+							st_cols<C>(srow_ptr(r, j), v);
+							if (age < t && (ol || orr)) st_box<C>(bxl + C * (t - 1 - age), v); // (entry t' of the box holds the penalty s0 + 1 + t')
+						}
+						auto flat = [&](int32_t (&reg)[C], int32_t code) {
+							const int32_t f0 = code * snap_per + rel;
+							if (own) st_cols<C>(x + f0, reg);
+#pragma unroll
+							for (int i = 0; i < C; ++i) reg[i] = f0 + i;
+						};
+#pragma unroll
+						for (int a = 0; a < E1; ++a) flat(se1h[a], nH + a), flat(sf1h[a], nH + E1 + a);
+#pragma unroll
+						for (int a = 0; a < E2; ++a) flat(se2h[a], nH + 2 * E1 + a), flat(sf2h[a], nH + 2 * E1 + E2 + a);
+						asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+						snap_next += A.step, ++snap_idx;
+						// what was requested for this penalty before the renumbering is stale: request it again
+						if (!lag_one) prefetch(r, curHk + 1 == nH ? 0 : curHk + 1);
+					}
 					if (TB && !deep_blk && seg_s == sc) { // checkpoint reset of the second pass (miniwfa.c:413-416): every slot knows the checkpoints
 						wl = wh = seg_c;
 						++sid;
@@ -630,8 +747,13 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 						inner = max(max(lo, xlo), max(alo, blo)) <= cb && min(min(hi, xhi), min(ahi, bhi)) >= cb + kW - 1;
 					}
 					int32_t hx[C], o1[C + 2], o2[C + 2];
+					int32_t shx[C], so1[C + 2], so2[C + 2]; // SEG: provenance of the same sources
 #pragma unroll
 					for (int i = 0; i < C; ++i) hx[i] = phx[i], o1[i + 1] = po1[i], o2[i + 1] = po2[i];
+					if (SEG) {
+#pragma unroll
+						for (int i = 0; i < C; ++i) shx[i] = sphx[i], so1[i + 1] = spo1[i], so2[i + 1] = spo2[i];
+					}
 					// the next penalty's rows: requested at once — they are at least two penalties old (every lag >= 2 here), and a whole
 					// penalty's work lies between this request and their use
 					if (!lag_one && t + 1 < P) prefetch(r, nextH);
@@ -656,6 +778,20 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 					for (int i = 1; i < C; ++i) g1m[i] = e1h[E1 - 1][i - 1], g2m[i] = e2h[E2 - 1][i - 1];
 #pragma unroll
 					for (int i = 0; i < C - 1; ++i) g1p[i] = f1h[E1 - 1][i + 1], g2p[i] = f2h[E2 - 1][i + 1];
+					int32_t sg1m[C], sg1p[C], sg2m[C], sg2p[C];
+					if (SEG) {
+						so1[0] = from_left(so1[C], -1), so1[C + 1] = from_right(so1[1], -1);
+						so2[0] = from_left(so2[C], -1), so2[C + 1] = from_right(so2[1], -1);
+						sg1m[0] = from_left(se1h[E1 - 1][C - 1], -1);
+						sg2m[0] = from_left(se2h[E2 - 1][C - 1], -1);
+						sg1p[C - 1] = from_right(sf1h[E1 - 1][0], -1);
+						sg2p[C - 1] = from_right(sf2h[E2 - 1][0], -1);
+#pragma unroll
+						for (int i = 1; i < C; ++i) sg1m[i] = se1h[E1 - 1][i - 1], sg2m[i] = se2h[E2 - 1][i - 1];
+#pragma unroll
+						for (int i = 0; i < C - 1; ++i) sg1p[i] = sf1h[E1 - 1][i + 1], sg2p[i] = sf2h[E2 - 1][i + 1];
+					}
+					int32_t sne1[C], snf1[C], sne2[C], snf2[C], shv[C];
 
 					int32_t ne1[C], nf1[C], ne2[C], nf2[C];
 					uint32_t tbw = 0, live = 0, gbits = 0;
@@ -666,8 +802,12 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 						// phantom (beyond the matrix) offsets, and both addresses stay inside the sequences' slack.
 #pragma unroll
 						for (int i = 0; i < C; ++i) {
-							const Cell v = sys_cell<TB>(hx[i], o1[i], g1m[i], o2[i], g2m[i], o1[i + 2], g1p[i], o2[i + 2], g2p[i]);
+							const Cell v = sys_cell<WTB>(hx[i], o1[i], g1m[i], o2[i], g2m[i], o1[i + 2], g1p[i], o2[i + 2], g2p[i]);
 							ne1[i] = v.e1, nf1[i] = v.f1, ne2[i] = v.e2, nf2[i] = v.f2;
+							if (SEG) { // provenance follows the choices the traceback byte records (miniwfa.c:504-523)
+								const Cell u = shadow_cell(v.tb, shx[i], so1[i], sg1m[i], so2[i], sg2m[i], so1[i + 2], sg1p[i], so2[i + 2], sg2p[i]);
+								sne1[i] = u.e1, snf1[i] = u.f1, sne2[i] = u.e2, snf2[i] = u.f2, shv[i] = u.h;
+							}
 							const int32_t jc = (int32_t)min((uint32_t)(v.h + 1), (uint32_t)rj[i]);
 							c_t8[i] = ld8(M.ts + jc), c_q8[i] = ld8((qsd + jc) + i);
 							c_hv[i] = v.h;
@@ -678,9 +818,13 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 					for (int i = 0; i < C; ++i) {
 						const int32_t c = c0 + i, d = c - 1 - tl;
 						const uint32_t act = inner ? 1u : (uint32_t)((c >= lo) & (c <= hi));
-						const Cell v = sys_cell<TB>(hx[i], o1[i], g1m[i], o2[i], g2m[i], o1[i + 2], g1p[i], o2[i + 2], g2p[i]);
+						const Cell v = sys_cell<WTB>(hx[i], o1[i], g1m[i], o2[i], g2m[i], o1[i + 2], g1p[i], o2[i + 2], g2p[i]);
 						ne1[i] = act ? v.e1 : kNegInf, nf1[i] = act ? v.f1 : kNegInf;
 						ne2[i] = act ? v.e2 : kNegInf, nf2[i] = act ? v.f2 : kNegInf;
+						if (SEG) { // (the provenance of a dead cell is never followed: no masks)
+							const Cell u = shadow_cell(v.tb, shx[i], so1[i], sg1m[i], so2[i], sg2m[i], so1[i + 2], sg1p[i], so2[i + 2], sg2p[i]);
+							sne1[i] = u.e1, snf1[i] = u.f1, sne2[i] = u.e2, snf2[i] = u.f2, shv[i] = u.h;
+						}
 						const uint32_t inm = act & inm_bit(d, v.h, tl, ql);
 						if (track_good)
 							gbits |= (act & (inm | inm_bit(d, v.e1, tl, ql) | inm_bit(d, v.f1, tl, ql) | inm_bit(d, v.e2, tl, ql) | inm_bit(d, v.f2, tl, ql))) << i;
@@ -695,6 +839,13 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 						tbw |= v.tb << (8 * i);
 					}
 					c_tbw = tbw, c_snew = s_new, c_newH = newH;
+					if (SEG) { // the provenance of the new H row is final here (the match extension moves offsets, not predecessors)
+#pragma unroll
+						for (int i = 0; i < C; ++i) c_shv[i] = shv[i];
+						st_cols<C>(srow_ptr(r, newH), shv);
+						const bool ol = lane >= PL && lane < 2 * PL, orr = lane >= 64 - 2 * PL && lane < 64 - PL;
+						if (ol || orr) st_box<C>(box + ((int64_t)r * 2 + par) * BOX_INTS + ((orr ? PL : 0) + (ol ? lane - PL : lane - (64 - 2 * PL))) * LANE_INTS + SH_OFF + C * t, shv);
+					}
 					if (TB) {
 						uint8_t *const tp = M.tb + ep_base + ((int64_t)(s_new - 1 - (ep << 8)) * n_ep + (g - gA)) * kW + C * lane;
 						if constexpr (C == 4) *(uint32_t*)tp = tbw;
@@ -727,13 +878,20 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 #pragma unroll
 						for (int a = E2 - 1; a > 0; --a) e2h[a][i] = e2h[a - 1][i], f2h[a][i] = f2h[a - 1][i];
 						e1h[0][i] = ne1[i], f1h[0][i] = nf1[i], e2h[0][i] = ne2[i], f2h[0][i] = nf2[i];
+						if (SEG) {
+#pragma unroll
+							for (int a = E1 - 1; a > 0; --a) se1h[a][i] = se1h[a - 1][i], sf1h[a][i] = sf1h[a - 1][i];
+#pragma unroll
+							for (int a = E2 - 1; a > 0; --a) se2h[a][i] = se2h[a - 1][i], sf2h[a][i] = sf2h[a - 1][i];
+							se1h[0][i] = sne1[i], sf1h[0][i] = snf1[i], se2h[0][i] = sne2[i], sf2h[0][i] = snf2[i];
+						}
 					}
 					curHk = newH;
 					}
 					MWF_T(ts_2);
 					if (!DEFER) {
 #pragma unroll
-						for (int i = 0; i < C; ++i) x_hv[i] = c_hv[i], x_t8[i] = c_t8[i], x_q8[i] = c_q8[i];
+						for (int i = 0; i < C; ++i) x_hv[i] = c_hv[i], x_shv[i] = c_shv[i], x_t8[i] = c_t8[i], x_q8[i] = c_q8[i];
 						x_tbw = c_tbw, x_snew = c_snew, x_newH = c_newH, x_t = t;
 						stage2a();
 					}
@@ -788,7 +946,7 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 							if (own_fin) {
 								const uint32_t f = in & (uint32_t)(c0 + i == cfin) & (uint32_t)(kk2 == tl - 1) & (uint32_t)(d + kk2 == ql - 1);
 								fin |= f;
-								done_info = f ? (nmat[i] == 0 ? (int32_t)((x_tbw >> (8 * i)) & 7u) : 0) : done_info;
+								done_info = f ? (SEG ? x_shv[i] : (nmat[i] == 0 ? (int32_t)((x_tbw >> (8 * i)) & 7u) : 0)) : done_info; // (SEG: where the chain through the snapshots starts, miniwfa.c:577)
 							}
 							hv[i] = kk2;
 						}
@@ -812,7 +970,7 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 					}
 					if (DEFER) {
 #pragma unroll
-						for (int i = 0; i < C; ++i) x_hv[i] = c_hv[i], x_t8[i] = c_t8[i], x_q8[i] = c_q8[i];
+						for (int i = 0; i < C; ++i) x_hv[i] = c_hv[i], x_shv[i] = c_shv[i], x_t8[i] = c_t8[i], x_q8[i] = c_q8[i];
 						x_tbw = c_tbw, x_snew = c_snew, x_newH = c_newH, x_t = t;
 					}
 #ifdef MWF_SYS_TIMING
@@ -846,6 +1004,17 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 						for (int a = 0; a < E2; ++a, dst += C) st_box<C>(dst, e2h[a]);
 #pragma unroll
 						for (int a = 0; a < E2; ++a, dst += C) st_box<C>(dst, f2h[a]);
+						if (SEG) {
+							dst = bx + ((orr ? PL : 0) + (ol ? lane - PL : lane - (64 - 2 * PL))) * LANE_INTS + SH_OFF + C * P;
+#pragma unroll
+							for (int a = 0; a < E1; ++a, dst += C) st_box<C>(dst, se1h[a]);
+#pragma unroll
+							for (int a = 0; a < E1; ++a, dst += C) st_box<C>(dst, sf1h[a]);
+#pragma unroll
+							for (int a = 0; a < E2; ++a, dst += C) st_box<C>(dst, se2h[a]);
+#pragma unroll
+							for (int a = 0; a < E2; ++a, dst += C) st_box<C>(dst, sf2h[a]);
+						}
 					}
 					if (lane < 2 * P) st_ag(bx + WIN_OFF + lane, lane < P ? L.mywl[sl][lane] : L.mywh[sl][lane - P]);
 					if (lane == 0) L.sv[sl].wl = wl, L.sv[sl].wh = wh;
@@ -864,8 +1033,10 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 			s = s0 + P;
 			for (int t = 0; t < P; ++t) curH = curH + 1 == nH ? 0 : curH + 1;
 			sid_blk = sid0;
+			if (SEG) while (snap_next_blk < s0 + P) snap_next_blk += A.step, ++snap_idx_blk;
 		}
 		pgA = gA, pgB = gB;
+		if (SEG) snap_next_blk = ep_snap_first + n_snap_ep * A.step, snap_idx_blk = ep_snap_idx0 + n_snap_ep, snap_used += n_snap_ep * snap_total;
 		MWF_T(tt_e1);
 
 		// ---- end of the epoch: everybody meets; edges from the log, n_iter, stop rules, end cell, shrink
@@ -973,6 +1144,7 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 #endif
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	R.s = s, R.cells = cells;
+	if (SEG) R.n_snap = A.step > 0 ? s / A.step : 0; // snapshots of the penalties that exist (miniwfa.c:585: none is taken once the end cell is found)
 	return R;
 }
 
@@ -1013,7 +1185,66 @@ __global__ __launch_bounds__(kT) void wfa_sys_kernel(const BatchArgs A)
 	}
 }
 
-// Checkpoints of the low-memory mode from the full traceback matrix of a first pass (see mwf_coop.hip coop_walk_kernel;
+// The provenance pass of the true low-memory mode (coop_pass == 3): no traceback, snapshots every `step` penalties.
+template <int E1, int E2, int P, bool DEFER, int C>
+__global__ __launch_bounds__(kT) void wfa_sys_seg_kernel(const BatchArgs A)
+{
+	__shared__ SysLds L;
+	const int32_t G = A.coop_group_size, grp = (int32_t)blockIdx.x / G, lb = (int32_t)blockIdx.x % G;
+	const int32_t pair = group_pair(A, grp);
+	int32_t *const state = group_state(A, grp);
+	PairMem M;
+	sys_pair_mem(A, grp, pair, M);
+	if (threadIdx.x == 0) L.red[0] = 0;
+	__syncthreads();
+	const PassResult R = sys_pass<E1, E2, false, P, DEFER, C, true>(A, M, L, 0, grp, lb, G);
+	if (lb == 0 && threadIdx.x == 0) {
+		state[0] = R.status, state[1] = R.s, state[2] = R.info; // info: the end cell's provenance
+		state[4] = (int32_t)(R.cells & 0xffffffff), state[5] = (int32_t)(R.cells >> 32);
+		state[6] = R.n_snap;
+	}
+}
+
+// Checkpoints of the true low-memory mode: chase the provenance of the end cell back through the snapshots (reference wf_traceback_seg,
+// miniwfa.c:528-549).  An index decodes to (slice, owner chunk, column) with the snapshot's chunk range; the slice gives the penalty: H ring
+// slices and E/F registers are numbered by age (0 = the penalty the snapshot was taken behind).
+__global__ void sys_trace_kernel(const BatchArgs A)
+{
+	if (threadIdx.x != 0) return;
+	const int32_t grp = (int32_t)blockIdx.x; // one block per pair
+	int32_t *st = group_state(A, grp);
+	st[3] = 0;
+	if (st[0] != ST_OK) return;
+	const Penalty &P = A.pen;
+	PairMem M;
+	sys_pair_mem(A, grp, group_pair(A, grp), M);
+	const int32_t n_snap = st[6];
+	if (n_snap > A.seg_slot) { st[0] = ST_SNAP_OVERFLOW; return; }
+	int32_t last = st[2];
+	for (int32_t j = n_snap - 1; j >= 0; --j) {
+		const int32_t *meta = M.snap_meta + (int64_t)j * 8;
+		const int64_t base = (int64_t)(uint32_t)meta[0] | (int64_t)meta[1] << 32;
+		const int32_t S = meta[2], gA = meta[4], n_ep = meta[5], OW = meta[6], per = n_ep * OW;
+		if (last < 0 || per <= 0) { st[0] = ST_INTERNAL; return; }
+		const int32_t id = last / per, rem = last - id * per, col = (gA + rem / OW) * OW + rem % OW;
+		int32_t age;
+		if (id < P.nH) age = id;
+		else {
+			const int32_t q = id - P.nH;
+			if (q < P.e1) age = q;
+			else if (q < 2 * P.e1) age = q - P.e1;
+			else if (q < 2 * P.e1 + P.e2) age = q - 2 * P.e1;
+			else if (q < 2 * P.e1 + 2 * P.e2) age = q - 2 * P.e1 - P.e2;
+			else { st[0] = ST_INTERNAL; return; }
+		}
+		M.seg[2 * j] = S - age, M.seg[2 * j + 1] = col;
+		last = M.snap[base + last];
+	}
+	if (last != -1) { st[0] = ST_INTERNAL; return; } // the chain must end at the origin (reference asserts, miniwfa.c:542,547)
+	st[3] = n_snap;
+}
+
+// Checkpoints of the low-memory mode from the full traceback matrix of a first pass (
 // reference miniwfa.c:495-549): the same walk over this kernel's traceback layout.
 __global__ void sys_walk_kernel(const BatchArgs A)
 {
@@ -1101,6 +1332,19 @@ int launch_pass_c(const BatchArgs &a, int grid, hipStream_t st)
 	case 16: hipLaunchKernelGGL((wfa_sys_kernel<E1, E2, 16, DEFER, TB, C>), dim3(grid), dim3(kT), 0, st, a); break;
 #endif
 	case 8: {
+		if (a.coop_pass == 3) { // the provenance pass of the true low-memory mode (never with traceback)
+			if constexpr (TB) return -1;
+			else {
+				if (a.sys_coop_launch) {
+					BatchArgs arg = a;
+					void *args[] = {(void*)&arg};
+					if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&wfa_sys_seg_kernel<E1, E2, 8, DEFER, C>), dim3(grid), dim3(kT), args, 0, st) == hipSuccess) return 0;
+					(void)hipGetLastError();
+				}
+				hipLaunchKernelGGL((wfa_sys_seg_kernel<E1, E2, 8, DEFER, C>), dim3(grid), dim3(kT), 0, st, a);
+				break;
+			}
+		}
 		// The waits between workgroups rely on every workgroup being resident.  The grid is sized for that (one per CU, sys_max_grid) and
 		// the engine keeps this library's other kernels off the device meanwhile; a cooperative launch makes the runtime refuse a grid
 		// that could not be resident whatever else the process runs.  (A plain launch if the runtime refuses: the waits are bounded.)
@@ -1133,6 +1377,12 @@ template <int E1, int E2, bool CAN_DEFER>
 int launch_pass_d(const BatchArgs &a, int grid, hipStream_t st)
 {
 	const bool defer = CAN_DEFER && a.pen.x >= 3 && a.pen.oe1 >= 3 && a.pen.oe2 >= 3;
+	if (a.coop_pass == 3) { // the provenance pass stores no traceback
+		if constexpr (CAN_DEFER) {
+			if (defer) return launch_pass_p<E1, E2, true, false>(a, grid, st);
+		}
+		return launch_pass_p<E1, E2, false, false>(a, grid, st);
+	}
 	if constexpr (CAN_DEFER) {
 		if (defer) return a.want_cigar ? launch_pass_p<E1, E2, true, true>(a, grid, st) : launch_pass_p<E1, E2, true, false>(a, grid, st);
 	}
@@ -1142,6 +1392,12 @@ int launch_pass_d(const BatchArgs &a, int grid, hipStream_t st)
 } // namespace
 
 int64_t sys_chunk_slots(int grid) { return (int64_t)grid * kNW * kK; }
+int64_t coop_chunk_slots(int grid) { return sys_chunk_slots(grid); }
+// penalties the whole-device kernel is instantiated for; the per-slot window history lives in LDS
+bool coop_supported(const Penalty &p)
+{
+	return ((p.e1 == 2 && p.e2 == 1) || (p.e1 == 2 && p.e2 == 2) || (p.e1 == 1 && p.e2 == 1)) && p.nH <= kMaxRing;
+}
 int sys_owned_cols(int p, int c) { return 64 * c - 2 * p; }
 bool sys_p_supported(int p)
 {
@@ -1151,7 +1407,14 @@ bool sys_p_supported(int p)
 	return p == 8; // the product build instantiates one block length (P = 4 and 16 measured slower)
 #endif
 }
-int64_t sys_box_ints(int p) { return (2 * p * (p + 8) + 2 * p + 31) / 32 * 32; } // (whatever the columns per lane: 2 (p/c) lanes x (p + 8) c ints)
+bool sys_c_supported(int c)
+{
+#ifdef MWF_SYS_C2
+	if (c == 2) return true; // (experiment: 128-column slots)
+#endif
+	return c == 1 || c == 4;
+}
+int64_t sys_box_ints(int p, bool seg) { return ((seg ? 4 : 2) * p * (p + 8) + 2 * p + 31) / 32 * 32; } // (whatever the columns per lane: 2 (p/c) lanes x (p + 8) c ints; twice that with provenance)
 
 int sys_max_grid()
 {
@@ -1168,6 +1431,12 @@ int launch_sys_pass(const BatchArgs &a, int grid, void *stream)
 	if (a.pen.e1 == 2 && a.pen.e2 == 2) return launch_pass_d<2, 2, true>(a, grid, (hipStream_t)stream);
 	if (a.pen.e1 == 1 && a.pen.e2 == 1) return launch_pass_d<1, 1, false>(a, grid, (hipStream_t)stream);
 	return -1;
+}
+
+int launch_sys_trace(const BatchArgs &a, void *stream)
+{
+	hipLaunchKernelGGL(sys_trace_kernel, dim3(a.coop_groups > 0 ? a.coop_groups : 1), dim3(64), 0, (hipStream_t)stream, a);
+	return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 int launch_sys_walk(const BatchArgs &a, void *stream)

@@ -8,7 +8,7 @@ NAME=$1; shift
 C=miniwfa_amd/csrc
 [ -f $C/build/mwf_engine.cpp.o ] || python miniwfa_amd/build.py > /dev/null
 mkdir -p /tmp/mwf_variant_$NAME
-KERNELS="mwf_band2.hip mwf_coop.hip mwf_sys.hip mwf_mid.hip mwf_lane.hip"
+KERNELS="mwf_band2.hip mwf_sys.hip mwf_mid.hip mwf_lane.hip"
 OBJS=""
 for f in $KERNELS; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-unused-value -I include -I $C "$@" -c $C/$f -o /tmp/mwf_variant_$NAME/$f.o &

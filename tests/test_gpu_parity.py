@@ -431,7 +431,7 @@ def test_band_kernel_stop_rules_and_shrink(oracle):
 
 
 def test_whole_device_kernel_against_oracle(oracle):
-    """mwf_coop.hip forced on (it is chosen automatically only for a few long pairs): score, CIGAR, low-memory mode
+    """The whole-device kernel (mwf_sys.hip) forced on (it is chosen automatically only for a few long pairs): score, CIGAR, low-memory mode
     (checkpoints read off the first pass's traceback matrix must give the reference's second-pass n_iter and CIGAR),
     stop rules, degenerate inputs.  Sizes reach several shrinks and tens of 256-column chunks."""
     eng = mw.Engine(0)
@@ -1501,5 +1501,27 @@ def test_whole_device_kernel_columns_per_lane(oracle, capfd):
     assert (int(s[0]), int(it[0])) == (es, eit)
     assert st.kernel_kind == 1 and st.n_retries == 1, (st.kernel_kind, st.n_retries)
     assert "re-running it on one workgroup" not in capfd.readouterr().err
+    b.free()
+    eng.close()
+
+
+def test_cached_plan_follows_every_tunable(oracle):
+    """mwf_gpu_batch_align caches the plan of an align (size classes, order, per-class maxima) per batch.  The cache key is a generation
+    count bumped by EVERY mwf_gpu_set(), not a hand-kept list of "the tunables that classify": flipping any tunable between two aligns
+    of one batch must give the results of a fresh plan — the oracle's."""
+    pairs = [synth_pair(97000 + i, (120, 300, 900, 2500, 6000)[i % 5], (0.03, 0.08)[i % 2]) for i in range(60)]
+    exp = [oracle.align(t, q, make_opt(flag=1)) for t, q in pairs]
+    eng = mw.Engine(0)
+    b = eng.upload(PackedBatch(pairs))
+    flips = [("lane_max_len", 0), ("lane_max_len", 400), ("mid_max_pairs", 0), ("mid_max_pairs", -1), ("seq2bit", 0), ("seq2bit", 1), ("band_pack", 0), ("band_pack", 1),
+             ("force_kind", 0), ("force_kind", -1), ("block", 256), ("block", 0), ("ring16", 0), ("ring16", 1), ("lane_chunks", 2), ("lane_chunks", 0),
+             ("mid_block", 512), ("mid_block", 0), ("band_span", 0), ("band_span", 1), ("wide_slots", 3), ("wide_slots", 0), ("slots_per_cu", 1), ("slots_per_cu", 0)]
+    for name, value in [(None, 0)] + flips:
+        if name:
+            eng.set(name, value)
+        b.align(mw.opt_init(flag=mw.MWF_F_CIGAR))
+        s, it, nc = b.results()
+        for i, (es, eit, ecig) in enumerate(exp):
+            assert (int(s[i]), int(it[i])) == (es, eit) and b.cigar(i, int(nc[i])).tolist() == ecig, (name, value, i)
     b.free()
     eng.close()
