@@ -26,6 +26,8 @@
 #include <numeric>
 #include <string>
 #include <chrono>
+#include <cmath>
+#include <functional>
 #include <thread>
 #include <vector>
 #include "miniwfa.h"
@@ -70,6 +72,7 @@ struct mwf_gpu_s {
 	std::string err;
 	// tunables
 	int block = 0;              // 0: choose from the batch
+	bool div_aware = true;      // weigh the size classes' length limits by the batch's estimated divergence (batches built from host memory)
 	int64_t tun_gen = 0;        // bumped by every successful mwf_gpu_set(): a cached plan of an align (PlanCache) is only replayed under the tunables it was made under
 	int slots_per_cu = 0;       // 0: occupancy of the kernel
 	int64_t coop_min_len = 0;
@@ -138,6 +141,7 @@ struct mwf_gpu_batch_s {
 	std::vector<int32_t> h_len_order; // pair ids, longest pair first (stable): what every grouping is dealt from
 	std::vector<int8_t> h_class;    // size class of every pair (0 generic, then band kernels: 1 wide, 2 small, 3 tiny, 4 micro; 5: the 1024-thread span geometry)
 	std::vector<int8_t> h_kind;     // kernel that ran the pair last (0 generic, 1 whole-device, 2 band)
+	float div_est = 0;              // divergence of the batch as a k-mer sketch of a few of its pairs saw it while the batch was built from host memory (0: unknown)
 	std::vector<int8_t> h_acgt;     // from the host's look at the bytes while a batch is built from host memory: 1 both sequences are plain
 	                                // A/C/G/T, 0 not (such a pair goes to the byte-wise sequence copy at once); empty: unknown (wrapped device
 	                                // buffers — the 2-bit copy finds out on the device and the pair comes back as ST_ALPHABET)
@@ -575,7 +579,10 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 			// overhead: 64 x 50 kb 88 ms against 73).  With the recurrence on the packed codes and 2-bit sequence copies the 16-bit kernel is
 			// the faster one at every batch size (profiles/ring16_small_batches.py: 8 pairs 63.8 against 67.4 ms, 64: 67.9 / 71.3, 200: 72.6 /
 			// 90.7; with traceback 67.6 / 77.8 ... 71.9 / 103.9): taken whenever the offsets fit.
-			ring16 = g->ring16 != 0 && !g->ring16_off_once && max_tl + max_len / 8 < 65500;
+			// (round 5: where the batch's divergence is known — estimate_divergence — the penalty is guessed from it, ~5.2 per diverged base
+			// with the default costs plus a third: 50 kb pairs at 5 % reach penalty 12 500 and never fitted, 64 of 64 were run twice)
+			const int64_t s_guess = b->div_est > 0 && g->div_aware ? (int64_t)(6.9 * b->div_est * (double)max_tl) + 256 : max_len / 8;
+			ring16 = g->ring16 != 0 && !g->ring16_off_once && max_tl + std::max<int64_t>(s_guess, max_len / 8) < 65500;
 			// 32-bit: one workgroup per CU either way (128 KB of LDS): twelve waves fit its 168-VGPR budget, 490 ms against 519 ms with eight
 			// 16-bit: 512 threads, two workgroups per CU (64 KB of LDS each, 128 VGPRs) — 354 ms on 1250 x 50 kb against 375 ms for
 			// 768 threads and one per CU (479 ms with 32-bit rows); with traceback the 512-thread copy spills too much: 768 (451 against 477 ms)
@@ -778,7 +785,8 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 	auto window_cap = [&](int c) -> int64_t { return (TC - 4) * (int64_t)sys_owned_cols(sysP, c) - 2 * (257 + sysP); };
 	bool wide_again = false;
 	for (int32_t pair : pairs) wide_again |= (b->h_flags[pair] & 16) != 0;
-	const int64_t est1 = std::min<int64_t>(len + 1, std::max<int64_t>(8192, len / 5));
+	// (first-pass window: a fifth of tl+ql — or, where the batch's divergence is known, 6.5 d (tl+ql): 50 kb pairs at 15 % outgrew the 64-column slots and ran twice)
+	const int64_t est1 = std::min<int64_t>(len + 1, std::max<int64_t>(8192, b->div_est > 0 && g->div_aware ? (int64_t)(6.5 * b->div_est * (double)len) : len / 5));
 	const int64_t est2 = std::min<int64_t>(len + 1, 2 * ((int64_t)opt.step + 2 * P.nH) + 8);
 	const int c_first = g->sys_c ? g->sys_c : (!wide_again && est1 <= window_cap(1)) ? 1 : 4;
 	const int c_second = g->sys_c ? g->sys_c : (!wide_again && est2 <= window_cap(1)) ? 1 : 4;
@@ -1093,6 +1101,45 @@ bool plain_acgt(const uint8_t *p, size_t n)
 	return bad == 0;
 }
 
+// How diverged are the pairs of a batch?  The size classes below are drawn from the pair LENGTHS for a prior of 5 % (window ~ 0.28 (tl+ql)); at 15 % and
+// 30 % every pair of a batch outgrew its class and was run twice (profiles/r04/chooser_regression.txt).  The reference has no classes to get wrong
+// (one loop serves any divergence, miniwfa.c:396-426); here a k-mer sketch of a few pairs says where the batch stands before anything is launched:
+// the share f of the query's 8-mers (prefix of up to 1500 bases) that occur in the target's prefix is about (1 - d)^8 plus chance hits.
+// A few microseconds per sampled pair, at most 16 pairs.
+float estimate_divergence(int32_t n, const int32_t *tl, const int32_t *ql, const std::function<const uint8_t*(int32_t, bool)> &seq)
+{
+	constexpr int K = 8;
+	constexpr uint32_t MASK = (1u << (2 * K)) - 1;
+	std::vector<uint64_t> bits((size_t)1 << (2 * K - 6));
+	double sum = 0;
+	int used = 0;
+	const int want = 16;
+	for (int k = 0; k < want && k < n; ++k) {
+		const int32_t i = (int32_t)((int64_t)k * n / std::min(want, n));
+		const int32_t lt = std::min(tl[i], 1500), lq = std::min(ql[i], 1500);
+		if (lt < 4 * K || lq < 4 * K) continue;
+		std::fill(bits.begin(), bits.end(), 0);
+		const uint8_t *t = seq(i, true), *q = seq(i, false);
+		uint32_t h = 0;
+		for (int32_t j = 0; j < lt; ++j) {
+			h = ((h << 2) | ((t[j] >> 1) & 3u)) & MASK;
+			if (j >= K - 1) bits[h >> 6] |= 1ull << (h & 63);
+		}
+		int32_t hit = 0, tot = 0;
+		h = 0;
+		for (int32_t j = 0; j < lq; ++j) {
+			h = ((h << 2) | ((q[j] >> 1) & 3u)) & MASK;
+			if (j >= K - 1) ++tot, hit += (int32_t)((bits[h >> 6] >> (h & 63)) & 1u);
+		}
+		const double fp = 1.0 - std::exp(-(double)(lt - K + 1) / (double)(MASK + 1)); // chance hits
+		double f = ((double)hit / tot - fp) / (1.0 - fp);
+		f = std::min(1.0, std::max(f, 1e-3));
+		sum += 1.0 - std::pow(f, 1.0 / K);
+		++used;
+	}
+	return used ? (float)(sum / used) : 0.f;
+}
+
 // A batch from host memory: pair i is (ts[i], tl[i]) / (qs[i], ql[i]) when `ts` is given, else it lies in `packed` at
 // t_off[i] / q_off[i].  Everything goes up in one stream of copies through the pinned buffer.
 mwf_gpu_batch_t *batch_from_host(mwf_gpu_t *g, int32_t n, const int32_t *tl, const char *const *ts, const int32_t *ql, const char *const *qs,
@@ -1130,6 +1177,9 @@ mwf_gpu_batch_t *batch_from_host(mwf_gpu_t *g, int32_t n, const int32_t *tl, con
 			b->h_acgt[i] = plain_acgt(pt, (size_t)tl[i]) && plain_acgt(pq, (size_t)ql[i]) ? 1 : 0;
 		}
 	};
+	b->div_est = estimate_divergence(n, tl, ql, [&](int32_t i, bool target) -> const uint8_t* {
+		return target ? (ts ? (const uint8_t*)ts[i] : (const uint8_t*)packed + p_t_off[i]) : (ts ? (const uint8_t*)qs[i] : (const uint8_t*)packed + p_q_off[i]);
+	});
 	std::vector<std::thread> th; // (joined behind the packing below: the classification is first needed by an align)
 	if (seq_bytes < ((int64_t)2 << 20) || n < 16) classify(0, n);
 	else { // megabytes of sequence: a few host threads, equal shares of the bytes (one thread does ~8 GB/s), WHILE this thread packs the batch into the pinned buffer
@@ -1283,6 +1333,7 @@ int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value)
 	else if (!strcmp(name, "coop_launch")) g->coop_launch = value != 0;
 	else if (!strcmp(name, "sys_p") && sys_p_supported((int)value)) g->sys_p = (int)value; // (8; 4 and 16 only in builds with -DMWF_SYS_ALL_P)
 	else if (!strcmp(name, "sys_c") && (value == 0 || sys_c_supported((int)value))) g->sys_c = (int)value; // (2: builds with -DMWF_SYS_C2 only — the host's box / traceback layout must be the launched kernel's)
+	else if (!strcmp(name, "div_aware")) g->div_aware = value != 0;
 	else if (!strcmp(name, "trim")) { (void)hipSetDevice(g->device); trim(g); }
 	else return -1;
 	++g->tun_gen; // (whatever the tunable: no hand-kept list of "the ones that classify" to forget an entry of)
@@ -1488,8 +1539,16 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		std::vector<int8_t> cls((size_t)b->n); // group of every pair
 		int32_t count[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 		const bool span_pen = pack_pen && g->band_span != 0 && g->seq2bit != 0;
+		// The classes' length limits stand for "the window stays inside the span at ~5 % divergence".  Where the batch's own divergence is known
+		// (estimate_divergence: batches built from host memory) the lengths are weighed by it: three times as diverged = as if three times as long.
+		// Only upwards of the prior, and a little downwards: a class too narrow costs a second run, one too wide a few per cent.
+		const double div_r = b->div_est > 0 && g->div_aware ? std::min(8.0, std::max(0.7, (double)b->div_est / 0.05)) : 1.0;
 		for (int32_t i = 0; i < b->n; ++i) {
 			const int64_t tl = b->h_tl[i], ql = b->h_ql[i], len = tl + ql;
+			const int64_t lenw = (int64_t)((double)len * div_r); // the pair's length as the classes' limits should see it
+			// the window the pair is expected to reach (0.27 (tl+ql) at 5 %), plus 15 %, where the divergence is known: the long classes' length limits
+			// were drawn for ~3 % (configs[4]) and sent 20 kb pairs at 15 % and 50 kb pairs at 5 % through the span geometry for nothing
+			const int64_t exp_win = b->div_est > 0 && g->div_aware ? std::min<int64_t>(len + 1, (int64_t)(6.2 * b->div_est * (double)len) + 64) : 0;
 			const int64_t bound1 = penalty_bound(*opt, tl, ql, false);
 			const int64_t bound = opt->max_s > 0 ? std::min<int64_t>(bound1, (int64_t)opt->max_s + 1) : bound1; // (= penalty_bound(..., true))
 			const bool step0 = low_mem && bound1 < opt->step;
@@ -1506,28 +1565,30 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 				// where the pairs whose windows will mostly fit are drawn: tl + ql below seven spans; bench.py long_batches)
 				const bool span_ok = span_pen && tl <= kBandSpanMaxSeq && ql <= kBandSpanMaxSeq && !(know_acgt && !b->h_acgt[i]);
 				if (span_ok && g->band_span == 2) c = 13;
-				else if (packable && (window <= kBandMicroWindow || len + 1 <= 2 * (int64_t)(1 * 3 * 256))) c = 4;
-				else if (packable && (window <= kBandTinyWindow || len + 1 <= 3 * (int64_t)(2 * 3 * 256))) c = 3;
-				else if (packable && (window <= kBandSmallWindow || len + 1 <= 3 * (int64_t)(4 * 3 * 256))) c = 2;
-				else if (packable && len + 1 <= 4 * (int64_t)(8 * 3 * 256)) c = 1;
+				// (round 5: the limits leave the mean window at 5 % — 0.27 (tl+ql) — a quarter of margin below each class's widest window; round 4's left 4-18 %,
+				// and 2 kb pairs, just inside the 128-thread class, were re-run at 7.8 %: profiles/r04/chooser_regression.txt)
+				else if (packable && (window <= kBandMicroWindow || lenw + 1 <= 1400)) c = 4;
+				else if (packable && (window <= kBandTinyWindow || lenw + 1 <= 3600)) c = 3;
+				else if (packable && (window <= kBandSmallWindow || lenw + 1 <= 8200)) c = 2;
+				else if (packable && (lenw + 1 <= 4 * (int64_t)(8 * 3 * 256) || window <= kBandWideWindow)) c = 1;
 				// (tl + ql up to 3.5 of its spans: a 12 kb pair at 5 % needs ~6000 of the 7872 columns; 512 x 15 kb @ 5 % — windows of ~7500 — lost 44 pairs to late
 				// overflows, 30.7 against 24.9 ms on the span geometry from the start)
-				else if (span_ok && g->wide_slots != 3 && len + 1 <= 7 * (int64_t)((band2_biased512_chunks() + 8) * 256) / 2) c = 14;
-				else if (span_ok && len + 1 <= 7 * band2_span_chunks() * 256) c = 13;
+				else if (span_ok && g->wide_slots != 3 && (exp_win ? exp_win + 768 <= ((int64_t)band2_biased512_chunks() + 8 - 1) * 256 - 64 : len + 1 <= 7 * (int64_t)((band2_biased512_chunks() + 8) * 256) / 2)) c = 14;
+				else if (span_ok && ((exp_win ? exp_win + 768 <= band_span_window() : len + 1 <= 7 * band2_span_chunks() * 256) || window <= band_span_window())) c = 13;
 			}
 			b->h_class[i] = (int8_t)(c == 5 ? 0 : c == 13 ? 5 : c == 14 ? 1 : c);
 			b->h_flags[i] = (int8_t)(step0 ? 1 : 0);
 			// short pairs: a window of 64 diagonals holds them while the penalty stays below ~45 (a 200 bp pair at 5 %)
 			// (in a batch small enough for the mid kernel the lane kernel keeps the pairs of up to 320 bases: 16 x 400 bp 0.31 ms on the lane
 			// kernel — pairs that outgrow its chunks are re-run — against 0.13 on the mid kernel, 1 x 300 bp 56 against 68 us; profiles/r04/lane_vs_mid.txt)
-			const bool to_lane = classes && lane_ok && c >= 1 && c <= 4 && std::max(tl, ql) <= (mid_ok ? std::min(g->lane_max_len, 320) : g->lane_max_len) && std::abs(tl - ql) <= 24;
+			const bool to_lane = classes && lane_ok && c >= 1 && c <= 4 && (int64_t)((double)std::max(tl, ql) * div_r) <= (mid_ok ? std::min(g->lane_max_len, 320) : g->lane_max_len) && std::abs(tl - ql) <= 24;
 			if (to_lane) c = (know_acgt && !b->h_acgt[i]) ? 12 : 10, b->h_class[i] = 4;
 			// a few mid-size pairs: a workgroup each, rings in LDS (a penalty then costs a fraction of what it costs the band kernels).  Admitted
 			// when the span the LDS can hold beside the sequences covers the window of a pair at ~6 % divergence (about 0.3 (tl+ql)); 16-bit offsets.
 			if (mid_ok && !to_lane && c <= 4 && (!low_mem || step0) && tl + bound < 32760) {
 				const int64_t seq_lds = ((tl + 7) & ~7LL) + 16 + ((ql + 7) & ~7LL) + 32;
 				const int64_t window = std::min<int64_t>(len + 1, 2 * bound + 3);
-				const int64_t want = std::min<int64_t>(window, len * 3 / 10 + 128) + 2 * P0.nH;
+				const int64_t want = std::min<int64_t>(window, lenw * 34 / 100 + 128) + 2 * P0.nH;
 				int groups = (int)std::min<int64_t>((window + 2 * P0.nH + 63) / 64, 128);
 				while (groups > 1 && mid_lds_bytes(P0, groups, seq_lds) > 158 * 1024) --groups;
 				if (mid_lds_bytes(P0, groups, seq_lds) <= 158 * 1024 && (int64_t)groups * 64 >= want && std::abs(tl - ql) < groups * 32) {
@@ -1679,6 +1740,8 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 			const int32_t st = b->h_status[i];
 			if (st == ST_OK || st == ST_STOPPED) continue;
 			const int kind = b->h_kind[i], step0 = b->h_flags[i] & 1;
+			static const bool dbg_route = getenv("MWF_DEBUG_REROUTE") != nullptr; // (diagnostics: why a pair is run again)
+			if (dbg_route) fprintf(stderr, "[libmwf_hip] re-route: pair %zu (tl %d ql %d) status %d kind %d class %d flags %d n_iter word %lld round %d\n", i, b->h_tl[i], b->h_ql[i], st, kind, (int)b->h_class[i], (int)b->h_flags[i], (long long)b->h_iter[i], round);
 			if (st == ST_BAND_OVERFLOW && kind == 0) {
 				to_generic32[step0].push_back((int32_t)i); // an offset outgrew the generic kernel's 16-bit ring rows: 32-bit rows
 			} else if (st == ST_ALPHABET && kind == 2 && b->h_class[i] == 5) {

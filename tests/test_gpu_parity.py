@@ -201,17 +201,18 @@ def test_generic_kernel_16_bit_ring_rows(oracle):
         assert (int(out[(2, 1)][0][i]), int(out[(2, 1)][1][i])) == (es, eit) and out[(2, 1)][2][i] == ecig, i
     big = [synth_pair(7200, 52000, 0.10)]
     res = []
-    for r16 in (0, 2):
+    for r16, aware in ((0, 0), (2, 0), (2, 1)):
         eng = mw.Engine(0)
         eng.set("ring16", r16)
         eng.set("force_kind", 0)
+        eng.set("div_aware", aware)   # (0: the round-4 behaviour — the 16-bit rows are tried and outgrown; 1: the batch's k-mer sketch says 10 %, the 32-bit rows are taken at once)
         b = eng.upload(PackedBatch(big))
         b.align(mw.opt_init())
         s, it, nc = b.results()
         res.append((int(s[0]), int(it[0]), eng.stats().n_retries))
         b.free()
         eng.close()
-    assert res[0][:2] == res[1][:2] and res[0][2] == 0 and res[1][2] == 1 and res[0][0] + 52000 > 65532, res
+    assert res[0][:2] == res[1][:2] == res[2][:2] and res[0][2] == 0 and res[1][2] == 1 and res[2][2] == 0 and res[0][0] + 52000 > 65532, res
 
 
 def test_generic_kernel_16_bit_ring_rows_fuzz(oracle):
@@ -1288,6 +1289,7 @@ def test_span_geometry_hands_back_what_it_cannot_hold(oracle):
     pairs = [synth_pair(7301, 40000, 0.11), synth_pair(7302, 60000, 0.025), synth_pair(7303, 62000, 0.022), (t[:20000] + b"N" + t[20001:], q), synth_pair(7304, 30000, 0.03)]
     eng = mw.Engine(0)
     eng.set("coop_min_len", 1 << 40)
+    eng.set("div_aware", 0)   # (the classes by length alone, as for device-resident batches: this test is about what the span geometry hands back)
     b = eng.upload(PackedBatch(pairs))
     for kw in (dict(), dict(flag=1)):
         b.align(mw.opt_init(**kw))
@@ -1491,18 +1493,20 @@ def test_whole_device_kernel_columns_per_lane(oracle, capfd):
     es, eit = len(bands), sum(h - l + 1 for l, h in bands)
     widest = max(h - l + 1 for l, h in bands)
     assert 11600 < widest < 59000, widest
-    eng = mw.Engine(0)
-    eng.set("force_kind", 1)
-    eng.set("coop_grid", 16)
-    b = eng.upload(PackedBatch([(t, q)]))
-    b.align(mw.opt_init())
-    s, it, _ = b.results()
-    st = eng.stats()
-    assert (int(s[0]), int(it[0])) == (es, eit)
-    assert st.kernel_kind == 1 and st.n_retries == 1, (st.kernel_kind, st.n_retries)
-    assert "re-running it on one workgroup" not in capfd.readouterr().err
-    b.free()
-    eng.close()
+    for aware in (0, 1):   # (1, the default: the batch's k-mer sketch sees the 25 % and the first pass takes the 256-column slots at once)
+        eng = mw.Engine(0)
+        eng.set("force_kind", 1)
+        eng.set("coop_grid", 16)
+        eng.set("div_aware", aware)
+        b = eng.upload(PackedBatch([(t, q)]))
+        b.align(mw.opt_init())
+        s, it, _ = b.results()
+        st = eng.stats()
+        assert (int(s[0]), int(it[0])) == (es, eit)
+        assert st.kernel_kind == 1 and st.n_retries == 1 - aware, (aware, st.kernel_kind, st.n_retries)
+        assert "re-running it on one workgroup" not in capfd.readouterr().err
+        b.free()
+        eng.close()
 
 
 def test_cached_plan_follows_every_tunable(oracle):
