@@ -436,6 +436,15 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 				const int32_t cb = g * OW - P;
 				for (int32_t j = lane; j < nH; j += 64) L.hist[sl][j] = make_int2(cb + kW, cb - 1);
 				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+				// Every row of the slot's ring starts DEAD: a row is only ever written dead outside the window it was computed for (`act` below,
+				// the reference's pads, miniwfa.c:96-99), so a read needs no window test — round 5: the three window-history reads and the masks
+				// they fed made a penalty of a slot at the window's edge 2.6 x as long as one inside it, and the edge slots set every epoch's pace.
+				{
+					int32_t dead[C];
+#pragma unroll
+					for (int i = 0; i < C; ++i) dead[i] = kNegInf;
+					for (int32_t j = 0; j < nH; ++j) st_cols<C>(row_ptr(r, j), dead);
+				}
 				if (s == 0) { // the origin (reference wf_stripe_init, miniwfa.c:103-121)
 					const int32_t c0 = tl + 1;
 					if (lane == 0) L.hist[sl][0] = make_int2(min(max(c0, cb), cb + kW), max(min(c0, cb + kW - 1), cb - 1));
@@ -626,6 +635,8 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 				for (int i = 0; i < C; ++i) rj[i] = max(min(tl, ql - (c0 + i - 1 - tl)), 0);
 				// what stage 2 needs of a penalty
 				int32_t x_hv[C] = {}, x_shv[C] = {}, x_snew = 0, x_newH = 0, x_t = 0;
+				int32_t rec_wl = 0, rec_wh = 0;
+				uint32_t rec_own = 0;
 				uint64_t x_t8[C] = {}, x_q8[C] = {};
 				uint32_t x_tbw = 0;
 #pragma unroll 1
@@ -732,19 +743,13 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 					const bool track_good = !deep_blk && (((256 - (s_new & 255)) & 255) < nH);
 					const int32_t lo = wl > 1 ? wl - 1 : 1;       // miniwfa.c:417-418, on this slot's view
 					const int32_t hi = wh < cmax ? wh + 1 : cmax;
-					int32_t xlo = 0, xhi = 0, alo = 0, ahi = 0, blo = 0, bhi = 0;
 					bool inner = true;
 					if (!deep_blk) {
-						int32_t jx = newH - lagx; if (jx < 0) jx += nH;
-						int32_t j1 = newH - lag1; if (j1 < 0) j1 += nH;
-						int32_t j2 = newH - lag2; if (j2 < 0) j2 += nH;
 						if (lag_one) prefetch(r, newH);
-						const int2 wx = L.hist[sl][jx], w1 = L.hist[sl][j1], w2 = L.hist[sl][j2];
-						if (lane == 0) L.hist[sl][newH] = make_int2(min(max(lo, cb), cb + kW), max(min(hi, cb + kW - 1), cb - 1));
+						if (lane == 0) L.hist[sl][newH] = make_int2(min(max(lo, cb), cb + kW), max(min(hi, cb + kW - 1), cb - 1)); // (read back at the hand-off: the chain of the block's exact windows starts from it)
 						if (lo > cb || hi < cb + kW - 1) cover_bad = s_new;
-						xlo = uni(wx.x), xhi = uni(wx.y), alo = uni(w1.x), ahi = uni(w1.y), blo = uni(w2.x), bhi = uni(w2.y);
-						// every column of the slot inside the window and inside every source window: no masks
-						inner = max(max(lo, xlo), max(alo, blo)) <= cb && min(min(hi, xhi), min(ahi, bhi)) >= cb + kW - 1;
+						// every column of the slot inside the window: nothing to mask (sources need no masks at all: rows are dead outside their windows)
+						inner = lo <= cb && hi >= cb + kW - 1;
 					}
 					int32_t hx[C], o1[C + 2], o2[C + 2];
 					int32_t shx[C], so1[C + 2], so2[C + 2]; // SEG: provenance of the same sources
@@ -757,15 +762,6 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 					// the next penalty's rows: requested at once — they are at least two penalties old (every lag >= 2 here), and a whole
 					// penalty's work lies between this request and their use
 					if (!lag_one && t + 1 < P) prefetch(r, nextH);
-					if (!inner) { // reads outside a source window yield "dead" (what the reference's pads supply, miniwfa.c:96-99)
-#pragma unroll
-						for (int i = 0; i < C; ++i) {
-							const int32_t c = c0 + i;
-							hx[i] = ((c >= xlo) & (c <= xhi)) ? hx[i] : kNegInf;
-							o1[i + 1] = ((c >= alo) & (c <= ahi)) ? o1[i + 1] : kNegInf;
-							o2[i + 1] = ((c >= blo) & (c <= bhi)) ? o2[i + 1] : kNegInf;
-						}
-					}
 					// the columns next to the slot's 256 are nobody's business: its outermost columns are never exact anyway
 					o1[0] = from_left(o1[C], kNegInf), o1[C + 1] = from_right(o1[1], kNegInf);
 					o2[0] = from_left(o2[C], kNegInf), o2[C + 1] = from_right(o2[1], kNegInf);
@@ -865,11 +861,10 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 						const int32_t vl = cb + 1 + t, vr = cb + kW - 2 - t;
 						if (lo >= vl && lo <= vr && __ballot(live & 1u)) wl = lo;
 						if (hi >= vl && hi <= vr && __ballot(live & 2u)) wh = hi;
-						if (lane == 0) {
-							L.mywl[sl][t] = wl, L.mywh[sl][t] = wh;
-							if ((uint32_t)(lo - (cb + P)) < (uint32_t)OW) st_ag(&logL[s_new], wl);   // the owner of the edge column keeps the log
-							if ((uint32_t)(hi - (cb + P)) < (uint32_t)OW) st_ag(&logH[s_new], wh);
-						}
+						// lane t keeps the view after penalty t (and whether this slot owns the edge columns, i.e. keeps the log): written behind the block
+						const bool mine = lane == t;
+						rec_wl = mine ? wl : rec_wl, rec_wh = mine ? wh : rec_wh;
+						rec_own = mine ? ((uint32_t)((uint32_t)(lo - (cb + P)) < (uint32_t)OW) | (uint32_t)((uint32_t)(hi - (cb + P)) < (uint32_t)OW) << 1) : rec_own;
 					}
 #pragma unroll
 					for (int i = 0; i < C; ++i) {
@@ -987,6 +982,11 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 					if (j >= nH) j %= nH;
 					L.hist[sl][j] = make_int2(cb, cb + kW - 1);
 					L.mywl[sl][lane] = wl, L.mywh[sl][lane] = wh;
+				}
+				if (!deep_blk && lane < P) { // the views of the block's penalties, and the edge log where this slot owned the edge column
+					L.mywl[sl][lane] = rec_wl, L.mywh[sl][lane] = rec_wh;
+					if (rec_own & 1u) st_ag(&logL[s0 + 1 + lane], rec_wl);
+					if (rec_own & 2u) st_ag(&logH[s0 + 1 + lane], rec_wh);
 				}
 				if (lane == 0) L.sv[sl].cover_bad = cover_bad;
 				MWF_T(tt_c);
