@@ -1,19 +1,20 @@
 #!/usr/bin/env python3
-"""profiles/traffic.json (what bench.py's `roofline.traffic` / candidates quote) from the rocprofv3 summaries under profiles/r04/:
+"""profiles/traffic.json (what bench.py's `roofline.traffic` / candidates quote) from the rocprofv3 summaries under profiles/r05/:
 per-launch means of FETCH_SIZE / WRITE_SIZE (KiB) and of the instruction counters, per kernel and workload."""
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # key in traffic.json -> (summary file, kernel name prefix(es) the numbers are taken from, read width in bytes per lane)
 SRC = {
-    "1024x10000@0.05s": ("profiles/r04/rocprof_band2_kernel_1024x10kb_score.txt", ["wfa_band2_kernel<512, 3, 2, 1, false, true>"], 8),
-    "1024x10000@0.05c": ("profiles/r04/rocprof_band2_kernel_1024x10kb_cigar.txt", ["wfa_band2_kernel<512, 3, 2, 1, true, true>"], 8),
-    "1250x50000@0.03s": ("profiles/r04/rocprof_band2_span_kernel_1250x50kb.txt", ["wfa_band2_kernel<1024, 5, 2, 1, false, true>"], 8),
-    "1250x50000@0.03s:generic16": ("profiles/r04/rocprof_generic_stream16_kernel_1250x50kb.txt", ["wfa_batch_kernel<512, true, true, true, 0>"], 8),
-    "c4_like_150kb:score": ("profiles/r04/rocprof_sys_kernel_c4_score.txt", ["wfa_sys_kernel"], 4),
-    "c4_like_150kb:cigar_highmem": ("profiles/r04/rocprof_sys_kernel_c4_cigar.txt", ["wfa_sys_kernel"], 4),
-    "c4_like_150kb:cigar_lowmem_p5000": ("profiles/r04/rocprof_sys_kernel_c4_lowmem.txt", ["wfa_sys_kernel"], 4),
-    "mhc_like_5Mb:score": ("profiles/r04/rocprof_sys_kernel_mhc_score.txt", ["wfa_sys_kernel"], 16),
-    "mhc_like_5Mb:cigar_lowmem_p5000": ("profiles/r04/rocprof_sys_kernel_mhc_lowmem.txt", ["wfa_sys_kernel"], 16),
+    # (round 5: the bench rotates four seeds through its steps — one runs on three chunk slots per wave, three on four: the launch-weighted mean of the two forms)
+    "1024x10000@0.05s": ("profiles/r05/rocprof_band2_kernel_1024x10kb_score.txt", ["wfa_band2_kernel<512, 3, 2, 1, false, true>", "wfa_band2_kernel<512, 4, 2, 1, false, true>"], 8),
+    "1024x10000@0.05c": ("profiles/r05/rocprof_band2_kernel_1024x10kb_cigar.txt", ["wfa_band2_kernel<512, 3, 2, 1, true, true>", "wfa_band2_kernel<512, 4, 2, 1, true, true>"], 8),
+    "1250x50000@0.03s": ("profiles/r05/rocprof_band2_span_kernel_1250x50kb.txt", ["wfa_band2_kernel<1024, 5, 2, 1, false, true>"], 8),
+    "1250x50000@0.03s:generic16": ("profiles/r05/rocprof_generic_stream16_kernel_1250x50kb.txt", ["wfa_batch_kernel<512, true, true, true, 0>"], 8),
+    "c4_like_150kb:score": ("profiles/r05/rocprof_sys_kernel_c4_score.txt", ["wfa_sys_kernel"], 4),
+    "c4_like_150kb:cigar_highmem": ("profiles/r05/rocprof_sys_kernel_c4_cigar.txt", ["wfa_sys_kernel"], 4),
+    "c4_like_150kb:cigar_lowmem_p5000": ("profiles/r05/rocprof_sys_kernel_c4_lowmem.txt", ["wfa_sys_kernel", "wfa_sys_seg_kernel"], 4),
+    "mhc_like_5Mb:score": ("profiles/r05/rocprof_sys_kernel_mhc_score.txt", ["wfa_sys_kernel"], 16),
+    "mhc_like_5Mb:cigar_lowmem_p5000": ("profiles/r05/rocprof_sys_kernel_mhc_lowmem.txt", ["wfa_sys_kernel", "wfa_sys_seg_kernel"], 16),
 }
 out = {}
 for key, (path, kerns, width) in SRC.items():
@@ -26,10 +27,13 @@ for key, (path, kerns, width) in SRC.items():
         name, val, n, kern = m.group(1), float(m.group(2)), int(m.group(3)), m.group(4)
         if any(k.split("<")[0] in kern and (("<" not in k) or k[:40] in kern or k.replace(", ", ",")[:30] in kern.replace(", ", ",")) for k in kerns):
             tot, cnt = pmc.get(name, (0.0, 0))
-            pmc[name] = (tot + val, max(cnt, n))     # a mode that launches the kernel in two forms (low-memory passes): their sum per call
+            if "wfa_band2_kernel" in kern and len(kerns) > 1:   # geometries of ONE class over the bench's rotation of seeds: launch-weighted mean
+                pmc[name] = ((tot * cnt + val * n) / (cnt + n), cnt + n)
+            else:
+                pmc[name] = (tot + val, max(cnt, n))     # a mode that launches the kernel in two forms (low-memory passes): their sum per call
     if "FETCH_SIZE" not in pmc:
         continue
-    forms = {m.group(4) for m in re.finditer(r"== pmc (FETCH_SIZE) = ([0-9.e+]+) per launch \((\d+) launches\) \[([^\]]*)", txt) if "wfa_sys_kernel" in m.group(4)}
+    forms = {m.group(4) for m in re.finditer(r"== pmc (FETCH_SIZE) = ([0-9.e+]+) per launch \((\d+) launches\) \[([^\]]*)", txt) if "wfa_sys_kernel" in m.group(4) or "wfa_sys_seg_kernel" in m.group(4)}
     if "lowmem" in key and len(forms) == 1:   # both passes of the low-memory mode ran the same kernel form: two launches per call
         pmc = {k: (v[0] * 2, v[1]) for k, v in pmc.items()}
     m = re.search(r"cells/launch (\d+)", txt)
