@@ -102,6 +102,7 @@ struct mwf_gpu_s {
 	int sys_c = 0;             // its columns per lane: 0 automatic (1 while the window is expected to fit the slots that way, else 4), 1, 4
 	// workspace (per-stream pool)
 	DevBuf ring, sring, good, tb, row_off, row_lo, cig_scratch, snap, snap_meta, seg, queue, dbg, coop_edge, coop_misc;
+	DevBuf retry_ids;          // pair ids of a re-run (finalize): kept by the engine — round 4 allocated and freed one per re-run, a hipMalloc + hipFree of ~0.15 ms behind a 0.5 ms launch
 	DevBuf sys_box, sys_prog, sys_log, sys_ep, sys_park, sys_ring, sys_sring, sys_good;
 	DevBuf spare_block, spare_cig; // allocations of freed batches, waiting for the next batch
 	int queue_next = 0;            // next unused work counter of the current align call
@@ -1281,7 +1282,7 @@ static void trim(mwf_gpu_t *g)
 {
 	(void)hipStreamSynchronize(g->stream);
 	for (DevBuf *b : {&g->ring, &g->sring, &g->good, &g->tb, &g->row_off, &g->row_lo, &g->cig_scratch, &g->snap, &g->snap_meta, &g->seg, &g->dbg,
-	                  &g->coop_edge, &g->coop_misc, &g->sys_box, &g->sys_prog, &g->sys_log, &g->sys_ep, &g->sys_park, &g->sys_ring, &g->sys_sring, &g->sys_good,
+	                  &g->coop_edge, &g->coop_misc, &g->sys_box, &g->sys_prog, &g->sys_log, &g->sys_ep, &g->sys_park, &g->sys_ring, &g->sys_sring, &g->sys_good, &g->retry_ids,
 	                  &g->spare_block, &g->spare_cig})
 		release(g, *b);
 	g->dev_bytes_peak = g->dev_bytes;
@@ -1831,8 +1832,8 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 				max_tl = std::max<int64_t>(max_tl, b->h_tl[i]);
 				max_seq_lds = std::max<int64_t>(max_seq_lds, (((int64_t)b->h_tl[i] + 3) & ~3LL) + 8 + (((int64_t)b->h_ql[i] + 3) & ~3LL) + 16);
 			}
-			DevBuf tmp; // the ids of this re-run (retries are rare: a scratch allocation of their own)
-			if (ensure(g, tmp, ids.size() * 4)) return -1;
+			DevBuf &tmp = g->retry_ids; // the ids of this re-run (the previous re-run's kernels are through: every rerun() ends with a stream synchronisation)
+			if (ensure(g, tmp, std::max<size_t>(ids.size() * 4, 4096))) return -1;
 			int rc = upload_segments(g, (char*)tmp.p, std::vector<Seg>{Seg{ids.data(), ids.size() * 4}});
 			int ran = 0;
 			// a handful of short pairs that outgrew the lane kernel (one read in tens of thousands): the mid kernel, whose span holds the widest
@@ -1845,7 +1846,6 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 			if (rc == 0) rc = run_batch_kernel(g, b, o, (const int32_t*)tmp.p, (int32_t)ids.size(), slots, max_len, max_bound, max_bound1, false,
 			                                   want_kind, max_tl, max_seq_lds, 0, to_mid ? 33 : geom, &ran, hint);
 			if (rc == 0) rc = hipStreamSynchronize(g->stream) == hipSuccess ? 0 : -1;
-			release(g, tmp);
 			if (rc) return -1;
 			for (int32_t i : ids) b->h_kind[i] = (int8_t)ran;
 			return 0;

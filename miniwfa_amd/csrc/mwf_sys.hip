@@ -1323,43 +1323,39 @@ __global__ __launch_bounds__(64) void sys_finish_kernel(const BatchArgs A)
 	finish_pair(A, M, grp, pair, R, status, cells1);
 }
 
+// One pass with P penalties per hand-off block: the provenance pass of the true low-memory mode (coop_pass == 3: never with traceback) or the plain / second pass.
+// The waits between workgroups rely on every workgroup being resident.  The grid is sized for that (one per CU, sys_max_grid) and the engine keeps this
+// library's other kernels off the device meanwhile; a cooperative launch makes the runtime refuse a grid that could not be resident whatever else the
+// process runs.  (A plain launch if the runtime refuses: the waits are bounded.)
+template <int E1, int E2, int P, bool DEFER, bool TB, int C>
+int launch_pass_pc(const BatchArgs &a, int grid, hipStream_t st)
+{
+	const void *fn;
+	if (a.coop_pass == 3) {
+		if constexpr (TB) return -1;
+		else fn = reinterpret_cast<const void*>(&wfa_sys_seg_kernel<E1, E2, P, DEFER, C>);
+	} else fn = reinterpret_cast<const void*>(&wfa_sys_kernel<E1, E2, P, DEFER, TB, C>);
+	BatchArgs arg = a;
+	void *args[] = {(void*)&arg};
+	if (a.sys_coop_launch) {
+		if (hipLaunchCooperativeKernel(fn, dim3(grid), dim3(kT), args, 0, st) == hipSuccess) return 0;
+		(void)hipGetLastError();
+	}
+	if (hipLaunchKernel(fn, dim3(grid), dim3(kT), args, 0, st) != hipSuccess) { (void)hipGetLastError(); return -2; }
+	return 0;
+}
+
 template <int E1, int E2, bool DEFER, bool TB, int C>
 int launch_pass_c(const BatchArgs &a, int grid, hipStream_t st)
 {
 	switch (a.sys_p) {
-#ifdef MWF_SYS_ALL_P // (experiments: profiles/coop_quick.py with MWF_SYS_P)
-	case 4:  hipLaunchKernelGGL((wfa_sys_kernel<E1, E2, 4, DEFER, TB, C>), dim3(grid), dim3(kT), 0, st, a); break;
-	case 16: hipLaunchKernelGGL((wfa_sys_kernel<E1, E2, 16, DEFER, TB, C>), dim3(grid), dim3(kT), 0, st, a); break;
+#ifdef MWF_SYS_ALL_P // (experiments: profiles/coop_quick.py with MWF_SYS_P, profiles/mhc_lowmem_p.py)
+	case 4:  return launch_pass_pc<E1, E2, 4, DEFER, TB, C>(a, grid, st);
+	case 16: return launch_pass_pc<E1, E2, 16, DEFER, TB, C>(a, grid, st);
 #endif
-	case 8: {
-		if (a.coop_pass == 3) { // the provenance pass of the true low-memory mode (never with traceback)
-			if constexpr (TB) return -1;
-			else {
-				if (a.sys_coop_launch) {
-					BatchArgs arg = a;
-					void *args[] = {(void*)&arg};
-					if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&wfa_sys_seg_kernel<E1, E2, 8, DEFER, C>), dim3(grid), dim3(kT), args, 0, st) == hipSuccess) return 0;
-					(void)hipGetLastError();
-				}
-				hipLaunchKernelGGL((wfa_sys_seg_kernel<E1, E2, 8, DEFER, C>), dim3(grid), dim3(kT), 0, st, a);
-				break;
-			}
-		}
-		// The waits between workgroups rely on every workgroup being resident.  The grid is sized for that (one per CU, sys_max_grid) and
-		// the engine keeps this library's other kernels off the device meanwhile; a cooperative launch makes the runtime refuse a grid
-		// that could not be resident whatever else the process runs.  (A plain launch if the runtime refuses: the waits are bounded.)
-		if (a.sys_coop_launch) {
-			BatchArgs arg = a;
-			void *args[] = {(void*)&arg};
-			if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&wfa_sys_kernel<E1, E2, 8, DEFER, TB, C>), dim3(grid), dim3(kT), args, 0, st) == hipSuccess) return 0;
-			(void)hipGetLastError();
-		}
-		hipLaunchKernelGGL((wfa_sys_kernel<E1, E2, 8, DEFER, TB, C>), dim3(grid), dim3(kT), 0, st, a);
-		break;
-	}
+	case 8:  return launch_pass_pc<E1, E2, 8, DEFER, TB, C>(a, grid, st);
 	default: return -1; // no kernel for this block length: the host's layout (boxes, traceback rows) would not be the kernel's
 	}
-	return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 template <int E1, int E2, bool DEFER, bool TB>
