@@ -634,14 +634,14 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 #pragma unroll
 				for (int i = 0; i < C; ++i) rj[i] = max(min(tl, ql - (c0 + i - 1 - tl)), 0);
 				// what stage 2 needs of a penalty
-				int32_t x_hv[C] = {}, x_shv[C] = {}, x_snew = 0, x_newH = 0, x_t = 0;
+				int32_t x_hv[C] = {}, x_fshv = -1, x_snew = 0, x_newH = 0, x_t = 0; // (x_fshv — SEG: the provenance of the end cell's column at that penalty, one scalar)
 				int32_t rec_wl = 0, rec_wh = 0;
 				uint32_t rec_own = 0;
 				uint64_t x_t8[C] = {}, x_q8[C] = {};
 				uint32_t x_tbw = 0;
 #pragma unroll 1
 				for (int t = 0; t < P + (DEFER ? 1 : 0); ++t) {
-					int32_t c_hv[C], c_shv[C] = {}, c_snew = 0, c_newH = 0;
+					int32_t c_hv[C], c_fshv = -1, c_snew = 0, c_newH = 0;
 					uint64_t c_t8[C], c_q8[C];
 					uint32_t c_tbw = 0;
 					// what stage 2a leaves for stage 2b
@@ -837,7 +837,8 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 					c_tbw = tbw, c_snew = s_new, c_newH = newH;
 					if (SEG) { // the provenance of the new H row is final here (the match extension moves offsets, not predecessors)
 #pragma unroll
-						for (int i = 0; i < C; ++i) c_shv[i] = shv[i];
+						for (int i = 0; i < C; ++i) (void)shv[i];
+						if (own_fin) c_fshv = __builtin_amdgcn_readlane(pickc<C>((cfin - cb) % C, shv), (cfin - cb) / C); // uniform: only the slot that owns the end cell's column keeps it
 						st_cols<C>(srow_ptr(r, newH), shv);
 						const bool ol = lane >= PL && lane < 2 * PL, orr = lane >= 64 - 2 * PL && lane < 64 - PL;
 						if (ol || orr) st_box<C>(box + ((int64_t)r * 2 + par) * BOX_INTS + ((orr ? PL : 0) + (ol ? lane - PL : lane - (64 - 2 * PL))) * LANE_INTS + SH_OFF + C * t, shv);
@@ -886,7 +887,8 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 					MWF_T(ts_2);
 					if (!DEFER) {
 #pragma unroll
-						for (int i = 0; i < C; ++i) x_hv[i] = c_hv[i], x_shv[i] = c_shv[i], x_t8[i] = c_t8[i], x_q8[i] = c_q8[i];
+						for (int i = 0; i < C; ++i) x_hv[i] = c_hv[i], x_t8[i] = c_t8[i], x_q8[i] = c_q8[i];
+						x_fshv = c_fshv;
 						x_tbw = c_tbw, x_snew = c_snew, x_newH = c_newH, x_t = t;
 						stage2a();
 					}
@@ -941,7 +943,7 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 							if (own_fin) {
 								const uint32_t f = in & (uint32_t)(c0 + i == cfin) & (uint32_t)(kk2 == tl - 1) & (uint32_t)(d + kk2 == ql - 1);
 								fin |= f;
-								done_info = f ? (SEG ? x_shv[i] : (nmat[i] == 0 ? (int32_t)((x_tbw >> (8 * i)) & 7u) : 0)) : done_info; // (SEG: where the chain through the snapshots starts, miniwfa.c:577)
+								done_info = f ? (SEG ? x_fshv : (nmat[i] == 0 ? (int32_t)((x_tbw >> (8 * i)) & 7u) : 0)) : done_info; // (SEG: where the chain through the snapshots starts, miniwfa.c:577)
 							}
 							hv[i] = kk2;
 						}
@@ -965,7 +967,8 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 					}
 					if (DEFER) {
 #pragma unroll
-						for (int i = 0; i < C; ++i) x_hv[i] = c_hv[i], x_shv[i] = c_shv[i], x_t8[i] = c_t8[i], x_q8[i] = c_q8[i];
+						for (int i = 0; i < C; ++i) x_hv[i] = c_hv[i], x_t8[i] = c_t8[i], x_q8[i] = c_q8[i];
+						x_fshv = c_fshv;
 						x_tbw = c_tbw, x_snew = c_snew, x_newH = c_newH, x_t = t;
 					}
 #ifdef MWF_SYS_TIMING
