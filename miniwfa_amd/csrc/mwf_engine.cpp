@@ -99,6 +99,7 @@ struct mwf_gpu_s {
 	int64_t coop_tb_mult = 1;                // ... times this; doubled after an overflow while memory lasts
 	int64_t lowmem_budget_mb = 0; // whole-device low-memory mode: first-pass traceback above this many MB -> true two-pass (0: automatic)
 	int sys_p = 8;             // whole-device (systolic) kernel: penalties per hand-off block (4, 8 or 16)
+	int sys_p2 = 0;            // ... of the SECOND pass of its low-memory mode (0: the same)
 	int sys_c = 0;             // its columns per lane: 0 automatic (1 while the window is expected to fit the slots that way, else 4), 1, 4
 	// workspace (per-stream pool)
 	DevBuf ring, sring, good, tb, row_off, row_lo, cig_scratch, snap, snap_meta, seg, queue, dbg, coop_edge, coop_misc;
@@ -777,7 +778,7 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 	const size_t NG = (size_t)n_groups;
 	// the systolic kernel (mwf_sys.hip) runs every pass but the provenance pass of the two-pass low-memory mode
 	const bool use_sys = true;
-	const int sysP = g->sys_p;
+	const int sysP = g->sys_p, sysP2 = g->sys_p2 > 0 && low_mem ? g->sys_p2 : g->sys_p;
 	// Columns per lane of the systolic kernel, per pass: one column per lane (64-column slots that own 48) quarters the
 	// per-column work a wave does per penalty — what a chain of penalties on a narrow window waits for — but needs five times
 	// the slots; taken while the window is EXPECTED to fit them (first pass: a fifth of tl+ql, real pairs stay far below;
@@ -870,7 +871,7 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 	}
 
 	const int64_t sys_rows = std::max(bound, bound1) + 2, sys_log_ints = 2 * (sys_rows + 256 + 8), sys_ep_words = 2 * (sys_rows / 256 + 3);
-	const int64_t sys_box_group = TC * 2 * sys_box_ints(sysP, two_pass), sys_park_group = TC * (two_pass ? 16 : 8) * 64 * 4;
+	const int64_t sys_box_group = TC * 2 * std::max(sys_box_ints(sysP, two_pass), sys_box_ints(sysP2, false)), sys_park_group = TC * (two_pass ? 16 : 8) * 64 * 4;
 	if (use_sys) {
 		if (ensure(g, g->sys_ring, NG * (size_t)TC * P.nH * 256 * 4)) return -1;
 		if (ensure(g, g->sys_good, NG * (size_t)P.nH * TC * 4 * 8)) return -1;
@@ -952,6 +953,7 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 		if (two_pass ? launch_sys_trace(as, g->stream) : launch_sys_walk(as, g->stream)) { g->err = "kernel launch failed (checkpoints)"; return -1; }
 		if (reset_sys(false)) return -1; // barrier counters and progress words of the second pass
 		a.coop_pass = as.coop_pass = 2;
+		as.sys_p = sysP2;
 		set_cols(c_second);
 		// the second pass is not traced: the band trace of a low-memory run is that of its second pass, traced below
 		if (launch_sys_pass(as, Gs * n_groups, g->stream)) { g->err = "kernel launch failed (second pass)"; return -1; }
@@ -1333,6 +1335,7 @@ int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value)
 	else if (!strcmp(name, "coop_grid")) g->coop_grid_cap = (int)std::max<int64_t>(0, value);
 	else if (!strcmp(name, "coop_launch")) g->coop_launch = value != 0;
 	else if (!strcmp(name, "sys_p") && sys_p_supported((int)value)) g->sys_p = (int)value; // (8; 4 and 16 only in builds with -DMWF_SYS_ALL_P)
+	else if (!strcmp(name, "sys_p2") && (value == 0 || sys_p_supported((int)value))) g->sys_p2 = (int)value;
 	else if (!strcmp(name, "sys_c") && (value == 0 || sys_c_supported((int)value))) g->sys_c = (int)value; // (2: builds with -DMWF_SYS_C2 only — the host's box / traceback layout must be the launched kernel's)
 	else if (!strcmp(name, "div_aware")) g->div_aware = value != 0;
 	else if (!strcmp(name, "trim")) { (void)hipSetDevice(g->device); trim(g); }

@@ -10,7 +10,9 @@ for line in open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__
 t, q = synth_pair(2002, 5000000, 0.008, 3, 15000)
 for p in [int(x) for x in sys.argv[1:]] or [8]:
     eng = mw.Engine(0)
-    eng.set("sys_p", p)
+    eng.set("sys_p", p % 100)
+    if p >= 100:
+        eng.set("sys_p2", p // 100)   # (e.g. 1608: first pass 8, second pass 16)
     b = eng.upload(PackedBatch([(t, q)])); o = mw.opt_init(flag=1, step=5000)
     for _ in range(2):
         t0 = time.perf_counter(); b.align(o); s, it, nc = b.results(); w = time.perf_counter() - t0
