@@ -44,7 +44,7 @@ extern __shared__ __attribute__((aligned(16))) uint8_t lds2[];
 #define MWF_B2_SPAN_K 5
 #endif
 #ifndef MWF_B2_W4K
-// Chunk slots per wave of the 512-thread geometry's copies on biased offsets (class 14 of mwf_engine.cpp: pairs of ~11-21 kb, two per CU instead of the span
+// Chunk slots per wave of the 512-thread geometry's copies on biased offsets (class 14 of mwf_plan.cpp: pairs of ~11-21 kb, two per CU instead of the span
 // geometry's one).  Measured (ms per align; span geometry | 4 | 5 | 6 slots): 1024 x 12 kb @ 5 % 34.9 | 24.6 | 24.8 | 27.7, 1024 x 15 kb @ 4 % 35.6 | - | 25.1 | 25.7,
 // 1024 x 17 kb @ 3 % 29.5 | - | 20.2 | 20.5, 512 x 18 kb @ 5 % 32.1 | - | - | 25.3, 1024 x 20 kb @ 3 % 37.3 | - | - | 26.9: five slots (40 chunks, 4 spilled VGPRs)
 // while target + query stay below 3.5 of their span, six (48 chunks) up to 3.5 of theirs.
@@ -895,7 +895,7 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 			return true;
 		}
 		if (forecast) { // will the window outgrow the chunks this workgroup holds? then hand the pair back now, with the estimate
-			est_window = window_forecast(s, uni(sh.word[3]), tl, ql, (NWK - 1) * kChunk - 64, NWK >= 24 && NWK < 64); // (the window this geometry is chosen for: kBand*Window in mwf_engine.cpp)
+			est_window = window_forecast(s, uni(sh.word[3]), tl, ql, (NWK - 1) * kChunk - 64, NWK >= 24 && NWK < 64); // (the window this geometry is chosen for: kBand*Window in mwf_plan.cpp)
 			if (est_window) { R.status = ST_BAND_OVERFLOW; return true; }
 		}
 		return false;
@@ -956,7 +956,7 @@ __global__ __launch_bounds__(T, MWF_IS_SPAN(T, K) ? (T == 1024 ? 4 : 3) : T == 1
 		}
 		const bool trace = A.dbg && pair == A.debug_pair;
 		if (R.status == ST_OK) R = band2_pass<T, K, E1, E2, TB, S2, BI4>(A, M, sh, edge_base, qoff, trace);
-		if (T == 512 && K == 4 && R.n_snap && threadIdx.x == 0 && fresh(A0).report_wide) atomicOr((unsigned int*)(fresh(A0).cig_head + 1), 1u); // (mwf_engine.cpp: PlanCache::wide_state)
+		if (T == 512 && K == 4 && R.n_snap && threadIdx.x == 0 && fresh(A0).report_wide) atomicOr((unsigned int*)(fresh(A0).cig_head + 1), 1u); // (mwf_plan.cpp: PlanCache::wide_state)
 		R.n_snap = 0;
 		if (S2) M.t2 = lds2, M.q2 = lds2 + qoff; // the traceback's back-match reads the 2-bit copies in LDS
 		finish_pair(fresh(A0), M, (int32_t)blockIdx.x, pair, R, R.status, 0, T <= 256 ? &cig_loc : nullptr); // (block mode: the geometries of the short pairs — thousands per launch)

@@ -1,4 +1,4 @@
-// mwf_internal.h — structures shared by the host engine (mwf_engine.cpp) and the HIP kernels
+// mwf_internal.h — structures shared by the host side (mwf_engine.cpp / mwf_memory.cpp / mwf_plan.cpp) and the HIP kernels
 // (mwf_kernels.hip).  Nothing here is part of the public ABI (include/miniwfa.h).
 #pragma once
 #include <stdint.h>

@@ -22,7 +22,7 @@
 //   * the traceback bytes go to the slot's arena as rows of 64 x chunks bytes that all start at the leftmost column: the shared
 //     traceback (mwf_device.h) finds a byte without reading a row table first — one memory round trip per step instead of two.
 // A pair whose window leaves the chunks, or that reaches the first shrink (penalty 256 - nH), comes back as ST_BAND_OVERFLOW and is
-// re-run on the packed band kernel (finalize(), mwf_engine.cpp).  Reference: wf_next_basic + wf_extend + the loop of mwf_wfa_core
+// re-run on the packed band kernel (finalize(), mwf_plan.cpp).  Reference: wf_next_basic + wf_extend + the loop of mwf_wfa_core
 // (miniwfa.c:252-326, :380-430).
 #include "mwf_device.h"
 
