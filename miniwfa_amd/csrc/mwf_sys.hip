@@ -1378,11 +1378,17 @@ int launch_pass_d(const BatchArgs &a, int grid, hipStream_t st)
 	const bool defer = CAN_DEFER && a.pen.x >= 3 && a.pen.oe1 >= 3 && a.pen.oe2 >= 3;
 	if (a.coop_pass == 3) { // the provenance pass stores no traceback
 		if constexpr (CAN_DEFER) {
-			if (defer) return launch_pass_p<E1, E2, true, false>(a, grid, st);
+			// (measured, round 5: the provenance pass carries twice the wavefront state — with four columns per lane the deferred form needs ~316 VGPRs
+			// and spills 60 of them; without the deferral 25, and the 5 Mb pair's first pass falls from 1.06 to 0.97 s; one column per lane: 125 -> 122 ms
+			// on the 150 kb pair.  MWF_SYS_DEFER_SEG=1 restores the deferred form.)
+			if (defer && getenv("MWF_SYS_DEFER_SEG")) return launch_pass_p<E1, E2, true, false>(a, grid, st);
 		}
 		return launch_pass_p<E1, E2, false, false>(a, grid, st);
 	}
 	if constexpr (CAN_DEFER) {
+		// (... and so does the traceback pass on four columns per lane, 59 spilled VGPRs: the 5 Mb pair in high-memory CIGAR mode 851 -> 808 ms undeferred;
+		// on one column per lane the deferral wins, 56.6 against 59.4 ms on the 150 kb pair)
+		if (defer && a.want_cigar && a.sys_c == 4) return launch_pass_p<E1, E2, false, true>(a, grid, st);
 		if (defer) return a.want_cigar ? launch_pass_p<E1, E2, true, true>(a, grid, st) : launch_pass_p<E1, E2, true, false>(a, grid, st);
 	}
 	return a.want_cigar ? launch_pass_p<E1, E2, false, true>(a, grid, st) : launch_pass_p<E1, E2, false, false>(a, grid, st);
