@@ -484,6 +484,10 @@ __device__ __forceinline__ void finish_pair(const ArgsT &A, const PairMem &M, in
 		A.out_cigoff[pair] = cig_off;
 		A.out_cells1[pair] = cells1;
 		A.out_status[pair] = status;
+		if (status == ST_BAND_OVERFLOW && A.retry_count) { // handed back: onto the list of the follow-up launch (BatchArgs::retry_ids)
+			const unsigned int k = atomicAdd(A.retry_count, 1u);
+			if (k < (unsigned int)A.retry_cap) A.retry_ids[k] = pair;
+		}
 	}
 	__syncthreads();
 }

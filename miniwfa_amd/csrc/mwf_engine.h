@@ -64,6 +64,8 @@ struct mwf_gpu_s {
 	std::string err;
 	// tunables
 	int block = 0;              // 0: choose from the batch
+	bool dev_retry = true;      // batches of reads: the pairs the lane kernel hands back are re-run by a follow-up launch from a device-side list, without the host
+	int retry_mode = 0;         // set around run_batch_kernel(): 1 the launch fills the list, 2 the launch takes its pairs from it
 	bool div_aware = true;      // weigh the size classes' length limits by the batch's estimated divergence (batches built from host memory)
 	int64_t tun_gen = 0;        // bumped by every successful mwf_gpu_set(): a cached plan of an align (PlanCache) is only replayed under the tunables it was made under
 	int slots_per_cu = 0;       // 0: occupancy of the kernel
@@ -182,6 +184,8 @@ struct mwf_gpu_batch_s {
 	// geometry and counters of the last align of THIS batch (finalize() must not read the engine's: another batch may have
 	// been aligned on the same engine in between)
 	int32_t last_grid = 0, n_retries = 0;
+	int32_t *d_retry_ids = nullptr;  // [kRetryCap] pairs a launch handed back for its follow-up launch; their count is the third word of the head (d_cig_head + 2)
+	bool dev_retry_used = false;     // this align made such a follow-up launch: the count is added to n_retries
 	// debug band trace (tests)
 	int32_t debug_pair = -1;
 };
@@ -211,8 +215,9 @@ int upload_segments(mwf_gpu_t *g, char *dst, const std::vector<Seg> &segs);
 int download(mwf_gpu_t *g, void *dst, const void *src, size_t bytes);
 struct BlockLayout {
 	size_t order = 0, t_off = 0, q_off = 0, tl = 0, ql = 0, seqs = 0, in_end = 0;
-	size_t head = 0, status = 0, s = 0, ncig = 0, iter = 0, cigoff = 0, cells1 = 0, score_end = 0, out_end = 0, dbg4 = 0, total = 0;
+	size_t head = 0, status = 0, s = 0, ncig = 0, iter = 0, cigoff = 0, cells1 = 0, score_end = 0, out_end = 0, dbg4 = 0, retry = 0, total = 0;
 };
+constexpr int kRetryCap = 256; // ids a launch can hand to its follow-up launch on the device (BatchArgs::retry_ids)
 BlockLayout layout_block(size_t n, size_t seq_bytes, bool owned);
 mwf_gpu_batch_t *batch_common(mwf_gpu_t *g, int32_t n, const int32_t *h_tl, const int32_t *h_ql, size_t seq_bytes, bool owned, BlockLayout &L);
 mwf_gpu_batch_t *batch_from_host(mwf_gpu_t *g, int32_t n, const int32_t *tl, const char *const *ts, const int32_t *ql, const char *const *qs,

@@ -100,6 +100,13 @@ struct BatchArgs {
 	int64_t coop_misc_stride;  // bytes between two groups' flags / barrier words / pass state / flag ring
 	const int32_t *coop_pair_ids; // [coop_groups] pair of every group (null: coop_pair)
 	uint32_t coop_spin_limit;  // polls after which a wait for another workgroup gives up (ST_INTERNAL)
+	// Re-runs without the host (round 5): a launch whose kernel hands pairs back (ST_BAND_OVERFLOW) appends their ids to retry_ids (at most retry_cap;
+	// retry_count counts every one); a follow-up launch of a wider kernel in the same stream takes its pairs from that list — n_pairs_dev — instead
+	// of the host reading the status words, re-launching and reading them again (~0.2 ms behind a 0.5 ms launch of 40 000 reads).
+	int32_t *retry_ids;
+	unsigned int *retry_count;
+	int32_t retry_cap;
+	const unsigned int *n_pairs_dev; // consumer: the pairs are order[0 .. min(*n_pairs_dev, n_pairs)), dealt blockIdx.x + k gridDim.x
 	int32_t coop_pass;         // 0: plain pass; 1: pass whose traceback feeds the checkpoint walk; 2: second pass (uses seg); 3: first pass with provenance and snapshots
 	int32_t *coop_edge;        // granules [nH][waves*2][2][4] x 8 B: E/F/H of every chunk's outer columns, tagged with their penalty
 	int32_t *coop_flags;       // [12..14] origin offset and shrink reduction; [1024 + 4*(penalty mod 64) ..] edge-live / end-cell flag ring

@@ -1198,7 +1198,7 @@ __global__ void reset_kernel(int32_t *status, int32_t *s, int32_t n, unsigned lo
 	const int32_t i = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
 	if (i < n) status[i] = -1, s[i] = -2;
 	if (i < n_queue) queue[i] = 0; // the work counters of the align call's launches (the grid covers n_queue)
-	if (i == 0) cig_head[0] = 0ull, cig_head[1] = 0ull; // (the second word: flags of the align's kernels for the host, BatchArgs::cig_head + 1)
+	if (i == 0) cig_head[0] = 0ull, cig_head[1] = 0ull, cig_head[2] = 0ull; // (the second word: flags of the align's kernels for the host, BatchArgs::cig_head + 1; the third: BatchArgs::retry_count)
 }
 
 int launch_reset(int32_t *status, int32_t *s, int32_t n, unsigned long long *cig_head, int32_t *queue, int32_t n_queue, void *stream)

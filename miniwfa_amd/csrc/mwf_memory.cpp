@@ -190,6 +190,7 @@ BlockLayout layout_block(size_t n, size_t seq_bytes, bool owned)
 	L.cells1 = at, at += N * 8;
 	L.out_end = at;
 	L.dbg4 = at, at += N * 16;
+	L.retry = at, at += (size_t)kRetryCap * 4;
 	L.total = at;
 	return L;
 }
@@ -223,6 +224,7 @@ mwf_gpu_batch_t *batch_common(mwf_gpu_t *g, int32_t n, const int32_t *h_tl, cons
 	b->d_status = (int32_t*)(base + L.status), b->d_s = (int32_t*)(base + L.s), b->d_ncig = (int32_t*)(base + L.ncig);
 	b->d_iter = (int64_t*)(base + L.iter), b->d_cigoff = (int64_t*)(base + L.cigoff), b->d_cells1 = (int64_t*)(base + L.cells1);
 	b->d_dbg4 = (int32_t*)(base + L.dbg4);
+	b->d_retry_ids = (int32_t*)(base + L.retry);
 	b->out_off = L.head, b->out_bytes = L.out_end - L.head, b->out_bytes_score = L.score_end - L.head;
 	// longest pairs first, so the persistent workgroups finish together
 	b->h_order.resize((size_t)n);

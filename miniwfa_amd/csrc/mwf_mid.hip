@@ -276,13 +276,15 @@ __global__ __launch_bounds__(T, 1) void wfa_mid_kernel(const BatchArgs)
 	const MidLayout L = mid_layout(A.pen.nH, A.pen.e1, A.pen.e2, A.lane_chunks * 64);
 	MidVars &V = *(MidVars*)(lds_mid + L.vars_off);
 	uint8_t *lt = lds_mid + L.seq_off;
+	// (a follow-up launch behind a kernel that handed pairs back: their number is on the device, BatchArgs::n_pairs_dev)
+	const int32_t n_dev = A.n_pairs_dev ? min((int32_t)*A.n_pairs_dev, A.n_pairs) : -1;
 	for (int32_t round = 0;; ++round) {
 		// a work counter, or — queue == null: a launch of one workgroup per pair — pair blockIdx.x and nothing else (no counter to zero first)
-		if (tid == 0) V.item = A.queue ? (int32_t)atomicAdd(A.queue, 1) : (round == 0 ? (int32_t)blockIdx.x : A.n_pairs), V.word = 0;
+		if (tid == 0) V.item = n_dev >= 0 ? (int32_t)(blockIdx.x + round * gridDim.x) : A.queue ? (int32_t)atomicAdd(A.queue, 1) : (round == 0 ? (int32_t)blockIdx.x : A.n_pairs), V.word = 0;
 		__syncthreads();
 		const int32_t item = uni(V.item);
 		__syncthreads();
-		if (item >= A.n_pairs) break;
+		if (item >= (n_dev >= 0 ? n_dev : A.n_pairs)) break;
 		const int32_t pair = A.order ? A.order[item] : item;
 		PairMem M;
 		pair_mem(fresh(A), (int32_t)blockIdx.x, pair, M);

@@ -320,6 +320,9 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 		a.queue = (int32_t*)g->queue.p;
 		HIP_TRY(g, hipMemsetAsync(g->queue.p, 0, 4, g->stream)); // (stream order: the launch that used it last is complete by then)
 	}
+	// re-runs without the host (BatchArgs::retry_ids): this launch fills the batch's list / takes its pairs from it
+	if (g->retry_mode == 1) a.retry_ids = b->d_retry_ids, a.retry_cap = kRetryCap, a.retry_count = (unsigned int*)(b->d_cig_head + 2);
+	if (g->retry_mode == 2) a.n_pairs_dev = (const unsigned int*)(b->d_cig_head + 2), a.queue = nullptr, a.queue_parts = 0;
 	a.scalar_generic = g->scalar_generic;
 	a.lds_e2_cols = lds_e2_cols;
 	a.ring16 = ring16 ? 1 : 0;
@@ -646,7 +649,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	(void)hipSetDevice(g->device);
 	b->opt = *opt;
 	b->aligned = false, b->finalized = false, b->h_cig_valid = false;
-	b->last_grid = 0, b->n_retries = 0;
+	b->last_grid = 0, b->n_retries = 0, b->dev_retry_used = false;
 	g->stats = mwf_gpu_stats_t{};
 	if (b->n == 0) { b->aligned = b->finalized = true; return 0; }
 	const bool cigar = (opt->flag & MWF_F_CIGAR) != 0;
@@ -884,12 +887,33 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		++done_groups;
 		int ran = 0;
 		const int cc = c == 14 ? 8 : c == 13 ? 7 : c == 11 ? 6 : (c == 10 || c == 12) ? 5 : c > 5 ? c - 5 : c;
+		// (the lane class of a batch of reads hands its overflows to a follow-up launch on the device, below)
+		const bool lane_retry = (c == 10 || c == 12) && g->dev_retry && G.n >= 1024 && !preset && g->force_kind < 0 && g->block == 0 && mid_supported(P0) && G.max_len <= 1200 &&
+		                        G.max_tl + G.max_bound < 32760 && !low_mem;
+		if (lane_retry) g->retry_mode = 1;
 		g->acgt_off_once = (c > 5 && c < 10) || (c == 11 && mid_bytes) || c == 12;
 		const int rc = run_batch_kernel(g, b, c == 5 ? *opt : opt_hi, b->d_order + at, G.n, slots, G.max_len, G.max_bound, G.max_bound1,
-		                                done_groups == 1, (classes || c >= 11) ? (c == 0 || c == 5 ? 0 : 2) : -1, G.max_tl, G.max_seq_lds, done_groups == n_groups,
+		                                done_groups == 1, (classes || c >= 11) ? (c == 0 || c == 5 ? 0 : 2) : -1, G.max_tl, G.max_seq_lds, lane_retry ? 0 : done_groups == n_groups,
 		                                cc == 8 ? 514 : cc == 7 ? 1024 : cc == 6 ? 33 : cc == 5 ? 32 : cc == 4 ? 64 : cc == 3 ? 128 : cc == 2 ? 256 : 0, &ran,
 		                                (c == 1 && (g->wide_slots == 4 || (g->wide_slots == 0 && PC.wide_state != 1 && g->queue_clean))) ? kBandWide4Window : 0);
+		g->retry_mode = 0;
 		if (c == 1 && g->wide_slots == 0 && PC.wide_state == 0 && g->queue_clean && ran == 2 && g->stats.block == 512) PC.wide_measured = true;
+		// Batches of reads: what the lane kernel hands back (a window that left its chunks: one read in tens of thousands) is re-run by a follow-up launch of
+		// the mid kernel, whose span holds the widest window such a pair can have — from a list the lane kernel filled ON THE DEVICE.  Round 4 read the status
+		// words back, launched, waited and read them again: ~0.2 ms behind a 0.5 ms launch.  (An empty list costs the launch of a few idle workgroups.)
+		if (rc == 0 && lane_retry) {
+			const mwf_gpu_stats_t keep = g->stats;
+			g->retry_mode = 2;
+			g->acgt_off_once = c == 12;
+			int ran2 = 0;
+			const int rc2 = run_batch_kernel(g, b, opt_hi, b->d_retry_ids, std::min<int32_t>(kRetryCap, 32), slots, G.max_len, G.max_bound, G.max_bound1, false, 2, G.max_tl, G.max_seq_lds,
+			                                 done_groups == n_groups, 33, &ran2, 0);
+			g->retry_mode = 0, g->acgt_off_once = false;
+			const int32_t launches = g->stats.n_launches;
+			g->stats = keep, g->stats.n_launches = launches; // (the statistics describe the class's own launch)
+			if (rc2) return -1;
+			b->dev_retry_used = true;
+		}
 		g->acgt_off_once = false;
 		if (rc) return -1;
 		// (bit 64: the pair ran on the plain three-slot 512-thread geometry — the only one whose LATE overflow says "this batch's wide class needs four slots")
@@ -967,6 +991,12 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 		return 0;
 	};
 	if (fetch()) return -1;
+	if (b->dev_retry_used) { // pairs a follow-up launch re-ran from the device-side list count as re-runs too (the third word of the head: BatchArgs::retry_count)
+		uint32_t k = 0;
+		memcpy(&k, b->host_out.data() + 16, 4);
+		b->n_retries += (int32_t)std::min<uint32_t>(k, (uint32_t)kRetryCap);
+	}
+
 	if (b->plan.wide_measured) { // the four-slot kernels' report (reset to 0 by the align's reset kernel): did any pair need more than three slots hold?
 		uint32_t aux = 0;
 		memcpy(&aux, host.data() + 8, 4);
