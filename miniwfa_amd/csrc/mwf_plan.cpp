@@ -324,6 +324,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	if (g->retry_mode == 1) a.retry_ids = b->d_retry_ids, a.retry_cap = kRetryCap, a.retry_count = (unsigned int*)(b->d_cig_head + 2);
 	if (g->retry_mode == 2) a.n_pairs_dev = (const unsigned int*)(b->d_cig_head + 2), a.queue = nullptr, a.queue_parts = 0;
 	a.scalar_generic = g->scalar_generic;
+	a.band_fold = g->band_fold ? 1 : 0;
 	a.lds_e2_cols = lds_e2_cols;
 	a.ring16 = ring16 ? 1 : 0;
 	a.lane_chunks = pl.kind == 2 && pl.band.lane ? pl.band.span / 64 : 0;

@@ -172,6 +172,33 @@ def fuzz_pairs(seed: int, n: int, max_len: int = 4000) -> list[tuple[bytes, byte
     return pairs
 
 
+def skewed_pairs(seed: int, n: int, lo: int, hi: int) -> list[tuple[bytes, bytes]]:
+    """Pairs whose wavefront window MOVES: every third one unrelated (target and query of independent lengths in [lo, hi): the window reaches
+    the corners of the matrix, diagonals run out of it and the window's start climbs across chunk boundaries), the others related through
+    one long deletion or insertion plus 2 / 8 / 20 % substitutions (the window drifts to one side); target and query swapped at random.
+    Used by profiles/fuzz_fold.py and tests/test_gpu_parity.py (the slot mapping of the packed band kernel must follow such windows)."""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    out = []
+    for i in range(n):
+        tl, ql = int(rng.integers(lo, hi)), int(rng.integers(lo, hi))
+        t = rng.integers(0, 4, tl).astype(np.uint8)
+        kind = i % 3
+        if kind == 0:
+            q = rng.integers(0, 4, ql).astype(np.uint8)
+        else:
+            cut = int(rng.integers(20, max(21, tl // 3)))
+            at = int(rng.integers(0, max(1, tl - cut)))
+            q = np.concatenate([t[:at], t[at + cut:]]) if kind == 1 else np.concatenate([t[:at], rng.integers(0, 4, cut).astype(np.uint8), t[at:]])
+            flip = rng.random(len(q)) < rng.choice([0.02, 0.08, 0.2])
+            q = q.copy()
+            q[flip] = (q[flip] + rng.integers(1, 4, int(flip.sum()))) & 3
+        if rng.random() < 0.5:
+            t, q = q, t
+        out.append((acgt[t].tobytes(), acgt[q].tobytes()))
+    return out
+
+
 class PackedBatch:
     """Pairs packed back to back in one byte buffer (+16 bytes of slack so word-sized device
     reads past the last sequence stay inside the allocation)."""

@@ -30,7 +30,14 @@ extern __shared__ __attribute__((aligned(16))) uint8_t lds2[];
 #ifndef MWF_B2_XPREF
 #define MWF_B2_XPREF 0 // request the first active chunk's rows of the coming penalty 1: before the barrier, 2: straight behind it (measured: no gain)
 #endif
-
+#ifndef MWF_B2_FOLD_PREF
+// folded form: 1 = the first active chunk's rows of the coming penalty requested before the barrier, 2 = the next slot's rows requested
+// while the current chunk probes, 3 = both
+#define MWF_B2_FOLD_PREF 0
+#endif
+#ifndef MWF_B2_NMODE
+#define MWF_B2_NMODE 0 // the word next to the chunk: 0 = every lane loads one, 1 = lanes 0 and 63 only, 2 = one 16-byte load brings the row's quad and both neighbours
+#endif
 #ifndef MWF_B2_WIDE_T
 #define MWF_B2_WIDE_T 512 // threads x chunk slots per wave of the widest geometry (24 chunks): 512 x 3; experiments: 256 x 6, 384 x 4
 #define MWF_B2_WIDE_K 3
@@ -60,6 +67,7 @@ extern __shared__ __attribute__((aligned(16))) uint8_t lds2[];
 #endif
 constexpr int kChunk = 256;
 constexpr int kFoldMaxLag = 8; // largest o1 + e1 the folded form of the packed kernel is launched for
+constexpr int kRingDepth = 4;  // penalties of H the folded form keeps in LDS (RING): the mismatch penalty x may be at most this
 constexpr int32_t kDeadPair = (int32_t)0x80008000u;
 
 __device__ __forceinline__ int32_t from_left(int32_t v, int32_t fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
@@ -307,8 +315,8 @@ __device__ __forceinline__ int32_t pair_of(int32_t lo, int32_t hi) { return (int
 __device__ __forceinline__ int32_t left_of_A(int32_t B, int32_t fill) { return __builtin_amdgcn_alignbit(B, from_left(B, fill), 16); }
 __device__ __forceinline__ int32_t right_of_B(int32_t A, int32_t fill) { return __builtin_amdgcn_alignbit(from_right(A, fill), A, 16); }
 
-template <int T, int K, int E1, int E2, bool TB, bool S2, bool BI4, bool FOLD, typename ArgsT>
-__device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, const int32_t edge_base, const int32_t qoff, bool trace_band)
+template <int T, int K, int E1, int E2, bool TB, bool S2, bool BI4, bool FOLD, bool RING, typename ArgsT>
+__device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, const int32_t edge_base, const int32_t qoff, bool trace_band, const int32_t ring_base)
 {
 	constexpr int NW = T / 64, NWK = NW * K, D = (E1 > E2 ? E1 : E2) + 1;
 	constexpr bool BI = MWF_IS_SPAN(T, K) || BI4; // biased offsets with range checks (wide_bias): the span geometry and the four-slot 512-thread one's copy for long pairs
@@ -320,6 +328,11 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 	// not load the row of lag o1+e1 at all.  A chunk that left the window keeps running until the rows it computed have been folded
 	// and aged out: kAgeOut penalties (the host asks for this form only when o1 + e1 <= kFoldMaxLag).
 	constexpr int kAgeOut = FOLD ? kFoldMaxLag : D;
+	// RING (with FOLD, mismatch lag x <= kRingDepth): the H values of the last kRingDepth penalties also stay in LDS, every lane's own four
+	// columns of every slot (8 bytes per penalty: [slot][wave][age][lane] behind the edge table) — the mismatch term reads what the SAME
+	// lane wrote x penalties ago, so no barrier, no neighbour, no bank conflict.  The rows in HBM are then read at the second gap piece's
+	// lag (o2 + e2) only: nothing the kernel needs soon lives in L2, which two workgroups per CU overrun.
+	static_assert(!RING || (FOLD && kAgeOut >= kRingDepth), "a slot that leaves the window writes its ring dead while it ages");
 	static_assert(!FOLD || !TB, "the traceback byte tells an opened gap from an extended one: it needs both terms");
 	constexpr int kAge = (NWK + 2) * 16; // bytes of one age of the edge table
 	static_assert(D == 2 || D == 3, "edge-table ages");
@@ -380,11 +393,18 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 		sh.word[3] = -1; // furthest offset seen at a forecast penalty (dev::window_forecast)
 	}
 	__syncthreads(); // (orders the dead rows before the origin's store)
+	if (RING) // every slot's ring starts dead (the last reads of the previous pair's ring lie before the barriers of its end)
+		for (int32_t q = tid; q < NWK * kRingDepth * 64; q += T) *(int2*)(lds2 + ring_base + q * 8) = make_int2(kDeadPair, kDeadPair);
+	if (RING) __syncthreads();
 	if (tid < 64) { // the origin's run, walked by the first wave
 		const int32_t k0 = (S2 ? run_wave16(qoff, 0, 0, min(tl, ql), 0) : run_wave2(0, qoff, min(tl, ql), 0)) - 1;
 		if (tid == 0) {
 			const int32_t c = tl + 1, e = c & 3;
 			*(int16_t*)(Hb + 8 + (size_t)(uint32_t)(((c & ~3) + ((e & 1) << 1) + (e >> 1)) << 1)) = (int16_t)(k0 - B);
+			if (RING) { // age 0 of the slot that holds the origin's chunk (chunk g -> slot g mod NWK = wave + NW k)
+				const int32_t sl = (c >> 8) % NWK, w0 = sl % NW, k_0 = sl / NW;
+				*(int16_t*)(lds2 + ring_base + ((k_0 * NW + w0) * kRingDepth * 64 + ((c & 255) >> 2)) * 8 + (((e & 1) << 1) + (e >> 1)) * 2) = (int16_t)(k0 - B);
+			}
 			sh.word[1] = k0;
 		}
 	}
@@ -405,14 +425,21 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 	struct Rows { int2 HX, O1, O2; int32_t N1, N2; } pre;
 	pre.HX = pre.O1 = pre.O2 = make_int2(0, 0), pre.N1 = pre.N2 = 0;
 	int32_t pre_g = -1;
-	constexpr int XMODE = MWF_B2_XPREF; // (measured: +1 % on 1024 x 10 kb; on the folded form -3 %: the row loads are not what the critical wave waits for; off)
-	constexpr bool XPREF = XMODE != 0;
-	constexpr int kRowLoads = FOLD ? 3 : 5; // loads of one request
+	constexpr int XMODE = FOLD ? (MWF_B2_FOLD_PREF & 1) : MWF_B2_XPREF; // (the unfolded form, measured: +1 % on 1024 x 10 kb — five loads, and they are not what its critical wave waits for; off)
+	constexpr bool ROLL = FOLD && (MWF_B2_FOLD_PREF & 2) != 0;
+	constexpr bool XPREF = XMODE != 0 || ROLL;
+	constexpr int kRowLoads = FOLD ? (RING ? 2 : 3) : 5; // loads of one request
 	const bool xpref = XPREF && min_lag >= 2;
 	auto load_rows = [&](Rows &r, const char *rx, const char *r1, const char *r2, uint32_t off) {
 		const uint32_t noff = off + (uint32_t)nd;
-		r.HX = *(const int2*)(rx + off), r.O2 = *(const int2*)(r2 + off);
-		r.N2 = *(const int32_t*)(r2 + noff);
+		if (!RING) r.HX = *(const int2*)(rx + off);
+		if (MWF_B2_NMODE == 2) {
+			const int4 w = *(const int4*)(r2 + off - 4); // (4-byte aligned)
+			r.O2 = make_int2(w.y, w.z), r.N2 = lane == 0 ? w.x : w.w;
+		} else {
+			r.O2 = *(const int2*)(r2 + off);
+			if (MWF_B2_NMODE == 0 || lane == 0 || lane == 63) r.N2 = *(const int32_t*)(r2 + noff);
+		}
 		if (!FOLD) r.O1 = *(const int2*)(r1 + off), r.N1 = *(const int32_t*)(r1 + noff);
 	};
 	int64_t cells = 0, tb_used = 0;
@@ -436,7 +463,7 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 	int32_t idle[K]; // penalties since the slot last held an active chunk (registers and edge-table entries start dead)
 #pragma unroll
 	for (int k = 0; k < K; ++k) idle[k] = kAgeOut;
-	int32_t up_wait = 0, up_min = 0; // penalties for which the window has started above chunk gl, the lowest start among them
+	int32_t up_wait = 0, up_min = 0; // FOLD: penalties for which the window has started above chunk gl, the lowest start among them
 
 	// One penalty; returns true when the pass ends.  A depth-2 history is two registers, [0] the newer: the penalty reads [1] for the last
 	// time, overwrites it, and the two trade places (v_swap_b32) — no copies, and a slot that is skipped leaves its registers alone.
@@ -459,9 +486,9 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 		}
 		// the window of penalty s_new+1 lies inside [lo-1, hi+1] whatever the flags say; it must fit the register span
 		const int32_t gl_next = (lo > 1 ? lo - 1 : 1) >> 8;
-		// (the mapping follows a window that moves UP kAgeOut penalties late — the chunks it leaves behind still run, see below)
-		if ((hi >> 8) - min(lo >> 8, gl + 1) + 3 > NWK - 1) // (only then can the exact test fail)
-			if (((hi < cmax ? hi + 1 : cmax) >> 8) - min(gl_next, gl) + 1 > NWK - 1) { R.status = ST_BAND_OVERFLOW; return true; }
+		// (FOLD: the mapping follows a window that moves up kAgeOut penalties late — the chunks it leaves behind still run)
+		if ((hi >> 8) - (FOLD ? min(lo >> 8, gl + 1) : (lo >> 8)) + 3 > NWK - 1) // (only then can the exact test fail)
+			if (((hi < cmax ? hi + 1 : cmax) >> 8) - (FOLD ? min(gl_next, gl) : gl_next) + 1 > NWK - 1) { R.status = ST_BAND_OVERFLOW; return true; }
 		// (the four-slot form of the 512-thread geometry notes whether the three-slot form would have held the pair: the host's choice for the next align)
 		if (T == 512 && K == 4 && (hi >> 8) - (lo >> 8) + 3 > 23)
 			if (((hi < cmax ? hi + 1 : cmax) >> 8) - gl_next + 1 > 23) R.n_snap = 1;
@@ -472,6 +499,9 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 		const bool track_good = (((256 - (s_new & 255)) & 255) < nH); // a shrink can still see this slice
 		// edge table: the ages to read (penalties s_new-E1 and s_new-E2) and the one to overwrite, as LDS addresses
 		const int32_t rE1 = ebase + epos[E1 - 1], rE2 = ebase + epos[E2 - 1];
+		// RING: this lane's entries of penalty s_new - x (read) and s_new (written; the same entry when x == kRingDepth: read first)
+		const int32_t ring_lane = RING ? ring_base + wave * (kRingDepth * 512) + lane * 8 : 0;
+		const int32_t ring_r = RING ? ring_lane + (((s_new - lagx) & (kRingDepth - 1)) << 9) : 0, ring_w = RING ? ring_lane + ((s_new & (kRingDepth - 1)) << 9) : 0;
 		const int32_t wE = lane == 63 ? ebase + epos[D - 1] : dump_lane, wF = lane == 0 ? ebase + epos[D - 1] : dump_lane;
 		auto put_edge = [&](int k, int32_t e1b, int32_t e2b, int32_t f1a, int32_t f2a) {
 			*(int2*)(lds2 + wE + (k * NW + 1) * 16) = make_int2(e1b, e2b);
@@ -573,7 +603,7 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 			// (measured and dropped, round 4: the rows of EVERY chunk the wave will run requested at the top of the penalty — 16 more VGPRs — 19.4 against 17.35 ms)
 			if (!XPREF || g != pre_g) load_rows(pre, rowx, row1, row2, off); // uniform; (else they were requested before the last barrier)
 			if (XPREF) pre_g = -1;
-			const int2 HX = pre.HX, O1 = pre.O1, O2 = pre.O2;
+			const int2 HX = RING ? *(const int2*)(lds2 + ring_r + k * NW * (kRingDepth * 512)) : pre.HX, O1 = pre.O1, O2 = pre.O2;
 			const int32_t N1 = pre.N1, N2 = pre.N2;
 			// gap-extension sources: E of column c-1, F of column c+1, e1 (e2) penalties ago; lane 0 / lane 63 take the neighbouring
 			// slot's outer columns from the edge table
@@ -599,6 +629,14 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 #if MWF_B2_TIMING == 2
 			if (timed) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc1) : "v"(hA), "v"(hB) : "memory");
 #endif
+			// ROLL: the rows of the wave's next slot are requested now — the registers they land in have just been read for the last time
+			if (ROLL && k + 1 < K) {
+				if (act[k + 1]) { // uniform
+					asm volatile("" :: "v"(hA), "v"(hB)); // (behind the recurrence)
+					load_rows(pre, rowx, row1, row2, (uint32_t)(gk[k + 1] << 9) + lane8);
+					pre_g = gk[k + 1];
+				}
+			}
 			uint32_t tbw = 0;
 			if (TB) {
 				// The byte from the RESULTS (miniwfa.c:289-306): H is the maximum of m, e1, e2, f1, f2 and the reference's tie-breaking
@@ -797,6 +835,7 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 				fm = __ballot(f != 0);
 			}
 			*(int2*)(rown + off) = make_int2(hxA, hxB);
+			if (RING) *(int2*)(lds2 + ring_w + k * NW * (kRingDepth * 512)) = make_int2(hxA, hxB);
 			++n_stores;
 #if MWF_B2_TIMING == 2
 			if (timed) {
@@ -882,13 +921,10 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 			for (int a = D - 1; a > 0; --a) epos[a] = epos[a - 1];
 			epos[0] = oldest;
 		}
-		// The slot mapping follows the window's start: down at once (the slot that wraps held a chunk beyond the window's reach under the old
-		// mapping: long idle), up only when the chunks below the start have been out of the window for kAgeOut penalties — until then
-		// they age (and, FOLD, fold the rows they computed) in place.  A slot that wrapped while it aged would run the chunk NWK further up
-		// through the ordinary code, and that chunk's dead stores may lie beyond the end of the row (found by profiles/fuzz_fold.py: a
-		// 2.3 kb unrelated pair on four slots lost cells of the NEXT row that way — n_iter off by 82).
-		if (gl_next < gl) gl = gl_next, remap(gl), up_wait = 0;
-		else if (gl_next > gl) {
+		if (!FOLD) {
+			if (gl_next != gl) gl = gl_next, remap(gl);
+		} else if (gl_next < gl) gl = gl_next, remap(gl), up_wait = 0; // (the slot that wraps held a chunk beyond the window's reach under the old mapping)
+		else if (gl_next > gl) { // the chunks below the window's start still fold and age: follow once they have been out for kAgeOut penalties
 			up_min = up_wait == 0 ? gl_next : min(up_min, gl_next);
 			if (++up_wait > kAgeOut) gl = up_min, remap(gl), up_wait = 0;
 		} else up_wait = 0;
@@ -937,7 +973,7 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 
 // Workgroups share a CU: 2 x 512, 4 x 256, 8 x 128 or 16 x 64 threads = 4 waves per SIMD, i.e. at most 128 VGPRs; with traceback
 // the smaller ones get 168 (3 per SIMD).  768 threads: one workgroup per CU.
-template <int T, int K, int E1, int E2, bool TB, bool S2, bool BI4 = false, bool FOLD = false>
+template <int T, int K, int E1, int E2, bool TB, bool S2, bool BI4 = false, bool FOLD = false, bool RING = false>
 __global__ __launch_bounds__(T, MWF_IS_SPAN(T, K) ? (T == 1024 ? 4 : 3) : T == 1024 ? 4 : T == MWF_B2_WIDE_T ? MWF_B2_WIDE_WAVES : T <= 512 ? ((TB && T < 512) ? 3 : 4) : MWF_B2_768_WAVES) void wfa_band2_kernel(const BatchArgs)
 {
 	constexpr int NWK = (T / 64) * K, D = (E1 > E2 ? E1 : E2) + 1;
@@ -983,7 +1019,7 @@ __global__ __launch_bounds__(T, MWF_IS_SPAN(T, K) ? (T == 1024 ? 4 : 3) : T == 1
 			__syncthreads();
 		}
 		const bool trace = A.dbg && pair == A.debug_pair;
-		if (R.status == ST_OK) R = band2_pass<T, K, E1, E2, TB, S2, BI4, FOLD>(A, M, sh, edge_base, qoff, trace);
+		if (R.status == ST_OK) R = band2_pass<T, K, E1, E2, TB, S2, BI4, FOLD, RING>(A, M, sh, edge_base, qoff, trace, lds_seq + (int32_t)sizeof(LdsT));
 		if (T == 512 && K == 4 && R.n_snap && threadIdx.x == 0 && fresh(A0).report_wide) atomicOr((unsigned int*)(fresh(A0).cig_head + 1), 1u); // (mwf_plan.cpp: PlanCache::wide_state)
 		R.n_snap = 0;
 		if (S2) M.t2 = lds2, M.q2 = lds2 + qoff; // the traceback's back-match reads the 2-bit copies in LDS
@@ -994,19 +1030,26 @@ __global__ __launch_bounds__(T, MWF_IS_SPAN(T, K) ? (T == 1024 ? 4 : 3) : T == 1
 template <int T, int K, int E1, int E2>
 constexpr int lds_tail() { return (int)sizeof(Band2Lds<(E1 > E2 ? E1 : E2) + 1, (T / 64) * K>); }
 
-template <int T, int K, int E1, int E2, bool TB, bool S2, bool BI4 = false, bool FOLD = false>
+template <int T, int K, int E1, int E2, bool TB, bool S2, bool BI4 = false, bool FOLD = false, bool RING = false>
 void launch_variant(const BatchArgs &a, int grid, int lds, hipStream_t st)
 {
-	// score-only on the 512-thread (and wider) geometries with o1 == x: the folded form (band2_pass), two row loads less per chunk
+	// score-only on the 512-thread (and wider) geometries with o1 == x: the folded form (band2_pass), one row load less per chunk;
+	// two 512-thread workgroups per CU with three or four chunk slots: the rows of the last penalties in LDS where they fit half a CU's
 	if constexpr (!TB && !FOLD && T >= 512) {
-		if (a.band_fold && a.pen.oe1 - a.pen.x == E1 && a.pen.oe1 < kFoldMaxLag) return launch_variant<T, K, E1, E2, TB, S2, BI4, true>(a, grid, lds, st);
+		if (a.band_fold && a.pen.oe1 - a.pen.x == E1 && a.pen.oe1 < kFoldMaxLag) {
+			if constexpr (T == 512 && S2 && !BI4 && (K == 3 || K == 4)) {
+				constexpr int ring_bytes = (T / 64) * K * kRingDepth * 512;
+				if (a.band_fold >= 2 && a.pen.x <= kRingDepth && lds + ring_bytes <= 80 * 1024) return launch_variant<T, K, E1, E2, TB, S2, BI4, true, true>(a, grid, lds + ring_bytes, st);
+			}
+			return launch_variant<T, K, E1, E2, TB, S2, BI4, true, false>(a, grid, lds, st);
+		}
 	}
 	// the attribute is per device and this may run on several host threads (mwf_wfa_batch_multi): set it on every launch that needs it
 	if (lds > 48 * 1024) {
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wfa_band2_kernel<T, K, E1, E2, TB, S2, BI4, FOLD>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wfa_band2_kernel<T, K, E1, E2, TB, S2, BI4, FOLD, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 		(void)hipGetLastError();
 	}
-	hipLaunchKernelGGL((wfa_band2_kernel<T, K, E1, E2, TB, S2, BI4, FOLD>), dim3(grid), dim3(T), lds, st, a);
+	hipLaunchKernelGGL((wfa_band2_kernel<T, K, E1, E2, TB, S2, BI4, FOLD, RING>), dim3(grid), dim3(T), lds, st, a);
 }
 
 template <int T, int K, int E1, int E2, bool BI4 = false>

@@ -8,6 +8,7 @@ from miniwfa_amd.api import lib
 import ctypes as C
 from miniwfa_amd.synth import synth_pair, PackedBatch
 eng = mw.Engine(0)
+if len(sys.argv) > 1: eng.set("band_fold", int(sys.argv[1]))
 for n in (1, 512):
     b = eng.upload(PackedBatch([synth_pair(50000, 10000, 0.05)] * n))
     o = mw.opt_init()

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import miniwfa_amd as mw
-from miniwfa_amd.synth import synth_pair, fuzz_pairs, PackedBatch
+from miniwfa_amd.synth import synth_pair, fuzz_pairs, skewed_pairs, PackedBatch
 from conftest import load_golden, golden_inputs
 from oracle.pyoracle import make_opt, cigar_str as ocig
 
@@ -683,6 +683,72 @@ def test_packed_band_kernel_fuzz_against_oracle(block, oracle):
                 assert b.cigar(i, int(nc[i])).tolist() == ecig, (block, kw, i)
         b.free()
         eng.close()
+
+
+def test_window_start_climbing_under_default_routing(oracle):
+    """Unrelated pairs of 2-3 kb in one batch take the four-slot 512-thread geometry under the default routing; their windows reach the top
+    of the matrix and their START climbs at the shrinks.  The slot mapping used to follow at once: the slot that wrapped ran the chunk 32
+    further up while it aged, and that chunk's dead stores fell beyond the end of the row, into the next one (n_iter off by 82 on one pair
+    of profiles/fuzz_fold.py seed 1 with x = o1 = 2).  Score and CIGAR, two penalty sets, against the oracle."""
+    pairs = skewed_pairs(1, 400, 200, 3000)
+    pairs = [p for i, p in enumerate(pairs) if i % 3 == 0 and max(len(p[0]), len(p[1])) >= 2000]
+    assert len(pairs) >= 60
+    pk = PackedBatch(pairs)
+    for kw in (dict(x=2, o1=2, e1=2, o2=12, e2=1), dict()):
+        exp = [oracle.align(t, q, make_opt(flag=1, **kw)) for t, q in pairs]
+        for flag in (0, 1):
+            for fold in (0, 1):
+                eng = mw.Engine(0)
+                eng.set("band_fold", fold)
+                b = eng.upload(pk)
+                b.align(mw.opt_init(flag=flag, **kw))
+                s, it, nc = b.results()
+                for i, (es, eit, ecig) in enumerate(exp):
+                    assert (int(s[i]), int(it[i])) == (es, eit), (kw, flag, fold, i)
+                    if flag:
+                        assert b.cigar(i, int(nc[i])).tolist() == ecig, (kw, flag, fold, i)
+                b.free()
+                eng.close()
+
+
+def test_folded_band_kernel_against_unfolded_and_oracle(oracle):
+    """Score-only with o1 == x (the default penalties) the packed band kernel keeps max(E1, H[s-x]) in the registers that held E1 and never loads
+    the row of lag o1+e1 (mwf_band2.hip: FOLD).  Pairs whose window moves UP (a query much shorter or longer than its target: diagonals run out
+    of the matrix and the window's start climbs across chunk boundaries — the slot mapping must follow late), shrinks, several penalty sets
+    with o1 == x and one without: folded == unfolded == oracle (s, n_iter)."""
+    rng = np.random.default_rng(4242)
+    pairs = []
+    for i in range(24):
+        tl, ql = ((2600, 700), (700, 2600), (1800, 1500), (3000, 2900))[i % 4]
+        t = rng.integers(0, 4, tl + int(rng.integers(0, 300))).astype(np.uint8)
+        if i % 8 < 4:   # unrelated: the window reaches the corners of the matrix
+            q = rng.integers(0, 4, ql + int(rng.integers(0, 300))).astype(np.uint8)
+        else:           # related with one long gap: the window drifts to one side
+            cut = int(rng.integers(50, 400))
+            q = np.concatenate([t[:len(t) // 3], t[len(t) // 3 + cut:]])[:max(ql, 400)].copy()
+            flip = rng.random(len(q)) < 0.06
+            q[flip] = (q[flip] + rng.integers(1, 4, int(flip.sum()))) & 3
+        pairs.append((bytes(b"ACGT"[int(c)] for c in t), bytes(b"ACGT"[int(c)] for c in q)))
+    pairs += fuzz_pairs(77, 24, 2500)
+    pk = PackedBatch(pairs)
+    for kw in (dict(), dict(x=2, o1=2, e1=2, o2=12, e2=1), dict(x=6, o1=6, e1=1, o2=30, e2=1), dict(x=3, o1=3, e1=2, o2=9, e2=2), dict(x=4, o1=5, e1=2)):
+        o = make_opt(**kw)
+        want = [oracle.align(t, q, o)[:2] for t, q in pairs]
+        for block in (0, 512, 1024):
+            got = {}
+            for fold in (1, 0):
+                eng = mw.Engine(0)
+                eng.set("band_fold", fold)
+                if block:
+                    eng.set("force_kind", 2), eng.set("block", block), eng.set("band_pack", 1)
+                b = eng.upload(pk)
+                b.align(mw.opt_init(**kw))
+                s, it, _ = b.results()
+                got[fold] = [(int(a), int(c)) for a, c in zip(s, it)]
+                b.free()
+                eng.close()
+            assert got[1] == want, (kw, block, [i for i in range(len(pairs)) if got[1][i] != want[i]][:5])
+            assert got[0] == want, (kw, block)
 
 
 @pytest.mark.parametrize("chunks", [1, 2, 4])
