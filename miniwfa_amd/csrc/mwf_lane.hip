@@ -38,7 +38,11 @@ constexpr int32_t kDead16 = -32768;
 
 __device__ __forceinline__ int32_t row_ints(int nc) { return 32 * nc + 2; } // a row: pad, 64 x nc columns, pad as int16, rounded up to dwords
 
-template <bool TB, bool S2, typename ArgsT>
+// FOLD (score-only, o1 == x as in the default penalties; the packed band kernel's form, mwf_band2.hip): the E1 / F1 rows hold
+// max(E1, H[s-x]) / max(F1, H[s-x]) — what the reference computes e1 penalties later from the row of lag o1+e1 (miniwfa.c:267-278) — and that
+// row is not read: two LDS reads less per chunk.  Windows never shrink here (the kernel hands a pair back before the first shrink), so a
+// column that held a live H was computed at every later penalty.
+template <bool TB, bool S2, bool FOLD, typename ArgsT>
 __device__ PassResult lane_pass(const ArgsT &A, PairMem &M, int16_t *rows, const uint8_t *lt, const uint8_t *lq, bool trace_band)
 {
 	const int32_t tl = M.tl, ql = M.ql, cmax = tl + ql + 1;
@@ -116,7 +120,8 @@ __device__ PassResult lane_pass(const ArgsT &A, PairMem &M, int16_t *rows, const
 			const int32_t d = c - center;
 			// sources (reference wf_next_prep, miniwfa.c:252-257): entries idx-1, idx, idx+1 at byte offsets 0, 2, 4 of `ga` in a row
 			const char *const pX = base + ga + oX, *const pA = base + ga + oA, *const pB = base + ga + oB;
-			const int32_t hx = *(const int16_t*)(pX + 2), o1m = *(const int16_t*)pA, o1p = *(const int16_t*)(pA + 4), o2m = *(const int16_t*)pB, o2p = *(const int16_t*)(pB + 4);
+			const int32_t hx = *(const int16_t*)(pX + 2), o2m = *(const int16_t*)pB, o2p = *(const int16_t*)(pB + 4);
+			const int32_t o1m = FOLD ? kDead16 : *(const int16_t*)pA, o1p = FOLD ? kDead16 : *(const int16_t*)(pA + 4);
 			char *const pE1 = base + ga + (bE1 + o1), *const pF1 = base + ga + (bF1 + o1), *const pE2 = base + ga + (bE2 + o2), *const pF2 = base + ga + (bF2 + o2);
 			int32_t g1m = *(const int16_t*)pE1, g1p = *(const int16_t*)(pF1 + 4), g2m = *(const int16_t*)pE2, g2p = *(const int16_t*)(pF2 + 4);
 			if (k > 0) { // lane 31: the column left of the previous chunk's first; lane 32: the column right of its last
@@ -130,7 +135,8 @@ __device__ PassResult lane_pass(const ArgsT &A, PairMem &M, int16_t *rows, const
 			}
 			const bool act = c >= lo && c <= hi;
 			const Cell v = wf_cell<TB>(hx, o1m, g1m, o2m, g2m, o1p, g1p, o2p, g2p);
-			*(int16_t*)(pE1 + 2) = (int16_t)(act ? max(v.e1, kDead16) : kDead16), *(int16_t*)(pF1 + 2) = (int16_t)(act ? max(v.f1, kDead16) : kDead16);
+			if (FOLD) *(int16_t*)(pE1 + 2) = (int16_t)max(act ? v.e1 : kDead16, hx), *(int16_t*)(pF1 + 2) = (int16_t)max(act ? v.f1 : kDead16, hx); // (hx >= kDead16: it was read as an int16)
+			else *(int16_t*)(pE1 + 2) = (int16_t)(act ? max(v.e1, kDead16) : kDead16), *(int16_t*)(pF1 + 2) = (int16_t)(act ? max(v.f1, kDead16) : kDead16);
 			*(int16_t*)(pE2 + 2) = (int16_t)(act ? max(v.e2, kDead16) : kDead16), *(int16_t*)(pF2 + 2) = (int16_t)(act ? max(v.f2, kDead16) : kDead16);
 			// match extension (reference wf_extend, miniwfa.c:208-246) of the cells inside the matrix
 			const bool inm = act && in_matrix(d, v.h, tl, ql);
@@ -176,7 +182,7 @@ __device__ PassResult lane_pass(const ArgsT &A, PairMem &M, int16_t *rows, const
 	return R;
 }
 
-template <bool TB, bool S2>
+template <bool TB, bool S2, bool FOLD = false>
 __global__ __launch_bounds__(64) void wfa_lane_kernel(const BatchArgs)
 {
 	// the arguments are read from the kernarg segment where they are used (mwf_device.h): nothing of them stays in SGPRs across the penalties
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(64) void wfa_lane_kernel(const BatchArgs)
 		}
 		__syncthreads(); // (one wave: orders the copies before the dword reads of the extension for the compiler)
 		const bool trace = A.dbg && pair == A.debug_pair;
-		if (R.status == ST_OK) R = lane_pass<TB, S2>(fresh(A), M, rows, lt, lq, trace);
+		if (R.status == ST_OK) R = lane_pass<TB, S2, FOLD>(fresh(A), M, rows, lt, lq, trace);
 		if (S2) M.t2 = lt, M.q2 = lq; // the traceback's back-match stays on chip
 		finish_pair(fresh(A), M, (int32_t)blockIdx.x, pair, R, R.status, 0, &cig_loc);
 	}
@@ -242,7 +248,8 @@ int launch_lane(const BatchArgs &a, int grid, int lds, bool seq2, void *stream)
 {
 	// deep rings (large gap-open costs) or a raised lane_max_len: beyond 48 KB of dynamic LDS the runtime wants to be told (the attribute is
 	// per device and this may run on several host threads: set on every launch that needs it, as the band kernels do)
-	const void *fn = a.want_cigar ? (seq2 ? reinterpret_cast<const void*>(&wfa_lane_kernel<true, true>) : reinterpret_cast<const void*>(&wfa_lane_kernel<true, false>))
+	const bool fold = !a.want_cigar && seq2 && a.band_fold && a.pen.oe1 - a.pen.x == a.pen.e1;
+	const void *fn = fold ? reinterpret_cast<const void*>(&wfa_lane_kernel<false, true, true>) : a.want_cigar ? (seq2 ? reinterpret_cast<const void*>(&wfa_lane_kernel<true, true>) : reinterpret_cast<const void*>(&wfa_lane_kernel<true, false>))
 	                              : (seq2 ? reinterpret_cast<const void*>(&wfa_lane_kernel<false, true>) : reinterpret_cast<const void*>(&wfa_lane_kernel<false, false>));
 	if (lds > 48 * 1024) {
 		(void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -251,7 +258,8 @@ int launch_lane(const BatchArgs &a, int grid, int lds, bool seq2, void *stream)
 	if (a.want_cigar) {
 		if (seq2) hipLaunchKernelGGL((wfa_lane_kernel<true, true>), dim3(grid), dim3(64), lds, (hipStream_t)stream, a);
 		else hipLaunchKernelGGL((wfa_lane_kernel<true, false>), dim3(grid), dim3(64), lds, (hipStream_t)stream, a);
-	} else {
+	} else if (fold) hipLaunchKernelGGL((wfa_lane_kernel<false, true, true>), dim3(grid), dim3(64), lds, (hipStream_t)stream, a);
+	else {
 		if (seq2) hipLaunchKernelGGL((wfa_lane_kernel<false, true>), dim3(grid), dim3(64), lds, (hipStream_t)stream, a);
 		else hipLaunchKernelGGL((wfa_lane_kernel<false, false>), dim3(grid), dim3(64), lds, (hipStream_t)stream, a);
 	}

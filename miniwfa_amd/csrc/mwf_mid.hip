@@ -76,7 +76,10 @@ __host__ __device__ inline MidLayout mid_layout(int32_t nH, int32_t e1, int32_t 
 	return L;
 }
 
-template <int T, bool TB, bool S2, typename ArgsT>
+// FOLD (score-only, o1 == x; the packed band kernel's form, mwf_band2.hip): the E1 / F1 rows hold max(E1, H[s-x]) / max(F1, H[s-x]) and the
+// row of lag o1+e1 is not read — two LDS reads less per group.  Every penalty writes the window and nH columns either side, and a window moves
+// by one column per penalty (a shrink only cuts it): the columns next to the window of penalty s were written at penalty s - e1.
+template <int T, bool TB, bool S2, bool FOLD, typename ArgsT>
 __device__ PassResult mid_pass(const ArgsT &A, PairMem &M, const MidLayout &L, const uint8_t *lt, const uint8_t *lq, bool trace_band)
 {
 	constexpr int NW = T / 64;
@@ -170,12 +173,14 @@ __device__ PassResult mid_pass(const ArgsT &A, PairMem &M, const MidLayout &L, c
 			const int32_t d = c - 1 - tl;
 			// sources (reference wf_next_prep, miniwfa.c:252-257)
 			const char *const pX = base + ga + oX, *const pA = base + ga + oA, *const pB = base + ga + oB;
-			const int32_t hx = *(const int16_t*)(pX + 2), o1m = *(const int16_t*)pA, o1p = *(const int16_t*)(pA + 4), o2m = *(const int16_t*)pB, o2p = *(const int16_t*)(pB + 4);
+			const int32_t hx = *(const int16_t*)(pX + 2), o2m = *(const int16_t*)pB, o2p = *(const int16_t*)(pB + 4);
+			const int32_t o1m = FOLD ? kDead16 : *(const int16_t*)pA, o1p = FOLD ? kDead16 : *(const int16_t*)(pA + 4);
 			const int32_t g1m = *(const int16_t*)(base + ga + (bE1 + oR1)), g1p = *(const int16_t*)(base + ga + (bF1 + oR1) + 4);
 			const int32_t g2m = *(const int16_t*)(base + ga + (bE2 + oR2)), g2p = *(const int16_t*)(base + ga + (bF2 + oR2) + 4);
 			const bool act = c >= lo && c <= hi;
 			const Cell v = wf_cell<TB>(hx, o1m, g1m, o2m, g2m, o1p, g1p, o2p, g2p);
-			*(int16_t*)(base + ga + (bE1 + oN1) + 2) = (int16_t)(act ? max(v.e1, kDead16) : kDead16), *(int16_t*)(base + ga + (bF1 + oN1) + 2) = (int16_t)(act ? max(v.f1, kDead16) : kDead16);
+			if (FOLD) *(int16_t*)(base + ga + (bE1 + oN1) + 2) = (int16_t)max(act ? v.e1 : kDead16, hx), *(int16_t*)(base + ga + (bF1 + oN1) + 2) = (int16_t)max(act ? v.f1 : kDead16, hx);
+			else *(int16_t*)(base + ga + (bE1 + oN1) + 2) = (int16_t)(act ? max(v.e1, kDead16) : kDead16), *(int16_t*)(base + ga + (bF1 + oN1) + 2) = (int16_t)(act ? max(v.f1, kDead16) : kDead16);
 			*(int16_t*)(base + ga + (bE2 + oN2) + 2) = (int16_t)(act ? max(v.e2, kDead16) : kDead16), *(int16_t*)(base + ga + (bF2 + oN2) + 2) = (int16_t)(act ? max(v.f2, kDead16) : kDead16);
 			// match extension (reference wf_extend, miniwfa.c:400-411) of the cells inside the matrix
 			const bool inm = act && in_matrix(d, v.h, tl, ql);
@@ -267,7 +272,7 @@ __device__ PassResult mid_pass(const ArgsT &A, PairMem &M, const MidLayout &L, c
 	return R;
 }
 
-template <int T, bool TB, bool S2>
+template <int T, bool TB, bool S2, bool FOLD = false>
 __global__ __launch_bounds__(T, 1) void wfa_mid_kernel(const BatchArgs)
 {
 	// the arguments are read from the kernarg segment where they are used (mwf_device.h): nothing of them stays in SGPRs across the penalties
@@ -305,21 +310,24 @@ __global__ __launch_bounds__(T, 1) void wfa_mid_kernel(const BatchArgs)
 			__syncthreads();
 		}
 		const bool trace = A.dbg && pair == A.debug_pair;
-		if (R.status == ST_OK) R = mid_pass<T, TB, S2>(fresh(A), M, L, lt, lq, trace);
+		if (R.status == ST_OK) R = mid_pass<T, TB, S2, FOLD>(fresh(A), M, L, lt, lq, trace);
 		if (S2) M.t2 = lt, M.q2 = lq; // the traceback's back-match stays on chip
 		finish_pair(fresh(A), M, (int32_t)blockIdx.x, pair, R, R.status, 0);
 	}
 }
 
-template <int T, bool TB, bool S2>
+template <int T, bool TB, bool S2, bool FOLD = false>
 int launch_v(const BatchArgs &a, int grid, int lds, hipStream_t st)
 {
+	if constexpr (!TB && S2 && !FOLD) {
+		if (a.band_fold && a.pen.oe1 - a.pen.x == a.pen.e1) return launch_v<T, TB, S2, true>(a, grid, lds, st);
+	}
 	// beyond 48 KB of dynamic LDS the runtime wants to be told (per device, and this may run on several host threads: on every launch)
 	if (lds > 48 * 1024) {
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wfa_mid_kernel<T, TB, S2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wfa_mid_kernel<T, TB, S2, FOLD>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 		(void)hipGetLastError();
 	}
-	hipLaunchKernelGGL((wfa_mid_kernel<T, TB, S2>), dim3(grid), dim3(T), lds, st, a);
+	hipLaunchKernelGGL((wfa_mid_kernel<T, TB, S2, FOLD>), dim3(grid), dim3(T), lds, st, a);
 	return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
