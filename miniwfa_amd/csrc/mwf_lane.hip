@@ -248,8 +248,8 @@ int launch_lane(const BatchArgs &a, int grid, int lds, bool seq2, void *stream)
 {
 	// deep rings (large gap-open costs) or a raised lane_max_len: beyond 48 KB of dynamic LDS the runtime wants to be told (the attribute is
 	// per device and this may run on several host threads: set on every launch that needs it, as the band kernels do)
-	const bool fold = !a.want_cigar && seq2 && a.band_fold && a.pen.oe1 - a.pen.x == a.pen.e1;
-	const void *fn = fold ? reinterpret_cast<const void*>(&wfa_lane_kernel<false, true, true>) : a.want_cigar ? (seq2 ? reinterpret_cast<const void*>(&wfa_lane_kernel<true, true>) : reinterpret_cast<const void*>(&wfa_lane_kernel<true, false>))
+	const bool fold = !a.want_cigar && a.band_fold && a.pen.oe1 - a.pen.x == a.pen.e1;
+	const void *fn = fold ? (seq2 ? reinterpret_cast<const void*>(&wfa_lane_kernel<false, true, true>) : reinterpret_cast<const void*>(&wfa_lane_kernel<false, false, true>)) : a.want_cigar ? (seq2 ? reinterpret_cast<const void*>(&wfa_lane_kernel<true, true>) : reinterpret_cast<const void*>(&wfa_lane_kernel<true, false>))
 	                              : (seq2 ? reinterpret_cast<const void*>(&wfa_lane_kernel<false, true>) : reinterpret_cast<const void*>(&wfa_lane_kernel<false, false>));
 	if (lds > 48 * 1024) {
 		(void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -258,8 +258,10 @@ int launch_lane(const BatchArgs &a, int grid, int lds, bool seq2, void *stream)
 	if (a.want_cigar) {
 		if (seq2) hipLaunchKernelGGL((wfa_lane_kernel<true, true>), dim3(grid), dim3(64), lds, (hipStream_t)stream, a);
 		else hipLaunchKernelGGL((wfa_lane_kernel<true, false>), dim3(grid), dim3(64), lds, (hipStream_t)stream, a);
-	} else if (fold) hipLaunchKernelGGL((wfa_lane_kernel<false, true, true>), dim3(grid), dim3(64), lds, (hipStream_t)stream, a);
-	else {
+	} else if (fold) {
+		if (seq2) hipLaunchKernelGGL((wfa_lane_kernel<false, true, true>), dim3(grid), dim3(64), lds, (hipStream_t)stream, a);
+		else hipLaunchKernelGGL((wfa_lane_kernel<false, false, true>), dim3(grid), dim3(64), lds, (hipStream_t)stream, a);
+	} else {
 		if (seq2) hipLaunchKernelGGL((wfa_lane_kernel<false, true>), dim3(grid), dim3(64), lds, (hipStream_t)stream, a);
 		else hipLaunchKernelGGL((wfa_lane_kernel<false, false>), dim3(grid), dim3(64), lds, (hipStream_t)stream, a);
 	}

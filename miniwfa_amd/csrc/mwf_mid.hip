@@ -319,7 +319,7 @@ __global__ __launch_bounds__(T, 1) void wfa_mid_kernel(const BatchArgs)
 template <int T, bool TB, bool S2, bool FOLD = false>
 int launch_v(const BatchArgs &a, int grid, int lds, hipStream_t st)
 {
-	if constexpr (!TB && S2 && !FOLD) {
+	if constexpr (!TB && !FOLD) {
 		if (a.band_fold && a.pen.oe1 - a.pen.x == a.pen.e1) return launch_v<T, TB, S2, true>(a, grid, lds, st);
 	}
 	// beyond 48 KB of dynamic LDS the runtime wants to be told (per device, and this may run on several host threads: on every launch)
