@@ -319,8 +319,11 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 	// max(E1, H[s-x]) (max(F1, H[s-x])) instead — the maximum is what the reference computes e1 penalties later — and the kernel does
 	// not load the row of lag o1+e1 at all.  A chunk that left the window keeps running until the rows it computed have been folded
 	// and aged out: kAgeOut penalties (the host asks for this form only when o1 + e1 <= kFoldMaxLag).
+	// With traceback the byte must tell an opened first gap piece from an extended one (miniwfa.c:289-306) — the comparison the fold no
+	// longer makes at the cell itself.  It makes it e1 penalties EARLIER, in the neighbouring column, where both terms are at hand:
+	// E1[s] > H[s-x] there means "the E1 of penalty s+e1 one column on is an extension".  Bits 3 and 4 of a folded byte say that
+	// (PairMem::tb_fwd), and the walk reads them from the cell an extension would come from (traceback_wave: one more byte per gap run).
 	constexpr int kAgeOut = FOLD ? kFoldMaxLag : D;
-	static_assert(!FOLD || !TB, "the traceback byte tells an opened gap from an extended one: it needs both terms");
 	constexpr int kAge = (NWK + 2) * 16; // bytes of one age of the edge table
 	static_assert(D == 2 || D == 3, "edge-table ages");
 	const int32_t tl = M.tl, ql = M.ql, cmax = tl + ql + 1;
@@ -609,8 +612,10 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 				zA = pk_mad(pk_ne1(hA, ne2A), zA, TWO), zB = pk_mad(pk_ne1(hB, ne2B), zB, TWO);
 				zA = pk_mad(pk_ne1(hA, ne1A), zA, ONE), zB = pk_mad(pk_ne1(hB, ne1B), zB, ONE);
 				zA = pk_mad(pk_ne1(hA, mA), zA, 0), zB = pk_mad(pk_ne1(hB, mB), zB, 0);
-				zA = pk_mad(pk_ne1(ne1A, o1mA), EIGHT, zA), zB = pk_mad(pk_ne1(ne1B, O1.x), EIGHT, zB);
-				zA = pk_mad(pk_ne1(pf1A, O1.y), C16, zA), zB = pk_mad(pk_ne1(pf1B, o1pB), C16, zB);
+				if (!FOLD) {
+					zA = pk_mad(pk_ne1(ne1A, o1mA), EIGHT, zA), zB = pk_mad(pk_ne1(ne1B, O1.x), EIGHT, zB);
+					zA = pk_mad(pk_ne1(pf1A, O1.y), C16, zA), zB = pk_mad(pk_ne1(pf1B, o1pB), C16, zB);
+				}
 				zA = pk_mad(pk_ne1(ne2A, o2mA), C32, zA), zB = pk_mad(pk_ne1(ne2B, O2.x), C32, zB);
 				zA = pk_mad(pk_ne1(pf2A, O2.y), C64, zA), zB = pk_mad(pk_ne1(pf2B, o2pB), C64, zB);
 				tbw = (uint32_t)zA | ((uint32_t)zB << 8); // bytes in column order: c0 = A.lo, c1 = B.lo, c2 = A.hi, c3 = B.hi
@@ -665,6 +670,12 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 			// ---- the new E/F are final: age the registers, publish this chunk's outer columns for the neighbouring slots
 			if (FOLD) { // with the row read for the mismatch term: what the gap opens from e1 penalties from now (HX is not masked: it is dead outside ITS window)
 				ne1A = pk_max(ne1A, HX.x), ne1B = pk_max(ne1B, HX.y), nf1A = pk_max(nf1A, HX.x), nf1B = pk_max(nf1B, HX.y);
+				if (TB) { // the forward bits: this cell's E1 / F1 (dead outside the window) exceed the H a gap would be opened from
+					const int32_t EIGHT = 0x00080008, C16 = 0x00100010;
+					const int32_t fA = pk_mad(pk_ne1(ne1A, HX.x), EIGHT, pk_mad(pk_ne1(nf1A, HX.x), C16, 0));
+					const int32_t fB = pk_mad(pk_ne1(ne1B, HX.y), EIGHT, pk_mad(pk_ne1(nf1B, HX.y), C16, 0));
+					tbw |= (uint32_t)fA | ((uint32_t)fB << 8);
+				}
 			}
 			e1h[P1][k][0] = ne1A, e1h[P1][k][1] = ne1B, f1h[P1][k][0] = nf1A, f1h[P1][k][1] = nf1B;
 			e2h[P2][k][0] = ne2A, e2h[P2][k][1] = ne2B, f2h[P2][k][0] = nf2A, f2h[P2][k][1] = nf2B;
@@ -987,6 +998,7 @@ __global__ __launch_bounds__(T, MWF_IS_SPAN(T, K) ? (T == 1024 ? 4 : 3) : T == 1
 		if (T == 512 && K == 4 && R.n_snap && threadIdx.x == 0 && fresh(A0).report_wide) atomicOr((unsigned int*)(fresh(A0).cig_head + 1), 1u); // (mwf_plan.cpp: PlanCache::wide_state)
 		R.n_snap = 0;
 		if (S2) M.t2 = lds2, M.q2 = lds2 + qoff; // the traceback's back-match reads the 2-bit copies in LDS
+		if (TB && FOLD) M.tb_fwd = 1;
 		finish_pair(fresh(A0), M, (int32_t)blockIdx.x, pair, R, R.status, 0, T <= 256 ? &cig_loc : nullptr); // (block mode: the geometries of the short pairs — thousands per launch)
 	}
 }
@@ -997,8 +1009,8 @@ constexpr int lds_tail() { return (int)sizeof(Band2Lds<(E1 > E2 ? E1 : E2) + 1, 
 template <int T, int K, int E1, int E2, bool TB, bool S2, bool BI4 = false, bool FOLD = false>
 void launch_variant(const BatchArgs &a, int grid, int lds, hipStream_t st)
 {
-	// score-only on the 512-thread (and wider) geometries with o1 == x: the folded form (band2_pass), two row loads less per chunk
-	if constexpr (!TB && !FOLD && T >= 512) {
+	// the 512-thread (and wider) geometries with o1 == x: the folded form (band2_pass), two row loads less per chunk
+	if constexpr (!FOLD && T >= 512) {
 		if (a.band_fold && a.pen.oe1 - a.pen.x == E1 && a.pen.oe1 < kFoldMaxLag) return launch_variant<T, K, E1, E2, TB, S2, BI4, true>(a, grid, lds, st);
 	}
 	// the attribute is per device and this may run on several host threads (mwf_wfa_batch_multi): set it on every launch that needs it

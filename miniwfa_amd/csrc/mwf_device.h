@@ -270,6 +270,10 @@ struct PairMem {
 	int32_t ep_ow, ep_p, ep_kw;
 	// rows of a fixed width that all start at the same column (mwf_lane.hip): byte of (row, col) at row * tb_stride + col - tb_left; 0: not this layout
 	int32_t tb_stride, tb_left;
+	// Packed band kernel, folded form with traceback (mwf_band2.hip): bits 3 and 4 of a byte look FORWARD — E1 (F1) of this cell exceeds the H it
+	// would be opened from, i.e. the E1 (F1) of penalty + e1 in the neighbouring column is an extension of this one — instead of saying whether
+	// this cell's own E1 (F1) was extended: the walk reads them from the cell an extension would come from.
+	int32_t tb_fwd;
 	// 2-bit copies of the two sequences in LDS (kernels that hold them: the traceback's back-match then stays on chip); null: compare
 	// the bytes at ts / qs (which may themselves point into LDS)
 	const uint8_t *t2, *q2;
@@ -383,14 +387,25 @@ static __device__ int32_t traceback_wave(const ArgsT &A, const PairMem &M, uint3
 		if (pf_now) asm volatile("" :: "v"(pf)); // (the prefetched bytes have arrived — and stay in L2)
 		const uint32_t x = x_next;
 		const int32_t state = last == 0 ? (int32_t)(x & 7u) : last;           // :346
-		const int32_t ext = state > 0 ? (int32_t)(x >> (state + 2)) & 1 : 0;  // :347
+		int32_t ext = state > 0 ? (int32_t)(x >> (state + 2)) & 1 : 0;        // :347
+		uint32_t x_from = 0;
+		const bool fwd = M.tb_fwd && (state == 1 || state == 2);
+		if (fwd) { // the first gap piece's bit sits in the cell the extension would come from; a cell its row does not hold was not computed: dead, no extension
+			const int32_t r2 = row - P.e1, c2 = i - k + M.tl + 1 + (state == 1 ? -1 : 1);
+			ext = 0;
+			if (r2 >= 0) {
+				const int64_t at = M.row_off[r2] + (c2 - M.row_lo[r2]);
+				if (c2 >= M.row_lo[r2] && at < M.row_off[r2 + 1]) x_from = M.tb[at], ext = (int32_t)(x_from >> (state + 2)) & 1;
+			}
+		}
 		if (state == 0) { push(8, 1); --i, --k; row -= P.x; }
 		else if (state == 1) { push(1, 1); --i; row -= ext ? P.e1 : P.oe1; }
 		else if (state == 3) { push(1, 1); --i; row -= ext ? P.e2 : P.oe2; }
 		else if (state == 2) { push(2, 1); --k; row -= ext ? P.e1 : P.oe1; }
 		else { push(2, 1); --k; row -= ext ? P.e2 : P.oe2; }
 		last = (state > 0 && ext) ? state : 0;                                // :365
-		if (row >= 0 && i >= 0 && k >= 0) x_next = tb_byte(M, row, i - k + M.tl + 1); // (the cell the path came from: its row holds it)
+		if (fwd && ext) x_next = x_from; // (the cell just looked at)
+		else if (row >= 0 && i >= 0 && k >= 0) x_next = tb_byte(M, row, i - k + M.tl + 1); // (the cell the path came from: its row holds it)
 	}
 	end_state[0] = row, end_state[1] = i, end_state[2] = k;
 	if (i >= 0) push(1, i + 1);          // :368-369
@@ -425,7 +440,7 @@ __device__ __forceinline__ void pair_mem(const ArgsT &A, int32_t slot, int32_t p
 	M.seg = A.seg ? A.seg + (int64_t)slot * 2 * A.seg_slot : 0;
 	M.dbg = A.dbg;
 	M.ep = 0, M.ep_ow = 0, M.ep_p = 0, M.ep_kw = 0;
-	M.tb_stride = 0, M.tb_left = 0;
+	M.tb_stride = 0, M.tb_left = 0, M.tb_fwd = 0;
 	M.t2 = M.q2 = 0;
 }
 

@@ -8,7 +8,7 @@ for seed in (50000, 60000, 70000, 80000):
     pk = PackedBatch([synth_pair(seed + i, 10000, 0.05) for i in range(1024)])
     eng = mw.Engine(0)
     if len(sys.argv) > 1: eng.set("band_fold", int(sys.argv[1]))  # 0: rows of all three lags from HBM, 1: folded form, 2: and the last penalties' rows in LDS (default)
-    b = eng.upload(pk); o = mw.opt_init()
+    b = eng.upload(pk); o = mw.opt_init(flag=int(sys.argv[2]) if len(sys.argv) > 2 else 0)  # second argument 1: with CIGAR
     w = []
     for _ in range(6):
         t0 = time.perf_counter(); b.align(o); s, it, _ = b.results(); w.append((time.perf_counter() - t0) * 1e3)

@@ -715,7 +715,7 @@ def test_folded_band_kernel_against_unfolded_and_oracle(oracle):
     """Score-only with o1 == x (the default penalties) the packed band kernel keeps max(E1, H[s-x]) in the registers that held E1 and never loads
     the row of lag o1+e1 (mwf_band2.hip: FOLD).  Pairs whose window moves UP (a query much shorter or longer than its target: diagonals run out
     of the matrix and the window's start climbs across chunk boundaries — the slot mapping must follow late), shrinks, several penalty sets
-    with o1 == x and one without: folded == unfolded == oracle (s, n_iter)."""
+    with o1 == x and one without: folded == unfolded == oracle (s, n_iter), and the folded form's CIGARs == the oracle's."""
     rng = np.random.default_rng(4242)
     pairs = []
     for i in range(24):
@@ -749,6 +749,19 @@ def test_folded_band_kernel_against_unfolded_and_oracle(oracle):
                 eng.close()
             assert got[1] == want, (kw, block, [i for i in range(len(pairs)) if got[1][i] != want[i]][:5])
             assert got[0] == want, (kw, block)
+        # with CIGAR the folded form records "this cell's E1 / F1 exceeds the H a gap would open from" and the walk reads that bit from the
+        # cell an extension would come from (PairMem::tb_fwd): the CIGARs must still be the reference's
+        exp = [oracle.align(t, q, make_opt(flag=1, **kw)) for t, q in pairs]
+        for block in (512, 1024):
+            eng = mw.Engine(0)
+            eng.set("force_kind", 2), eng.set("block", block), eng.set("band_pack", 1)
+            b = eng.upload(pk)
+            b.align(mw.opt_init(flag=1, **kw))
+            s, it, nc = b.results()
+            for i, (es, eit, ecig) in enumerate(exp):
+                assert (int(s[i]), int(it[i])) == (es, eit) and b.cigar(i, int(nc[i])).tolist() == (ecig or []), (kw, block, i)
+            b.free()
+            eng.close()
 
 
 @pytest.mark.parametrize("chunks", [1, 2, 4])
