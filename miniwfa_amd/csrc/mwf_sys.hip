@@ -354,7 +354,10 @@ __device__ PassResult sys_pass(const BatchArgs &A, const PairMem &M, SysLds &L, 
 	}
 	if (!sys_grid_sync(spin_limit, sync, &gflags[15], (unsigned)lb, L, epoch, G)) { R.status = ST_INTERNAL; return R; }
 	const int32_t k0 = uni(ld_ag(&gflags[12]));
-	if (k0 == tl - 1 && k0 == ql - 1) return R;
+	if (k0 == tl - 1 && k0 == ql - 1) {
+		if (SEG) R.info = -1; // the end cell IS the origin, whose provenance is -1 (miniwfa.c:119): the checkpoint trace expects the chain to end there
+		return R;
+	}
 
 	int32_t s = 0, wf_lo = tl + 1, wf_hi = tl + 1;
 	if (TB) n_seg = seg_effective(M.seg, n_seg);

@@ -1145,6 +1145,30 @@ def test_whole_device_kernel_true_low_memory_mode(oracle):
     eng.close()
 
 
+def test_identical_pair_side_by_side_in_two_pass_low_memory_mode(oracle, capfd):
+    """Six or more pairs side by side on the whole-device kernel take the two-pass low-memory form (their walk arenas together exceed the
+    budget).  A pair of IDENTICAL sequences ends at penalty 0; its provenance pass used to report the end cell's provenance as 0 instead of
+    -1 (the origin, miniwfa.c:119), the checkpoint trace refused the chain and the pair was re-run on the one-workgroup generic kernel with
+    a "gave up waiting" warning (found by profiles/fuzz_all_kernels_oracle.py).  No re-run, no warning, the reference's answers."""
+    same = synth_pair(96100, 2048, 0.0)[0]
+    pairs = [synth_pair(96000 + i, 2000, 0.1) for i in range(8)] + [(same, same)]
+    eng = mw.Engine(0)
+    eng.set("force_kind", 1)
+    o = make_opt(flag=1, step=97)
+    b = eng.upload(PackedBatch(pairs))
+    b.align(mw.opt_init(flag=1, step=97))
+    s, it, nc = b.results()
+    st = eng.stats()
+    assert st.kernel_kind == 1 and st.lowmem_two_pass == 1 and st.n_retries == 0
+    for i, (t, q) in enumerate(pairs):
+        es, eit, ecig = oracle.align(t, q, o)
+        assert (int(s[i]), int(it[i])) == (es, eit) and b.cigar(i, int(nc[i])).tolist() == ecig, i
+    assert int(s[-1]) == 0
+    b.free()
+    eng.close()
+    assert "gave up" not in capfd.readouterr().err
+
+
 def test_two_threads_on_the_whole_device_kernel(oracle, capfd):
     """Two host threads, each aligning long pairs through the drop-in API at the same time: both land on the whole-device
     kernel, whose workgroups wait for one another and therefore must all be resident — launches are serialised per device,
