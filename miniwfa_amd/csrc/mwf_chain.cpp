@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <chrono>
 #include "miniwfa.h"
 #include "kalloc.h"
 
@@ -28,6 +29,30 @@ inline int base_code(unsigned char c)
 	case 'T': case 't': case 'U': case 'u': return 3;
 	default: return 4;
 	}
+}
+
+// Ascending sort of 64-bit keys: least-significant-digit radix sort on the bytes that differ between keys (the reference sorts its k-mers and
+// anchor pairs with a radix sort too, miniwfa.c:699-716 — tens of thousands of keys per call, where std::sort was a third of a call's host time);
+// any correct sort gives the reference's order: the keys are compared whole.
+void sort_u64(std::vector<uint64_t> &a)
+{
+	const size_t n = a.size();
+	if (n < 512) { std::sort(a.begin(), a.end()); return; }
+	uint64_t all_or = 0, all_and = ~0ULL;
+	for (uint64_t v : a) all_or |= v, all_and &= v;
+	const uint64_t varies = all_or ^ all_and; // bits that are not the same in every key
+	std::vector<uint64_t> tmp(n);
+	uint64_t *src = a.data(), *dst = tmp.data();
+	for (int shift = 0; shift < 64; shift += 8) {
+		if (((varies >> shift) & 0xff) == 0) continue;
+		size_t count[256] = {0};
+		for (size_t i = 0; i < n; ++i) ++count[(src[i] >> shift) & 0xff];
+		size_t at = 0;
+		for (int d = 0; d < 256; ++d) { const size_t c = count[d]; count[d] = at, at += c; }
+		for (size_t i = 0; i < n; ++i) dst[count[(src[i] >> shift) & 0xff]++] = src[i];
+		std::swap(src, dst);
+	}
+	if (src != a.data()) std::copy(src, src + n, a.data());
 }
 
 // every k-mer of seq as (kmer << 1 | rid) << 32 | end position  (reference mg_fc_kmer, miniwfa.c:718-730)
@@ -78,7 +103,7 @@ std::vector<uint64_t> chain_anchors(int32_t tl, const char *ts, int32_t ql, cons
 	a.reserve((size_t)tl + ql);
 	collect_kmers(tl, ts, 0, k, a);
 	collect_kmers(ql, qs, 1, k, a);
-	std::sort(a.begin(), a.end()); // keys are unique, so any correct sort gives the reference's order
+	sort_u64(a); // keys are unique, so any correct sort gives the reference's order
 	std::vector<uint64_t> b;
 	for (size_t i0 = 0, i = 1; i <= a.size(); ++i) {
 		if (i == a.size() || (a[i0] >> 33) != (a[i] >> 33)) {
@@ -91,7 +116,7 @@ std::vector<uint64_t> chain_anchors(int32_t tl, const char *ts, int32_t ql, cons
 			i0 = i;
 		}
 	}
-	std::sort(b.begin(), b.end());
+	sort_u64(b);
 	for (uint64_t &v : b) v = v >> 32 | v << 32; // order by target position, compare by query position
 	const std::vector<int32_t> lis = longest_increasing(b);
 	anchors.reserve(lis.size());
@@ -125,7 +150,7 @@ double kmer_similarity(int32_t l1, const char *s1, int32_t l2, const char *s2, i
 	std::vector<uint64_t> a;
 	collect_kmers(l1, s1, 0, k, a);
 	collect_kmers(l2, s2, 1, k, a);
-	std::sort(a.begin(), a.end());
+	sort_u64(a);
 	int64_t n1 = 0, n2 = 0, shared = 0;
 	for (size_t i0 = 0, i = 1; i <= a.size(); ++i) {
 		if (i == a.size() || (a[i0] >> 33) != (a[i] >> 33)) {
@@ -172,8 +197,11 @@ inline int32_t gap_cost(const mwf_opt_t *o, int32_t len)
 
 extern "C" void mwf_wfa_chain(void *km, const mwf_opt_t *opt, int32_t tl, const char *ts, int32_t ql, const char *qs, mwf_rst_t *r)
 {
+	static const bool timing = getenv("MWF_CHAIN_TIMING") != nullptr; // (diagnostics: where a call's time goes)
+	const auto t_0 = std::chrono::steady_clock::now();
 	std::vector<uint64_t> anchors = chain_anchors(tl, ts, ql, qs, opt->kmer, opt->max_occ);
 	filter_anchors(anchors, tl, ql, opt->kmer, opt->min_len);
+	const auto t_1 = std::chrono::steady_clock::now();
 	const int32_t n_a = (int32_t)anchors.size();
 	const bool want_cigar = (opt->flag & MWF_F_CIGAR) != 0;
 
@@ -202,8 +230,10 @@ extern "C" void mwf_wfa_chain(void *km, const mwf_opt_t *opt, int32_t tl, const 
 
 	// ---- every gap fill in one device batch (the reference calls mwf_wfa_exact per gap, miniwfa.c:877)
 	std::vector<mwf_rst_t> fills(ftl.size());
+	const auto t_2 = std::chrono::steady_clock::now();
 	if (!ftl.empty())
 		mwf_wfa_batch(nullptr, opt, (int32_t)ftl.size(), ftl.data(), fts.data(), fql.data(), fqs.data(), fills.data());
+	const auto t_3 = std::chrono::steady_clock::now();
 
 	// ---- stitch
 	CigarBuf c;
@@ -230,5 +260,12 @@ extern "C" void mwf_wfa_chain(void *km, const mwf_opt_t *opt, int32_t tl, const 
 	if (!c.w.empty()) {
 		r->cigar = (uint32_t*)kmalloc(km, c.w.size() * sizeof(uint32_t));
 		memcpy(r->cigar, c.w.data(), c.w.size() * sizeof(uint32_t));
+	}
+	if (timing) {
+		auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+		int64_t fill_bases = 0;
+		for (size_t i = 0; i < ftl.size(); ++i) fill_bases += ftl[i] + fql[i];
+		fprintf(stderr, "[libmwf_hip] chain %d x %d: anchors %.2f ms (%d kept), gaps %.2f ms, batch of %zu fills (%lld bases) %.2f ms, stitch %.2f ms\n", tl, ql, ms(t_0, t_1), n_a,
+		        ms(t_1, t_2), ftl.size(), (long long)fill_bases, ms(t_2, t_3), ms(t_3, std::chrono::steady_clock::now()));
 	}
 }
