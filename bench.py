@@ -27,7 +27,7 @@ Printed JSON (one line, rank 0): the driver contract fields plus
                  49 / 97 B per cell x cells / time — exceeds 1 for kernels that keep four of the five arrays on chip), issue fractions
   cpu_baseline — the compiled reference (oracle/_ref, kind "reference") or our C restatement (kind "port")
                  on the host cores, bounded sample of the same batch (rank 0, N=1 only)
-  call_latency_us, short_reads, long_pairs, peak_device_bytes, n_retries — extras (rank 0, N=1 only)
+  call_latency_us, chain_mode, short_reads, long_pairs, peak_device_bytes, n_retries — extras (rank 0, N=1 only)
 """
 from __future__ import annotations
 
@@ -116,6 +116,36 @@ def call_latency(mw, synth_pair, reps=40):
                     ref.align(t, q, ro)
                 rec["cpu_reference_us"] = (time.perf_counter() - t0) / n * 1e6
             out[f"{tl}bp_{label}"] = rec
+    return out
+
+
+def chain_mode(mw, synth_pair, reps=8):
+    """Per-call time of the drop-in mwf_wfa_chain (reference miniwfa.c:850-896: k-mer chaining on the host, every gap fill in one device batch) with
+    CIGAR on a warm engine, next to the compiled reference's; answers compared."""
+    out = {}
+    try:
+        from oracle.pyoracle import Reference, make_opt
+        ref = Reference(arena=True) if Reference.available() else None
+    except Exception:
+        ref = None
+    for tl, p in ((5000, 0.05), (30000, 0.04), (100000, 0.03)):
+        t, q = synth_pair(4242, tl, p, 2, 800)
+        o = mw.opt_init(flag=1)
+        for _ in range(3):
+            s, _, cig = mw.wfa_chain(t, q, o)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            mw.wfa_chain(t, q, o)
+        rec = {"gpu_ms": (time.perf_counter() - t0) / reps * 1e3, "s": int(s)}
+        if ref is not None:
+            ro = make_opt(flag=1)
+            es, _, ecig = ref.chain(t, q, ro)
+            t0 = time.perf_counter()
+            for _ in range(max(2, reps // 2)):
+                ref.chain(t, q, ro)
+            rec["cpu_reference_ms"] = (time.perf_counter() - t0) / max(2, reps // 2) * 1e3
+            rec["matches_reference"] = bool(s == es and (None if cig is None else list(cig)) == ecig)
+        out[f"{tl}bp@{p}"] = rec
     return out
 
 
@@ -712,6 +742,10 @@ def main():
             out["call_latency_us"] = call_latency(mw, synth_pair)
         except Exception as e:  # never lose the headline line over the extras
             out["call_latency_us"] = {"error": repr(e)}
+        try:
+            out["chain_mode"] = chain_mode(mw, synth_pair)
+        except Exception as e:
+            out["chain_mode"] = {"error": repr(e)}
         try:
             out["short_reads"] = short_reads(mw, synth_pair, PackedBatch)
         except Exception as e:
