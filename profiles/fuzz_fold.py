@@ -36,7 +36,8 @@ for name, pairs in sets.items():
             res = {}
             for fold in (1, 0):
                 eng = mw.Engine(0); eng.set("band_fold", fold)
-                if block: eng.set("force_kind", 2); eng.set("block", block); eng.set("band_pack", 1)
+                if block == 1024: eng.set("band_span", 2)   # (the span geometry: 1024 threads x 5 slots)
+                elif block: eng.set("force_kind", 2); eng.set("block", block); eng.set("band_pack", 1)
                 b = eng.upload(pk); b.align(mw.opt_init(**kw)); s, it, _ = b.results()
                 res[fold] = (s.copy(), it.copy(), eng.stats().n_retries)
                 b.free(); eng.close()

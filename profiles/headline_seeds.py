@@ -8,6 +8,7 @@ for seed in (50000, 60000, 70000, 80000):
     pk = PackedBatch([synth_pair(seed + i, 10000, 0.05) for i in range(1024)])
     eng = mw.Engine(0)
     if len(sys.argv) > 1: eng.set("band_fold", int(sys.argv[1]))  # 0: rows of all three lags from HBM, 1: folded form, 2: and the last penalties' rows in LDS (default)
+    if len(sys.argv) > 3 and sys.argv[3] == "span": eng.set("band_span", 2)  # third argument "span": every pair on the 1024-thread span geometry
     b = eng.upload(pk); o = mw.opt_init(flag=int(sys.argv[2]) if len(sys.argv) > 2 else 0)  # second argument 1: with CIGAR
     w = []
     for _ in range(6):

@@ -739,11 +739,15 @@ def test_folded_band_kernel_against_unfolded_and_oracle(oracle):
             for fold in (1, 0):
                 eng = mw.Engine(0)
                 eng.set("band_fold", fold)
-                if block:
+                if block == 1024:
+                    eng.set("band_span", 2)   # every pair the span geometry can hold takes it (1024 threads x 5 slots, biased offsets)
+                elif block:
                     eng.set("force_kind", 2), eng.set("block", block), eng.set("band_pack", 1)
                 b = eng.upload(pk)
                 b.align(mw.opt_init(**kw))
                 s, it, _ = b.results()
+                if block == 1024:
+                    assert eng.stats().block == 1024
                 got[fold] = [(int(a), int(c)) for a, c in zip(s, it)]
                 b.free()
                 eng.close()
@@ -754,7 +758,10 @@ def test_folded_band_kernel_against_unfolded_and_oracle(oracle):
         exp = [oracle.align(t, q, make_opt(flag=1, **kw)) for t, q in pairs]
         for block in (512, 1024):
             eng = mw.Engine(0)
-            eng.set("force_kind", 2), eng.set("block", block), eng.set("band_pack", 1)
+            if block == 1024:
+                eng.set("band_span", 2)
+            else:
+                eng.set("force_kind", 2), eng.set("block", block), eng.set("band_pack", 1)
             b = eng.upload(pk)
             b.align(mw.opt_init(flag=1, **kw))
             s, it, nc = b.results()
