@@ -620,8 +620,25 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 				zA = pk_mad(pk_ne1(pf2A, O2.y), C64, zA), zB = pk_mad(pk_ne1(pf2B, o2pB), C64, zB);
 				tbw = (uint32_t)zA | ((uint32_t)zB << 8); // bytes in column order: c0 = A.lo, c1 = B.lo, c2 = A.hi, c3 = B.hi
 			}
+			// ---- lane geometry of the chunk: j = k + 1 may reach rj = min(tl, ql - d); query index = j + d, d = c - 1 - tl
+			const int32_t cbp = both16(cb);
+			const int32_t xA = pk_sub(pk_sub(T0, cbp), RA);                  // ql - d of A's columns (garbage beyond cmax, where H is dead)
+			const int32_t rjA = pk_minu(xA, TLp), rjB = pk_minu(pk_sub(xA, ONE), TLp);
+			const int32_t dA = pk_sub(pk_add(RA, cbp), TL1), dB = pk_add(dA, ONE);
+			// ---- the rare work in front of the extension — the chunk sticks out of the window, holds a window edge, a shrink is near — behind ONE
+			// uniform test: an interior chunk (most chunks) pays one branch for the three (a uniform branch costs a wave 17-31 cycles,
+			// profiles/r05/branch_rates_microbench.txt): 1024 x 10 kb -2 % score-only, -3 % with CIGAR.  (The rare work behind the extension — end
+			// cell, good-bit words, flag word — under the same test as well: no further gain, seven more spilled SGPRs; left as it was.)
+			// (not in the span geometry and the score-only five / six-slot copies on biased offsets: that much slot state leaves no scalar register for the
+			// flag — 1250 x 50 kb +1.6 %, 1024 x 15 kb +1.7 %; with CIGAR the biased copies gain 2 % like the rest)
+#ifndef MWF_B2_MERGE_OFF
+#define MWF_B2_MERGE_OFF 0 // experiment: 1 = every chunk tests the three separately, as before round 5
+#endif
+			const bool special = MWF_B2_MERGE_OFF || MWF_IS_SPAN(T, K) || (BI4 && !TB) || !inside || g == ga || g == gb || track_good;
 			// ---- a chunk that sticks out of the window: the columns outside are not computed by the reference — dead
 			int32_t outA = 0, outB = 0; // 0xffff in the halves of columns outside [lo, hi]
+			uint32_t bits = 0, gbits = 0;
+			if (special) { // uniform
 			if (!inside) { // uniform
 				const int32_t lo_r = both16(min(max(lo - cb, 0), 256)), hi_r1 = both16(min(max(hi - cb + 1, 0), 256));
 				const int32_t RB = pk_add(RA, 0x00010001), RB1 = pk_add(RA, 0x00020002);
@@ -634,7 +651,6 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 				nf2A = bfi(outA, kDeadPair, nf2A), nf2B = bfi(outB, kDeadPair, nf2B);
 			}
 			// ---- edge rule (miniwfa.c:325-326): H is the max of the five, so "any live" == "H live"; one lane holds the edge column
-			uint32_t bits = 0;
 			if (g == ga || g == gb) { // uniform
 				if (g == ga) {
 					const int32_t rel = lo - cb;
@@ -647,13 +663,7 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 					bits |= v >= -1 - B ? 2u : 0u;
 				}
 			}
-			// ---- lane geometry of the chunk: j = k + 1 may reach rj = min(tl, ql - d); query index = j + d, d = c - 1 - tl
-			const int32_t cbp = both16(cb);
-			const int32_t xA = pk_sub(pk_sub(T0, cbp), RA);                  // ql - d of A's columns (garbage beyond cmax, where H is dead)
-			const int32_t rjA = pk_minu(xA, TLp), rjB = pk_minu(pk_sub(xA, ONE), TLp);
-			const int32_t dA = pk_sub(pk_add(RA, cbp), TL1), dB = pk_add(dA, ONE);
 			// good bits: some array holds an in-matrix offset (miniwfa.c:139-142) <=> j <= rj for a live value (dead: j is huge)
-			uint32_t gbits = 0;
 			if (track_good) { // uniform
 				auto bad = [&](int32_t v, int32_t rj) { return pk_subsat(pk_add(v, ONEB), rj); }; // zero iff good
 				const int32_t bA = pk_minu(pk_minu(bad(hA, rjA), pk_minu(bad(ne1A, rjA), bad(nf1A, rjA))), pk_minu(bad(ne2A, rjA), bad(nf2A, rjA))) | outA;
@@ -667,6 +677,7 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 					if (__ballot(any != 0)) bits |= 0x80u;
 				}
 			}
+			} // special
 			// ---- the new E/F are final: age the registers, publish this chunk's outer columns for the neighbouring slots
 			if (FOLD) { // with the row read for the mismatch term: what the gap opens from e1 penalties from now (HX is not masked: it is dead outside ITS window)
 				ne1A = pk_max(ne1A, HX.x), ne1B = pk_max(ne1B, HX.y), nf1A = pk_max(nf1A, HX.x), nf1B = pk_max(nf1B, HX.y);
