@@ -215,6 +215,21 @@ def divergence_sweep(mw, synth_pair, PackedBatch, n=1024, tl=2000):
         w = time.perf_counter() - t0
         out[f"{div:g}"] = {"gbps": pk.bases / w / 1e9, "step_ms": w * 1e3, "re_run_frac": int(eng.stats().n_retries) / n, "first_align_re_run_frac": first_rr / n}
         b.free()
+        # the same batch DEVICE-RESIDENT (torch tensors wrapped zero-copy — the path `value` is timed on): its classes follow an 8-mer sketch
+        # computed on the device when the batch is wrapped (round 5 classified such a batch by length alone: ~every pair of a 15 % batch twice)
+        try:
+            import torch
+            bw = eng.wrap_packed(pk, torch.device("cuda", 0))
+            bw.align(o); bw.results()
+            first_rr = int(eng.stats().n_retries)
+            t0 = time.perf_counter()
+            bw.align(o)
+            bw.results()
+            w = time.perf_counter() - t0
+            out[f"{div:g}"]["wrapped"] = {"gbps": pk.bases / w / 1e9, "step_ms": w * 1e3, "re_run_frac": int(eng.stats().n_retries) / n, "first_align_re_run_frac": first_rr / n}
+            bw.free()
+        except Exception as e:
+            out[f"{div:g}"]["wrapped"] = {"error": repr(e)}
     eng.close()
     return out
 

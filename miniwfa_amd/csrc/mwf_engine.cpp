@@ -158,6 +158,9 @@ mwf_gpu_batch_t *mwf_gpu_batch_wrap(mwf_gpu_t *g, int32_t n, const void *d_seqs,
 		mwf_gpu_batch_free(b);
 		return nullptr;
 	}
+	// the batch's divergence from an 8-mer sketch of a few of its pairs, like a batch built from host memory gets while it is packed (the
+	// classes of a resident 15 % or 30 % batch were drawn from its lengths alone and ran ~every pair twice: VERDICT r5)
+	if (g->div_aware) b->div_est = estimate_divergence_device(g, b);
 	return b;
 }
 

@@ -66,6 +66,7 @@ struct mwf_gpu_s {
 	int block = 0;              // 0: choose from the batch
 	bool dev_retry = true;      // batches of reads: the pairs the lane kernel hands back are re-run by a follow-up launch from a device-side list, without the host
 	int retry_mode = 0;         // set around run_batch_kernel(): 1 the launch fills the list, 2 the launch takes its pairs from it
+	int retry_slot = 0;         // ... which of the batch's kRetrySlots lists
 	bool band_fold = true;      // packed band kernel: the folded score-only form where the penalties allow it (o1 == x)
 	bool div_aware = true;      // weigh the size classes' length limits by the batch's estimated divergence (batches built from host memory)
 	int64_t tun_gen = 0;        // bumped by every successful mwf_gpu_set(): a cached plan of an align (PlanCache) is only replayed under the tunables it was made under
@@ -177,7 +178,7 @@ struct mwf_gpu_batch_s {
 		// four slots, and the kernel reports whether three would have held every pair; 1: three hold this batch under these options; 2: four are needed.
 		int8_t wide_state = 0;
 		bool wide_measured = false; // this align's first launch of the class ran on four slots with the report word zeroed
-		struct GI { int32_t n = 0; int64_t max_len = 0, max_bound = 0, max_bound1 = 0, max_tl = 0, max_seq_lds = 0; } gi[15];
+		struct GI { int32_t n = 0; int64_t max_len = 0, max_bound = 0, max_bound1 = 0, max_tl = 0, max_seq_lds = 0, max_exp_win = 0; } gi[15];
 		std::vector<int8_t> cls0, flags0;
 	} plan;
 	std::vector<char> host_out;     // the fixed-size results as they came back (finalize)
@@ -185,7 +186,7 @@ struct mwf_gpu_batch_s {
 	// geometry and counters of the last align of THIS batch (finalize() must not read the engine's: another batch may have
 	// been aligned on the same engine in between)
 	int32_t last_grid = 0, n_retries = 0;
-	int32_t *d_retry_ids = nullptr;  // [kRetryCap] pairs a launch handed back for its follow-up launch; their count is the third word of the head (d_cig_head + 2)
+	int32_t *d_retry_ids = nullptr;  // [kRetrySlots][kRetryCap] pairs a launch handed back for its follow-up launch; their count is the third word of the head (d_cig_head + 2)
 	bool dev_retry_used = false;     // this align made such a follow-up launch: the count is added to n_retries
 	// debug band trace (tests)
 	int32_t debug_pair = -1;
@@ -219,10 +220,12 @@ struct BlockLayout {
 	size_t head = 0, status = 0, s = 0, ncig = 0, iter = 0, cigoff = 0, cells1 = 0, score_end = 0, out_end = 0, dbg4 = 0, retry = 0, total = 0;
 };
 constexpr int kRetryCap = 256; // ids a launch can hand to its follow-up launch on the device (BatchArgs::retry_ids)
+constexpr int kRetrySlots = 2; // lists (and counters: words 2 and 3 of the head) per batch: one per lane class, so that the second class's follow-up never sees the first one's pairs
 BlockLayout layout_block(size_t n, size_t seq_bytes, bool owned);
 mwf_gpu_batch_t *batch_common(mwf_gpu_t *g, int32_t n, const int32_t *h_tl, const int32_t *h_ql, size_t seq_bytes, bool owned, BlockLayout &L);
 mwf_gpu_batch_t *batch_from_host(mwf_gpu_t *g, int32_t n, const int32_t *tl, const char *const *ts, const int32_t *ql, const char *const *qs,
                                  const char *packed, int64_t packed_bytes, const int64_t *p_t_off, const int64_t *p_q_off);
+float estimate_divergence_device(mwf_gpu_t *g, mwf_gpu_batch_t *b); // 8-mer sketch of a few pairs of a device-resident batch (0: unknown)
 
 // ---- mwf_plan.cpp: penalties, kernel choice, launches, the whole-device passes, re-runs
 Penalty make_penalty(const mwf_opt_t &o);

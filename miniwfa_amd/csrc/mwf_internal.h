@@ -138,6 +138,8 @@ struct BatchArgs {
 // launch wrappers implemented in mwf_kernels.hip (generic kernel: any penalties, any band, low-memory mode)
 int launch_reset(int32_t *status, int32_t *s, int32_t n, unsigned long long *cig_head, int32_t *queue, int32_t n_queue, void *stream);
 int launch_batch(const BatchArgs &a, int grid, int block, void *stream);
+// 8-mer sketch of `samples` (<= 16) pairs of a device-resident batch: out[k] = 8-mers of pair (k n / samples)'s query prefix that occur in its target prefix
+int launch_sketch(const uint8_t *seqs, const int64_t *t_off, const int32_t *tl, const int64_t *q_off, const int32_t *ql, int32_t n, int32_t samples, int32_t *out, void *stream);
 int  bigring_kernel_occupancy();                      // ... of the big-ring form (penalty sets with max(x, o1+e1, o2+e2) >= 256)
 int  batch_kernel_occupancy(int block, bool stream_pass, int lds_e2_cols, bool ring16);   // resident workgroups per CU for that block size
 

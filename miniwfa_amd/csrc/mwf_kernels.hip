@@ -1198,13 +1198,58 @@ __global__ void reset_kernel(int32_t *status, int32_t *s, int32_t n, unsigned lo
 	const int32_t i = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
 	if (i < n) status[i] = -1, s[i] = -2;
 	if (i < n_queue) queue[i] = 0; // the work counters of the align call's launches (the grid covers n_queue)
-	if (i == 0) cig_head[0] = 0ull, cig_head[1] = 0ull, cig_head[2] = 0ull; // (the second word: flags of the align's kernels for the host, BatchArgs::cig_head + 1; the third: BatchArgs::retry_count)
+	if (i == 0) cig_head[0] = 0ull, cig_head[1] = 0ull, cig_head[2] = 0ull, cig_head[3] = 0ull; // (the second word: flags of the align's kernels for the host, BatchArgs::cig_head + 1; the third and fourth: BatchArgs::retry_count of the two lane classes)
 }
 
 int launch_reset(int32_t *status, int32_t *s, int32_t n, unsigned long long *cig_head, int32_t *queue, int32_t n_queue, void *stream)
 {
 	const int grid = (std::max(n, n_queue) + 255) / 256 > 0 ? (std::max(n, n_queue) + 255) / 256 : 1;
 	hipLaunchKernelGGL(reset_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, status, s, n, cig_head, queue, n_queue);
+	return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ---- divergence sketch of a device-resident batch (mwf_gpu_batch_wrap: the host never sees the bytes).  The same statistic as
+// host::estimate_divergence (mwf_memory.cpp) computes while it packs a batch from host memory: how many of the 8-mers of a query's
+// prefix (up to 1500 bases) occur in its target's prefix — (1 - d)^8 plus chance hits.  One workgroup per sampled pair (at most 16:
+// pair k n / samples), the 4^8-bit set in LDS; out[k] = hits.  The reference has no size classes to get wrong (one loop serves any
+// divergence, miniwfa.c:396-426): this is what lets the classes of a WRAPPED batch follow its divergence too.
+constexpr int kSketchK = 8, kSketchLen = 1500;
+__device__ __forceinline__ uint32_t sketch_kmer(const uint8_t *p)
+{
+	uint32_t h = 0;
+#pragma unroll
+	for (int i = 0; i < kSketchK; ++i) h = (h << 2) | ((p[i] >> 1) & 3u);
+	return h;
+}
+__global__ __launch_bounds__(256) void sketch_kernel(const uint8_t *seqs, const int64_t *t_off, const int32_t *tl, const int64_t *q_off, const int32_t *ql,
+                                                      int32_t n, int32_t samples, int32_t *out)
+{
+	__shared__ uint32_t bits[(1 << (2 * kSketchK)) / 32];
+	__shared__ int32_t hits;
+	const int32_t i = (int32_t)((int64_t)blockIdx.x * n / samples);
+	const int32_t lt = min(tl[i], kSketchLen), lq = min(ql[i], kSketchLen);
+	for (int32_t j = threadIdx.x; j < (1 << (2 * kSketchK)) / 32; j += 256) bits[j] = 0;
+	if (threadIdx.x == 0) hits = 0;
+	__syncthreads();
+	const uint8_t *t = seqs + t_off[i], *q = seqs + q_off[i];
+	for (int32_t j = threadIdx.x; j + kSketchK <= lt; j += 256) {
+		const uint32_t h = sketch_kmer(t + j);
+		atomicOr(&bits[h >> 5], 1u << (h & 31));
+	}
+	__syncthreads();
+	int32_t mine = 0;
+	for (int32_t j = threadIdx.x; j + kSketchK <= lq; j += 256) {
+		const uint32_t h = sketch_kmer(q + j);
+		mine += (int32_t)((bits[h >> 5] >> (h & 31)) & 1u);
+	}
+	if (mine) atomicAdd(&hits, mine);
+	__syncthreads();
+	if (threadIdx.x == 0) out[blockIdx.x] = hits;
+}
+
+int launch_sketch(const uint8_t *seqs, const int64_t *t_off, const int32_t *tl, const int64_t *q_off, const int32_t *ql, int32_t n, int32_t samples, int32_t *out, void *stream)
+{
+	hipLaunchKernelGGL(sketch_kernel, dim3(samples), dim3(256), 0, (hipStream_t)stream, seqs, t_off, tl, q_off, ql, n, samples, out);
 	return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

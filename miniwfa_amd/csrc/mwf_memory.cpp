@@ -190,7 +190,7 @@ BlockLayout layout_block(size_t n, size_t seq_bytes, bool owned)
 	L.cells1 = at, at += N * 8;
 	L.out_end = at;
 	L.dbg4 = at, at += N * 16;
-	L.retry = at, at += (size_t)kRetryCap * 4;
+	L.retry = at, at += (size_t)kRetrySlots * kRetryCap * 4;
 	L.total = at;
 	return L;
 }
@@ -278,13 +278,38 @@ bool plain_acgt(const uint8_t *p, size_t n)
 // (one loop serves any divergence, miniwfa.c:396-426); here a k-mer sketch of a few pairs says where the batch stands before anything is launched:
 // the share f of the query's 8-mers (prefix of up to 1500 bases) that occur in the target's prefix is about (1 - d)^8 plus chance hits.
 // A few microseconds per sampled pair, at most 16 pairs.
+// One sampled pair's estimate from its hit count: hits of `tot` query 8-mers in a target prefix of lt bases.
+double sketch_divergence(int32_t hit, int32_t tot, int32_t lt)
+{
+	constexpr int K = 8;
+	const double fp = 1.0 - std::exp(-(double)(lt - K + 1) / 65536.0); // chance hits
+	double f = ((double)hit / std::max(tot, 1) - fp) / (1.0 - fp);
+	f = std::min(1.0, std::max(f, 1e-3));
+	return 1.0 - std::pow(f, 1.0 / K);
+}
+
+// The batch's figure from the sampled pairs': the MEDIAN (a mean lets a few unrelated pairs among the samples — chain-mode gap
+// fills are such a mix — push every pair of the batch into wider, slower classes, and a low mean under-sizes the diverged ones), and "unknown"
+// (0: the length-only classes) when the samples disagree strongly — quartiles more than a factor of three apart: no one figure describes the batch.
+float combine_divergence(std::vector<double> &d)
+{
+	if (d.empty()) return 0.f;
+	std::sort(d.begin(), d.end());
+	const size_t n = d.size();
+	const double med = n & 1 ? d[n / 2] : 0.5 * (d[n / 2 - 1] + d[n / 2]);
+	if (n >= 4) {
+		const double q1 = d[n / 4], q3 = d[(3 * n) / 4];
+		if (q3 > 3.0 * std::max(q1, 0.02)) return 0.f;
+	}
+	return (float)med;
+}
+
 float estimate_divergence(int32_t n, const int32_t *tl, const int32_t *ql, const std::function<const uint8_t*(int32_t, bool)> &seq)
 {
 	constexpr int K = 8;
 	constexpr uint32_t MASK = (1u << (2 * K)) - 1;
 	std::vector<uint64_t> bits((size_t)1 << (2 * K - 6));
-	double sum = 0;
-	int used = 0;
+	std::vector<double> est;
 	const int want = 16;
 	for (int k = 0; k < want && k < n; ++k) {
 		const int32_t i = (int32_t)((int64_t)k * n / std::min(want, n));
@@ -303,13 +328,29 @@ float estimate_divergence(int32_t n, const int32_t *tl, const int32_t *ql, const
 			h = ((h << 2) | ((q[j] >> 1) & 3u)) & MASK;
 			if (j >= K - 1) ++tot, hit += (int32_t)((bits[h >> 6] >> (h & 63)) & 1u);
 		}
-		const double fp = 1.0 - std::exp(-(double)(lt - K + 1) / (double)(MASK + 1)); // chance hits
-		double f = ((double)hit / tot - fp) / (1.0 - fp);
-		f = std::min(1.0, std::max(f, 1e-3));
-		sum += 1.0 - std::pow(f, 1.0 / K);
-		++used;
+		est.push_back(sketch_divergence(hit, tot, lt));
 	}
-	return used ? (float)(sum / used) : 0.f;
+	return combine_divergence(est);
+}
+
+// The same for a batch whose sequences live in device memory (mwf_gpu_batch_wrap): one small kernel over the sampled pairs' prefixes, its
+// sixteen counts read back (a launch and a 64-byte copy: ~30 us per wrapped batch, once).  0 (unknown) when anything fails — an estimate only.
+float estimate_divergence_device(mwf_gpu_t *g, mwf_gpu_batch_t *b)
+{
+	const int32_t n = b->n, samples = std::min(16, n);
+	if (n <= 0 || !b->d_seqs || !b->d_t_off || !b->d_q_off || !b->d_tl || !b->d_ql) return 0.f;
+	int32_t *d_out = b->d_dbg4; // (16 bytes per pair of scratch behind the results: nothing uses it before an align)
+	if (launch_sketch(b->d_seqs, b->d_t_off, b->d_tl, b->d_q_off, b->d_ql, n, samples, d_out, g->stream)) { (void)hipGetLastError(); return 0.f; }
+	int32_t hits[16];
+	if (hipMemcpyAsync(hits, d_out, (size_t)samples * 4, hipMemcpyDeviceToHost, g->stream) != hipSuccess || hipStreamSynchronize(g->stream) != hipSuccess) { (void)hipGetLastError(); return 0.f; }
+	std::vector<double> est;
+	for (int32_t k = 0; k < samples; ++k) {
+		const int32_t i = (int32_t)((int64_t)k * n / samples);
+		const int32_t lt = std::min(b->h_tl[i], 1500), lq = std::min(b->h_ql[i], 1500);
+		if (lt < 32 || lq < 32) continue;
+		est.push_back(sketch_divergence(hits[k], lq - 7, lt));
+	}
+	return combine_divergence(est);
 }
 
 // A batch from host memory: pair i is (ts[i], tl[i]) / (qs[i], ql[i]) when `ts` is given, else it lies in `packed` at

@@ -102,7 +102,10 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 		const int64_t need_lds = ((max_len >> 4) + 4) * 4;
 		if (g->seq2bit == 0 || g->acgt_off_once || need_lds > 70 * 1024) return;
 		// (five chunk slots per wave while target + query stay below 3.5 of that span, else six)
-		const int chunks = band2_biased512_chunks() + (max_len + 1 <= 7 * (int64_t)(band2_biased512_chunks() * 256) / 2 ? 0 : 8);
+		// (... or when the class was admitted on a forecast window — divergence known, window_hint = the class's largest — that five slots cannot hold: the
+		// admission test is against the SIX-slot window, a 17 kb pair at 10 % must not start on five and overflow)
+		const bool six = max_len + 1 > 7 * (int64_t)(band2_biased512_chunks() * 256) / 2 || (window_hint > 0 && window_hint + 768 > ((int64_t)band2_biased512_chunks() - 1) * 256 - 64);
+		const int chunks = band2_biased512_chunks() + (six ? 8 : 0);
 		pl.kind = 2, pl.band = BandGeom{512, 2, chunks * 256, (int)((need_lds + 15) / 16 * 16), 1, 0}; // (packed 2: the copy that computes on biased offsets)
 		return;
 	}
@@ -321,8 +324,8 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 		HIP_TRY(g, hipMemsetAsync(g->queue.p, 0, 4, g->stream)); // (stream order: the launch that used it last is complete by then)
 	}
 	// re-runs without the host (BatchArgs::retry_ids): this launch fills the batch's list / takes its pairs from it
-	if (g->retry_mode == 1) a.retry_ids = b->d_retry_ids, a.retry_cap = kRetryCap, a.retry_count = (unsigned int*)(b->d_cig_head + 2);
-	if (g->retry_mode == 2) a.n_pairs_dev = (const unsigned int*)(b->d_cig_head + 2), a.queue = nullptr, a.queue_parts = 0;
+	if (g->retry_mode == 1) a.retry_ids = b->d_retry_ids + g->retry_slot * kRetryCap, a.retry_cap = kRetryCap, a.retry_count = (unsigned int*)(b->d_cig_head + 2 + g->retry_slot);
+	if (g->retry_mode == 2) a.n_pairs_dev = (const unsigned int*)(b->d_cig_head + 2 + g->retry_slot), a.queue = nullptr, a.queue_parts = 0;
 	a.scalar_generic = g->scalar_generic;
 	a.band_fold = g->band_fold ? 1 : 0;
 	a.lds_e2_cols = lds_e2_cols;
@@ -852,7 +855,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 			cls[i] = (int8_t)c, ++count[c];
 			G.max_len = std::max(G.max_len, len), G.max_bound = std::max(G.max_bound, bound);
 			G.max_bound1 = std::max(G.max_bound1, bound1);
-			G.max_tl = std::max<int64_t>(G.max_tl, tl);
+			G.max_tl = std::max<int64_t>(G.max_tl, tl), G.max_exp_win = std::max(G.max_exp_win, exp_win);
 			G.max_seq_lds = std::max<int64_t>(G.max_seq_lds, ((tl + 3) & ~3LL) + 8 + ((ql + 3) & ~3LL) + 16);
 		}
 		// The processing order: groups in run order, longest first inside a group (the persistent workgroups finish together).  h_order is
@@ -891,12 +894,12 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		// (the lane class of a batch of reads hands its overflows to a follow-up launch on the device, below)
 		const bool lane_retry = (c == 10 || c == 12) && g->dev_retry && G.n >= 1024 && !preset && g->force_kind < 0 && g->block == 0 && mid_supported(P0) && G.max_len <= 1200 &&
 		                        G.max_tl + G.max_bound < 32760 && !low_mem;
-		if (lane_retry) g->retry_mode = 1;
+		if (lane_retry) g->retry_mode = 1, g->retry_slot = c == 12 ? 1 : 0;
 		g->acgt_off_once = (c > 5 && c < 10) || (c == 11 && mid_bytes) || c == 12;
 		const int rc = run_batch_kernel(g, b, c == 5 ? *opt : opt_hi, b->d_order + at, G.n, slots, G.max_len, G.max_bound, G.max_bound1,
 		                                done_groups == 1, (classes || c >= 11) ? (c == 0 || c == 5 ? 0 : 2) : -1, G.max_tl, G.max_seq_lds, lane_retry ? 0 : done_groups == n_groups,
 		                                cc == 8 ? 514 : cc == 7 ? 1024 : cc == 6 ? 33 : cc == 5 ? 32 : cc == 4 ? 64 : cc == 3 ? 128 : cc == 2 ? 256 : 0, &ran,
-		                                (c == 1 && (g->wide_slots == 4 || (g->wide_slots == 0 && PC.wide_state != 1 && g->queue_clean))) ? kBandWide4Window : 0);
+		                                (c == 1 && (g->wide_slots == 4 || (g->wide_slots == 0 && PC.wide_state != 1 && g->queue_clean))) ? kBandWide4Window : c == 14 ? G.max_exp_win : 0);
 		g->retry_mode = 0;
 		if (c == 1 && g->wide_slots == 0 && PC.wide_state == 0 && g->queue_clean && ran == 2 && g->stats.block == 512) PC.wide_measured = true;
 		// Batches of reads: what the lane kernel hands back (a window that left its chunks: one read in tens of thousands) is re-run by a follow-up launch of
@@ -907,7 +910,8 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 			g->retry_mode = 2;
 			g->acgt_off_once = c == 12;
 			int ran2 = 0;
-			const int rc2 = run_batch_kernel(g, b, opt_hi, b->d_retry_ids, std::min<int32_t>(kRetryCap, 32), slots, G.max_len, G.max_bound, G.max_bound1, false, 2, G.max_tl, G.max_seq_lds,
+			// (every entry of the list — the mid kernel strides over it by its grid —, on at most 32 workgroups: an empty list costs the launch of a few idle ones)
+			const int rc2 = run_batch_kernel(g, b, opt_hi, b->d_retry_ids + g->retry_slot * kRetryCap, kRetryCap, std::min(slots, 32), G.max_len, G.max_bound, G.max_bound1, false, 2, G.max_tl, G.max_seq_lds,
 			                                 done_groups == n_groups, 33, &ran2, 0);
 			g->retry_mode = 0, g->acgt_off_once = false;
 			const int32_t launches = g->stats.n_launches;
@@ -993,9 +997,11 @@ int finalize(mwf_gpu_t *g, mwf_gpu_batch_t *b)
 	};
 	if (fetch()) return -1;
 	if (b->dev_retry_used) { // pairs a follow-up launch re-ran from the device-side list count as re-runs too (the third word of the head: BatchArgs::retry_count)
-		uint32_t k = 0;
-		memcpy(&k, b->host_out.data() + 16, 4);
-		b->n_retries += (int32_t)std::min<uint32_t>(k, (uint32_t)kRetryCap);
+		for (int slot = 0; slot < kRetrySlots; ++slot) { // (what a list could not hold stayed ST_BAND_OVERFLOW and is counted by the host path below)
+			uint32_t k = 0;
+			memcpy(&k, b->host_out.data() + 16 + 8 * slot, 4);
+			b->n_retries += (int32_t)std::min<uint32_t>(k, (uint32_t)kRetryCap);
+		}
 	}
 
 	if (b->plan.wide_measured) { // the four-slot kernels' report (reset to 0 by the align's reset kernel): did any pair need more than three slots hold?

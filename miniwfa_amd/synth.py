@@ -225,3 +225,27 @@ class PackedBatch:
     @property
     def bases(self) -> int:
         return int(self.tl.sum() + self.ql.sum())
+
+
+def spec_pair(spec: dict) -> tuple[bytes, bytes]:
+    """(target, query) from a small generator spec — what tests/golden/blind_classes.jsonl stores instead of sequences.  Only
+    the counter-based generators above are used, so a spec means the same bytes on every numpy version.
+      unrelated: independent uniform sequences of tl and ql bases
+      window   : the query is bases [at, at+w) of the target mutated at rate p (length-skewed, related)
+      identical: query == target
+      fit      : synth_pair(seed, tl, p) with the query cut or padded (random bases) to exactly ql bases
+    `swap`: exchange target and query afterwards."""
+    kind, seed = spec["kind"], int(spec["seed"])
+    if kind == "unrelated":
+        t, q = random_seq(seed, int(spec["tl"])), random_seq(seed + 1, int(spec["ql"]))
+    elif kind == "window":
+        t = random_seq(seed, int(spec["tl"]))
+        q = mutate(t[int(spec["at"]):int(spec["at"]) + int(spec["w"])], seed + 1, float(spec["p"]))
+    elif kind == "identical":
+        t = q = random_seq(seed, int(spec["tl"]))
+    elif kind == "fit":
+        t = random_seq(seed, int(spec["tl"]))
+        q = (mutate(t, seed, float(spec["p"])) + random_seq(seed + 2, int(spec["ql"])))[:int(spec["ql"])]
+    else:
+        raise ValueError(kind)
+    return (q, t) if spec.get("swap") else (t, q)

@@ -14,6 +14,17 @@ LIB = os.path.join(CSRC, "libmwf_hip.so")
 REF_MAIN = os.path.join(ROOT, "oracle", "_ref", "ref-main-on-libmwf_hip")
 
 
+def _drop_stale() -> None:
+    """A rebuild was due (the sources are here and the binary is older than libmwf_hip.so or main.c) and FAILED: an old binary would be
+    linked against last week's library and headers and report the drop-in check as passing — remove it, the test then skips.
+    (Where the reference's sources are absent — the GPU box — the binary that travelled with the snapshot is what there is, and is used.)"""
+    try:
+        os.remove(REF_MAIN)
+    except OSError:
+        pass
+    return None
+
+
 def build_ref_main(ref: str = "/root/reference") -> str | None:
     """The reference's OWN, unchanged caller (main.c:19-92) compiled against this repo's headers
     and linked with libmwf_hip.so — the drop-in claim with the reference's program rather than ours.  Only where the reference's
@@ -38,10 +49,10 @@ def build_ref_main(ref: str = "/root/reference") -> str | None:
         if r.returncode != 0:  # best effort: a test artefact must never break the library's build entry point (tests/test_cli.py skips without it)
             sys.stderr.write(r.stdout + r.stderr)
             sys.stderr.write("warning: could not build the reference's main.c against include/ + libmwf_hip.so; tests/test_cli.py will skip that check\n")
-            return REF_MAIN if os.path.exists(REF_MAIN) else None
+            return _drop_stale()
     except OSError as e:  # no gcc
         sys.stderr.write(f"warning: {e}; tests/test_cli.py will skip the reference-main check\n")
-        return REF_MAIN if os.path.exists(REF_MAIN) else None
+        return _drop_stale()
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return REF_MAIN

@@ -1,0 +1,248 @@
+"""The randomised cross-checks (tests/fuzzlib.py) with fixed seeds, and the blind-class golden vectors, inside the driver-run `-m gpu` suite.
+
+Round 5's fuzzers — then builder scripts under profiles/ — found two bit-exactness bugs that 977 golden vectors and 80 GPU tests had let
+through (a slot mapping that followed a climbing window too early: n_iter off by 82; an identical pair side by side in two-pass mode).  Each
+fuzzer now runs here on a budget of roughly half a minute, and tests/golden/blind_classes.jsonl (187 answers of the compiled reference,
+tests/golden/make_golden_blind.py) covers the input classes those bugs lived in: unrelated pairs, length-skewed pairs, windows whose start
+climbs across a chunk boundary, identical pairs side by side in low-memory mode, pairs exactly on the host's class limits.
+Reference semantics at stake: miniwfa.c:139-171 (shrink), :396-426 (driver loop, edge rule :325-326), :413-416 and :551-601 (checkpoints)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import miniwfa_amd as mw
+from miniwfa_amd.synth import PackedBatch, spec_pair, synth_pair
+from conftest import load_golden
+from oracle.pyoracle import Reference, make_opt, cigar_str as ocig
+import fuzzlib as F
+
+pytestmark = pytest.mark.gpu
+
+OPT_KEYS = ("flag", "x", "o1", "e1", "o2", "e2", "step", "max_s", "max_iter")
+BLIND = load_golden("blind_classes.jsonl")
+
+
+def no_mismatches(bad):
+    assert not bad, (len(bad), bad[:5])
+
+
+# ---- the fuzzers ------------------------------------------------------------------------------------------------------------------
+
+def test_fuzz_fold_vs_unfolded_vs_oracle():
+    """Folded == unfolded on forced 512-thread, span and automatic geometries; default routing == oracle (score and CIGAR); shapes whose
+    window start climbs.  (profiles/fuzz_fold.py seed 1 found the slot-mapping bug of round 5.)"""
+    no_mismatches(F.fuzz_fold(seed=1, n=160, long_sets=False, penalty_sets=(dict(), dict(x=2, o1=2, e1=2, o2=12, e2=1))))
+    no_mismatches(F.fuzz_fold(seed=5, n=100, long_sets=True, penalty_sets=(dict(), dict(x=3, o1=3, e1=2, o2=9, e2=2))))
+
+
+def test_fuzz_default_routing_on_mixed_batches():
+    """What a caller of mwf_wfa_batch gets for a mixed batch (reads, medium, skewed, unrelated, a few 5-12 kb pairs): oracle's s, n_iter, CIGAR."""
+    no_mismatches(F.fuzz_default_routing(seed=3, scale=0.8, penalty_sets=(dict(), dict(x=6, o1=2, e1=2, o2=20, e2=1))))
+    no_mismatches(F.fuzz_default_routing(seed=4, scale=0.4, penalty_sets=(dict(x=2, o1=2, e1=2, o2=12, e2=1), dict(x=1, o1=0, e1=1, o2=0, e2=1))))
+
+
+def test_fuzz_all_kernels_side_by_side_including_two_pass():
+    """Generic kernel (one / four columns per lane, 16-bit rows), forced band geometries, whole-device kernel; score, CIGAR, low-memory
+    two-pass (step = 97: groups of pairs side by side take the provenance pass) — against the oracle."""
+    no_mismatches(F.fuzz_all_kernels(seed=2, n_pairs=70, wd_pairs=10))
+
+
+def test_fuzz_packed_band_geometries():
+    no_mismatches(F.fuzz_band2(seed=6, n_pairs=150, blocks=(0, 64, 128, 256, 512, 768),
+                               modes=(dict(), dict(flag=1), dict(flag=1, x=1, o1=0, e1=1, o2=0, e2=1), dict(flag=0, x=6, o1=2, e1=2, o2=20, e2=1))))
+
+
+def test_fuzz_ring16_rows_vs_32_bit_rows():
+    no_mismatches(F.fuzz_ring16(seed=2, n_pairs=24))
+
+
+def test_fuzz_seq2bit_vs_byte_copies():
+    no_mismatches(F.fuzz_seq2(seed=3, n_pairs=400, modes=(dict(), dict(flag=1), dict(flag=1, o2=4, e2=2), dict(flag=1, max_s=300))))
+
+
+@pytest.mark.skipif(not Reference.available(), reason="oracle/_ref/libmwf_ref.so (the compiled reference) did not travel; chain_fresh.jsonl covers chain mode")
+def test_fuzz_chain_and_auto_vs_compiled_reference():
+    no_mismatches(F.fuzz_chain(seed=7, n_pairs=10))
+
+
+# ---- the device-side retry list (no pytest reached it) -------------------------------------------------------------------
+
+def test_device_side_retry_list_with_both_lane_classes(oracle):
+    """A read batch in which BOTH lane classes (10: plain A/C/G/T, 12: reads with an N) hold >= 1024 pairs and both hand pairs back (20-25 %
+    divergence outgrows the lane kernel's chunks): the follow-up launches take their pairs from device-side lists (mwf_plan.cpp lane_retry,
+    BatchArgs::retry_ids).  dev_retry 1 and 0 must both give the oracle's s, n_iter and CIGARs; no pair may be run twice into the CIGAR pool."""
+    rng = np.random.default_rng(99)
+    pairs = []
+    for i in range(2600):
+        tl = int(rng.integers(100, 300))
+        p = float(rng.choice([0.02, 0.05, 0.2, 0.25], p=[0.45, 0.45, 0.05, 0.05]))
+        t, q = synth_pair(880000 + i, tl, p)
+        if i % 2 and len(q) > 10:   # half of the reads carry an N: the byte-wise lane class
+            k = int(rng.integers(0, len(q)))
+            q = q[:k] + b"N" + q[k + 1:]
+        if abs(len(t) - len(q)) <= 24:
+            pairs.append((t, q))
+    assert len(pairs) >= 2300
+    pk = PackedBatch(pairs)
+    for flag in (0, 1):
+        exp = F.oracle_many(oracle, pairs, make_opt(flag=flag))
+        seen = {}
+        for dev_retry in (1, 0):
+            s, it, cig, st = F.run_engine(pk, dict(flag=flag), [("dev_retry", dev_retry)])
+            bad = []
+            F.compare((s, it, cig, st), exp, f"dev_retry {dev_retry} flag {flag}", pairs, bad, False)
+            no_mismatches(bad)
+            seen[dev_retry] = st.n_retries
+        assert seen[1] > 0 and seen[0] > 0, seen   # the batch did hand pairs back on both paths
+        assert seen[1] <= seen[0] + 2 * 256, seen  # (the device path counts what it re-ran, never more than the lists hold on top of the host path)
+
+
+def test_cached_plan_follows_the_round5_tunables(oracle):
+    """test_cached_plan_follows_every_tunable for the tunables it left out: dev_retry, band_fold, div_aware."""
+    pairs = [synth_pair(97500 + i, (120, 300, 900, 2500, 6000)[i % 5], (0.03, 0.08)[i % 2]) for i in range(60)]
+    exp = [oracle.align(t, q, make_opt(flag=1)) for t, q in pairs]
+    eng = mw.Engine(0)
+    b = eng.upload(PackedBatch(pairs))
+    for name, value in [(None, 0), ("dev_retry", 0), ("dev_retry", 1), ("band_fold", 0), ("band_fold", 1), ("div_aware", 0), ("div_aware", 1)]:
+        if name:
+            eng.set(name, value)
+        for flag in (mw.MWF_F_CIGAR, 0):
+            b.align(mw.opt_init(flag=flag))
+            s, it, nc = b.results()
+            for i, (es, eit, ecig) in enumerate(exp):
+                assert (int(s[i]), int(it[i])) == (es, eit) and (not flag or b.cigar(i, int(nc[i])).tolist() == ecig), (name, value, flag, i)
+    b.free()
+    eng.close()
+
+
+# ---- blind-class golden vectors (answers of the compiled reference) ----------------------------------------------------------------
+
+def check_vector(v, s, n_iter, words):
+    exp = v["expect"]
+    assert (int(s), int(n_iter)) == (exp["s"], exp["n_iter"]), (v["id"], int(s), int(n_iter), exp["s"], exp["n_iter"])
+    if exp["n_cigar"] is None:
+        assert words is None or len(words) == 0, v["id"]
+        return
+    assert len(words) == exp["n_cigar"], (v["id"], len(words), exp["n_cigar"])
+    if exp.get("cigar") is not None:
+        assert ocig(words) == exp["cigar"], v["id"]
+    else:
+        assert hashlib.sha256(np.asarray(words, dtype="<u4").tobytes()).hexdigest() == exp["cigar_sha256"], v["id"]
+
+
+def run_golden_batch(vs, tunables=()):
+    """The vectors of one option set as ONE device batch under the given tunables."""
+    key = tuple(vs[0]["opt"][k] for k in OPT_KEYS)
+    assert all(tuple(v["opt"][k] for k in OPT_KEYS) == key for v in vs)
+    pairs = [spec_pair(v["spec"]) for v in vs]
+    for v, (t, q) in zip(vs, pairs):
+        assert (len(t), len(q)) == (v["tl"], v["ql"]), v["id"]
+    eng = mw.Engine(0)
+    for k, val in tunables:
+        eng.set(k, val)
+    b = eng.upload(PackedBatch(pairs))
+    b.align(mw.opt_init(**dict(zip(OPT_KEYS, key))))
+    s, it, nc = b.results()
+    for i, v in enumerate(vs):
+        check_vector(v, s[i], it[i], b.cigar(i, int(nc[i])) if key[0] & 1 else None)
+    st = eng.stats()
+    b.free()
+    eng.close()
+    return st
+
+
+def by_opt(vecs):
+    groups = {}
+    for v in vecs:
+        groups.setdefault(tuple(v["opt"][k] for k in OPT_KEYS), []).append(v)
+    return list(groups.values())
+
+
+def test_blind_golden_vectors_default_routing():
+    assert len(BLIND) >= 150
+    for vs in by_opt(BLIND):
+        run_golden_batch(vs)
+
+
+def test_blind_golden_vectors_in_a_batch_too_large_for_the_mid_kernel():
+    """The same vectors three times over in one batch (> 256 pairs: the small-batch classes — mid kernel, whole-device kernel — are off, every
+    pair runs in its band / span / generic class)."""
+    for vs in by_opt([v for v in BLIND if not v["opt"]["step"]]):
+        if len(vs) >= 20:
+            big = vs * (256 // len(vs) + 2)
+            assert len(big) > 256
+            run_golden_batch(big)
+
+
+@pytest.mark.parametrize("tunables", [
+    (("force_kind", 2), ("block", 512), ("band_pack", 1), ("band_fold", 1)),
+    (("force_kind", 2), ("block", 512), ("band_pack", 1), ("band_fold", 0)),
+    (("band_span", 2),),
+    (("wide_slots", 4),),
+    (("force_kind", 0),),
+    (("force_kind", 0), ("ring16", 2)),
+], ids=["512-folded", "512-unfolded", "span", "four-slots", "generic", "generic-16bit"])
+def test_blind_golden_vectors_forced_kernels(tunables):
+    """Unrelated, skewed and climbing-window vectors of up to 10 kb per sequence through forced geometries of the packed band kernel (folded
+    and unfolded), the span geometry, the four-slot geometry and the generic kernel."""
+    vecs = [v for v in BLIND if v["group"] in ("unrelated", "skewed", "climb") and max(v["tl"], v["ql"]) <= 10000 and not v["opt"]["step"]
+            and (v["opt"]["x"], v["opt"]["e1"], v["opt"]["e2"]) == (4, 2, 1)]
+    assert len(vecs) >= 80
+    for vs in by_opt(vecs):
+        run_golden_batch(vs, tunables)
+
+
+@pytest.mark.parametrize("group", ["side-by-side-0", "side-by-side-1"])
+def test_blind_golden_side_by_side_low_memory_groups(group):
+    """Eight pairs — identical ones among them — side by side in low-memory mode: default routing, and forced onto the whole-device kernel
+    (six or more side by side take the two-pass provenance form, miniwfa.c:551-601)."""
+    vs = [v for v in BLIND if v["group"] == group]
+    assert len(vs) == 8 and sum(v["spec"]["kind"] == "identical" for v in vs) >= 2
+    run_golden_batch(vs)
+    st = run_golden_batch(vs, (("force_kind", 1),))
+    assert st.kernel_kind == 1
+    run_golden_batch(vs, (("force_kind", 0),))
+
+
+def test_blind_golden_class_limit_pairs_one_call_each():
+    """Pairs exactly on the class limits through the drop-in call, one pair per call (batch of 1: lane / mid / whole-device admission)."""
+    for v in BLIND:
+        if v["group"] != "class-limit":
+            continue
+        t, q = spec_pair(v["spec"])
+        s, n_iter, cig = mw.wfa_exact(t, q, mw.opt_init(**v["opt"]))
+        check_vector(v, s, n_iter, cig)
+
+
+# ---- divergence-aware classes for device-resident batches -----------------------------------------------------
+
+@pytest.mark.parametrize("div", [0.01, 0.15, 0.30])
+def test_wrapped_batch_classes_follow_its_divergence(div, oracle):
+    """mwf_gpu_batch_wrap (sequences already in HBM: the library never sees the bytes on the host) sketches a few pairs' 8-mers ON THE DEVICE
+    when the batch is wrapped, so that its size classes follow its divergence like a host-built batch's do.  A resident 15 % or 30 % batch
+    used to run ~every pair twice; now none — and the answers are the oracle's.  The reference has no classes (miniwfa.c:396-426)."""
+    torch = pytest.importorskip("torch")
+    pairs = [synth_pair(33000 + i, 2000, div) for i in range(300)]
+    pk = PackedBatch(pairs)
+    eng = mw.Engine(0)
+    b = eng.wrap_packed(pk, torch.device("cuda", 0))
+    b.align(mw.opt_init())
+    s, it, _ = b.results()
+    assert eng.stats().n_retries == 0, (div, eng.stats().n_retries)
+    for i in range(0, len(pairs), 7):
+        es, eit, _ = oracle.align(pairs[i][0], pairs[i][1], make_opt())
+        assert (int(s[i]), int(it[i])) == (es, eit), (div, i)
+    # with the sketch switched off the 30 % batch does re-run (the test is looking at the right thing)
+    if div == 0.30:
+        eng2 = mw.Engine(0)
+        eng2.set("div_aware", 0)
+        b2 = eng2.wrap_packed(pk, torch.device("cuda", 0))
+        b2.align(mw.opt_init())
+        s2, it2, _ = b2.results()
+        assert eng2.stats().n_retries > 0
+        assert (np.array(s2) == np.array(s)).all() and (np.array(it2) == np.array(it)).all()
+        b2.free()
+        eng2.close()
+    b.free()
+    eng.close()

@@ -38,6 +38,7 @@ def _check(oracle, v):
 
 SMALL = [v for v in load_golden("exact_small.jsonl") if v["entry"] != "chain"]
 BIG = [v for v in load_golden("bench_shaped.jsonl") if v["entry"] != "chain"]
+BLIND = load_golden("blind_classes.jsonl")       # unrelated / length-skewed / climbing-window / side-by-side / class-limit pairs (tests/golden/make_golden_blind.py)
 BIGPEN = load_golden("big_penalties.jsonl")   # max(x, o1+e1, o2+e2) >= 256: rings deeper than the fast kernels' tables (tests/golden/make_golden_bigpen.py)
 
 
@@ -74,6 +75,29 @@ def test_big_penalty_golden(oracle, chunk):
     assert len(BIGPEN) >= 200
     for v in BIGPEN[chunk::4]:
         _check(oracle, v)
+
+
+@pytest.mark.parametrize("chunk", range(4))
+def test_blind_class_golden(oracle, chunk):
+    """The input classes round 5's fuzzers found bugs in (187 answers of the compiled reference): the restatement reproduces s, n_iter and
+    the CIGAR (as text, or as the SHA-256 of its words where it is long)."""
+    import hashlib
+    import numpy as np
+    from miniwfa_amd.synth import spec_pair
+    assert len(BLIND) >= 150
+    small = [v for v in BLIND if v["expect"]["n_iter"] <= 5e7]   # what the restatement finishes in about a minute in all; the GPU tests take every vector
+    assert len(small) >= 150
+    for v in small[chunk::4]:
+        t, q = spec_pair(v["spec"])
+        assert (len(t), len(q)) == (v["tl"], v["ql"]), v["id"]
+        s, n_iter, cig = oracle.align(t, q, make_opt(**v["opt"]))
+        exp = v["expect"]
+        assert (s, n_iter) == (exp["s"], exp["n_iter"]), v["id"]
+        assert (None if cig is None else len(cig)) == exp["n_cigar"], v["id"]
+        if cig is not None and exp.get("cigar") is not None:
+            assert cigar_str(cig) == exp["cigar"], v["id"]
+        elif cig is not None:
+            assert hashlib.sha256(np.asarray(cig, dtype="<u4").tobytes()).hexdigest() == exp["cigar_sha256"], v["id"]
 
 
 @pytest.mark.parametrize("v", BIG, ids=[v["id"] for v in BIG])
