@@ -255,7 +255,7 @@ def long_batches(mw, synth_pair, PackedBatch, n=1250, tl=50000, div=0.03):
            "gbp_s": pk.bases / wall / 1e9, "gcells_per_s": cells / wall / 1e9, "cells": cells, "n_retries": int(st.n_retries), "mean_s": float(s.mean()),
            "kernel_kind": int(st.kernel_kind), "block": int(st.block), "ring_bits": 16 if (st.packed == 16 or st.kernel_kind == 2) else 32,
            "kernel": KERNEL_NAMES.get(3 if (st.kernel_kind == 2 and st.packed) else st.kernel_kind, "?"), "kernel_bytes_per_cell": kb,
-           "roofline": counter_roofline(ks, TRAFFIC.get(f"{n}x{tl}@{div:g}s", {}), float(kb) * cells, 48.0 * cells, "48 B x cells")}
+           "roofline": counter_roofline(ks, TRAFFIC.get(f"{n}x{tl}@{div:g}s", {}), float(kb) * cells, 48.0 * cells, "48 B x cells", ran_symbol(st))}
     b.free()
     eng.close()
     return rec
@@ -267,7 +267,39 @@ LONG_SPECS = (("c4_like_150kb", 2001, 150000, 0.035, 0, 0,
                (("cigar_lowmem_p5000", {"flag": 1, "step": 5000}, "mhc-lowmem"), ("score", {}, "mhc-score"))))
 
 
-def counter_roofline(kernel_s: float, prof: dict, own_bytes: float, nominal_bytes: float, nominal_label: str) -> dict:
+def profile_matches_tree(prof: dict, ran_symbol: str | None) -> dict:
+    """Does the counter profile describe the code that was just timed?  traffic.json entries carry the symbols of the kernels they were
+    collected over and a fingerprint of those kernels' source file (profiles/summarize.py records it on the GPU box, profiles/make_traffic.py
+    stores it): compared here with the tree bench.py runs from and with the kernel the library says it launched.  `frac_stale` true = the
+    traffic figure (and so `frac`) belongs to other code — re-run profiles/r06_profiles.sh + r06_collect.sh."""
+    if not prof.get("hbm_bytes_per_launch"):
+        return {}
+    try:
+        from miniwfa_amd.build import kernel_fingerprint
+        kerns = prof.get("kernels") or []
+        now = kernel_fingerprint(kerns[0]) if kerns else None
+        same_src = bool(kerns) and prof.get("kernel_fingerprint") is not None and now == prof.get("kernel_fingerprint")
+        same_kernel = None if ran_symbol is None else any(k.replace(" ", "").startswith(ran_symbol.replace(" ", "")) for k in kerns)
+        return {"frac_stale": not (same_src and same_kernel is not False),
+                "traffic_check": {"profiled_kernels": kerns, "timed_kernel": ran_symbol, "kernel_matches": same_kernel,
+                                  "profiled_source_fingerprint": prof.get("kernel_fingerprint"), "tree_source_fingerprint": now,
+                                  "source_matches": same_src, "collected_at_commit": prof.get("collected_at_commit")}}
+    except Exception as e:  # pragma: no cover
+        return {"frac_stale": True, "traffic_check": {"error": repr(e)}}
+
+
+def ran_symbol(st) -> str | None:
+    """Start of the symbol of the kernel the library launched last, from its statistics."""
+    if st.kernel_kind == 2 and st.packed and st.block >= 64:
+        return f"wfa_band2_kernel<{st.block},"
+    if st.kernel_kind == 1:
+        return "wfa_sys"
+    if st.kernel_kind == 0:
+        return "wfa_batch_kernel<"
+    return None
+
+
+def counter_roofline(kernel_s: float, prof: dict, own_bytes: float, nominal_bytes: float, nominal_label: str, ran: str | None = None) -> dict:
     """THE roofline block of this line, one definition for every kernel: achieved = HBM bytes per launch measured by the PMC counters
     (profiles/traffic.json; 2048 B x FETCH_SIZE + 1024 B x WRITE_SIZE, the units calibrated by profiles/micro/fetch_calib.hip) / the kernel
     time measured live with HIP events; frac = achieved / 8 TB/s.  Without a counter profile of the workload (non-default arguments) the
@@ -293,6 +325,7 @@ def counter_roofline(kernel_s: float, prof: dict, own_bytes: float, nominal_byte
         rf["issue_source"] = prof.get("valu_source")
     if prof.get("wait_any_over_wave_cycles") is not None:
         rf["wait_any_over_wave_cycles"] = prof["wait_any_over_wave_cycles"]
+    rf.update(profile_matches_tree(prof, ran))
     return rf
 
 
@@ -370,7 +403,7 @@ def long_pairs(mw, synth_pair, PackedBatch, cpu: bool, mhc_cpu: bool):
                 own = (16 + (1 if kw.get("flag") else 0)) * int(it_[0])
             ks = max(st_.kernel_ms * 1e-3, 1e-9)
             rec["roofline"] = counter_roofline(ks, TRAFFIC.get(f"{name}:{label}", {}), own, nominal,
-                                               "97 B x first-pass cells + 49 B x second-pass cells" if kw.get("step") else ("49 B x cells" if kw.get("flag") else "48 B x cells"))
+                                               "97 B x first-pass cells + 49 B x second-pass cells" if kw.get("step") else ("49 B x cells" if kw.get("flag") else "48 B x cells"), ran_symbol(st_))
             rec["roofline"]["us_per_penalty"] = ks / max(1, int(s_[0])) * 1e6 / (2 if kw.get("step") else 1)
             rec["roofline"]["binding"] = "per-penalty latency of ONE sequential chain of penalties (hand-offs between chunk slots + single-wave issue), not bytes"
             if kw.get("flag"):
@@ -672,7 +705,7 @@ def main():
     else:
         kb = 16 + (1 if args.cigar else 0)
     key = f"{pk.n}x{args.tl}@{args.div:g}{'c' if args.cigar else 's'}"
-    rf = counter_roofline(k_ms * 1e-3, TRAFFIC.get(key, {}), float(kb) * cells, float(bytes_per_cell) * cells, f"{bytes_per_cell} B x cells")
+    rf = counter_roofline(k_ms * 1e-3, TRAFFIC.get(key, {}), float(kb) * cells, float(bytes_per_cell) * cells, f"{bytes_per_cell} B x cells", ran_symbol(st))
     rf.update({"kernel_bytes_per_cell": kb, "cells_per_launch": cells, "kernel_ms": k_ms,
                "note": "frac = counter traffic / kernel time / 8 TB/s (the same definition in long_pairs.*.roofline and long_batches.roofline). Nothing physical binds "
                        "this kernel: what is left is per-penalty synchronisation (wait_any_over_wave_cycles) and single-wave issue latency (DESIGN.md section 4)."})
@@ -682,6 +715,11 @@ def main():
         "unit": "Gbp/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
+        # Which reading of BASELINE's metric `value` is: the measurement contract's (inputs already resident in HBM when the timed region
+        # starts; results on the host when it ends).  SURVEY 8(d)'s reading — host buffers in to host results out, H2D + kernels + D2H — is
+        # the top-level `end_to_end` block of this line (same batches, same run), never `value`.
+        "value_definition": "resident: sequences in HBM before the clock starts, alignment kernels + (s, n_iter) records on the host (+ the RCCL gather at N > 1) inside it; "
+                            "SURVEY 8(d)'s host-to-host figure is `end_to_end.gbps`",
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         # the arithmetic the timed kernel computes in (results are bit-exact to the reference's int32 either way)
         "dtype": ("int16x2 packed, range-guarded (bit-exact to the reference's int32)" if (st.kernel_kind == 2 and st.packed) else
@@ -722,6 +760,9 @@ def main():
             # one shot = a fresh batch each time: pack + H2D + FIRST align (its plan, the wide class on four chunk slots) + records + free
             out["one_shot"] = {"ms": float(np.mean(shots)), "gbps": pk.bases / float(np.mean(shots)) / 1e6, "first_align_ms": float(np.mean(firsts)),
                                "what": "host buffers in -> host results out of a batch aligned ONCE on a warm engine (SURVEY 8(d)'s reading of the metric)"}
+            out["end_to_end"] = {"metric": "aligned Gbp/s (q+t)", "gbps": out["one_shot"]["gbps"], "ms_per_batch": out["one_shot"]["ms"], "unit": "Gbp/s",
+                                 "definition": "SURVEY 8(d): host buffers in -> host results out (pack + H2D + first align of a FRESH batch, plan and all, + D2H of the records + free), "
+                                               "warm engine, mean over the rotation's batches", "ratio_to_value": out["one_shot"]["gbps"] / max(out["value"], 1e-12)}
         except Exception as e:
             out["end_to_end_gbps"] = repr(e)
 
@@ -732,23 +773,49 @@ def main():
         cores = host_cores()
         o = make_opt(flag=1 if args.cigar else 0)
         orc = Oracle()
-        arena = None
-        if Reference.available():
-            ref = Reference()
-            fn, kind, arena = ref.exact_addr(), "reference", ref.arena_addrs()   # one pair per thread, private arena
-        else:
-            fn, kind = None, "port"
         threads = min(cores, n)
-        cs, cit, sec = orc.batch(pk, o, threads, exact_fn=fn, n=n, arena=arena)   # pthread pool in C, one pair per thread at a time
-        ok = bool((cs == s[:n]).all() and (cit == n_iter[:n]).all())
+        n1 = min(n, 48)   # the one-thread leg: a bounded sample (~1.5 s of one core)
         sb = int(pk.tl[:n].sum() + pk.ql[:n].sum())
+        sb1 = int(pk.tl[:n1].sum() + pk.ql[:n1].sum())
+
+        def timed(fn, arena, label):
+            """N threads over the n pairs and ONE thread over the first n1 (both figures), answers compared with the GPU's."""
+            cs, cit, sec = orc.batch(pk, o, threads, exact_fn=fn, n=n, arena=arena)   # pthread pool in C, one pair per thread at a time
+            c1, i1, sec1 = orc.batch(pk, o, 1, exact_fn=fn, n=n1, arena=arena)
+            return {"build": label, "threads": threads, "gbps": sb / sec / 1e9, "gcells_per_s": float(cit.sum()) / sec / 1e9, "wall_s": sec,
+                    "one_thread_gbps": sb1 / sec1 / 1e9, "one_thread_pairs": n1, "one_thread_wall_s": sec1,
+                    "matches_gpu": bool((cs == s[:n]).all() and (cit == n_iter[:n]).all() and (c1 == s[:n1]).all() and (i1 == n_iter[:n1]).all())}
+
+        builds = {}
+        if Reference.available():
+            kind = "reference"
+            # the README's recommended build and the widest vector build this host can run (SURVEY 8(d): "-msse4 and -march=native" — native of the
+            # build container would not be portable to this box, so the x86-64-v3 / v4 levels are built there and checked against /proc/cpuinfo here)
+            for variant in ("sse4.2", "v3", "v4"):
+                if not Reference.variant_usable(variant):
+                    continue
+                try:
+                    ref = Reference(variant=variant)
+                    builds[variant] = timed(ref.exact_addr(), ref.arena_addrs(), f"lh3/miniwfa {ref.flags} (oracle/_ref), a private kalloc arena per thread")
+                except Exception as e:  # pragma: no cover
+                    builds[variant] = {"error": repr(e)}
+        else:
+            kind = "port"
+            builds["port"] = timed(None, None, "oracle/mwf_oracle.c (this repo's C restatement of the path), -O3 -msse4.2")
+        good = {k: v for k, v in builds.items() if "gbps" in v}
+        best = max(good, key=lambda k: good[k]["gbps"])
         out["cpu_baseline"] = {
-            "value": sb / sec / 1e9, "unit": "Gbp/s", "cores": threads, "kind": kind,
+            "value": good[best]["gbps"], "unit": "Gbp/s", "cores": threads, "kind": kind,
             "sample": f"first {n} of the {pk.n} pairs, pthread pool of {threads} threads (= usable CPUs: affinity mask capped by the cgroup quota; os.cpu_count() = {os.cpu_count()}), "
-                      f"{'lh3/miniwfa compiled -O3 -msse4.2 (oracle/_ref), a private kalloc arena per thread' if kind == 'reference' else 'oracle/mwf_oracle.c'}, {sec:.3f} s wall",
-            "gcells_per_s": float(cit.sum()) / sec / 1e9,
-            "gpu_matches_cpu_on_sample": ok,
+                      f"{good[best]['build']}, {good[best]['wall_s']:.3f} s wall; the fastest of the builds listed under `builds` (each also timed on ONE thread over the first {n1} pairs)",
+            "gcells_per_s": good[best]["gcells_per_s"],
+            "one_thread_gbps": good[best]["one_thread_gbps"],
+            "gpu_matches_cpu_on_sample": all(v["matches_gpu"] for v in good.values()),
+            "builds": builds,
         }
+        if kind != "reference":
+            out["cpu_baseline"]["fallback"] = ("oracle/_ref/libmwf_ref.so is absent (a fresh clone: the compiled reference is a git-ignored binary that only a build container "
+                                               "with /root/reference produces) — this repo's own C restatement was timed instead, hence kind = 'port'")
     for bk, _, _ in batches:
         bk.free()
     eng.close()

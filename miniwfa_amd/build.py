@@ -67,6 +67,29 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+# which source file defines a kernel (by the start of its symbol): what a counter profile of that kernel is a profile OF
+KERNEL_FILES = {"wfa_band2_kernel": "mwf_band2.hip", "wfa_sys_kernel": "mwf_sys.hip", "wfa_sys_seg_kernel": "mwf_sys.hip", "wfa_batch_kernel": "mwf_kernels.hip",
+                "wfa_lane_kernel": "mwf_lane.hip", "wfa_mid_kernel": "mwf_mid.hip"}
+
+
+def kernel_fingerprint(symbol: str) -> str | None:
+    """SHA-256 (first 16 hex digits) of the source file that defines `symbol` plus the device headers every kernel includes.  profiles/
+    make_traffic.py stores it with a kernel's counter traffic; bench.py recomputes it on the tree it runs from and marks `roofline.frac_stale`
+    when they differ — the profile then describes other code than the kernel that was timed."""
+    import hashlib
+    name = symbol.split("<")[0].strip()
+    f = KERNEL_FILES.get(name)
+    if f is None:
+        return None
+    h = hashlib.sha256()
+    for p in (os.path.join(CSRC, f), os.path.join(CSRC, "mwf_device.h"), os.path.join(CSRC, "mwf_internal.h")):
+        try:
+            h.update(open(p, "rb").read())
+        except OSError:
+            return None
+    return h.hexdigest()[:16]
+
+
 CLI = os.path.join(ROOT, "tools", "test-mwf")
 
 

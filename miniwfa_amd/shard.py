@@ -8,8 +8,8 @@ ragged batch does not leave one GPU with all the long pairs.  Every rank compute
 
 The only communication is the final gather of the fixed-size per-pair records: ONE `all_gather_into_tensor` of
 (s, n_iter) packed as two int64 per pair — RCCL over xGMI on GPUs (backend "nccl"), gloo in the CPU tests.  CIGARs,
-when wanted, are variable-length: their lengths travel in one more fixed-record gather, the words as one broadcast per rank
-of exactly that rank's size (no padding to the largest payload).
+when wanted, are variable-length: their lengths travel in one more fixed-record gather, the words in ONE grouped send/recv exchange,
+each message exactly its sender's size (no padding to the largest payload, no per-rank broadcast loop).
 """
 from __future__ import annotations
 
@@ -71,12 +71,16 @@ def gather_records(dist, s_local, it_local, n_total: int, device=None, deal=None
     return s, it
 
 
-def gather_cigars(dist, cigars_local, n_total: int, device=None, deal=None):
-    """Variable-length payload: list (share order) of uint32 numpy arrays -> list for all n_total pairs on every rank.
+def gather_cigars(dist, cigars_local, n_total: int, device=None, deal=None, dst=None):
+    """Variable-length payload: list (share order) of uint32 numpy arrays -> list for all n_total pairs (on every rank, or — `dst` given —
+    on rank `dst` only; the others get None).
 
-    Two steps, neither padded to the largest payload: the per-pair lengths travel in ONE all_gather of fixed-size records (one int64
-    per pair, padded to the largest share like the (s, n_iter) records — a few bytes per pair), then every rank's CIGAR words travel
-    as ONE broadcast of exactly that rank's size (a rank with one long pair no longer makes every other rank ship that many words)."""
+    Two steps (fixed records first, payloads "via grouped send/recv sized from the gathered n_cigar"), neither padded to the
+    largest payload:
+      1. the per-pair lengths in ONE all_gather of fixed-size records (one int64 per pair, padded to the largest share — a few bytes per pair);
+      2. the words in ONE grouped point-to-point exchange (`batch_isend_irecv`: on RCCL a single ncclGroupStart/End of sends and receives over
+         xGMI, each exactly as long as its sender's payload; gloo runs the same ops in the CPU tests).  Every rank posts its sends and receives
+         at once — no rank-by-rank broadcast loop, no host synchronisation between peers: one wait, one copy to the host at the end."""
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
     if deal is None:
@@ -91,17 +95,28 @@ def gather_cigars(dist, cigars_local, n_total: int, device=None, deal=None):
         pad_len[:sizes[rank]] = torch.tensor([len(c) for c in cigars_local], dtype=torch.int64, device=dev)
     all_len = torch.empty((world * cap,), dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(all_len, pad_len)
-    all_len = all_len.view(world, cap).cpu().numpy()
+    all_len = all_len.view(world, cap).cpu().numpy()          # (the one host read: the receive buffers are sized from it)
     words = [int(all_len[r, :sizes[r]].sum()) for r in range(world)]
     flat = np.concatenate([np.asarray(c, dtype=np.uint32) for c in cigars_local]) if words[rank] else np.zeros(0, dtype=np.uint32)
-    payload = []
-    for r in range(world):   # sized exchange: rank r's words, exactly, to everybody
-        if words[r] == 0:
-            payload.append(np.zeros(0, dtype=np.uint32))
-            continue
-        buf = torch.from_numpy(flat.view(np.int32).copy()).to(dev) if r == rank else torch.empty((words[r],), dtype=torch.int32, device=dev)
-        dist.broadcast(buf, src=r)
-        payload.append(buf.cpu().numpy().view(np.uint32))
+    mine = torch.from_numpy(flat.view(np.int32).copy()).to(dev)
+    receivers = list(range(world)) if dst is None else [int(dst)]
+    bufs = {rank: mine}
+    ops = []
+    if rank in receivers:
+        for r in range(world):
+            if r != rank and words[r]:
+                bufs[r] = torch.empty((words[r],), dtype=torch.int32, device=dev)
+                ops.append(dist.P2POp(dist.irecv, bufs[r], r))
+    if words[rank]:
+        for r in receivers:
+            if r != rank:
+                ops.append(dist.P2POp(dist.isend, mine, r))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    if rank not in receivers:
+        return None
+    payload = [bufs[r].cpu().numpy().view(np.uint32) if words[r] else np.zeros(0, dtype=np.uint32) for r in range(world)]
     out: list = [None] * n_total
     for r in range(world):
         off = 0

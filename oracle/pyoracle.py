@@ -56,7 +56,7 @@ def build(force: bool = False) -> None:
     src = os.path.join(HERE, "mwf_oracle.c")
     need = force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src)
     ref_so = os.path.join(HERE, "_ref", "libmwf_ref.so")
-    if os.path.exists("/root/reference/miniwfa.c") and not os.path.exists(ref_so):
+    if os.path.exists("/root/reference/miniwfa.c") and not all(os.path.exists(os.path.join(HERE, "_ref", f)) for f in ("libmwf_ref.so", "libmwf_ref_v3.so", "libmwf_ref_v4.so")):
         need = True
     if need:
         subprocess.run(["make", "-C", HERE], check=True, capture_output=True)
@@ -186,12 +186,35 @@ class Reference(_Aligner):
                 return False
         return os.path.exists(cls.path)
 
-    def __init__(self, arena: bool = False):
+    # the builds oracle/Makefile makes of the same three reference sources: flags, what the host must support (/proc/cpuinfo flags)
+    VARIANTS = {"sse4.2": ("libmwf_ref.so", "-O3 -msse4.2", ("sse4_2",)),
+                "v3": ("libmwf_ref_v3.so", "-O3 -march=x86-64-v3", ("avx2", "bmi2", "fma")),
+                "v4": ("libmwf_ref_v4.so", "-O3 -march=x86-64-v4", ("avx512f", "avx512bw", "avx512cd", "avx512dq", "avx512vl"))}
+
+    @classmethod
+    def variant_usable(cls, variant: str) -> bool:
+        """The build exists AND this host's CPU has every instruction-set extension it was compiled for."""
+        so, _, need = cls.VARIANTS[variant]
+        if not os.path.exists(os.path.join(HERE, "_ref", so)):
+            return False
+        try:
+            flags = set()
+            for line in open("/proc/cpuinfo"):
+                if line.startswith("flags"):
+                    flags = set(line.split(":", 1)[1].split())
+                    break
+            return all(f in flags for f in need)
+        except OSError:
+            return variant == "sse4.2"
+
+    def __init__(self, arena: bool = False, variant: str = "sse4.2"):
         """arena=True: every call allocates inside one kalloc arena owned by this object (km_init) instead of km = NULL —
-        what a long-running caller of the library would do; saves the page faults of a fresh arena per call."""
+        what a long-running caller of the library would do; saves the page faults of a fresh arena per call.
+        variant: which build of the reference (VARIANTS); the default is the README's recommendation."""
         if not self.available():
             raise FileNotFoundError(self.path)
-        L = C.CDLL(self.path)
+        self.variant, self.flags = variant, self.VARIANTS[variant][1]
+        L = C.CDLL(os.path.join(HERE, "_ref", self.VARIANTS[variant][0]))
         self.lib = L
         sig = [C.c_void_p, C.POINTER(Opt), C.c_int32, C.c_char_p, C.c_int32, C.c_char_p, C.POINTER(Rst)]
         for name in ("mwf_wfa_exact", "mwf_wfa_auto", "mwf_wfa_chain"):

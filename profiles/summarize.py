@@ -21,3 +21,12 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
         for k, c, v, n in rows:
             if "wfa" in k:
                 print(f"== pmc {c} = {v / max(1, n):.6g} per launch ({n} launches) [{k[:70]}]")
+# the tree these counters were collected on (the snapshot on the GPU box): fingerprints of the kernels' source files, which
+# profiles/make_traffic.py stores in traffic.json and bench.py compares with the tree it times (roofline.frac_stale)
+try:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from miniwfa_amd.build import KERNEL_FILES, kernel_fingerprint
+    for name in sorted(KERNEL_FILES):
+        print(f"== fingerprint {name} {kernel_fingerprint(name)}")
+except Exception as e:  # pragma: no cover
+    print("== fingerprint unavailable:", e)

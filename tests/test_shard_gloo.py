@@ -128,3 +128,55 @@ def test_two_rank_gloo_gather(n):
         assert s == [e[0] for e in expect], rank
         assert it == [e[1] for e in expect], rank
         assert cigs == [e[2] for e in expect], rank
+
+
+# ---- BASELINE configs[4] at world_size 8 (no 8-GPU node is available to the build: the deal and the gather on gloo) -------------------
+
+def _worker_config5(rank, world, port, lengths, q):
+    """One rank of configs[4]'s result exchange: no alignment — record i carries (i, 3 i + 1), CIGAR i is i % 5 words of value i — so that every
+    rank can check the ORDER of what it gathered for 10 000 pairs dealt by work."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = len(lengths)
+        deal = deal_pairs(lengths, world)
+        mine = deal[rank]
+        s, it = gather_records(dist, torch.from_numpy(mine.astype(np.int32)), torch.from_numpy(3 * mine + 1), n, deal=deal)
+        ok = bool((s.numpy() == np.arange(n)).all() and (it.numpy() == 3 * np.arange(n) + 1).all())
+        cig = gather_cigars(dist, [np.full(int(i) % 5, int(i), dtype=np.uint32) for i in mine], n, deal=deal, dst=0)
+        if rank == 0:
+            ok = ok and all(len(c) == i % 5 and (c == i).all() for i, c in enumerate(cig))
+        else:
+            ok = ok and cig is None
+        work = float(((lengths[mine].astype(np.float64) + 1) ** 2).sum())
+        q.put((rank, ok, len(mine), work))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shape", ["uniform", "ragged"])
+def test_eight_rank_gloo_deal_of_config5(shape):
+    """BASELINE configs[4]: 10 000 pairs dealt over 8 ranks, ONE all_gather of the records (+ the grouped send/recv of CIGARs to rank 0).
+    Uniform 50 kb pairs and a ragged variant (lengths 5-100 kb); per-rank work (cells ~ (tl+ql)^2) within 2 % of the mean, every pair
+    exactly once, gathered in global pair order on every rank."""
+    world, n = 8, 10000
+    rng = np.random.default_rng(5)
+    lengths = np.full(n, 100000, dtype=np.int64) if shape == "uniform" else (2 * rng.integers(5000, 100000, n)).astype(np.int64)
+    deal = deal_pairs(lengths, world)
+    assert sorted(np.concatenate(deal).tolist()) == list(range(n))
+    work = np.array([float(((lengths[d].astype(np.float64) + 1) ** 2).sum()) for d in deal])
+    assert work.max() / work.mean() < 1.02 and work.min() / work.mean() > 0.98, work / work.mean()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_config5, args=(r, world, port, lengths, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(g[0] for g in got) == list(range(world))
+    assert all(g[1] for g in got), got
+    assert sum(g[2] for g in got) == n
