@@ -116,6 +116,43 @@ def call_latency(mw, synth_pair, reps=40):
                     ref.align(t, q, ro)
                 rec["cpu_reference_us"] = (time.perf_counter() - t0) / n * 1e6
             out[f"{tl}bp_{label}"] = rec
+    # The caller that keeps the reference's one-pair-per-call shape (main.c:67-72) but has SEVERAL host threads: every thread takes its own
+    # pooled engine (stream + device pools), so their single-pair kernels share the device — the call RATE of 16 threads looping
+    # mwf_wfa_exact on 1 kb pairs against one thread's (ctypes drops the GIL inside the call; the Python between calls is ~10 us of a 300 us call).
+    try:
+        pairs = [synth_pair(5000 + i, 1000, 0.05) for i in range(16)]
+        o = mw.opt_init()
+
+        def loop(k, n_calls, box):
+            t, q = pairs[k]
+            for _ in range(n_calls):
+                box.append(mw.wfa_exact(t, q, o)[0])
+
+        def rate(n_threads, n_calls):
+            box = []
+            th = [threading.Thread(target=loop, args=(k, n_calls, box)) for k in range(n_threads)]
+            t0 = time.perf_counter()
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            return n_threads * n_calls / (time.perf_counter() - t0)
+
+        rate(16, 5)   # sixteen warm engines
+        r1, r16 = rate(1, 100), rate(16, 100)
+        out["threads16_1000bp_score"] = {"calls_per_s_one_thread": r1, "calls_per_s_16_threads": r16, "ratio": r16 / r1,
+                                         "what": "16 host threads each looping mwf_wfa_exact on its own 1 kb pair (one pooled engine per thread, kernels of different threads share the device)"}
+        # the same loop with "submit" as its body and the waits behind it (mwf_wfa_submit / mwf_wfa_wait: one dispatcher thread, one batch launch per ~100 us of submissions)
+        many = [pairs[i % 16] for i in range(1600)]
+        for _ in range(2):
+            t0 = time.perf_counter()
+            jobs = [mw.wfa_submit(t, q, o) for t, q in many]
+            res = [j.wait() for j in jobs]
+            w = time.perf_counter() - t0
+        out["submit_wait_1000bp_score"] = {"calls_per_s": len(many) / w, "ratio_to_one_thread_calls": len(many) / w / r1, "ok": all(r[0] == res[i % 16][0] for i, r in enumerate(res)),
+                                           "what": "one host thread: 1600 x mwf_wfa_submit, then 1600 x mwf_wfa_wait (Python binding overhead included)"}
+    except Exception as e:
+        out["threads16_1000bp_score"] = {"error": repr(e)}
     return out
 
 

@@ -92,6 +92,19 @@ void mwf_wfa_batch(void *km, const mwf_opt_t *opt, int32_t n, const int32_t *tl,
 void mwf_wfa_batch_multi(void *km, const mwf_opt_t *opt, int32_t n, const int32_t *tl, const char *const *ts,
                          const int32_t *ql, const char *const *qs, mwf_rst_t *r, int32_t n_dev, const int32_t *devices);
 
+/* Batch throughput for callers that keep the reference's one-pair-per-call loop (reference main.c:67-72).
+ * mwf_wfa_submit() queues one pair (ts / qs / *opt are read later: they must stay valid until the job has been waited for) and returns at once;
+ * a dispatcher thread aligns everything submitted so far as ONE mwf_wfa_batch call per option set — while it runs, the caller may keep submitting.
+ * mwf_wfa_wait() blocks until the job is done, fills *r exactly as mwf_wfa_exact would (CIGAR allocated from `km` on the waiting thread) and
+ * frees the job.  A pair waits at most MWF_COALESCE_US microseconds (default 100) for company unless a wait arrives first.
+ * MWF_COALESCE_US=n (n > 0) in the environment also routes plain mwf_wfa_exact calls through the same dispatcher: calls from different host
+ * threads that arrive within n microseconds share one launch (opt-in: a lone caller pays up to n microseconds per call). */
+typedef struct mwf_job_s mwf_job_t;
+mwf_job_t *mwf_wfa_submit(const mwf_opt_t *opt, int32_t tl, const char *ts, int32_t ql, const char *qs);
+void mwf_wfa_wait(void *km, mwf_job_t *job, mwf_rst_t *r);
+/* diagnostics: batches the dispatcher has run so far, pairs in them */
+void mwf_wfa_async_stats(int64_t *n_batches, int64_t *n_jobs);
+
 typedef struct mwf_gpu_s mwf_gpu_t;             /* engine: one device, one stream, one memory pool */
 typedef struct mwf_gpu_batch_s mwf_gpu_batch_t; /* a set of pairs resident in that device's HBM */
 

@@ -51,7 +51,7 @@ class KmStat(C.Structure):
 # every symbol include/miniwfa.h and include/kalloc.h declare
 ABI_SYMBOLS = (
     "mwf_opt_init", "mwf_wfa_exact", "mwf_wfa_auto", "mwf_wfa_chain", "mwf_cigar2score", "mwf_assert_cigar",
-    "mwf_wfa_batch", "mwf_wfa_batch_multi", "mwf_gpu_batch_dev_status", "mwf_gpu_batch_fetch_cigars", "mwf_gpu_device_count", "mwf_gpu_create", "mwf_gpu_destroy", "mwf_gpu_last_error",
+    "mwf_wfa_batch", "mwf_wfa_batch_multi", "mwf_wfa_submit", "mwf_wfa_wait", "mwf_wfa_async_stats", "mwf_gpu_batch_dev_status", "mwf_gpu_batch_fetch_cigars", "mwf_gpu_device_count", "mwf_gpu_create", "mwf_gpu_destroy", "mwf_gpu_last_error",
     "mwf_gpu_batch_upload", "mwf_gpu_batch_wrap", "mwf_gpu_batch_free", "mwf_gpu_batch_align", "mwf_gpu_batch_results",
     "mwf_gpu_batch_dev_scores", "mwf_gpu_batch_dev_iters", "mwf_gpu_batch_cigar", "mwf_gpu_get_stats", "mwf_gpu_set",
     "mwf_gpu_debug_band",
@@ -87,6 +87,12 @@ def lib() -> C.CDLL:
     L.mwf_wfa_batch.restype = None
     L.mwf_wfa_batch_multi.argtypes = L.mwf_wfa_batch.argtypes + [C.c_int32, P(C.c_int32)]
     L.mwf_wfa_batch_multi.restype = None
+    L.mwf_wfa_submit.argtypes = [P(MwfOpt), C.c_int32, C.c_char_p, C.c_int32, C.c_char_p]
+    L.mwf_wfa_submit.restype = C.c_void_p
+    L.mwf_wfa_wait.argtypes = [C.c_void_p, C.c_void_p, P(MwfRst)]
+    L.mwf_wfa_wait.restype = None
+    L.mwf_wfa_async_stats.argtypes = [P(C.c_int64), P(C.c_int64)]
+    L.mwf_wfa_async_stats.restype = None
     L.mwf_gpu_batch_dev_status.argtypes = [C.c_void_p]
     L.mwf_gpu_batch_dev_status.restype = C.c_void_p
     L.mwf_gpu_batch_fetch_cigars.argtypes = [C.c_void_p, C.c_void_p]
@@ -171,6 +177,35 @@ def wfa_chain(t: bytes, q: bytes, opt: MwfOpt, km=None):
     r = MwfRst()
     lib().mwf_wfa_chain(km, C.byref(opt), len(t), t, len(q), q, C.byref(r))
     return _take(r, km)
+
+
+class Job:
+    """A pair submitted with mwf_wfa_submit; keeps the buffers it borrows alive until wait()."""
+
+    def __init__(self, t: bytes, q: bytes, opt: MwfOpt):
+        self._keep = (t, q, opt)
+        self.h = lib().mwf_wfa_submit(C.byref(opt), len(t), t, len(q), q)
+        if not self.h:
+            raise ValueError("mwf_wfa_submit refused the pair")
+
+    def wait(self, km=None):
+        """mwf_wfa_wait -> (s, n_iter, cigar words or None), exactly what wfa_exact returns for the pair."""
+        r = MwfRst()
+        lib().mwf_wfa_wait(km, self.h, C.byref(r))
+        self.h = None
+        return _take(r, km)
+
+
+def wfa_submit(t: bytes, q: bytes, opt: MwfOpt) -> Job:
+    """mwf_wfa_submit: queue one pair for the dispatcher (include/miniwfa.h part 2); job.wait() collects it."""
+    return Job(t, q, opt)
+
+
+def async_stats():
+    """(batches the dispatcher has run, pairs in them)."""
+    a, b = C.c_int64(), C.c_int64()
+    lib().mwf_wfa_async_stats(C.byref(a), C.byref(b))
+    return a.value, b.value
 
 
 def wfa_batch(pairs: Sequence[tuple[bytes, bytes]], opt: MwfOpt, km=None):

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libmwf_hip.so")
-SOURCES = ["mwf_kernels.hip", "mwf_band2.hip", "mwf_lane.hip", "mwf_mid.hip", "mwf_sys.hip", "mwf_engine.cpp", "mwf_memory.cpp", "mwf_plan.cpp", "mwf_chain.cpp", "kalloc.cpp", "mwf_dbg.cpp"]
+SOURCES = ["mwf_kernels.hip", "mwf_band2.hip", "mwf_lane.hip", "mwf_mid.hip", "mwf_sys.hip", "mwf_engine.cpp", "mwf_memory.cpp", "mwf_plan.cpp", "mwf_chain.cpp", "mwf_async.cpp", "kalloc.cpp", "mwf_dbg.cpp"]
 HEADERS = [os.path.join(CSRC, "mwf_internal.h"), os.path.join(CSRC, "mwf_device.h"), os.path.join(CSRC, "mwf_engine.h"), os.path.join(ROOT, "include", "miniwfa.h"), os.path.join(ROOT, "include", "kalloc.h")]
 
 

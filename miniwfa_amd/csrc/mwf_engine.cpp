@@ -422,6 +422,7 @@ void mwf_wfa_batch(void *km, const mwf_opt_t *opt, int32_t n, const int32_t *tl,
 
 void mwf_wfa_exact(void *km, const mwf_opt_t *opt, int32_t tl, const char *ts, int32_t ql, const char *qs, mwf_rst_t *r)
 {
+	if (coalesce_window_us() > 0) { exact_coalesced(km, opt, tl, ts, ql, qs, r); return; } // MWF_COALESCE_US: calls of different host threads share a launch (mwf_async.cpp)
 	const int32_t dev = default_device();
 	mwf_wfa_batch_multi(km, opt, 1, &tl, &ts, &ql, &qs, r, 1, &dev);
 }

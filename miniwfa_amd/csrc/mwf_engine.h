@@ -225,7 +225,10 @@ BlockLayout layout_block(size_t n, size_t seq_bytes, bool owned);
 mwf_gpu_batch_t *batch_common(mwf_gpu_t *g, int32_t n, const int32_t *h_tl, const int32_t *h_ql, size_t seq_bytes, bool owned, BlockLayout &L);
 mwf_gpu_batch_t *batch_from_host(mwf_gpu_t *g, int32_t n, const int32_t *tl, const char *const *ts, const int32_t *ql, const char *const *qs,
                                  const char *packed, int64_t packed_bytes, const int64_t *p_t_off, const int64_t *p_q_off);
-float estimate_divergence_device(mwf_gpu_t *g, mwf_gpu_batch_t *b); // 8-mer sketch of a few pairs of a device-resident batch (0: unknown)
+float estimate_divergence_device(mwf_gpu_t *g, mwf_gpu_batch_t *b);
+// ---- mwf_async.cpp: submit / wait and the opt-in coalescing of single calls
+int64_t coalesce_window_us();
+void exact_coalesced(void *km, const mwf_opt_t *opt, int32_t tl, const char *ts, int32_t ql, const char *qs, mwf_rst_t *r); // 8-mer sketch of a few pairs of a device-resident batch (0: unknown)
 
 // ---- mwf_plan.cpp: penalties, kernel choice, launches, the whole-device passes, re-runs
 Penalty make_penalty(const mwf_opt_t &o);

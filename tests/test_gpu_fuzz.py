@@ -264,3 +264,58 @@ def test_batch_multi_eight_engines_on_one_device_config5_share(oracle):
     assert len(got) == 160 and [r[:2] for r in got] == [r[:2] for r in one]
     for i in (0, 77, 159):
         assert got[i][:2] == oracle.align(pairs[i][0], pairs[i][1], make_opt())[:2], i
+
+
+# ---- one-pair-per-call callers: submit / wait and the opt-in coalescer -----------------------------------------
+
+def test_submit_wait_gives_the_drop_in_answers(oracle):
+    """mwf_wfa_submit / mwf_wfa_wait (include/miniwfa.h part 2): the loop of reference main.c:67-72 with "submit" as its body — 600 pairs of
+    mixed lengths under three option sets interleaved, waited for in a different order; every result is what mwf_wfa_exact returns (the
+    oracle's s, n_iter, CIGAR), CIGARs come from the caller's kalloc arena, and the dispatcher ran far fewer batches than there were pairs."""
+    rng = np.random.default_rng(17)
+    pairs = [synth_pair(66000 + i, int(rng.choice([60, 150, 400, 1000, 2500, 6000], p=[0.3, 0.3, 0.2, 0.1, 0.07, 0.03])), float(rng.choice([0.02, 0.08]))) for i in range(600)]
+    kws = [dict(flag=1), dict(flag=0), dict(flag=1, x=2, o1=2, e1=2, o2=12, e2=1)]
+    exp = [oracle.align(t, q, make_opt(**kws[i % 3])) for i, (t, q) in enumerate(pairs)]
+    b0, j0 = mw.async_stats()
+    L = mw.lib()
+    km = L.km_init()
+    jobs = [mw.wfa_submit(t, q, mw.opt_init(**kws[i % 3])) for i, (t, q) in enumerate(pairs)]
+    got = [None] * len(jobs)
+    for i in list(range(len(jobs) - 1, -1, -2)) + list(range(len(jobs) - 2, -1, -2)):   # odd ones first, backwards
+        got[i] = jobs[i].wait(km)
+    L.km_destroy(km)
+    assert got == exp
+    b1, j1 = mw.async_stats()
+    assert j1 - j0 == 600 and b1 - b0 <= 60, (b1 - b0, j1 - j0)
+
+
+def test_coalesced_single_calls_from_many_threads(oracle):
+    """MWF_COALESCE_US (read once per process: a child process here): 16 host threads each looping plain mwf_wfa_exact on 1 kb pairs share
+    launches through the dispatcher — same answers as the oracle's, and several calls per batch on average."""
+    import subprocess, sys, json, os
+    code = r'''
+import json, sys, threading
+sys.path.insert(0, %r)
+import torch  # noqa: F401  (its HIP runtime first, like tests/conftest.py)
+import miniwfa_amd as mw
+from miniwfa_amd.synth import synth_pair
+pairs = [synth_pair(67000 + i, 1000, 0.05) for i in range(16)]
+out = [[] for _ in pairs]
+def loop(k):
+    t, q = pairs[k]
+    for _ in range(40):
+        out[k].append(mw.wfa_exact(t, q, mw.opt_init(flag=1)))
+th = [threading.Thread(target=loop, args=(k,)) for k in range(16)]
+[x.start() for x in th]; [x.join() for x in th]
+print(json.dumps({"stats": mw.async_stats(), "res": [[r[0], r[1], r[2]] for r in (o[-1] for o in out)], "same": all(all(r == o[0] for r in o) for o in out)}))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MWF_COALESCE_US="150")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["same"]
+    for k, (s, it, cig) in enumerate(d["res"]):
+        t, q = synth_pair(67000 + k, 1000, 0.05)
+        assert (s, it, cig) == tuple(oracle.align(t, q, make_opt(flag=1))), k
+    batches, jobs = d["stats"]
+    assert jobs == 16 * 40 and batches * 3 <= jobs, d["stats"]   # at least three calls per launch on average
