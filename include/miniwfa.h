@@ -12,7 +12,7 @@
  *
  * There is no CPU fallback anywhere behind this header: every alignment runs in the HIP
  * kernels under miniwfa_amd/csrc/ (mwf_kernels.hip generic, mwf_band2.hip packed band,
- * mwf_lane.hip short pairs, mwf_mid.hip the mid-size pairs of small batches, mwf_sys.hip + mwf_coop.hip whole device), and every entry point aborts with a message
+ * mwf_lane.hip short pairs, mwf_mid.hip the mid-size pairs of small batches, mwf_sys.hip whole device), and every entry point aborts with a message
  * if no gfx950 device can be opened.
  */
 #ifndef MWF_HIP_MINIWFA_H

@@ -16,5 +16,5 @@ for f in $KERNELS; do
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared $OBJS \
-  $C/build/mwf_kernels.hip.o $C/build/mwf_engine.cpp.o $C/build/mwf_memory.cpp.o $C/build/mwf_plan.cpp.o $C/build/mwf_chain.cpp.o $C/build/kalloc.cpp.o $C/build/mwf_dbg.cpp.o -o profiles/_${NAME}_libmwf_hip.so -lpthread
+  $C/build/mwf_kernels.hip.o $C/build/mwf_engine.cpp.o $C/build/mwf_memory.cpp.o $C/build/mwf_plan.cpp.o $C/build/mwf_chain.cpp.o $C/build/mwf_async.cpp.o $C/build/kalloc.cpp.o $C/build/mwf_dbg.cpp.o -o profiles/_${NAME}_libmwf_hip.so -lpthread
 echo profiles/_${NAME}_libmwf_hip.so
