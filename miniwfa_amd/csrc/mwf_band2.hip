@@ -957,489 +957,6 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 	return R;
 }
 
-// ============================================================================================================================
-// The BLOCK form of the packed band kernel (round 6): kBP = 4 penalties per workgroup barrier, halo columns instead of an edge table.
-//
-// band2_pass above pays, per penalty and wave, a header (~400-480 cycles), a drain, one s_barrier with its flag word and the window
-// bookkeeping behind it (600-1800 cycles even for the wave that arrives last: profiles/r03/band2_phase_cycles.txt), and one edge-table
-// exchange per chunk.  With the default penalties every H row a penalty reads is at least min(x, o2+e2) = 4 penalties old
-// (miniwfa.c:252-257; the row of lag o1+e1 is folded away, FOLD above), so for FOUR consecutive penalties the only dependence between
-// neighbouring chunks is E/F of the neighbouring COLUMN at lags e1 = 2 and e2 = 1 (miniwfa.c:267-278) — which mwf_sys.hip already
-// solves across workgroups with halo columns.  Here, inside the workgroup:
-//   * a chunk still computes 256 columns, but OWNS the inner kBS = 240; kBH = 8 columns (two lanes) either side duplicate the
-//     neighbours' outer owned columns.  After a hand-off every column is exact; each penalty without one costs one column per side
-//     (the lag-1 E2/F2 of a column the chunk does not hold), so after four penalties everything at least four columns inside is
-//     still exact — the owned columns with four to spare;
-//   * a wave runs its chunks one after the other, four penalties each, talking to nobody: no edge table, no per-penalty header.
-//     Only owned columns are stored to the H rows; at the block's end the lanes that hold a chunk's outer owned columns (2, 3, 60,
-//     61) publish their twelve E/F registers in LDS, ONE s_barrier, and every chunk refreshes its halo lanes (0, 1, 62, 63) from its
-//     neighbours' boxes;
-//   * the window (reference wf_lo / wf_hi: grown by the liveness of the edge cells, miniwfa.c:417-418, :325-326) is followed per
-//     chunk as a VIEW during the block.  Between shrinks the lower edge can only sit in U = [wf_lo - 4, wf_lo - 1] during the block
-//     (upper edge alike), known to everybody at the block's start.  The chunk that OWNS the edge cell of a penalty has held every
-//     edge cell of the block so far at least 8 - 3 columns from its ends, i.e. exactly: it publishes "the edge moved at penalty j"
-//     (one bit per penalty and side in the block's flag word), and after the barrier every thread re-derives the exact chain of
-//     windows, n_iter (miniwfa.c:421), the stop rules (:422-425) and the end cell (:405-409) penalty by penalty.  A chunk that
-//     holds a column of U without owning one may follow a wrong view — it then computes cells the reference does not, or masks
-//     cells it does: only in columns it does not own, and what is wrong there travels one column per penalty, never as far as an
-//     owned column (all its owned columns are either beyond the widest window of the block, masked dead unconditionally, or at
-//     least eight columns inside it);
-//   * the shrink (miniwfa.c:144-171) falls on a block boundary (256 = 64 x 4); good bits are kept for owned columns only.
-// Score-only, 2-bit sequence copies, FOLD penalties with min(x, o2+e2) >= kBP: the host asks for it (launch_variant) where those hold.
-constexpr int kBP = 4, kBH = 8, kBS = kChunk - 2 * kBH;
-constexpr int kBoxInts = 4 + 2 * 2 * 12; // per chunk slot and block parity: tag | [side][lane][twelve E/F registers]
-
-template <int NWK>
-struct alignas(16) Band4Lds {
-	Shared sh;
-	int32_t box[2][NWK][kBoxInts];
-};
-
-template <int K, typename ArgsT>
-__device__ PassResult band4_pass(const ArgsT &A, const PairMem &M, Shared &sh, const int32_t box_base, const int32_t qoff, bool trace_band)
-{
-	constexpr int T = 512, NW = T / 64, NWK = NW * K, E1 = 2, E2 = 1, FULL = 16;
-	const int32_t tl = M.tl, ql = M.ql, cmax = tl + ql + 1;
-	const int32_t tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
-	const int32_t W = A.W, nH = A.pen.nH, lagx = A.pen.x, lag2 = A.pen.oe2;
-	// H rows: W int16 per row; column c lives in quad (c + kBH) >> 2 (a chunk's first column is 240 g - 8), a quad holds its columns as (c0, c2, c1, c3);
-	// 8 bytes of slack in front (lane 0 of chunk 0 looks one word to the left)
-	char *const Hb = (char*)M.H;
-	const uint32_t RS = (uint32_t)W << 1;
-	// The ring is kBP - 1 rows deeper than the reference's (miniwfa.c:90: max lag + 1).  Between two barriers a wave may be three penalties ahead of
-	// its neighbour, whose halo lanes still read the row of lag o2+e2 of THEIR penalty from the columns this wave owns: the row of a block's last
-	// penalty must not land on the row its first penalty reads.  (With nH rows it did: unrelated pairs lost cells behind every shrink, and differently
-	// from run to run.)  The good bits and the window table stay nH deep: they are only read at a shrink, behind a barrier.
-	const int32_t RR = nH + kBP - 1;
-	PassResult R;
-	R.status = ST_OK, R.s = 0, R.info = 0, R.n_snap = 0, R.cells = 0;
-#ifdef MWF_B4_DEBUG
-#define B4CHK(o, n, what) do { if ((uint64_t)(uint32_t)(o) + (n) > (uint64_t)RR * RS) { printf("band4 %s: offset %u beyond %u x %u (tl %d ql %d lane %d wave %d)\n", what, (unsigned)(o), (unsigned)nH, (unsigned)RS, tl, ql, lane, wave); __builtin_trap(); } } while (0)
-#define B4GOOD(i, what) do { if ((int64_t)(i) < 0 || (int64_t)(i) + 4 > (int64_t)nH * fresh(A).GW) { printf("band4 %s: good index %lld beyond %d x %d\n", what, (long long)(i), nH, fresh(A).GW); __builtin_trap(); } } while (0)
-#else
-#define B4CHK(o, n, what)
-#define B4GOOD(i, what)
-#endif
-
-	int32_t e1h[E1][K][2], f1h[E1][K][2], e2h[E2][K][2], f2h[E2][K][2];
-#pragma unroll
-	for (int k = 0; k < K; ++k)
-#pragma unroll
-		for (int i = 0; i < 2; ++i) {
-#pragma unroll
-			for (int a = 0; a < E1; ++a) e1h[a][k][i] = f1h[a][k][i] = kDeadPair;
-#pragma unroll
-			for (int a = 0; a < E2; ++a) e2h[a][k][i] = f2h[a][k][i] = kDeadPair;
-		}
-	const int32_t RA = pair_of(4 * lane, 4 * lane + 2);
-	const uint32_t lane8 = ((uint32_t)lane << 3) + 8u;
-	const int32_t nd = lane == 0 ? -4 : 8;
-	const int32_t T0 = both16(cmax), TLp = both16(tl), TL1 = both16(tl + 1);
-	const bool owned_lane = lane >= 2 && lane < 62;
-	const unsigned long long owned_mask = (~0ull << 2) & (~0ull >> 2);
-
-	// ---- every row reads as dead around the origin (band2_pass); whole chunks, halos included
-	{
-		const int32_t reach = RR + 1 + 2 * kBH;
-		const int32_t g_a = max((tl + 1 - reach) / kBS - 1, 0), g_b = (tl + 1 + reach) / kBS + 1, per_row = (g_b - g_a + 1) * 60 + 8;
-		for (int32_t q = tid; q < RR * per_row; q += T) {
-			const int32_t row = q / per_row, rem = q - row * per_row;
-			B4CHK((uint32_t)row * RS + (uint32_t)((g_a * 60 + rem) * 8 + 8), 8, "dead init");
-			*(int2*)(Hb + (size_t)((uint32_t)row * RS + (uint32_t)((g_a * 60 + rem) * 8 + 8))) = make_int2(kDeadPair, kDeadPair);
-		}
-	}
-	for (int32_t j = tid; j < 2 * NWK; j += T) *(int32_t*)(lds2 + box_base + j * kBoxInts * 4) = -1; // no box has been published
-	if (tid == 0) {
-		for (int32_t j = 0; j < nH; ++j) sh.rng_lo[j] = 1, sh.rng_hi[j] = 0;
-		for (int32_t j = 0; j < 12; ++j) (&sh.flags[0][0])[j] = 0;
-		sh.rng_lo[0] = sh.rng_hi[0] = tl + 1;
-	}
-	__syncthreads();
-	if (tid < 64) { // the origin's run (reference wf_stripe_init, miniwfa.c:103-121, and its extension)
-		const int32_t k0 = run_wave16(qoff, 0, 0, min(tl, ql), 0) - 1;
-		if (tid == 0) {
-			const int32_t c = tl + 1 + kBH, e = c & 3;
-			*(int16_t*)(Hb + 8 + (size_t)(uint32_t)(((c & ~3) + ((e & 1) << 1) + (e >> 1)) << 1)) = (int16_t)k0;
-			sh.word[1] = k0;
-		}
-	}
-	__syncthreads();
-	{
-		const int32_t k0 = uni(sh.word[1]);
-		if (k0 == tl - 1 && k0 == ql - 1) return R;
-	}
-
-	int32_t s = 0, wf_lo = tl + 1, wf_hi = tl + 1;
-	int32_t curH = 0, par = 0, blk = 0;
-	const uint32_t ring_bytes = (uint32_t)RR * RS;
-	// rows of the coming penalty and of its two lags, as byte offsets (penalty 1 first)
-	uint32_t bn = (uint32_t)(1 % RR) * RS, bx = (uint32_t)((RR - lagx + 1) % RR) * RS, b2 = (uint32_t)((RR - lag2 + 1) % RR) * RS;
-	int64_t cells = 0;
-	const int64_t iter_limit = A.max_iter > 0 ? A.max_iter : INT64_MAX;
-	const int32_t s_limit = A.max_s > 0 ? A.max_s : INT32_MAX;
-	const int32_t cfin = ql + 1;
-	const int32_t gmax = cmax / kBS;
-
-	int32_t gl = max(wf_lo - kBP, 1) / kBS, gk[K];
-	auto remap = [&](int32_t g_lo) {
-		const int32_t base = g_lo - g_lo % NWK;
-#pragma unroll
-		for (int k = 0; k < K; ++k) {
-			int32_t g = base + wave + NW * k;
-			if (g < g_lo) g += NWK;
-			gk[k] = g;
-		}
-	};
-	remap(gl);
-	int32_t idle[K]; // blocks since the slot last held an active chunk (two = kFoldMaxLag penalties: aged out, registers dead)
-#pragma unroll
-	for (int k = 0; k < K; ++k) idle[k] = 2;
-	int32_t up_wait = 0, up_min = 0;
-
-	for (;;) {
-		// ---- the block's header: what everybody knows exactly — the widest window of its four penalties, the chunks that can meet it
-		const int32_t LO = max(wf_lo - kBP, 1), HI = min(wf_hi + kBP, cmax);
-		const int32_t gA = LO / kBS, gB = HI / kBS;
-		const int32_t gl_next = max(LO - kBP, 1) / kBS;         // the lowest chunk the NEXT block can reach
-		if (min(HI + kBP, cmax) / kBS - min(gl_next, gl) + 1 > NWK - 1) { R.status = ST_BAND_OVERFLOW; break; }
-		if (K == 4 && min(HI + kBP, cmax) / kBS - gl_next + 1 > 23) R.n_snap = 1; // (would the three-slot form have held the pair? the host's choice for the next align)
-		const bool track_blk = (((256 - ((s + kBP) & 255)) & 255) < nH) || (((256 - ((s + 1) & 255)) & 255) < nH); // a shrink can still see a slice of this block
-		if (wave == 0) sh.flags[par + 1 >= 3 ? par - 2 : par + 1][0] = 0; // the flag word of the NEXT block (its last readers passed two barriers ago)
-
-		bool act[K], runs[K];
-#pragma unroll
-		for (int k = 0; k < K; ++k) {
-			act[k] = (uint32_t)(gk[k] - gA) <= (uint32_t)(gB - gA);
-			runs[k] = act[k] || idle[k] < 2;
-			if (act[k]) idle[k] = 0;
-			else if (runs[k]) ++idle[k];
-		}
-		// ---- the rows of this block read as dead in the chunk either side of the widest window (owned columns only: the outer lanes' columns
-		// are the neighbouring chunks'); a later window reaches at most nH + kBP columns beyond this one (the reference's pads, miniwfa.c:96-99)
-		{
-			uint32_t r = bn;
-#pragma unroll
-			for (int j = 0; j < kBP; ++j) {
-				B4CHK(r + ((uint32_t)((gB + 1) * (kBS * 2)) + lane8), 8, "dead chunk");
-				if (owned_lane && gA >= 1 && wave == (gA - 1) % NW) *(int2*)(Hb + r + ((uint32_t)((gA - 1) * (kBS * 2)) + lane8)) = make_int2(kDeadPair, kDeadPair);
-				if (owned_lane && gB + 1 <= gmax && wave == (gB + 1) % NW) *(int2*)(Hb + r + ((uint32_t)((gB + 1) * (kBS * 2)) + lane8)) = make_int2(kDeadPair, kDeadPair);
-				r = r + RS == ring_bytes ? 0u : r + RS;
-			}
-		}
-		const int32_t rbox = box_base + (1 - (blk & 1)) * NWK * kBoxInts * 4, wbox = box_base + (blk & 1) * NWK * kBoxInts * 4;
-		uint32_t bits = 0;
-
-#pragma unroll
-		for (int k = 0; k < K; ++k) {
-			if (!runs[k]) continue; // uniform
-			const int32_t g = gk[k], cb = g * kBS - kBH, sl = g % NWK;
-			// ---- hand-off: the halo lanes become what the neighbours computed (nothing published before the first block: tags are -1)
-			{
-				const int32_t sl_l = sl == 0 ? NWK - 1 : sl - 1, sl_r = sl + 1 == NWK ? 0 : sl + 1;
-				const int32_t al = rbox + sl_l * kBoxInts * 4, ar = rbox + sl_r * kBoxInts * 4;
-				const bool ok_l = blk > 0 && g > 0 && uni(*(const int32_t*)(lds2 + al)) == (int32_t)((uint32_t)(blk - 1) << 12 | (uint32_t)((g - 1) & 4095));
-				const bool ok_r = blk > 0 && uni(*(const int32_t*)(lds2 + ar)) == (int32_t)((uint32_t)(blk - 1) << 12 | (uint32_t)((g + 1) & 4095));
-				if (lane < 2 || lane >= 62) {
-					const bool left = lane < 2;
-					const int32_t src = (left ? al + 16 + (24 + lane * 12) * 4 : ar + 16 + ((lane - 62) * 12) * 4);
-					int4 v0 = make_int4(kDeadPair, kDeadPair, kDeadPair, kDeadPair), v1 = v0, v2 = v0;
-					if (left ? ok_l : ok_r) v0 = *(const int4*)(lds2 + src), v1 = *(const int4*)(lds2 + src + 16), v2 = *(const int4*)(lds2 + src + 32);
-					e1h[0][k][0] = v0.x, e1h[0][k][1] = v0.y, e1h[1][k][0] = v0.z, e1h[1][k][1] = v0.w;
-					f1h[0][k][0] = v1.x, f1h[0][k][1] = v1.y, f1h[1][k][0] = v1.z, f1h[1][k][1] = v1.w;
-					e2h[0][k][0] = v2.x, e2h[0][k][1] = v2.y, f2h[0][k][0] = v2.z, f2h[0][k][1] = v2.w;
-				}
-			}
-			const int32_t cbp = both16(cb);
-			const int32_t xA = pk_sub(pk_sub(T0, cbp), RA);                  // ql - d of A's columns (garbage outside the matrix, where H is dead)
-			const int32_t rjA = pk_minu(xA, TLp), rjB = pk_minu(pk_sub(xA, 0x00010001), TLp);
-			const int32_t dA = pk_sub(pk_add(RA, cbp), TL1), dB = pk_add(dA, 0x00010001);
-			const uint32_t off = (uint32_t)((cb + kBH) << 1) + lane8;
-			const bool own_fin = (uint32_t)(cfin - (cb + kBH)) < (uint32_t)kBS;
-			// this chunk's view of the window; a chunk that is only ageing (outside the widest window) computes nothing but dead cells
-			int32_t lo_v = act[k] ? wf_lo : 0x3fffffff, hi_v = act[k] ? wf_hi : -2;
-			uint32_t rn = bn, rx = bx, r2 = b2;
-			int32_t newH = curH;
-#pragma unroll 1
-			for (int32_t j = 0; j < kBP; ++j) {
-				constexpr int P1 = E1 - 1, P2 = E2 - 1;
-				const int32_t s_new = s + j + 1;
-				newH = newH + 1 == nH ? 0 : newH + 1;
-				const int32_t lo = act[k] ? (lo_v > 1 ? lo_v - 1 : 1) : 0x3fffffff;       // miniwfa.c:417-418, on this chunk's view
-				const int32_t hi = act[k] ? (hi_v < cmax ? hi_v + 1 : cmax) : -2;
-				const bool track_good = track_blk && (((256 - (s_new & 255)) & 255) < nH);
-				B4CHK(rx + off, 8, "HX"); B4CHK(r2 + off + (uint32_t)nd, 4, "N2"); B4CHK(r2 + off, 8, "O2"); B4CHK(rn + off, 8, "store");
-				const int2 HX = *(const int2*)(Hb + rx + off), O2 = *(const int2*)(Hb + r2 + off);
-				const int32_t N2 = *(const int32_t*)(Hb + (r2 + off + (uint32_t)nd)); // (the sum in 32 bits: nd may be -4)
-				const bool inside = cb >= lo && cb + kChunk - 1 <= hi;
-				// ---- recurrence (dev::wf_cell, miniwfa.c:267-278) on pairs of columns, folded form; beyond the chunk: nothing (halo columns)
-				const int32_t E1a = e1h[P1][k][0], E1b = e1h[P1][k][1], F1a = f1h[P1][k][0], F1b = f1h[P1][k][1];
-				const int32_t E2a = e2h[P2][k][0], E2b = e2h[P2][k][1], F2a = f2h[P2][k][0], F2b = f2h[P2][k][1];
-				const int32_t o2mA = left_of_A(O2.y, N2), g1mA = left_of_A(E1b, kDeadPair), g2mA = left_of_A(E2b, kDeadPair);
-				const int32_t o2pB = right_of_B(O2.x, N2), g1pB = right_of_B(F1a, kDeadPair), g2pB = right_of_B(F2a, kDeadPair);
-				const int32_t ONE = 0x00010001;
-				int32_t ne1A = g1mA, ne2A = pk_max(o2mA, g2mA);
-				int32_t ne1B = E1a, ne2B = pk_max(O2.x, E2a);
-				const int32_t pf1A = F1b, pf2A = pk_max(O2.y, F2b);
-				const int32_t pf1B = g1pB, pf2B = pk_max(o2pB, g2pB);
-				int32_t nf1A = pk_add(pf1A, ONE), nf2A = pk_add(pf2A, ONE), nf1B = pk_add(pf1B, ONE), nf2B = pk_add(pf2B, ONE);
-				const int32_t mA = pk_add(HX.x, ONE), mB = pk_add(HX.y, ONE);
-				int32_t hA = pk_max(pk_max(mA, pk_max(ne1A, ne2A)), pk_max(nf1A, nf2A));
-				int32_t hB = pk_max(pk_max(mB, pk_max(ne1B, ne2B)), pk_max(nf1B, nf2B));
-				const bool lo_here = act[k] && (uint32_t)(lo - cb) < (uint32_t)kChunk, hi_here = act[k] && (uint32_t)(hi - cb) < (uint32_t)kChunk;
-				const bool special = !inside || lo_here || hi_here || track_good;
-				int32_t outA = 0, outB = 0;
-				uint32_t gbits = 0;
-				bool lo_live = true, hi_live = true; // an edge cell this chunk does not hold: assume the window grew (a view may only err towards the widest window)
-				if (special) { // uniform
-					if (!inside) { // uniform: columns outside the window are not computed by the reference — dead
-						const int32_t lo_r = both16(min(max(lo - cb, 0), 256)), hi_r1 = both16(min(max(hi - cb + 1, 0), 256));
-						const int32_t RB = pk_add(RA, 0x00010001), RB1 = pk_add(RA, 0x00020002);
-						outA = pk_nonzero_mask(pk_subsat(lo_r, RA) | pk_subsat(RB, hi_r1));
-						outB = pk_nonzero_mask(pk_subsat(lo_r, RB) | pk_subsat(RB1, hi_r1));
-						hA = bfi(outA, kDeadPair, hA), hB = bfi(outB, kDeadPair, hB);
-						ne1A = bfi(outA, kDeadPair, ne1A), ne1B = bfi(outB, kDeadPair, ne1B);
-						ne2A = bfi(outA, kDeadPair, ne2A), ne2B = bfi(outB, kDeadPair, ne2B);
-						nf1A = bfi(outA, kDeadPair, nf1A), nf1B = bfi(outB, kDeadPair, nf1B);
-						nf2A = bfi(outA, kDeadPair, nf2A), nf2B = bfi(outB, kDeadPair, nf2B);
-					}
-					// ---- edge rule (miniwfa.c:325-326): "any of the five live" == "H live"
-					if (lo_here) {
-						const int32_t rel = lo - cb;
-						lo_live = half_of(__builtin_amdgcn_readlane((rel & 1) ? hB : hA, rel >> 2), (rel >> 1) & 1) >= -1;
-						if (lo_live && (uint32_t)(rel - kBH) < (uint32_t)kBS) bits |= 1u << j;          // the owner's word is the exact one
-					}
-					if (hi_here) {
-						const int32_t rel = hi - cb;
-						hi_live = half_of(__builtin_amdgcn_readlane((rel & 1) ? hB : hA, rel >> 2), (rel >> 1) & 1) >= -1;
-						if (hi_live && (uint32_t)(rel - kBH) < (uint32_t)kBS) bits |= 1u << (4 + j);
-					}
-					if (track_good) { // uniform: some array holds an in-matrix offset (miniwfa.c:139-142)
-						auto bad = [&](int32_t v, int32_t rj) { return pk_subsat(pk_add(v, ONE), rj); }; // zero iff good
-						const int32_t bA = pk_minu(pk_minu(bad(hA, rjA), pk_minu(bad(ne1A, rjA), bad(nf1A, rjA))), pk_minu(bad(ne2A, rjA), bad(nf2A, rjA))) | outA;
-						const int32_t bB = pk_minu(pk_minu(bad(hB, rjB), pk_minu(bad(ne1B, rjB), bad(nf1B, rjB))), pk_minu(bad(ne2B, rjB), bad(nf2B, rjB))) | outB;
-						gbits = (uint32_t)((bA & 0xffff) == 0) | (uint32_t)((bB & 0xffff) == 0) << 1 | (uint32_t)(((uint32_t)bA >> 16) == 0) << 2 | (uint32_t)(((uint32_t)bB >> 16) == 0) << 3;
-					}
-				}
-				if (act[k]) { // the view after this penalty
-					if (lo_live) lo_v = lo;
-					if (hi_live) hi_v = hi;
-				}
-				// ---- fold the row read for the mismatch term into E1 / F1 (what the gap opens from e1 penalties from now), age the registers
-				ne1A = pk_max(ne1A, HX.x), ne1B = pk_max(ne1B, HX.y), nf1A = pk_max(nf1A, HX.x), nf1B = pk_max(nf1B, HX.y);
-				e1h[P1][k][0] = ne1A, e1h[P1][k][1] = ne1B, f1h[P1][k][0] = nf1A, f1h[P1][k][1] = nf1B;
-				e2h[P2][k][0] = ne2A, e2h[P2][k][1] = ne2B, f2h[P2][k][0] = nf2A, f2h[P2][k][1] = nf2B;
-#pragma unroll
-				for (int i = 0; i < 2; ++i) {
-					asm volatile("v_swap_b32 %0, %1" : "+v"(e1h[0][k][i]), "+v"(e1h[1][k][i]));
-					asm volatile("v_swap_b32 %0, %1" : "+v"(f1h[0][k][i]), "+v"(f1h[1][k][i]));
-				}
-				// ---- match extension, first probe (sixteen bases of the 2-bit copies): j clamped to rj makes room zero for dead and phantom offsets
-				const int32_t jA = pk_minu(pk_add(hA, ONE), rjA), jB = pk_minu(pk_add(hB, ONE), rjB);
-				const int32_t iqA = pk_add(jA, dA), iqB = pk_add(jB, dB);
-				int32_t cnt[4];
-				{
-					uint64_t tw[4], qw[4];
-#pragma unroll
-					for (int u = 0; u < 4; ++u) {
-						const uint32_t J = (uint32_t)((u & 1) ? jB : jA), Q = (uint32_t)((u & 1) ? iqB : iqA);
-						const uint32_t ta = (u & 2) ? (J >> 18) & 0x3ffcu : (J >> 2) & 0x3ffcu;
-						const uint32_t qa = ((u & 2) ? (Q >> 20) : ((Q >> 4) & 0xfffu)) * 4u + (uint32_t)qoff;
-						asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(tw[u]) : "v"(ta));
-						asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(qw[u]) : "v"(qa));
-					}
-					asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tw[0]), "+v"(tw[1]), "+v"(tw[2]), "+v"(tw[3]), "+v"(qw[0]), "+v"(qw[1]), "+v"(qw[2]), "+v"(qw[3]));
-#pragma unroll
-					for (int u = 0; u < 4; ++u) {
-						const uint32_t J = (uint32_t)((u & 1) ? jB : jA), Q = (uint32_t)((u & 1) ? iqB : iqA);
-						const uint32_t tsh = (u & 2) ? J >> 15 : J << 1, qsh = (u & 2) ? (Q >> 15) & 30u : Q << 1;
-						cnt[u] = lead_eq2(__builtin_amdgcn_alignbit((uint32_t)(tw[u] >> 32), (uint32_t)tw[u], tsh) ^ __builtin_amdgcn_alignbit((uint32_t)(qw[u] >> 32), (uint32_t)qw[u], qsh));
-					}
-				}
-				typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
-				const int32_t cA = MWF_BC(int32_t, (us2_t)__builtin_amdgcn_cvt_pk_u16((uint32_t)cnt[0], (uint32_t)cnt[2]));
-				const int32_t cB = MWF_BC(int32_t, (us2_t)__builtin_amdgcn_cvt_pk_u16((uint32_t)cnt[1], (uint32_t)cnt[3]));
-				const int32_t FULLp = both16(FULL);
-				const int32_t m9A = pk_minu(cA, pk_sub(rjA, jA)), m9B = pk_minu(cB, pk_sub(rjB, jB));
-				int32_t nmA = pk_minu(m9A, FULLp), nmB = pk_minu(m9B, FULLp);
-				const int32_t pendp = pk_subsat(m9A, FULLp) | pk_subsat(m9B, FULLp);
-				if (__ballot(pendp != 0)) { // a run of >= 16 matches continues: per lane four trips, then the whole wave (band2_pass)
-					const int32_t c0 = cb + 4 * lane;
-					int32_t hv[4] = {half_of(hA, 0), half_of(hB, 0), half_of(hA, 1), half_of(hB, 1)};
-					int32_t nmat[4] = {(int32_t)((uint32_t)nmA & 0xffffu), (int32_t)((uint32_t)nmB & 0xffffu), (int32_t)((uint32_t)nmA >> 16), (int32_t)((uint32_t)nmB >> 16)};
-					const uint32_t pend = (uint32_t)(((uint32_t)m9A & 0xffffu) > (uint32_t)FULL) | (uint32_t)(((uint32_t)m9B & 0xffffu) > (uint32_t)FULL) << 1 |
-					                      (uint32_t)(((uint32_t)m9A >> 16) > (uint32_t)FULL) << 2 | (uint32_t)(((uint32_t)m9B >> 16) > (uint32_t)FULL) << 3;
-					uint32_t open = 0;
-#pragma unroll
-					for (int i = 0; i < 4; ++i) {
-						if (__ballot((pend >> i) & 1u) == 0) continue; // uniform
-						if ((pend >> i) & 1u) {
-							int32_t n = FULL;
-							const int32_t jj = hv[i] + 1, q = c0 + i - 1 - tl + jj, rm = min(tl - jj, ql - q);
-							for (int trip = 0; n < rm; ++trip) {
-								if (trip == 4) { open |= 1u << i; break; }
-								const int32_t m = min(lead_eq2(seq16(0, jj + n) ^ seq16(qoff, q + n)), 16);
-								n += m;
-								if (m < 16) break;
-							}
-							nmat[i] = min(n, rm);
-						}
-					}
-					for (unsigned long long owners = __ballot(open != 0); owners; owners &= owners - 1) {
-						const int32_t src = (int32_t)__builtin_ctzll(owners);
-						const int32_t c0s = cb + 4 * src;
-						const uint32_t ob = (uint32_t)__builtin_amdgcn_readlane((int32_t)open, src);
-#pragma unroll
-						for (int i = 0; i < 4; ++i) {
-							if (!((ob >> i) & 1u)) continue; // uniform
-							const int32_t hh = __builtin_amdgcn_readlane(hv[i], src);
-							const int32_t jj = hh + 1, q = c0s + i - 1 - tl + jj, rm = min(tl - jj, ql - q);
-							const int32_t n = run_wave16(qoff, jj, q, rm, 80);
-							nmat[i] = lane == src ? n : nmat[i];
-						}
-					}
-					nmA = pair_of(nmat[0], nmat[2]), nmB = pair_of(nmat[1], nmat[3]);
-				}
-				const int32_t hxA = pk_add(hA, nmA), hxB = pk_add(hB, nmB); // extended
-				// ---- termination test (miniwfa.c:405-409): only column ql + 1 can hold the end cell; its owner's word counts
-				if (own_fin && cfin >= lo && cfin <= hi) { // uniform
-					const int32_t rel = cfin - cb, hi_half = (rel >> 1) & 1;
-					const int32_t hvf = half_of((rel & 1) ? hxB : hxA, hi_half), nm = (int32_t)((uint32_t)((rel & 1) ? nmB : nmA) >> (hi_half ? 16 : 0) & 0xffffu);
-					const uint32_t f = (uint32_t)(lane == (rel >> 2)) & (uint32_t)(hvf == tl - 1) & inm_bit(ql - tl, hvf - nm, tl, ql);
-					if (__ballot(f != 0)) bits |= 1u << (8 + j);
-				}
-				if (owned_lane) *(int2*)(Hb + rn + off) = make_int2(hxA, hxB);
-				if (track_good) {
-					B4GOOD((int64_t)newH * fresh(A).GW + g * 4, "good write");
-					unsigned long long *gword = M.good + (int64_t)newH * fresh(A).GW + g * 4;
-#pragma unroll
-					for (int i = 0; i < 4; ++i) {
-						const unsigned long long m = __ballot((gbits >> i) & 1u) & owned_mask;
-						if (lane == 0) gword[i] = m;
-					}
-				}
-				rn = rn + RS == ring_bytes ? 0u : rn + RS, rx = rx + RS == ring_bytes ? 0u : rx + RS, r2 = r2 + RS == ring_bytes ? 0u : r2 + RS;
-			}
-			// ---- publish the outer owned columns' E/F registers for the neighbours' halos
-			{
-				const int32_t dst0 = wbox + sl * kBoxInts * 4;
-				if (lane == 0) *(int32_t*)(lds2 + dst0) = (int32_t)((uint32_t)blk << 12 | (uint32_t)(g & 4095));
-				if (lane == 2 || lane == 3 || lane == 60 || lane == 61) {
-					const int32_t dst = dst0 + 16 + ((lane < 32 ? lane - 2 : 2 + lane - 60) * 12) * 4;
-					*(int4*)(lds2 + dst) = make_int4(e1h[0][k][0], e1h[0][k][1], e1h[1][k][0], e1h[1][k][1]);
-					*(int4*)(lds2 + dst + 16) = make_int4(f1h[0][k][0], f1h[0][k][1], f1h[1][k][0], f1h[1][k][1]);
-					*(int4*)(lds2 + dst + 32) = make_int4(e2h[0][k][0], e2h[0][k][1], f2h[0][k][0], f2h[0][k][1]);
-				}
-			}
-		}
-		if (bits && lane == 0) atomicOr((unsigned int*)&sh.flags[par][0], bits);
-		// everything of this block must be complete before another wave may load it: rows (vmcnt), boxes and the flag word (lgkmcnt)
-		asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-		__builtin_amdgcn_s_barrier();
-		asm volatile("" ::: "memory");
-
-		// ---- bookkeeping, identical on every thread: the exact chain of the block's windows from the owners' bits
-		const uint32_t fl = (uint32_t)uni(sh.flags[par][0]);
-		bool ended = false;
-#pragma unroll 1
-		for (int32_t j = 0; j < kBP; ++j) {
-			const int32_t lo = wf_lo > 1 ? wf_lo - 1 : 1, hi = wf_hi < cmax ? wf_hi + 1 : cmax;
-			const int32_t s_new = s + 1;
-			curH = curH + 1 == nH ? 0 : curH + 1;
-			if (wave == 0) {
-				sh.rng_lo[curH] = lo, sh.rng_hi[curH] = hi;
-				if (trace_band && s_new - 1 < fresh(A).dbg_cap) M.dbg[2 * (s_new - 1)] = lo, M.dbg[2 * (s_new - 1) + 1] = hi;
-			}
-			if ((fl >> j) & 1u) wf_lo = lo;
-			if ((fl >> (4 + j)) & 1u) wf_hi = hi;
-			s = s_new;
-			bn = bn + RS == ring_bytes ? 0u : bn + RS, bx = bx + RS == ring_bytes ? 0u : bx + RS, b2 = b2 + RS == ring_bytes ? 0u : b2 + RS;
-			cells += hi - lo + 1;
-			if (cells > iter_limit || s > s_limit) { R.status = ST_STOPPED; ended = true; break; } // miniwfa.c:422-425
-			if ((fl >> (8 + j)) & 1u) { ended = true; break; }
-		}
-		if (ended) break;
-		par = par + 1 == 3 ? 0 : par + 1;
-		++blk;
-		if (gl_next < gl) gl = gl_next, remap(gl), up_wait = 0;
-		else if (gl_next > gl) {
-			up_min = up_wait == 0 ? gl_next : min(up_min, gl_next);
-			if (++up_wait > 2) gl = up_min, remap(gl), up_wait = 0;
-		} else up_wait = 0;
-		if ((s & 0xff) == 0) { // shrink (reference wf_stripe_shrink, miniwfa.c:144-171) on the good bits of the owned columns
-			if (tid == 0) sh.red[0] = 0x7fffffff, sh.red[1] = -1;
-			__syncthreads();
-			const int32_t gfirst = wf_lo / kBS, n_words = (wf_hi / kBS - gfirst + 1) * 4, GWc = fresh(A).GW;
-			for (int32_t q = tid; q < n_words; q += T) {
-				const int32_t gg = gfirst + (q >> 2), kq = q & 3, base = gg * kBS - kBH;
-				unsigned long long m = 0;
-				for (int32_t j = 0; j < nH; ++j)
-					if (sh.rng_lo[j] <= sh.rng_hi[j] && sh.rng_lo[j] <= base + kBH + kBS - 1 && sh.rng_hi[j] >= base + kBH) {
-						B4GOOD((int64_t)j * GWc + gg * 4 + kq - 3, "good read");
-						m |= M.good[(int64_t)j * GWc + gg * 4 + kq];
-					}
-				m &= lane_mask(base, kq, wf_lo, wf_hi) & owned_mask;
-				if (m) {
-					atomicMin(&sh.red[0], base + 4 * (int32_t)__builtin_ctzll(m) + kq);
-					atomicMax(&sh.red[1], base + 4 * (63 - (int32_t)__builtin_clzll(m)) + kq);
-				}
-			}
-			__syncthreads();
-			const int32_t glo = uni(sh.red[0]), ghi = uni(sh.red[1]);
-			if (ghi < 0) { R.status = ST_INTERNAL; break; }
-			wf_lo = glo, wf_hi = ghi;
-		}
-	}
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	R.s = s, R.cells = cells;
-	return R;
-}
-
-
-template <int K>
-__global__ __launch_bounds__(512, MWF_B2_WIDE_WAVES) void wfa_band4_kernel(const BatchArgs)
-{
-	constexpr int T = 512, NWK = (T / 64) * K;
-	KArgs &A0 = kernel_args();
-	if ((uint32_t)(uintptr_t)lds2 != 0u) __builtin_trap(); // (the probes' inline-asm reads take LDS byte addresses: the sequence copy starts at 0)
-	typedef Band4Lds<NWK> LdsT;
-	const int32_t lds_seq = A0.band_lds_seq;
-	LdsT *const L = (LdsT*)(lds2 + lds_seq);
-	Shared &sh = L->sh;
-	const int32_t box_base = lds_seq + (int32_t)offsetof(LdsT, box);
-	for (int32_t round = 0;; ++round) {
-		KArgs &A = fresh(A0);
-		if (threadIdx.x == 0) sh.item = A.queue ? (int32_t)atomicAdd(A.queue, 1) : (round == 0 ? (int32_t)blockIdx.x : A.n_pairs), sh.word[2] = 0;
-		__syncthreads();
-		const int32_t item = uni(sh.item);
-		__syncthreads();
-		if (item >= A.n_pairs) break;
-		const int32_t pair = A.order ? A.order[item] : item;
-		PairMem M;
-		pair_mem(A, (int32_t)blockIdx.x, pair, M);
-		const int32_t qoff = ((M.tl >> 4) + 2) * 4;
-		PassResult R;
-		R.status = ST_OK, R.s = 0, R.info = 0, R.n_snap = 0, R.cells = 0;
-		uint32_t bad = pack2bit<T>(M.ts, M.tl, 0);
-		bad |= pack2bit<T>(M.qs, M.ql, qoff);
-		if (bad) sh.word[2] = 1; // a base other than A/C/G/T: the host re-runs the pair on a byte-wise copy
-		__syncthreads();
-		if (uni(sh.word[2])) R.status = ST_ALPHABET;
-		const bool trace = A.dbg && pair == A.debug_pair;
-		if (R.status == ST_OK) R = band4_pass<K>(A, M, sh, box_base, qoff, trace);
-		if (K == 4 && R.n_snap && threadIdx.x == 0 && fresh(A0).report_wide) atomicOr((unsigned int*)(fresh(A0).cig_head + 1), 1u);
-		R.n_snap = 0;
-		M.t2 = lds2, M.q2 = lds2 + qoff;
-		finish_pair(fresh(A0), M, (int32_t)blockIdx.x, pair, R, R.status, 0, nullptr);
-	}
-}
-
-// the block form applies: score-only folded penalties whose H rows are all read at least kBP penalties late, 512 threads, 2-bit copies
-__host__ inline bool band4_applies(const BatchArgs &a, int T, int K, int E1, int E2, bool TB, bool S2, bool BI4)
-{
-	return a.band_blk && a.band_fold && T == 512 && (K == 3 || K == 4) && E1 == 2 && E2 == 1 && !TB && S2 && !BI4 &&
-	       a.pen.oe1 - a.pen.x == E1 && a.pen.oe1 < kFoldMaxLag && a.pen.x >= kBP && a.pen.oe2 >= kBP;
-}
-
 // Workgroups share a CU: 2 x 512, 4 x 256, 8 x 128 or 16 x 64 threads = 4 waves per SIMD, i.e. at most 128 VGPRs; with traceback
 // the smaller ones get 168 (3 per SIMD).  768 threads: one workgroup per CU.
 template <int T, int K, int E1, int E2, bool TB, bool S2, bool BI4 = false, bool FOLD = false>
@@ -1503,14 +1020,6 @@ constexpr int lds_tail() { return (int)sizeof(Band2Lds<(E1 > E2 ? E1 : E2) + 1, 
 template <int T, int K, int E1, int E2, bool TB, bool S2, bool BI4 = false, bool FOLD = false>
 void launch_variant(const BatchArgs &a, int grid, int lds, hipStream_t st)
 {
-	// the block form (band4_pass): four penalties per barrier, where it applies
-	if constexpr (!FOLD && T == 512 && (K == 3 || K == 4) && E1 == 2 && E2 == 1 && !TB && S2 && !BI4) {
-		if (band4_applies(a, T, K, E1, E2, TB, S2, BI4)) {
-			const int lds4 = a.band_lds_seq + (int)sizeof(Band4Lds<(T / 64) * K>);
-			hipLaunchKernelGGL((wfa_band4_kernel<K>), dim3(grid), dim3(T), lds4, st, a);
-			return;
-		}
-	}
 	// the 512-thread (and wider) geometries with o1 == x: the folded form (band2_pass), two row loads less per chunk
 	if constexpr (!FOLD && T >= 512) {
 		if (a.band_fold && a.pen.oe1 - a.pen.x == E1 && a.pen.oe1 < kFoldMaxLag) return launch_variant<T, K, E1, E2, TB, S2, BI4, true>(a, grid, lds, st);

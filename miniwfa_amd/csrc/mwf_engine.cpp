@@ -114,7 +114,6 @@ int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value)
 	else if (!strcmp(name, "div_aware")) g->div_aware = value != 0;
 	else if (!strcmp(name, "dev_retry")) g->dev_retry = value != 0;
 	else if (!strcmp(name, "band_fold")) g->band_fold = value != 0;
-	else if (!strcmp(name, "band_blk")) g->band_blk = value != 0;
 	else if (!strcmp(name, "trim")) { (void)hipSetDevice(g->device); trim(g); }
 	else return -1;
 	++g->tun_gen; // (whatever the tunable: no hand-kept list of "the ones that classify" to forget an entry of)

@@ -67,7 +67,6 @@ struct mwf_gpu_s {
 	bool dev_retry = true;      // batches of reads: the pairs the lane kernel hands back are re-run by a follow-up launch from a device-side list, without the host
 	int retry_mode = 0;         // set around run_batch_kernel(): 1 the launch fills the list, 2 the launch takes its pairs from it
 	int retry_slot = 0;         // ... which of the batch's kRetrySlots lists
-	bool band_blk = false;      // ... and its block form (four penalties per barrier, mwf_band2.hip band4_pass) where that applies
 	bool band_fold = true;      // packed band kernel: the folded score-only form where the penalties allow it (o1 == x)
 	bool div_aware = true;      // weigh the size classes' length limits by the batch's estimated divergence (batches built from host memory)
 	int64_t tun_gen = 0;        // bumped by every successful mwf_gpu_set(): a cached plan of an align (PlanCache) is only replayed under the tunables it was made under

@@ -94,7 +94,6 @@ struct BatchArgs {
 	int32_t ring16;            // generic kernel with E2/F2 in LDS: the ring rows in HBM hold 16-bit codes (half the traffic; offsets up to 65532)
 	int32_t scalar_generic;    // generic kernel: 1 = one column per lane (forward_pass) also where the four-columns-per-lane pass applies
 	int32_t band_lds_seq;      // band kernel with the sequences in LDS: bytes of the sequence copy (bookkeeping words and edge table sit behind it)
-	int32_t band_blk;          // packed band kernel, 512 threads, folded score-only form: the BLOCK form (mwf_band2.hip band4_pass) — four penalties per workgroup barrier, halo columns
 	int32_t band_fold;         // packed band kernel, score-only, o1 == x: the folded form (mwf_band2.hip: FOLD) — no loads of the row the first gap piece opens from
 	int32_t coop_groups, coop_group_size; // pairs side by side on the whole-device kernel and workgroups per pair (grid = product)
 	int64_t coop_edge_stride;  // ints between two groups' granule arrays

@@ -256,7 +256,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	pl.grid = std::max(1, std::min<int>(slots, n_items));
 	// row stride: whole 256-column chunks plus room for the band kernel's neighbour loads past the last chunk
 	pl.W = (int32_t)((max_len + 3 + 255) / 256 * 256 + 512);
-	pl.GW = pl.W / 60 + 8; // (four words per chunk; the block form's chunks are 240 columns apart)
+	pl.GW = pl.W / 64 + 2;
 	pl.ring_slot_ints = (int64_t)(P.nH + 2 * P.n1 + 2 * P.n2) * pl.W;
 	if (pl.kind == 2 && pl.band.lane) pl.ring_slot_ints = 64; // its rings are in LDS
 	const size_t S = (size_t)pl.grid;
@@ -328,7 +328,6 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	if (g->retry_mode == 2) a.n_pairs_dev = (const unsigned int*)(b->d_cig_head + 2 + g->retry_slot), a.queue = nullptr, a.queue_parts = 0;
 	a.scalar_generic = g->scalar_generic;
 	a.band_fold = g->band_fold ? 1 : 0;
-	a.band_blk = g->band_blk ? 1 : 0;
 	a.lds_e2_cols = lds_e2_cols;
 	a.ring16 = ring16 ? 1 : 0;
 	a.lane_chunks = pl.kind == 2 && pl.band.lane ? pl.band.span / 64 : 0;
