@@ -500,7 +500,6 @@ def parse_args(argv=None):
     ap.add_argument("--div", type=float, default=None)
     ap.add_argument("--cigar", action="store_true", help="score+CIGAR (high-memory) instead of score-only")
     ap.add_argument("--block", type=int, default=0)
-    ap.add_argument("--slots-per-cu", type=int, default=0)
     ap.add_argument("--band-pack", type=int, default=-1, help="band kernel: 1 forces the int16-packed variants where the forced block has both")
     ap.add_argument("--cpu-sample", type=int, default=None, help="pairs in the cpu_baseline sample (0: skip)")
     ap.add_argument("--long-pairs", type=int, default=1, help="also time the single-pair configs (C4-like 150 kb, MHC-like 5 Mb) on rank 0 at N=1")
@@ -650,8 +649,6 @@ def main():
     pk = rot[0][0]
     if args.block:
         eng.set("block", args.block)
-    if args.slots_per_cu:
-        eng.set("slots_per_cu", args.slots_per_cu)
     if args.band_pack >= 0:
         eng.set("band_pack", args.band_pack)
     batches = []

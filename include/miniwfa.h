@@ -165,27 +165,24 @@ void mwf_gpu_get_stats(const mwf_gpu_t *g, mwf_gpu_stats_t *st);
  * wavefront slice the core pass opened for `pair`; returns the number of penalties written (<= cap). */
 int32_t mwf_gpu_debug_band(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt, int32_t pair, int32_t *lohi, int32_t cap);
 
-/* Tunables (call before align): name in {"block", "slots_per_cu", "coop_min_len", "tb_budget_mb", "force_kind", "coop_tb_cap_mb", "band_pack",
- * "coop_spin_limit", "scalar_generic", "lds_e2", "seq2bit" (packed band kernel: 0 = always keep the byte-wise sequence copy; default 1:
- * pairs of plain A/C/G/T are held at 2 bits per base, any other pair is re-run byte-wise — batches built from HOST memory are classified
- * while they are packed and never take that re-run), "ring16" (generic kernel: 0 = always 32-bit ring rows; default 1: 16-bit rows — half
- * the HBM traffic — while target length + penalty fits 16 bits, with 2-bit copies of the
- * sequences in device memory; a pair that outgrows 16 bits or holds a byte outside A/C/G/T is re-run with 32-bit rows and byte probes;
- * 2: the same), "ring16_block" (0, 512, 768), "band_span" (default 1: pairs too long or with windows too wide for the packed band kernel's
- * 512-thread geometry — up to 62 000 bases per sequence, windows of up to ~20 000 columns: 50 kb pairs at 3 % — run on its 1024-thread span
- * geometry, 16-bit offsets biased by the target length, instead of the generic kernel; 0: never; 2: every pair it can take (tests)),
- * "wide_slots" (chunk slots per wave of the packed band kernel's 512-thread geometry: 3 = 24 chunks, 4 = 32 chunks, 2 % slower where three suffice; default 0: four
- * for a batch's first align under given options, three from then on if that align showed that they hold every pair);
- * whole-device (systolic) kernel: "lowmem_budget_mb" (low-memory mode: a first-pass traceback above this many MB switches to the two-pass
- * form whose first pass stores none; 0 = a quarter of the device), "sys_p" (penalties per hand-off block: 8, the one the library is built with; 4 and 16 only in builds with -DMWF_SYS_ALL_P — any other value is refused),
- * "sys_c" (columns per lane: 0 = chosen per pass from the expected window, 1, 4), "coop_grid" (at most this many workgroups; 0 = one
- * per CU), "coop_launch" (default 1: launched through hipLaunchCooperativeKernel; 0: plain launch),
- * "mid_max_pairs" (a batch of at most this many pairs runs its mid-size pairs — beyond the lane kernel, up to ~9 kb of target + query — on the
- * one-workgroup-per-pair kernel with every ring in LDS, mwf_mid.hip; default -1: one pair per CU; 0: never), "mid_block" (its threads per workgroup: 0 by pair
- * length, 256, 512, 1024),
- * "lane_max_len" (default 400: pairs whose longer sequence has at most this many bases try the one-wave-per-pair lane kernel first; 0: never), "lane_chunks" (its window in 64-column chunks,
- * 1-4; default 0: by pair length), "host_results" (default 1: a score-only batch of up to 64 pairs gets its result arrays in pinned host memory — the mwf_gpu_batch_dev_*() pointers then
- * point there, still readable from device code; 0: always device memory)}; "trim" frees the engine's workspace pools (they grow back on demand). */
+/* Tunables (call before align; every call invalidates the cached plans of the engine's batches).  Thirteen names and one action:
+ *   "tb_budget_mb"      traceback arena of the one-workgroup-per-pair kernels (0 = automatic: four fifths of what is free, at most a quarter of the device)
+ *   "lowmem_budget_mb"  whole-device kernel, opt.step > 0: a first-pass traceback above this many MB switches to the two-pass form whose first pass stores none (0 = a quarter of the device)
+ *   "coop_min_len"      tl + ql from which a batch of at most sixteen pairs runs on the whole-device kernel (0 = 20 000 score-only, 15 000 with CIGAR)
+ *   "seq2bit"           1 (default): pairs of plain A/C/G/T are held at 2 bits per base in LDS, any other pair runs on the byte-wise copy; 0: always bytes
+ *   "ring16"            generic kernel: 1 (default) = 16-bit ring rows while target length + penalty fits 16 bits (half the HBM traffic); 0: always 32-bit rows
+ *   "band_span"         1 (default): pairs beyond the 512-thread geometry (to 62 000 bases per sequence, windows to ~20 000 columns) run on the packed kernel's
+ *                       1024-thread span geometry instead of the generic kernel; 0: never; 2: every pair it can take
+ *   "wide_slots"        chunk slots per wave of the 512-thread geometry: 0 (default) = four on a batch's first align, three afterwards if that align showed they hold every pair; 3; 4
+ *   "lane_max_len"      pairs whose longer sequence has at most this many bases try the one-wave-per-pair kernel first (default 400; 0: never)
+ *   "mid_max_pairs"     a batch of at most this many pairs runs its mid-size pairs on the one-workgroup-per-pair kernel with every ring in LDS (default -1: one pair per CU; 0: never)
+ *   "host_results"      1 (default): a score-only batch of up to 64 pairs gets its result arrays in pinned host memory (the mwf_gpu_batch_dev_*() pointers then point there); 0: device memory
+ *   "div_aware"         1 (default): the size classes follow the batch's divergence (an 8-mer sketch of a few pairs: on the host while a batch is packed, on the device when one is wrapped); 0: lengths only
+ *   "dev_retry"         1 (default): what the short-pair kernel hands back is re-run from a device-side list by a follow-up launch; 0: through the host
+ *   "band_fold"         1 (default): score-only with o1 == x the packed kernel folds the gap-open row into its E1 / F1 registers (one row load less per chunk); 0: never
+ *   "trim"              (action) free the engine's workspace pools; they grow back on demand.
+ * (The hooks tests and profiling scripts force kernels, geometries and failure paths with — "force_kind", "block", "sys_c" ... — are a separate, undeclared entry point,
+ * mwf_gpu_test_hook in csrc/mwf_engine.cpp.) */
 int mwf_gpu_set(mwf_gpu_t *g, const char *name, int64_t value);
 
 #ifdef __cplusplus

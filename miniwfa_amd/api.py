@@ -124,6 +124,8 @@ def lib() -> C.CDLL:
     L.mwf_gpu_get_stats.restype = None
     L.mwf_gpu_set.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     L.mwf_gpu_set.restype = C.c_int
+    L.mwf_gpu_test_hook.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    L.mwf_gpu_test_hook.restype = C.c_int
     L.mwf_gpu_debug_band.argtypes = [C.c_void_p, C.c_void_p, P(MwfOpt), C.c_int32, C.c_void_p, C.c_int32]
     L.mwf_gpu_debug_band.restype = C.c_int32
     for name, res, args in (("kmalloc", C.c_void_p, [C.c_void_p, C.c_size_t]), ("kcalloc", C.c_void_p, [C.c_void_p, C.c_size_t, C.c_size_t]),
@@ -275,7 +277,9 @@ class Engine:
         return lib().mwf_gpu_last_error(self.h).decode()
 
     def set(self, name: str, value: int):
-        if lib().mwf_gpu_set(self.h, name.encode(), int(value)) != 0:
+        """A user tunable (mwf_gpu_set, include/miniwfa.h) or — for tests and profiling scripts — one of the library's test hooks
+        (mwf_gpu_test_hook: forced kernels / geometries / failure paths; exported, not part of the public header)."""
+        if lib().mwf_gpu_set(self.h, name.encode(), int(value)) != 0 and lib().mwf_gpu_test_hook(self.h, name.encode(), int(value)) != 0:
             raise ValueError(f"bad tunable {name}={value}")
 
     def stats(self) -> GpuStats:

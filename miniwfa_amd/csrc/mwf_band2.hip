@@ -27,37 +27,22 @@ namespace {
 
 extern __shared__ __attribute__((aligned(16))) uint8_t lds2[];
 
-#ifndef MWF_B2_XPREF
-#define MWF_B2_XPREF 0 // request the first active chunk's rows of the coming penalty 1: before the barrier, 2: straight behind it (measured: no gain)
-#endif
-
-#ifndef MWF_B2_WIDE_T
-#define MWF_B2_WIDE_T 512 // threads x chunk slots per wave of the widest geometry (24 chunks): 512 x 3; experiments: 256 x 6, 384 x 4
-#define MWF_B2_WIDE_K 3
-#endif
-#ifndef MWF_B2_768_WAVES
-#define MWF_B2_768_WAVES 1 // waves per SIMD the 768-thread geometry is compiled for (1: one workgroup per CU, up to 168 VGPRs; experiment: 6 = two per CU at 80)
-#endif
-#ifndef MWF_B2_SPAN_K
+// Geometry constants (round 6: plain constants — rounds 3-5 overrode them with -D for experiments whose results are in profiles/HISTORY.md and the comments here;
+// the experiment switches MWF_B2_XPREF / MWF_B2_MERGE_OFF / MWF_B2_NOPRIO and their dead branches are gone, see profiles/experiments/).
+constexpr int kWideT = 512, kWideK = 3; // threads x chunk slots per wave of the widest two-per-CU geometry (24 chunks): 512 x 3; measured: 256 x 6 equal, 384 x 4 slower
+constexpr int kWaves768 = 1;            // waves per SIMD the 768-thread geometry is compiled for (one workgroup per CU, up to 168 VGPRs; two per CU at 80 VGPRs: slower)
 // chunk slots per wave of the 1024-thread geometry (16 waves, one workgroup per CU): 80 chunks = windows of up to 20 224 columns.  Measured on
 // 1250 x 50 kb @ 3 % (windows of up to 16 900 columns): 4 slots 172 ms + 24 pairs re-run on the generic kernel = 240 ms, 5 slots (4 spilled VGPRs)
 // 174.6 ms and no re-run, 6 slots (12 spilled) 177.0; 256 x 50 kb: 36.2 (+ 9 re-runs: 104) / 38.7 / 39.6 ms; generic kernel 279 and 78 ms.
-#define MWF_B2_SPAN_K 5
-#endif
-#ifndef MWF_B2_W4K
+constexpr int kSpanK = 5;
 // Chunk slots per wave of the 512-thread geometry's copies on biased offsets (class 14 of mwf_plan.cpp: pairs of ~11-21 kb, two per CU instead of the span
 // geometry's one).  Measured (ms per align; span geometry | 4 | 5 | 6 slots): 1024 x 12 kb @ 5 % 34.9 | 24.6 | 24.8 | 27.7, 1024 x 15 kb @ 4 % 35.6 | - | 25.1 | 25.7,
 // 1024 x 17 kb @ 3 % 29.5 | - | 20.2 | 20.5, 512 x 18 kb @ 5 % 32.1 | - | - | 25.3, 1024 x 20 kb @ 3 % 37.3 | - | - | 26.9: five slots (40 chunks, 4 spilled VGPRs)
 // while target + query stay below 3.5 of their span, six (48 chunks) up to 3.5 of theirs.
-#define MWF_B2_W4K 5
-#endif
-#ifndef MWF_B2_SPAN_T
-#define MWF_B2_SPAN_T 1024 // threads of the span geometry (measured: 768 x 7 slots — twelve waves, 168 VGPRs, no spills — 187.6 against 178.7 ms on 1250 x 50 kb, 768 x 6 189.6)
-#endif
-#define MWF_IS_SPAN(T, K) ((T) == MWF_B2_SPAN_T && (K) == MWF_B2_SPAN_K)
-#ifndef MWF_B2_WIDE_WAVES
-#define MWF_B2_WIDE_WAVES 4 // waves per SIMD the widest geometry is compiled for (4: 128 VGPRs, two 512-thread workgroups per CU)
-#endif
+constexpr int kW4K = 5;
+constexpr int kSpanT = 1024;  // threads of the span geometry (measured: 768 x 7 slots — twelve waves, 168 VGPRs, no spills — 187.6 against 178.7 ms on 1250 x 50 kb, 768 x 6 189.6)
+constexpr bool is_span(int T, int K) { return T == kSpanT && K == kSpanK; }
+constexpr int kWideWaves = 4; // waves per SIMD the widest geometry is compiled for (4: 128 VGPRs, two 512-thread workgroups per CU)
 constexpr int kChunk = 256;
 constexpr int kFoldMaxLag = 8; // largest o1 + e1 the folded form of the packed kernel is launched for
 constexpr int32_t kDeadPair = (int32_t)0x80008000u;
@@ -311,7 +296,7 @@ template <int T, int K, int E1, int E2, bool TB, bool S2, bool BI4, bool FOLD, t
 __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, const int32_t edge_base, const int32_t qoff, bool trace_band)
 {
 	constexpr int NW = T / 64, NWK = NW * K, D = (E1 > E2 ? E1 : E2) + 1;
-	constexpr bool BI = MWF_IS_SPAN(T, K) || BI4; // biased offsets with range checks (wide_bias): the span geometry and the four-slot 512-thread one's copy for long pairs
+	constexpr bool BI = is_span(T, K) || BI4; // biased offsets with range checks (wide_bias): the span geometry and the four-slot 512-thread one's copy for long pairs
 	constexpr int FULL = S2 ? 16 : 8; // bases the first probe of the match extension looks at
 	// FOLD (score-only, gap-open lag - mismatch lag == e1, i.e. o1 == x as in the default penalties): the row a penalty reads for its
 	// mismatch term, H[s-x], IS the row the first gap piece opens from e1 penalties later (miniwfa.c:267-278: both E1 and F1 take
@@ -402,16 +387,11 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 	const uint32_t ring_bytes = (uint32_t)nH * RS;
 	// rows of the coming penalty and of its three lags, as byte offsets that advance by one row per penalty (penalty 1 first)
 	uint32_t bn = (uint32_t)(1 % nH) * RS, bx = (uint32_t)((nH - lagx + 1) % nH) * RS, b1 = (uint32_t)((nH - lag1 + 1) % nH) * RS, b2 = (uint32_t)((nH - lag2 + 1) % nH) * RS;
-	// The rows of ONE chunk: H at the three lags (one 8-byte load each) and the word next to the chunk for the two gap-open rows.  These
-	// registers are where every chunk's rows land; at the end of a penalty they are loaded with the coming penalty's rows of the wave's
-	// first active chunk (`pre_g`), which travel while the wave waits at the barrier — every lag >= 2: those rows are final by then.
+	// The rows of ONE chunk: H at the three lags (one 8-byte load each) and the word next to the chunk for the two gap-open rows.
+	// (Requesting the coming penalty's rows of the wave's first chunk before or straight behind the barrier was measured in rounds 3-5: no gain, -3 % on the
+	// folded form — the row loads are not what the critical wave waits for; the variants are in profiles/experiments/.)
 	struct Rows { int2 HX, O1, O2; int32_t N1, N2; } pre;
 	pre.HX = pre.O1 = pre.O2 = make_int2(0, 0), pre.N1 = pre.N2 = 0;
-	int32_t pre_g = -1;
-	constexpr int XMODE = MWF_B2_XPREF; // (measured: +1 % on 1024 x 10 kb; on the folded form -3 %: the row loads are not what the critical wave waits for; off)
-	constexpr bool XPREF = XMODE != 0;
-	constexpr int kRowLoads = FOLD ? 3 : 5; // loads of one request
-	const bool xpref = XPREF && min_lag >= 2;
 	auto load_rows = [&](Rows &r, const char *rx, const char *r1, const char *r2, uint32_t off) {
 		const uint32_t noff = off + (uint32_t)nd;
 		r.HX = *(const int2*)(rx + off), r.O2 = *(const int2*)(r2 + off);
@@ -509,7 +489,6 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 		bool busy;
 		if ((NW & (NW - 1)) == 0) busy = ((wave - ga) & (NW - 1)) < gspan + 1 - NW;
 		else busy = (int)act[0] + (int)act[1] + (K > 2 ? (int)act[K - 1] : 0) >= 2;
-#ifndef MWF_B2_NOPRIO
 		// One priority level per active chunk of the wave (0 ... 3), kept through the barrier and the next header: 18.4 -> 17.7 ms on
 		// 1024 x 10 kb against "two or more chunks: 3, else 0"; stepping it down as chunks complete 19.1, other maps 17.8 ... 18.3, one more
 		// level for a wave that walked a long run at the last penalty: no change.
@@ -530,9 +509,6 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 			else __builtin_amdgcn_s_setprio(0);
 			(void)busy;
 		}
-#else
-		(void)busy;
-#endif
 #ifdef MWF_B2_TIMING
 		int n_act = 0;
 #pragma unroll
@@ -574,8 +550,7 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 #endif
 			const uint32_t off = (uint32_t)(cb << 1) + lane8;
 			// (measured and dropped, round 4: the rows of EVERY chunk the wave will run requested at the top of the penalty — 16 more VGPRs — 19.4 against 17.35 ms)
-			if (!XPREF || g != pre_g) load_rows(pre, rowx, row1, row2, off); // uniform; (else they were requested before the last barrier)
-			if (XPREF) pre_g = -1;
+			load_rows(pre, rowx, row1, row2, off);
 			const int2 HX = pre.HX, O1 = pre.O1, O2 = pre.O2;
 			const int32_t N1 = pre.N1, N2 = pre.N2;
 			// gap-extension sources: E of column c-1, F of column c+1, e1 (e2) penalties ago; lane 0 / lane 63 take the neighbouring
@@ -631,10 +606,7 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 			// cell, good-bit words, flag word — under the same test as well: no further gain, seven more spilled SGPRs; left as it was.)
 			// (not in the span geometry and the score-only five / six-slot copies on biased offsets: that much slot state leaves no scalar register for the
 			// flag — 1250 x 50 kb +1.6 %, 1024 x 15 kb +1.7 %; with CIGAR the biased copies gain 2 % like the rest)
-#ifndef MWF_B2_MERGE_OFF
-#define MWF_B2_MERGE_OFF 0 // experiment: 1 = every chunk tests the three separately, as before round 5
-#endif
-			const bool special = MWF_B2_MERGE_OFF || MWF_IS_SPAN(T, K) || (BI4 && !TB) || !inside || g == ga || g == gb || track_good;
+			const bool special = is_span(T, K) || (BI4 && !TB) || !inside || g == ga || g == gb || track_good;
 			// ---- a chunk that sticks out of the window: the columns outside are not computed by the reference — dead
 			int32_t outA = 0, outB = 0; // 0xffff in the halves of columns outside [lo, hi]
 			uint32_t bits = 0, gbits = 0;
@@ -854,29 +826,14 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 		// the coming penalty: its rows, and the request for the first active chunk's (five loads, younger than every store)
 		bn = bn + RS == ring_bytes ? 0u : bn + RS, bx = bx + RS == ring_bytes ? 0u : bx + RS;
 		b1 = b1 + RS == ring_bytes ? 0u : b1 + RS, b2 = b2 + RS == ring_bytes ? 0u : b2 + RS;
-		bool requested = false;
-		const int32_t gf = !XPREF ? -1 : act[0] ? gk[0] : act[1] ? gk[1] : (K > 2 && act[K - 1]) ? gk[K - 1] : -1;
-		if (XMODE == 1 && xpref && gf >= 0) { // variant 1: before the barrier
-			load_rows(pre, Hb + bx, Hb + b1, Hb + b2, (uint32_t)(gf << 9) + lane8);
-			pre_g = gf, requested = true;
-		}
 		const bool young_store = relaxed_stores && n_stores > 0 && !TB && !track_good;
-		if (requested) {
-			if (young_store) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(kRowLoads + 1) : "memory");
-			else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(kRowLoads) : "memory");
-		} else {
-			if (young_store) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
-			else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-		}
+		if (young_store) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+		else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #ifdef MWF_B2_TIMING
 		const uint64_t tm3 = __builtin_readcyclecounter();
 #endif
 		__builtin_amdgcn_s_barrier();
 		asm volatile("" ::: "memory");
-		if (XMODE == 2 && gf >= 0) { // variant 2: straight behind the barrier, on the guess that the wave's first chunk stays what it was
-			load_rows(pre, Hb + bx, Hb + b1, Hb + b2, (uint32_t)(gf << 9) + lane8);
-			pre_g = gf;
-		}
 
 		// ---- bookkeeping, identical on every thread
 		const uint32_t fl = (uint32_t)uni(sh.flags[npar][0]);
@@ -960,7 +917,7 @@ __device__ PassResult band2_pass(const ArgsT &A, const PairMem &M, Shared &sh, c
 // Workgroups share a CU: 2 x 512, 4 x 256, 8 x 128 or 16 x 64 threads = 4 waves per SIMD, i.e. at most 128 VGPRs; with traceback
 // the smaller ones get 168 (3 per SIMD).  768 threads: one workgroup per CU.
 template <int T, int K, int E1, int E2, bool TB, bool S2, bool BI4 = false, bool FOLD = false>
-__global__ __launch_bounds__(T, MWF_IS_SPAN(T, K) ? (T == 1024 ? 4 : 3) : T == 1024 ? 4 : T == MWF_B2_WIDE_T ? MWF_B2_WIDE_WAVES : T <= 512 ? ((TB && T < 512) ? 3 : 4) : MWF_B2_768_WAVES) void wfa_band2_kernel(const BatchArgs)
+__global__ __launch_bounds__(T, is_span(T, K) ? (T == 1024 ? 4 : 3) : T == 1024 ? 4 : T == kWideT ? kWideWaves : T <= 512 ? ((TB && T < 512) ? 3 : 4) : kWaves768) void wfa_band2_kernel(const BatchArgs)
 {
 	constexpr int NWK = (T / 64) * K, D = (E1 > E2 ? E1 : E2) + 1;
 	// the arguments are read from the kernarg segment where they are used (dev::kernel_args / dev::fresh), never held for the kernel's lifetime
@@ -1021,7 +978,9 @@ template <int T, int K, int E1, int E2, bool TB, bool S2, bool BI4 = false, bool
 void launch_variant(const BatchArgs &a, int grid, int lds, hipStream_t st)
 {
 	// the 512-thread (and wider) geometries with o1 == x: the folded form (band2_pass), two row loads less per chunk
-	if constexpr (!FOLD && T >= 512) {
+	// (only on 2-bit sequence copies and with e1 == 2 — the default penalties and main.c's -a preset: the byte-wise geometry serves the rare pairs outside
+	// plain A/C/G/T, and a folded copy of every kernel for e1 == 1 penalties bought nothing a benchmark showed; round 6 pruning: 132 -> 56 kernels in this object)
+	if constexpr (!FOLD && T >= 512 && S2 && E1 == 2) {
 		if (a.band_fold && a.pen.oe1 - a.pen.x == E1 && a.pen.oe1 < kFoldMaxLag) return launch_variant<T, K, E1, E2, TB, S2, BI4, true>(a, grid, lds, st);
 	}
 	// the attribute is per device and this may run on several host threads (mwf_wfa_batch_multi): set it on every launch that needs it
@@ -1038,16 +997,18 @@ int launch_one(const BatchArgs &a0, int grid, int lds_seq, bool seq2, hipStream_
 	BatchArgs a = a0;
 	a.band_lds_seq = lds_seq;
 	const int lds = lds_seq + lds_tail<T, K, E1, E2>();
-	if constexpr (MWF_IS_SPAN(T, K) || (T == 512 && K >= 4)) { // the 1024-thread and the 512 x 4 geometries exist on 2-bit sequence copies only (the host knows)
+	if constexpr (is_span(T, K) || (T == 512 && K >= 4)) { // the 1024-thread and the 512 x 4 geometries exist on 2-bit sequence copies only (the host knows)
 		if (!seq2) return -1;
 		if (a.want_cigar) launch_variant<T, K, E1, E2, true, true, BI4>(a, grid, lds, st);
 		else launch_variant<T, K, E1, E2, false, true, BI4>(a, grid, lds, st);
-	} else if (a.want_cigar) {
-		if (seq2) launch_variant<T, K, E1, E2, true, true>(a, grid, lds, st);
-		else launch_variant<T, K, E1, E2, true, false>(a, grid, lds, st);
-	} else {
-		if (seq2) launch_variant<T, K, E1, E2, false, true>(a, grid, lds, st);
+	} else if constexpr (T == 768) { // the byte-wise geometry: every pair outside plain A/C/G/T that the packed kernel takes runs here (the host knows: choose_kernel)
+		if (seq2) return -1;
+		if (a.want_cigar) launch_variant<T, K, E1, E2, true, false>(a, grid, lds, st);
 		else launch_variant<T, K, E1, E2, false, false>(a, grid, lds, st);
+	} else { // 64 ... 512 threads x 3 slots: 2-bit copies only
+		if (!seq2) return -1;
+		if (a.want_cigar) launch_variant<T, K, E1, E2, true, true>(a, grid, lds, st);
+		else launch_variant<T, K, E1, E2, false, true>(a, grid, lds, st);
 	}
 	return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -1058,14 +1019,19 @@ int occ_one(int lds_seq, bool seq2, bool tb)
 	const int lds = lds_seq + lds_tail<T, K, E1, E2>();
 	int n = 0;
 	hipError_t e;
-	if constexpr (MWF_IS_SPAN(T, K) || (T == 512 && K >= 4)) {
+	if constexpr (is_span(T, K) || (T == 512 && K >= 4)) {
 		if (!seq2) return 0;
 		e = tb ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, true, true, BI4>, T, lds)
 		       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, false, true, BI4>, T, lds);
-	} else if (tb) e = seq2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, true, true>, T, lds)
-	                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, true, false>, T, lds);
-	else e = seq2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, false, true>, T, lds)
-	              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, false, false>, T, lds);
+	} else if constexpr (T == 768) {
+		if (seq2) return 0;
+		e = tb ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, true, false>, T, lds)
+		       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, false, false>, T, lds);
+	} else {
+		if (!seq2) return 0;
+		e = tb ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, true, true>, T, lds)
+		       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wfa_band2_kernel<T, K, E1, E2, false, true>, T, lds);
+	}
 	return e == hipSuccess ? n : 0;
 }
 
@@ -1095,26 +1061,23 @@ bool band2_supported(const Penalty &p)
 		if (a_e1 == 1 && a_e2 == 1) return FN<T, K, 1, 1>(__VA_ARGS__);             \
 	}
 #endif
+/* (the five / six-slot copies on biased offsets: gap extensions (2, 1) only — band2_biased512_supported; other penalty sets take the span geometry) */
 #define MWF_BAND2_PEN4B(FN, ...)                                                    \
 	{                                                                               \
-		if (a_e1 == 2 && a_e2 == 1) return FN<512, MWF_B2_W4K, 2, 1, true>(__VA_ARGS__);     \
-		if (a_e1 == 2 && a_e2 == 2) return FN<512, MWF_B2_W4K, 2, 2, true>(__VA_ARGS__);     \
-		if (a_e1 == 1 && a_e2 == 1) return FN<512, MWF_B2_W4K, 1, 1, true>(__VA_ARGS__);     \
+		if (a_e1 == 2 && a_e2 == 1) return FN<512, kW4K, 2, 1, true>(__VA_ARGS__);     \
 	}
 #define MWF_BAND2_PEN4C(FN, ...)                                                    \
 	{                                                                               \
-		if (a_e1 == 2 && a_e2 == 1) return FN<512, MWF_B2_W4K + 1, 2, 1, true>(__VA_ARGS__); \
-		if (a_e1 == 2 && a_e2 == 2) return FN<512, MWF_B2_W4K + 1, 2, 2, true>(__VA_ARGS__); \
-		if (a_e1 == 1 && a_e2 == 1) return FN<512, MWF_B2_W4K + 1, 1, 1, true>(__VA_ARGS__); \
+		if (a_e1 == 2 && a_e2 == 1) return FN<512, kW4K + 1, 2, 1, true>(__VA_ARGS__); \
 	}
 #define MWF_BAND2_DISPATCH(FN, ...)                                                 \
 	do {                                                                            \
-		if (g.block == 512 && g.span > 8 * MWF_B2_W4K * 256 && g.packed == 2) MWF_BAND2_PEN4C(FN, __VA_ARGS__) /* ... six slots on biased offsets (pairs of up to ~21 kb) */ \
+		if (g.block == 512 && g.span > 8 * kW4K * 256 && g.packed == 2) MWF_BAND2_PEN4C(FN, __VA_ARGS__) /* ... six slots on biased offsets (pairs of up to ~21 kb) */ \
 		if (g.block == 512 && g.span > 512 / 64 * 3 * 256 && g.packed == 2) MWF_BAND2_PEN4B(FN, __VA_ARGS__) /* ... five slots on biased offsets (pairs of up to ~18 kb) */ \
 		if (g.block == 512 && g.span > 512 / 64 * 3 * 256) MWF_BAND2_PEN(FN, 512, 4, __VA_ARGS__) /* 32 chunks: windows of up to 7872 columns */ \
-		if (g.block == 512) MWF_BAND2_PEN(FN, MWF_B2_WIDE_T, MWF_B2_WIDE_K, __VA_ARGS__) \
+		if (g.block == 512) MWF_BAND2_PEN(FN, kWideT, kWideK, __VA_ARGS__) \
 		if (g.block == 768) MWF_BAND2_PEN(FN, 768, 2, __VA_ARGS__)                  \
-		if (g.block == 1024) MWF_BAND2_PEN(FN, MWF_B2_SPAN_T, MWF_B2_SPAN_K, __VA_ARGS__) \
+		if (g.block == 1024) MWF_BAND2_PEN(FN, kSpanT, kSpanK, __VA_ARGS__) \
 		MWF_BAND2_REST(FN, __VA_ARGS__)                                             \
 	} while (0)
 
@@ -1125,8 +1088,9 @@ int launch_band2(const BatchArgs &a, int grid, const BandGeom &g, void *stream)
 	return -1;
 }
 
-int band2_span_chunks() { return MWF_B2_SPAN_T / 64 * MWF_B2_SPAN_K; }
-int band2_biased512_chunks() { return 8 * MWF_B2_W4K; }
+int band2_span_chunks() { return kSpanT / 64 * kSpanK; }
+int band2_biased512_chunks() { return 8 * kW4K; }
+bool band2_biased512_supported(const Penalty &p) { return p.e1 == 2 && p.e2 == 1; }
 
 int band2_kernel_occupancy(const Penalty &p, const BandGeom &g, bool cigar)
 {

@@ -70,7 +70,6 @@ struct mwf_gpu_s {
 	bool band_fold = true;      // packed band kernel: the folded score-only form where the penalties allow it (o1 == x)
 	bool div_aware = true;      // weigh the size classes' length limits by the batch's estimated divergence (batches built from host memory)
 	int64_t tun_gen = 0;        // bumped by every successful mwf_gpu_set(): a cached plan of an align (PlanCache) is only replayed under the tunables it was made under
-	int slots_per_cu = 0;       // 0: occupancy of the kernel
 	int64_t coop_min_len = 0;
 	int64_t tb_budget_mb = 0;   // 0: automatic
 	int force_kind = -1;
@@ -84,7 +83,6 @@ struct mwf_gpu_s {
 	int wide_slots = 0;        // chunk slots per wave of the 512-thread packed geometry: 0 by batch (four until an align has shown that three hold every pair), 3, 4
 	int band_span = 1;         // the 1024-thread geometry of the packed band kernel (80 chunks, biased offsets: pairs of up to ~60 kb whose windows stay below ~20 000 columns): 0 never, 2: every pair it can take (tests)
 	int ring16 = 1;            // generic kernel with E2/F2 in LDS: 16-bit ring rows in HBM while target length + penalty fits 16 bits (0: never)
-	int ring16_block = 0;      // its threads per workgroup (0: 512 score-only — two workgroups per CU with the 64 KB LDS copy —, 768 with traceback)
 	bool ring16_off_once = false; // set around the re-run of pairs whose offsets outgrew 16 bits
 	int seq2bit = 1;           // packed band kernel: 2-bit sequence copy in LDS for pairs of plain A/C/G/T (0: always bytes)
 	bool acgt_off_once = false; // set around the re-run of pairs that are not plain ACGT
@@ -95,7 +93,6 @@ struct mwf_gpu_s {
 	int64_t coop_tb_mult = 1;                // ... times this; doubled after an overflow while memory lasts
 	int64_t lowmem_budget_mb = 0; // whole-device low-memory mode: first-pass traceback above this many MB -> true two-pass (0: automatic)
 	int sys_p = 8;             // whole-device (systolic) kernel: penalties per hand-off block (4, 8 or 16)
-	int sys_p2 = 0;            // ... of the SECOND pass of its low-memory mode (0: the same)
 	int sys_c = 0;             // its columns per lane: 0 automatic (1 while the window is expected to fit the slots that way, else 4), 1, 4
 	// workspace (per-stream pool)
 	DevBuf ring, sring, good, tb, row_off, row_lo, cig_scratch, snap, snap_meta, seg, queue, dbg, coop_edge, coop_misc;
@@ -119,7 +116,6 @@ struct mwf_gpu_s {
 	std::map<uint64_t, int> occ_cache;         // kernel variant -> resident workgroups per CU
 	int coop_grid = -1;
 	int coop_grid_cap = 0;      // "coop_grid": at most this many workgroups for the whole-device kernel (0: one per CU)
-	int coop_launch = 1;        // "coop_launch": whole-device kernel through hipLaunchCooperativeKernel (0: plain launch)
 };
 
 struct mwf_gpu_batch_s {
@@ -226,6 +222,7 @@ mwf_gpu_batch_t *batch_common(mwf_gpu_t *g, int32_t n, const int32_t *h_tl, cons
 mwf_gpu_batch_t *batch_from_host(mwf_gpu_t *g, int32_t n, const int32_t *tl, const char *const *ts, const int32_t *ql, const char *const *qs,
                                  const char *packed, int64_t packed_bytes, const int64_t *p_t_off, const int64_t *p_q_off);
 float estimate_divergence_device(mwf_gpu_t *g, mwf_gpu_batch_t *b);
+extern "C" int mwf_gpu_test_hook(mwf_gpu_t *g, const char *name, int64_t value); // mwf_engine.cpp: forced kernels / geometries / failure paths for tests/ and profiles/
 // ---- mwf_async.cpp: submit / wait and the opt-in coalescing of single calls
 int64_t coalesce_window_us();
 void exact_coalesced(void *km, const mwf_opt_t *opt, int32_t tl, const char *ts, int32_t ql, const char *qs, mwf_rst_t *r); // 8-mer sketch of a few pairs of a device-resident batch (0: unknown)

@@ -183,6 +183,7 @@ int  launch_mid(const BatchArgs &a, int grid, int block, int lds, bool seq2, voi
 bool band2_supported(const Penalty &p);
 int  launch_band2(const BatchArgs &a, int grid, const BandGeom &g, void *stream);
 int  band2_kernel_occupancy(const Penalty &p, const BandGeom &g, bool cigar);
+bool band2_biased512_supported(const Penalty &p);  // its five / six-slot copies on biased offsets exist for gap extensions (2, 1) only
 int  band2_biased512_chunks();                       // ... and the 512-thread geometry's copy on biased offsets (8 waves x slots per wave)
 int  band2_span_chunks();                            // 256-column chunks its 1024-thread geometry holds (16 waves x slots per wave)
 

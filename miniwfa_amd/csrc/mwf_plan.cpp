@@ -100,7 +100,7 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 	if (want_kind == 0 || low_mem || !can_packed) return;
 	if (geom_block == 514) { // the 512-thread geometry with four chunk slots on biased offsets (the caller checked the lengths: kBandSpanMaxSeq); 2-bit copies only
 		const int64_t need_lds = ((max_len >> 4) + 4) * 4;
-		if (g->seq2bit == 0 || g->acgt_off_once || need_lds > 70 * 1024) return;
+		if (g->seq2bit == 0 || g->acgt_off_once || need_lds > 70 * 1024 || !band2_biased512_supported(P)) return;
 		// (five chunk slots per wave while target + query stay below 3.5 of that span, else six)
 		// (... or when the class was admitted on a forecast window — divergence known, window_hint = the class's largest — that five slots cannot hold: the
 		// admission test is against the SIX-slot window, a 17 kb pair at 10 % must not start on five and overflow)
@@ -155,10 +155,13 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 	bg.seq2 = seq2 && bg.lds_bytes > 0;
 	// byte-wise copy (pairs outside plain ACGT) with wide windows: three slots of state plus six probe words per column do not fit the 128
 	// VGPRs two 512-thread workgroups per CU leave each wave (~500 bytes of scratch); 768 x 2 holds the same 24 chunks without spilling
-	if (!bg.seq2 && bg.block == 512 && four_slots) bg.span = 512 / 64 * 3 * 256; // (no byte-wise form of the four-slot geometry)
-	if (!bg.seq2 && bg.block == 512 && g->block == 0 && max_seq_lds <= 140 * 1024) {
+	// Round 6: the byte-wise copy exists in ONE geometry, 768 x 2 (24 chunks like 512 x 3, one workgroup per CU) — whatever the window class or a forced block:
+	// pairs outside plain A/C/G/T are rare (reads with an N take the lane kernel's byte-wise copy), and a byte-wise twin of every geometry was 40 % of this
+	// kernel family's code.  The 768-thread geometry in turn has no 2-bit form.
+	if (bg.block == 768) bg.seq2 = 0, bg.lds_bytes = max_seq_lds <= 140 * 1024 ? (int)((max_seq_lds + 15) / 16 * 16) : 0;
+	else if (!bg.seq2) {
 		bg.block = 768, bg.span = 768 / 64 * 2 * 256;
-		bg.lds_bytes = (int)((max_seq_lds + 15) / 16 * 16);
+		bg.lds_bytes = max_seq_lds <= 140 * 1024 ? (int)((max_seq_lds + 15) / 16 * 16) : 0;
 	}
 	if (bg.lds_bytes == 0) return; // the packed kernel keeps the sequences in LDS: what does not fit takes the generic kernel
 	pl.kind = 2, pl.band = bg;
@@ -218,7 +221,7 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 	bool ring16 = false;
 	if (pl.kind == 2) {
 		pl.block = pl.band.block;
-		per_cu = g->slots_per_cu > 0 ? g->slots_per_cu : cached_occupancy(g, P, pl, 0, false);
+		per_cu = cached_occupancy(g, P, pl, 0, false);
 	} else {
 		// wide windows (the 512-thread choice above), default gap extension: E2/F2 stay in LDS while the window fits 16 k columns
 		if (g->lds_e2 && pl.block == 512 && g->block == 0 && P.e2 == 1 && !g->scalar_generic && !pl.low_mem && P.nH <= kMaxRing) {
@@ -238,10 +241,10 @@ int run_batch_kernel(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, con
 			// 32-bit: one workgroup per CU either way (128 KB of LDS): twelve waves fit its 168-VGPR budget, 490 ms against 519 ms with eight
 			// 16-bit: 512 threads, two workgroups per CU (64 KB of LDS each, 128 VGPRs) — 354 ms on 1250 x 50 kb against 375 ms for
 			// 768 threads and one per CU (479 ms with 32-bit rows); with traceback the 512-thread copy spills too much: 768 (451 against 477 ms)
-			pl.block = ring16 ? (g->ring16_block ? g->ring16_block : (pl.cigar ? 768 : 512)) : 768;
+			pl.block = ring16 ? (pl.cigar ? 768 : 512) : 768;
 		}
 		if (P.nH > kMaxRing) pl.block = 256; // the big-ring form of the generic kernel (launch_batch): one column per lane, 256 threads
-		per_cu = g->slots_per_cu > 0 ? g->slots_per_cu : cached_occupancy(g, P, pl, lds_e2_cols, !g->scalar_generic, ring16);
+		per_cu = cached_occupancy(g, P, pl, lds_e2_cols, !g->scalar_generic, ring16);
 	}
 	slots = std::max(1, std::min(slots, g->n_cu * std::max(1, per_cu)));
 	if (P.nH > kMaxRing) {
@@ -432,7 +435,7 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 	const size_t NG = (size_t)n_groups;
 	// the systolic kernel (mwf_sys.hip) runs every pass but the provenance pass of the two-pass low-memory mode
 	const bool use_sys = true;
-	const int sysP = g->sys_p, sysP2 = g->sys_p2 > 0 && low_mem ? g->sys_p2 : g->sys_p;
+	const int sysP = g->sys_p, sysP2 = g->sys_p;
 	// Columns per lane of the systolic kernel, per pass: one column per lane (64-column slots that own 48) quarters the
 	// per-column work a wave does per penalty — what a chain of penalties on a narrow window waits for — but needs five times
 	// the slots; taken while the window is EXPECTED to fit them (first pass: a fifth of tl+ql, real pairs stay far below;
@@ -576,7 +579,7 @@ int run_coop_group(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t &opt, const
 		as.ring = (int32_t*)g->sys_ring.p, as.good = (unsigned long long*)g->sys_good.p; // (sized for four columns per lane)
 		as.rows_slot = sys_rows;
 		as.sys_p = sysP;
-		as.sys_coop_launch = g->coop_launch;
+		as.sys_coop_launch = 1;
 		as.sys_spread = 1; // consecutive chunks on consecutive workgroups: 763 against 787 ms on the 5 Mb pair, 63.5 against 65.0 on the 150 kb pair
 		as.sys_box = (int32_t*)g->sys_box.p, as.sys_box_stride = sys_box_group;
 		as.sys_prog = (unsigned long long*)g->sys_prog.p, as.sys_prog_stride = TC * 8;
@@ -826,7 +829,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 				else if (packable && (lenw + 1 <= 4 * (int64_t)(8 * 3 * 256) || window <= kBandWideWindow)) c = 1;
 				// (tl + ql up to 3.5 of its spans: a 12 kb pair at 5 % needs ~6000 of the 7872 columns; 512 x 15 kb @ 5 % — windows of ~7500 — lost 44 pairs to late
 				// overflows, 30.7 against 24.9 ms on the span geometry from the start)
-				else if (span_ok && g->wide_slots != 3 && (exp_win ? exp_win + 768 <= ((int64_t)band2_biased512_chunks() + 8 - 1) * 256 - 64 : len + 1 <= 7 * (int64_t)((band2_biased512_chunks() + 8) * 256) / 2)) c = 14;
+				else if (span_ok && band2_biased512_supported(P0) && g->wide_slots != 3 && (exp_win ? exp_win + 768 <= ((int64_t)band2_biased512_chunks() + 8 - 1) * 256 - 64 : len + 1 <= 7 * (int64_t)((band2_biased512_chunks() + 8) * 256) / 2)) c = 14;
 				else if (span_ok && ((exp_win ? exp_win + 768 <= band_span_window() : len + 1 <= 7 * band2_span_chunks() * 256) || window <= band_span_window())) c = 13;
 			}
 			b->h_class[i] = (int8_t)(c == 5 ? 0 : c == 13 ? 5 : c == 14 ? 1 : c);

@@ -1383,8 +1383,7 @@ int launch_pass_d(const BatchArgs &a, int grid, hipStream_t st)
 		if constexpr (CAN_DEFER) {
 			// (measured, round 5: the provenance pass carries twice the wavefront state — with four columns per lane the deferred form needs ~316 VGPRs
 			// and spills 60 of them; without the deferral 25, and the 5 Mb pair's first pass falls from 1.06 to 0.97 s; one column per lane: 125 -> 122 ms
-			// on the 150 kb pair.  MWF_SYS_DEFER_SEG=1 restores the deferred form.)
-			if (defer && getenv("MWF_SYS_DEFER_SEG")) return launch_pass_p<E1, E2, true, false>(a, grid, st);
+			// on the 150 kb pair: the deferred provenance kernel is no longer built.)
 		}
 		return launch_pass_p<E1, E2, false, false>(a, grid, st);
 	}

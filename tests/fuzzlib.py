@@ -131,7 +131,6 @@ ALL_KERNEL_CONFIGS = [
     ("generic, one column per lane", dict(force_kind=0, scalar_generic=1)),
     ("generic, four columns per lane", dict(force_kind=0)),
     ("generic, 16-bit ring rows (packed recurrence)", dict(force_kind=0, ring16=2)),
-    ("generic, 16-bit ring rows, 768 threads", dict(force_kind=0, ring16=2, ring16_block=768)),
     ("band, unpacked 256", dict(force_kind=2, block=256, band_pack=0)),
     ("band, unpacked 768", dict(force_kind=2, block=768, band_pack=0)),
     ("whole-device", dict(force_kind=1)),

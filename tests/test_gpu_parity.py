@@ -388,8 +388,8 @@ def test_sequence_copy_modes_and_alphabet_fallback(mode, oracle):
         # is left are the pairs whose window outgrows their size class, the same in both modes
         RETRIES.setdefault((o.flag, o.o2, o.x), {})[mode] = eng.stats().n_retries
         seen = RETRIES[(o.flag, o.o2, o.x)]
-        if len(seen) == 2:
-            assert seen["2bit"] == seen["bytes"], seen
+        if len(seen) == 2:   # (round 6: the byte-wise copy runs in ONE geometry, 768 x 2 — its 24 chunks hold windows the small 2-bit classes hand back)
+            assert seen["bytes"] <= seen["2bit"], seen
         b.free()
     if mode == "2bit":
         # device-resident inputs (mwf_gpu_batch_wrap): nobody looked at the bytes, the 2-bit copy finds out on the device and
@@ -1629,7 +1629,7 @@ def test_cached_plan_follows_every_tunable(oracle):
     b = eng.upload(PackedBatch(pairs))
     flips = [("lane_max_len", 0), ("lane_max_len", 400), ("mid_max_pairs", 0), ("mid_max_pairs", -1), ("seq2bit", 0), ("seq2bit", 1), ("band_pack", 0), ("band_pack", 1),
              ("force_kind", 0), ("force_kind", -1), ("block", 256), ("block", 0), ("ring16", 0), ("ring16", 1), ("lane_chunks", 2), ("lane_chunks", 0),
-             ("mid_block", 512), ("mid_block", 0), ("band_span", 0), ("band_span", 1), ("wide_slots", 3), ("wide_slots", 0), ("slots_per_cu", 1), ("slots_per_cu", 0)]
+             ("mid_block", 512), ("mid_block", 0), ("band_span", 0), ("band_span", 1), ("wide_slots", 3), ("wide_slots", 0), ("host_results", 0), ("host_results", 1)]
     for name, value in [(None, 0)] + flips:
         if name:
             eng.set(name, value)
