@@ -391,7 +391,26 @@ class BackgroundReference:
         return self
 
 
-def long_pairs(mw, synth_pair, PackedBatch, cpu: bool, mhc_cpu: bool):
+def read_first_fasta(path: str) -> bytes:
+    """First record of a FASTA / FASTQ file (plain or .gz), sequence bytes as they stand in the file (the reference compares bytes verbatim, main.c:67-72)."""
+    import gzip
+    op = gzip.open if path.endswith(".gz") else open
+    seq, started = [], False
+    with op(path, "rb") as f:
+        first = f.readline()
+        fastq = first.startswith(b"@")
+        for line in f:
+            if line.startswith(b">") or (fastq and line.startswith(b"+")):
+                break
+            seq.append(line.strip())
+    return b"".join(seq)
+
+
+# the reference's own evaluation pairs (Zenodo record 6056061, README.md:82-88,146) and the penalties its README publishes for them with the DEFAULT costs
+REAL_PAIRS = {"c4_like_150kb": ("--c4", 26917), "mhc_like_5Mb": ("--mhc", 229868)}
+
+
+def long_pairs(mw, synth_pair, PackedBatch, cpu: bool, mhc_cpu: bool, real=None):
     """BASELINE configs[1] and configs[3] (stand-ins): one pair on the whole device, each mode on a fresh
     engine so that `peak_device_bytes` is that mode's own need; the compiled reference timed beside it in the same run:
     inline for the 150 kb pair (seconds), on a host thread that runs while the GPU legs do for the 5 Mb pair (minutes)."""
@@ -411,6 +430,9 @@ def long_pairs(mw, synth_pair, PackedBatch, cpu: bool, mhc_cpu: bool):
         except Exception:
             ref = None
     seqs = {name: synth_pair(seed, tl_, p_, nl, lm) for name, seed, tl_, p_, nl, lm, _ in LONG_SPECS}
+    real = real or {}
+    for name, files in real.items():   # the real pair instead of its synthetic stand-in, the moment the files are there
+        seqs[name] = (read_first_fasta(files[0]), read_first_fasta(files[1]))
     bg = None
     if ref is not None and mhc_cpu:   # configs[3]'s CPU baseline: started before the GPU legs, joined behind them
         t_, q_ = seqs["mhc_like_5Mb"]
@@ -446,7 +468,9 @@ def long_pairs(mw, synth_pair, PackedBatch, cpu: bool, mhc_cpu: bool):
             if kw.get("flag"):
                 cg = bb.cigar(0, int(nc_[0])).tolist()
                 rec["cigar_rescored_ok"] = mw.cigar2score(mw.opt_init(), cg) == (int(s_[0]), len(t_), len(q_))
-            g = gold.get(gid)
+            if name in real:   # the README's published penalty for this pair under the default costs (README.md:83-86) must come out
+                rec["real_data"] = {"files": list(real[name]), "readme_s": REAL_PAIRS[name][1], "s_matches_readme": int(s_[0]) == REAL_PAIRS[name][1]}
+            g = None if name in real else gold.get(gid)
             if g:
                 rec["matches_reference_golden"] = (int(s_[0]), int(it_[0])) == (g["expect"]["s"], g["expect"]["n_iter"])
                 rec["cpu_reference_s_build_container"] = g.get("reference_wall_s")
@@ -506,6 +530,8 @@ def parse_args(argv=None):
     ap.add_argument("--mhc-cpu", type=int, default=1, help="1: time the compiled reference on the 5 Mb pair in this run (one host thread beside the GPU legs, ~4 min); 0: skip")
     ap.add_argument("--long-batches", type=int, default=1, help="also time one GPU's share of configs[4] (1250 x 50 kb, score-only) on rank 0 at N=1")
     ap.add_argument("--extras", type=int, default=1, help="0: skip end_to_end / call latency / long pairs (profiling runs)")
+    ap.add_argument("--c4", nargs=2, metavar=("TARGET.fa", "QUERY.fa"), default=None, help="the reference's NA19240 C4A / C4B pair (Zenodo 6056061) instead of the synthetic 150 kb stand-in: s must be 26917 (README.md:83)")
+    ap.add_argument("--mhc", nargs=2, metavar=("TARGET.fa", "QUERY.fa"), default=None, help="the reference's GRCh38 / CHM13 MHC pair instead of the synthetic 5 Mb stand-in: s must be 229868 (README.md:86)")
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--seeds", type=int, default=4, help="batches of the headline shape rotated through the timed steps (config 3): value is the mean over them")
     args = ap.parse_args(argv)
@@ -877,7 +903,8 @@ def main():
                 out["long_batches"] = {"error": repr(e)}
         if args.long_pairs and not strong:
             try:
-                out["long_pairs"] = long_pairs(mw, synth_pair, PackedBatch, cpu=args.cpu_sample > 0, mhc_cpu=bool(args.mhc_cpu))
+                out["long_pairs"] = long_pairs(mw, synth_pair, PackedBatch, cpu=args.cpu_sample > 0, mhc_cpu=bool(args.mhc_cpu),
+                                               real={k: v for k, v in (("c4_like_150kb", args.c4), ("mhc_like_5Mb", args.mhc)) if v})
             except Exception as e:
                 out["long_pairs"] = {"error": repr(e)}
     print(json.dumps(out))

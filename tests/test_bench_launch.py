@@ -67,3 +67,20 @@ def test_single_rank_dry_run_and_no_gpu_message():
     if not torch.cuda.is_available():   # the real path refuses to run without a GPU: no CPU fallback
         r = _run(["--steps", "1", "--warmup", "0", "--extras", "0", "--cpu-sample", "0"])
         assert r.returncode != 0 and "needs a GPU" in (r.stderr + r.stdout)
+
+
+def test_bench_reads_the_real_pairs_when_they_are_dropped_in(tmp_path):
+    """bench.py --c4 A B / --mhc A B (the reference's Zenodo pairs, README.md:82-88): the FASTA / FASTQ(.gz) reader takes the first record's bytes as they are."""
+    import gzip
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    fa = tmp_path / "a.fa"
+    fa.write_bytes(b">one desc\nACGT\nacgtN\n>two\nTTTT\n")
+    fq = tmp_path / "b.fq.gz"
+    with gzip.open(fq, "wb") as f:
+        f.write(b"@r1\nGATTACA\n+\nIIIIIII\n@r2\nCC\n+\nII\n")
+    assert bench.read_first_fasta(str(fa)) == b"ACGTacgtN"
+    assert bench.read_first_fasta(str(fq)) == b"GATTACA"
+    assert bench.REAL_PAIRS["c4_like_150kb"][1] == 26917 and bench.REAL_PAIRS["mhc_like_5Mb"][1] == 229868
