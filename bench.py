@@ -151,6 +151,22 @@ def call_latency(mw, synth_pair, reps=40):
             w = time.perf_counter() - t0
         out["submit_wait_1000bp_score"] = {"calls_per_s": len(many) / w, "ratio_to_one_thread_calls": len(many) / w / r1, "ok": all(r[0] == res[i % 16][0] for i, r in enumerate(res)),
                                            "what": "one host thread: 1600 x mwf_wfa_submit, then 1600 x mwf_wfa_wait (Python binding overhead included)"}
+        # ... and the same sixteen looping threads with MWF_COALESCE_US=150 (read once per process: a child process): calls of different threads that
+        # arrive within 150 us share one batch launch (mwf_async.cpp) — no change to the calling program at all
+        try:
+            import subprocess
+            code = ("import sys, threading, time, json\nsys.path.insert(0, %r)\nimport torch\nimport miniwfa_amd as mw\nfrom miniwfa_amd.synth import synth_pair\n"
+                    "pairs = [synth_pair(5000 + i, 1000, 0.05) for i in range(16)]\no = mw.opt_init()\n"
+                    "def loop(k, n):\n    t, q = pairs[k]\n    for _ in range(n): mw.wfa_exact(t, q, o)\n"
+                    "def rate(nt, n):\n    th = [threading.Thread(target=loop, args=(k, n)) for k in range(nt)]\n    t0 = time.perf_counter()\n    [x.start() for x in th]; [x.join() for x in th]\n    return nt * n / (time.perf_counter() - t0)\n"
+                    "rate(16, 5)\nprint(json.dumps({'calls_per_s_16_threads': rate(16, 100), 'async_stats': mw.async_stats()}))\n") % ROOT
+            r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, MWF_COALESCE_US="150"))
+            rec = json.loads(r.stdout.strip().splitlines()[-1])
+            rec["ratio_to_one_thread_calls"] = rec["calls_per_s_16_threads"] / r1
+            rec["what"] = "the same sixteen threads with MWF_COALESCE_US=150 in the environment: concurrent mwf_wfa_exact calls share batch launches (async_stats: batches run, calls in them)"
+            out["threads16_coalesced_1000bp_score"] = rec
+        except Exception as e:
+            out["threads16_coalesced_1000bp_score"] = {"error": repr(e)}
     except Exception as e:
         out["threads16_1000bp_score"] = {"error": repr(e)}
     return out
