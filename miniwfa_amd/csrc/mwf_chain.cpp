@@ -20,16 +20,16 @@
 namespace {
 
 // A/a C/c G/g T/t U/u -> 0..3, anything else breaks the k-mer (reference seq_nt4_table, miniwfa.c:699-716)
-inline int base_code(unsigned char c)
-{
-	switch (c) {
-	case 'A': case 'a': return 0;
-	case 'C': case 'c': return 1;
-	case 'G': case 'g': return 2;
-	case 'T': case 't': case 'U': case 'u': return 3;
-	default: return 4;
+struct BaseCodes {
+	uint8_t v[256];
+	BaseCodes()
+	{
+		memset(v, 4, sizeof(v));
+		v['A'] = v['a'] = 0, v['C'] = v['c'] = 1, v['G'] = v['g'] = 2, v['T'] = v['t'] = v['U'] = v['u'] = 3;
 	}
-}
+};
+const BaseCodes kBaseCodes;
+inline int base_code(unsigned char c) { return kBaseCodes.v[c]; }
 
 // Ascending sort of 64-bit keys: least-significant-digit radix sort on the bytes that differ between keys (the reference sorts its k-mers and
 // anchor pairs with a radix sort too, miniwfa.c:699-716 — tens of thousands of keys per call, where std::sort was a third of a call's host time);
@@ -55,6 +55,30 @@ void sort_u64(std::vector<uint64_t> &a)
 	if (src != a.data()) std::copy(src, src + n, a.data());
 }
 
+// Stable least-significant-digit radix sort of 64-bit keys on the bit field [lo_bit, lo_bit + n_bits) only, digits of up to 13 bits (two passes for the 26 bits
+// of a 13-mer).  Round 6: the k-mer list is generated target first, then query, positions ascending — i.e. already in the order the full key
+// (kmer << 1 | rid) << 32 | pos breaks ties in — so a STABLE sort on the k-mer bits alone yields exactly the fully sorted list, in two passes instead of six.
+void radix_sort_field(std::vector<uint64_t> &a, int lo_bit, int n_bits)
+{
+	const size_t n = a.size();
+	if (n < 2 || n_bits <= 0) return;
+	std::vector<uint64_t> tmp(n);
+	uint64_t *src = a.data(), *dst = tmp.data();
+	std::vector<uint32_t> count;
+	for (int done = 0; done < n_bits;) {
+		const int w = std::min(13, n_bits - done), shift = lo_bit + done;
+		const uint64_t m = (1ULL << w) - 1;
+		count.assign((size_t)1 << w, 0);
+		for (size_t i = 0; i < n; ++i) ++count[(src[i] >> shift) & m];
+		uint32_t at = 0;
+		for (size_t d = 0; d < count.size(); ++d) { const uint32_t c = count[d]; count[d] = at, at += c; }
+		for (size_t i = 0; i < n; ++i) dst[count[(src[i] >> shift) & m]++] = src[i];
+		std::swap(src, dst);
+		done += w;
+	}
+	if (src != a.data()) std::copy(src, src + n, a.data());
+}
+
 // every k-mer of seq as (kmer << 1 | rid) << 32 | end position  (reference mg_fc_kmer, miniwfa.c:718-730)
 void collect_kmers(int32_t len, const char *seq, int rid, int k, std::vector<uint64_t> &out)
 {
@@ -76,16 +100,19 @@ std::vector<int32_t> longest_increasing(const std::vector<uint64_t> &a)
 {
 	const int32_t n = (int32_t)a.size();
 	std::vector<int32_t> tail(n + 1, 0), pred(n, 0);
+	std::vector<uint64_t> tailv(n + 1, 0); // a[tail[.]]: the binary search then walks one contiguous array instead of chasing indices into a
 	int32_t L = 0;
 	for (int32_t i = 0; i < n; ++i) {
+		const uint64_t v = a[i];
 		int32_t lo = 1, hi = L;
-		while (lo <= hi) {
+		if (L > 0 && tailv[L] < v) lo = L + 1; // (colinear anchors: nearly every element extends the longest run)
+		else while (lo <= hi) {
 			const int32_t mid = (lo + hi + 1) >> 1;
-			if (a[tail[mid]] < a[i]) lo = mid + 1;
+			if (tailv[mid] < v) lo = mid + 1;
 			else hi = mid - 1;
 		}
 		pred[i] = tail[lo - 1];
-		tail[lo] = i;
+		tail[lo] = i, tailv[lo] = v;
 		if (lo > L) L = lo;
 	}
 	std::vector<int32_t> out(L);
@@ -103,7 +130,7 @@ std::vector<uint64_t> chain_anchors(int32_t tl, const char *ts, int32_t ql, cons
 	a.reserve((size_t)tl + ql);
 	collect_kmers(tl, ts, 0, k, a);
 	collect_kmers(ql, qs, 1, k, a);
-	sort_u64(a); // keys are unique, so any correct sort gives the reference's order
+	radix_sort_field(a, 33, 2 * k); // (keys are unique: the reference's fully sorted order — ties of the k-mer broken by rid, then position — is the generation order)
 	std::vector<uint64_t> b;
 	for (size_t i0 = 0, i = 1; i <= a.size(); ++i) {
 		if (i == a.size() || (a[i0] >> 33) != (a[i] >> 33)) {
@@ -116,7 +143,17 @@ std::vector<uint64_t> chain_anchors(int32_t tl, const char *ts, int32_t ql, cons
 			i0 = i;
 		}
 	}
-	sort_u64(b);
+	// b must be ordered by target position, then query position (the reference radix-sorts it whole, miniwfa.c:760).  Every pair of one target position
+	// comes out of ONE k-mer group with its query positions ascending, so a stable counting sort on the target position alone is that order: one pass.
+	{
+		std::vector<uint32_t> at((size_t)tl + 1, 0);
+		for (uint64_t v : b) ++at[(size_t)(v >> 32)];
+		uint32_t sum = 0;
+		for (uint32_t &c : at) { const uint32_t x = c; c = sum, sum += x; }
+		std::vector<uint64_t> sorted(b.size());
+		for (uint64_t v : b) sorted[at[(size_t)(v >> 32)]++] = v;
+		b.swap(sorted);
+	}
 	for (uint64_t &v : b) v = v >> 32 | v << 32; // order by target position, compare by query position
 	const std::vector<int32_t> lis = longest_increasing(b);
 	anchors.reserve(lis.size());
