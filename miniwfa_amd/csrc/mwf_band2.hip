@@ -979,7 +979,7 @@ void launch_variant(const BatchArgs &a, int grid, int lds, hipStream_t st)
 {
 	// the 512-thread (and wider) geometries with o1 == x: the folded form (band2_pass), two row loads less per chunk
 	// (only on 2-bit sequence copies and with e1 == 2 — the default penalties and main.c's -a preset: the byte-wise geometry serves the rare pairs outside
-	// plain A/C/G/T, and a folded copy of every kernel for e1 == 1 penalties bought nothing a benchmark showed; round 6 pruning: 132 -> 56 kernels in this object)
+	// plain A/C/G/T, and a folded copy of every kernel for e1 == 1 penalties bought nothing a benchmark showed; round 6 pruning: 132 -> 62 kernels in this object)
 	if constexpr (!FOLD && T >= 512 && S2 && E1 == 2) {
 		if (a.band_fold && a.pen.oe1 - a.pen.x == E1 && a.pen.oe1 < kFoldMaxLag) return launch_variant<T, K, E1, E2, TB, S2, BI4, true>(a, grid, lds, st);
 	}
