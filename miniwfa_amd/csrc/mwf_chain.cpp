@@ -301,7 +301,13 @@ extern "C" void mwf_wfa_chain(void *km, const mwf_opt_t *opt, int32_t tl, const 
 	if (timing) {
 		auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
 		int64_t fill_bases = 0;
-		for (size_t i = 0; i < ftl.size(); ++i) fill_bases += ftl[i] + fql[i];
+		int32_t longest = 0, n_100 = 0, n_1000 = 0;
+		for (size_t i = 0; i < ftl.size(); ++i) {
+			fill_bases += ftl[i] + fql[i];
+			const int32_t l = std::max(ftl[i], fql[i]);
+			longest = std::max(longest, l), n_100 += l > 100, n_1000 += l > 1000;
+		}
+		fprintf(stderr, "[libmwf_hip] chain fills: longest %d, %d above 100 bp, %d above 1000 bp\n", longest, n_100, n_1000);
 		fprintf(stderr, "[libmwf_hip] chain %d x %d: anchors %.2f ms (%d kept), gaps %.2f ms, batch of %zu fills (%lld bases) %.2f ms, stitch %.2f ms\n", tl, ql, ms(t_0, t_1), n_a,
 		        ms(t_1, t_2), ftl.size(), (long long)fill_bases, ms(t_2, t_3), ms(t_3, std::chrono::steady_clock::now()));
 	}

@@ -329,12 +329,29 @@ void run_share(int dev, const mwf_opt_t *opt, const std::vector<int32_t> &ids, c
 	std::vector<int32_t> ltl((size_t)m), lql((size_t)m);
 	std::vector<const char*> lts((size_t)m), lqs((size_t)m);
 	for (int32_t j = 0; j < m; ++j) ltl[j] = tl[ids[j]], lql[j] = ql[ids[j]], lts[j] = ts[ids[j]], lqs[j] = qs[ids[j]];
+	static const bool timing = getenv("MWF_SHARE_TIMING") != nullptr; // (diagnostics: where a drop-in batch call's time goes)
+	const auto t_0 = std::chrono::steady_clock::now();
 	mwf_gpu_batch_t *b = batch_from_host(g, m, ltl.data(), lts.data(), lql.data(), lqs.data(), nullptr, 0, nullptr, nullptr);
 	const bool cigar = (opt->flag & MWF_F_CIGAR) != 0;
 	if (!b) R.err = std::string("batch upload failed: ") + mwf_gpu_last_error(g);
 	else {
 		R.s.resize((size_t)m), R.ncig.resize((size_t)m), R.iter.resize((size_t)m);
-		if (mwf_gpu_batch_align(g, b, opt) || mwf_gpu_batch_results(g, b, R.s.data(), R.iter.data(), R.ncig.data()) || (cigar && fetch_cigars(g, b)))
+		const auto t_1 = std::chrono::steady_clock::now();
+		int rc = mwf_gpu_batch_align(g, b, opt);
+		const auto t_2 = std::chrono::steady_clock::now();
+		rc = rc || mwf_gpu_batch_results(g, b, R.s.data(), R.iter.data(), R.ncig.data());
+		const auto t_3 = std::chrono::steady_clock::now();
+		rc = rc || (cigar && fetch_cigars(g, b));
+		if (timing) {
+			auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+			int32_t longest = 0;
+			for (int32_t j = 0; j < m; ++j) longest = std::max(longest, std::max(ltl[j], lql[j]));
+			mwf_gpu_stats_t st;
+			mwf_gpu_get_stats(g, &st);
+			fprintf(stderr, "[libmwf_hip] share of %d pairs (longest %d): upload %.3f ms, align %.3f ms (kernels %.3f ms, %d launch(es), %lld re-run), results %.3f ms, cigars %.3f ms\n", m, longest,
+			        ms(t_0, t_1), ms(t_1, t_2), st.kernel_ms, (int)st.n_launches, (long long)st.n_retries, ms(t_2, t_3), ms(t_3, std::chrono::steady_clock::now()));
+		}
+		if (rc)
 			R.err = std::string("alignment failed: ") + mwf_gpu_last_error(g);
 		else {
 			if (cigar) R.cig.swap(b->h_cig), R.cigoff = b->h_cigoff;

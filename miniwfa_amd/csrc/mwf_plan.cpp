@@ -91,7 +91,9 @@ void choose_kernel(const mwf_gpu_t *g, const mwf_opt_t &opt, const Penalty &P, i
 		if (lds <= 158 * 1024) {
 			// eight waves while the windows stay below ~700 columns (pairs of up to ~1.2 kb at 5 %), else sixteen (measured: 1 kb 0.255 against
 			// 0.314 ms, 2 kb 0.572 / 0.556, 4 kb 1.60 / 1.43; profiles/mid_kernel_probe.py)
-			const int block = g->mid_block ? g->mid_block : (max_len <= 1000 ? 256 : max_len <= 2500 ? 512 : 1024); // (4 x 400 bp: 131 us on four waves, 145 on eight)
+			// (window_hint: the widest window the class's pairs are expected to reach — a pair of very different lengths opens a gap its length does not tell)
+			const int64_t by_len = window_hint > 0 ? std::max<int64_t>(max_len, window_hint * 100 / 28) : max_len;
+			const int block = g->mid_block ? g->mid_block : (by_len <= 1000 ? 256 : by_len <= 2500 ? 512 : 1024); // (4 x 400 bp: 131 us on four waves, 145 on eight)
 			const int seq2 = g->seq2bit != 0 && !g->acgt_off_once;
 			pl.kind = 2, pl.band = BandGeom{block, 1, 64 * groups, lds, seq2, 2};
 			return;
@@ -789,7 +791,11 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	} else {
 		const bool lane_ok = g->lane_max_len > 0 && lane_supported(P0);
 		const int mid_cap = g->mid_max_pairs < 0 ? g->n_cu : g->mid_max_pairs;
-		const bool mid_ok = g->force_kind < 0 && g->block == 0 && mid_cap > 0 && b->n <= mid_cap && mid_supported(P0);
+		// the mid kernel (a workgroup per pair, one per CU) serves a FEW pairs: a batch of at most mid_cap pairs, or the at most mid_cap pairs of a
+		// larger batch that are neither short reads (lane kernel) nor long (classes 0-2 ... see below) — mwf_wfa_chain's gap fills are hundreds of
+		// tiny pairs and a handful of longer ones, and the handful sets the call's time
+		const bool mid_batch = g->force_kind < 0 && g->block == 0 && mid_cap > 0 && mid_supported(P0);
+		const bool mid_ok = mid_batch && b->n <= mid_cap;
 		const bool know_acgt = !b->h_acgt.empty() && g->seq2bit != 0;
 		const bool pack_pen = g->band_pack != 0 && band2_supported(P0);
 		std::vector<int8_t> cls((size_t)b->n); // group of every pair
@@ -799,14 +805,25 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		// (estimate_divergence: batches built from host memory) the lengths are weighed by it: three times as diverged = as if three times as long.
 		// Only upwards of the prior, and a little downwards: a class too narrow costs a second run, one too wide a few per cent.
 		const double div_r = b->div_est > 0 && g->div_aware ? std::min(8.0, std::max(0.7, (double)b->div_est / 0.05)) : 1.0;
-		for (int32_t i = 0; i < b->n; ++i) {
+		struct PairInfo { int64_t bound, bound1, exp_win; };
+		std::vector<PairInfo> info((size_t)b->n);
+		std::vector<int8_t> mid_cand;   // large batches: pairs the mid kernel would take if they are few
+		int32_t n_cand = 0;
+		if (mid_batch && !mid_ok) mid_cand.assign((size_t)b->n, 0);
+		// class of pair i; allow_mid: the mid kernel may take it
+		auto classify = [&](int32_t i, bool allow_mid) -> int {
 			const int64_t tl = b->h_tl[i], ql = b->h_ql[i], len = tl + ql;
-			const int64_t lenw = (int64_t)((double)len * div_r); // the pair's length as the classes' limits should see it
+			// A pair of very different lengths must open a gap of |tl - ql|: its window reaches that diagonal whatever its divergence (two columns per
+			// penalty of the gap, until the matrix ends), so the length limits see it as if it were longer — beyond what indels of a related pair add up
+			// to.  (Found on mwf_wfa_chain's gap fills: a 54 x 740 fill sat in the 64-thread class and was run twice, every call.)
+			const int64_t skew = std::abs(tl - ql), skew_len = 6 * std::max<int64_t>(0, skew - len / 16);
+			const int64_t lenw = (int64_t)((double)len * div_r) + skew_len; // the pair's length as the classes' limits should see it
 			// the window the pair is expected to reach (0.27 (tl+ql) at 5 %), plus 15 %, where the divergence is known: the long classes' length limits
 			// were drawn for ~3 % (configs[4]) and sent 20 kb pairs at 15 % and 50 kb pairs at 5 % through the span geometry for nothing
 			const int64_t exp_win = b->div_est > 0 && g->div_aware ? std::min<int64_t>(len + 1, (int64_t)(6.2 * b->div_est * (double)len) + 64) : 0;
 			const int64_t bound1 = penalty_bound(*opt, tl, ql, false);
 			const int64_t bound = opt->max_s > 0 ? std::min<int64_t>(bound1, (int64_t)opt->max_s + 1) : bound1; // (= penalty_bound(..., true))
+			info[(size_t)i] = PairInfo{bound, bound1, exp_win};
 			const bool step0 = low_mem && bound1 < opt->step;
 			int c = low_mem && !step0 ? 5 : 0;
 			const bool packable = tl + bound < 32767 && pack_pen;
@@ -837,27 +854,50 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 			// short pairs: a window of 64 diagonals holds them while the penalty stays below ~45 (a 200 bp pair at 5 %)
 			// (in a batch small enough for the mid kernel the lane kernel keeps the pairs of up to 320 bases: 16 x 400 bp 0.31 ms on the lane
 			// kernel — pairs that outgrow its chunks are re-run — against 0.13 on the mid kernel, 1 x 300 bp 56 against 68 us; profiles/r04/lane_vs_mid.txt)
-			const bool to_lane = classes && lane_ok && c >= 1 && c <= 4 && (int64_t)((double)std::max(tl, ql) * div_r) <= (mid_ok ? std::min(g->lane_max_len, 320) : g->lane_max_len) && std::abs(tl - ql) <= 24;
+			const bool to_lane = classes && lane_ok && c >= 1 && c <= 4 && (int64_t)((double)std::max(tl, ql) * div_r) <= (mid_ok ? std::min(g->lane_max_len, 320) : g->lane_max_len) && skew <= 24;
 			if (to_lane) c = (know_acgt && !b->h_acgt[i]) ? 12 : 10, b->h_class[i] = 4;
 			// a few mid-size pairs: a workgroup each, rings in LDS (a penalty then costs a fraction of what it costs the band kernels).  Admitted
-			// when the span the LDS can hold beside the sequences covers the window of a pair at ~6 % divergence (about 0.3 (tl+ql)); 16-bit offsets.
-			if (mid_ok && !to_lane && c <= 4 && (!low_mem || step0) && tl + bound < 32760) {
+			// when the span the LDS can hold beside the sequences covers the window of a pair at ~6 % divergence (about 0.3 (tl+ql)) and the gap its lengths
+			// force — or every column the pair can ever reach; 16-bit offsets.
+			if (mid_batch && !to_lane && c <= 4 && (!low_mem || step0) && tl + bound < 32760) {
 				const int64_t seq_lds = ((tl + 7) & ~7LL) + 16 + ((ql + 7) & ~7LL) + 32;
 				const int64_t window = std::min<int64_t>(len + 1, 2 * bound + 3);
 				const int64_t want = std::min<int64_t>(window, lenw * 34 / 100 + 128) + 2 * P0.nH;
 				int groups = (int)std::min<int64_t>((window + 2 * P0.nH + 63) / 64, 128);
 				while (groups > 1 && mid_lds_bytes(P0, groups, seq_lds) > 158 * 1024) --groups;
-				if (mid_lds_bytes(P0, groups, seq_lds) <= 158 * 1024 && (int64_t)groups * 64 >= want && std::abs(tl - ql) < groups * 32) {
-					b->h_class[i] = (int8_t)((c >= 1 && c <= 4) || (classes && packable) ? 2 : 0); // where an overflow goes: the wide packed band kernel, else generic
-					c = 11;
-					mid_bytes |= know_acgt && !b->h_acgt[i]; // a pair the host knows not to be plain A/C/G/T: the (few) pairs of this class all take the byte-wise copy
+				// (the span lies around the middle of diagonals 0 and ql - tl, mwf_mid.hip: all the columns a window can reach — the matrix, or what the penalty
+				// bound allows either side of diagonal 0 — plus the dead margins)
+				const int64_t C = (int64_t)groups * 64, left = tl + 1 + (ql - tl) / 2 - C / 2, right = left + C - 1;
+				const bool holds_all = std::max<int64_t>(1, tl + 1 - (bound + 1)) - P0.nH >= left && std::min<int64_t>(len + 1, tl + 1 + bound + 1) + P0.nH <= right;
+				if (mid_lds_bytes(P0, groups, seq_lds) <= 158 * 1024 && (holds_all || (C >= want && skew < groups * 32))) {
+					if (!allow_mid) {
+						// (a large batch: counted; the pairs move to the mid kernel afterwards if they are few, and only the band kernels' SMALL classes give
+						// pairs away — wide windows are the 512-thread geometry's work whatever their number)
+						if (!mid_cand.empty() && c >= 3 && c <= 4 && !mid_cand[(size_t)i]) mid_cand[(size_t)i] = 1, ++n_cand;
+					} else {
+						b->h_class[i] = (int8_t)((c >= 1 && c <= 4) || (classes && packable) ? 2 : 0); // where an overflow goes: the wide packed band kernel, else generic
+						c = 11;
+						mid_bytes |= know_acgt && !b->h_acgt[i]; // a pair the host knows not to be plain A/C/G/T: the (few) pairs of this class all take the byte-wise copy
+					}
 				}
 			}
 			if (c >= 1 && c <= 4 && know_acgt && !b->h_acgt[i] && packable) c += 5;
+			return c;
+		};
+		for (int32_t i = 0; i < b->n; ++i) cls[(size_t)i] = (int8_t)classify(i, mid_ok);
+		if (n_cand > 0 && n_cand <= mid_cap)
+			for (int32_t i = 0; i < b->n; ++i)
+				if (mid_cand[(size_t)i]) cls[(size_t)i] = (int8_t)classify(i, true);
+		for (int32_t i = 0; i < b->n; ++i) {
+			const int64_t tl = b->h_tl[i], ql = b->h_ql[i], len = tl + ql;
+			const int c = cls[(size_t)i];
+			const PairInfo &pi = info[(size_t)i];
 			GroupInfo &G = gi[c];
-			cls[i] = (int8_t)c, ++count[c];
-			G.max_len = std::max(G.max_len, len), G.max_bound = std::max(G.max_bound, bound);
-			G.max_bound1 = std::max(G.max_bound1, bound1);
+			++count[c];
+			G.max_len = std::max(G.max_len, len), G.max_bound = std::max(G.max_bound, pi.bound);
+			G.max_bound1 = std::max(G.max_bound1, pi.bound1);
+			// (the mid class: the window its pairs are expected to reach, forced gap included — its launch picks the workgroup size by it)
+			const int64_t exp_win = c == 11 ? std::min<int64_t>(len + 1, (int64_t)((double)len * div_r * 0.28) + 2 * std::abs(tl - ql)) : pi.exp_win;
 			G.max_tl = std::max<int64_t>(G.max_tl, tl), G.max_exp_win = std::max(G.max_exp_win, exp_win);
 			G.max_seq_lds = std::max<int64_t>(G.max_seq_lds, ((tl + 3) & ~3LL) + 8 + ((ql + 3) & ~3LL) + 16);
 		}
@@ -902,7 +942,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		const int rc = run_batch_kernel(g, b, c == 5 ? *opt : opt_hi, b->d_order + at, G.n, slots, G.max_len, G.max_bound, G.max_bound1,
 		                                done_groups == 1, (classes || c >= 11) ? (c == 0 || c == 5 ? 0 : 2) : -1, G.max_tl, G.max_seq_lds, lane_retry ? 0 : done_groups == n_groups,
 		                                cc == 8 ? 514 : cc == 7 ? 1024 : cc == 6 ? 33 : cc == 5 ? 32 : cc == 4 ? 64 : cc == 3 ? 128 : cc == 2 ? 256 : 0, &ran,
-		                                (c == 1 && (g->wide_slots == 4 || (g->wide_slots == 0 && PC.wide_state != 1 && g->queue_clean))) ? kBandWide4Window : c == 14 ? G.max_exp_win : 0);
+		                                (c == 1 && (g->wide_slots == 4 || (g->wide_slots == 0 && PC.wide_state != 1 && g->queue_clean))) ? kBandWide4Window : (c == 14 || c == 11) ? G.max_exp_win : 0);
 		g->retry_mode = 0;
 		if (c == 1 && g->wide_slots == 0 && PC.wide_state == 0 && g->queue_clean && ran == 2 && g->stats.block == 512) PC.wide_measured = true;
 		// Batches of reads: what the lane kernel hands back (a window that left its chunks: one read in tens of thousands) is re-run by a follow-up launch of

@@ -102,6 +102,38 @@ def test_device_side_retry_list_with_both_lane_classes(oracle):
         assert seen[1] <= seen[0] + 2 * 256, seen  # (the device path counts what it re-ran, never more than the lists hold on top of the host path)
 
 
+def test_gap_fill_like_batch_few_mid_size_pairs_among_hundreds_of_tiny_ones(oracle):
+    """mwf_wfa_chain's gap fills (reference miniwfa.c:861-891 calls mwf_wfa_exact per gap): hundreds of tiny pairs and a handful of longer ones, some
+    of very different lengths — a 54 x 740 fill must open a 686-base gap, so its window reaches that diagonal whatever its divergence.  Until
+    round 6 the length limits put such fills into the 64-thread band class (run twice, every call), and a batch of more than 256 pairs kept its
+    few mid-size pairs off the mid kernel.  Now: no pair is run twice, with the mid kernel (default) and without it (mid_max_pairs 0), and
+    every answer is the oracle's."""
+    rng = np.random.default_rng(606)
+    pairs = [synth_pair(606000 + i, int(rng.integers(12, 90)), 0.06) for i in range(600)]
+    t, q = synth_pair(606900, 900, 0.04)
+    pairs += [(t[:54], q[:740]), (t[:555], q[:17]), (t[:899], q[400:499]), (t[:310], q[:330]), synth_pair(606901, 420, 0.10), (t[:120], q[:610])]
+    order = rng.permutation(len(pairs))
+    pairs = [pairs[i] for i in order]
+    pk = PackedBatch(pairs)
+    for flag in (1, 0):
+        exp = F.oracle_many(oracle, pairs, make_opt(flag=flag))
+        for tunables in ((), (("mid_max_pairs", 0),)):
+            got = F.run_engine(pk, dict(flag=flag), list(tunables))
+            bad = []
+            F.compare(got, exp, f"gap fills flag {flag} {tunables}", pairs, bad, False)
+            no_mismatches(bad)
+            assert got[3].n_retries == 0, (flag, tunables, got[3].n_retries)
+    # ... and the same handful in a batch small enough for the mid kernel anyway
+    few = [pairs[i] for i in range(len(pairs)) if max(len(pairs[i][0]), len(pairs[i][1])) > 100]
+    assert len(few) == 6
+    exp = F.oracle_many(oracle, few, make_opt(flag=1))
+    got = F.run_engine(PackedBatch(few), dict(flag=1))
+    bad = []
+    F.compare(got, exp, "the handful alone", few, bad, False)
+    no_mismatches(bad)
+    assert got[3].n_retries == 0 and got[3].packed == 33, (got[3].n_retries, got[3].packed)
+
+
 def test_cached_plan_follows_the_round5_tunables(oracle):
     """test_cached_plan_follows_every_tunable for the tunables it left out: dev_retry, band_fold, div_aware."""
     pairs = [synth_pair(97500 + i, (120, 300, 900, 2500, 6000)[i % 5], (0.03, 0.08)[i % 2]) for i in range(60)]
@@ -170,8 +202,8 @@ def test_blind_golden_vectors_default_routing():
 
 
 def test_blind_golden_vectors_in_a_batch_too_large_for_the_mid_kernel():
-    """The same vectors three times over in one batch (> 256 pairs: the small-batch classes — mid kernel, whole-device kernel — are off, every
-    pair runs in its band / span / generic class)."""
+    """The same vectors three times over in one batch (> 256 pairs, and more than 256 of them in the small band classes: the small-batch
+    classes — mid kernel, whole-device kernel — are off, every pair runs in its band / span / generic class)."""
     for vs in by_opt([v for v in BLIND if not v["opt"]["step"]]):
         if len(vs) >= 20:
             big = vs * (256 // len(vs) + 2)
