@@ -174,7 +174,7 @@ int32_t mwf_gpu_debug_band(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *op
  *   "band_span"         1 (default): pairs beyond the 512-thread geometry (to 62 000 bases per sequence, windows to ~20 000 columns) run on the packed kernel's
  *                       1024-thread span geometry instead of the generic kernel; 0: never; 2: every pair it can take
  *   "wide_slots"        chunk slots per wave of the 512-thread geometry: 0 (default) = four on a batch's first align, three afterwards if that align showed they hold every pair; 3; 4
- *   "lane_max_len"      pairs whose longer sequence has at most this many bases try the one-wave-per-pair kernel first (default 400; 0: never)
+ *   "lane_max_len"      pairs whose longer sequence has at most this many bases try the one-wave-per-pair kernel first (default 325, weighed by the batch's divergence where it is known; 0: never)
  *   "mid_max_pairs"     a batch of at most this many pairs runs its mid-size pairs on the one-workgroup-per-pair kernel with every ring in LDS (default -1: one pair per CU; 0: never)
  *   "host_results"      1 (default): a score-only batch of up to 64 pairs gets its result arrays in pinned host memory (the mwf_gpu_batch_dev_*() pointers then point there); 0: device memory
  *   "div_aware"         1 (default): the size classes follow the batch's divergence (an 8-mer sketch of a few pairs: on the host while a batch is packed, on the device when one is wrapped); 0: lengths only

@@ -75,7 +75,8 @@ struct mwf_gpu_s {
 	int force_kind = -1;
 	int res_pin_on = 1;        // small score-only batches: results written straight into pinned host memory (0: always copied back)
 	int lane_chunks = 0;       // its window: 64-column chunks of LDS rows (1-4; 0: three for pairs of up to 400 bases of target + query, else four); a penalty only passes over the chunks the window has reached
-	int lane_max_len = 400;    // (measured: 20 000 x 400 bp @ 5 % 1.37 against 1.58 ms with 767 pairs re-run, x 500 bp @ 2 % 0.69 / 1.17, profiles/r03/lane_longer_pairs.txt)
+	int lane_max_len = 325;    // (weighed by the batch's divergence / 5 % where known.  Round 3 set 400 against the band kernel of that round; against round 6's 64-thread geometry the lane kernel
+	                           // wins up to ~370 bases at 5 %, ~200 at 10 %, everywhere at 2 %, and loses by half beyond: 2000 x 450 bp @ 5 % 1.46 against 0.77 ms, profiles/r06/lane_crossover.txt)
 	                           // pairs whose longer sequence has at most this many bases try the one-diagonal-per-lane kernel first (0: never)
 	int mid_max_pairs = -1;    // a batch of at most this many pairs may use the one-workgroup-per-pair, rings-in-LDS kernel (mwf_mid.hip) for its mid-size pairs (-1: one per CU; 0: never)
 	int mid_block = 0;         // its threads per workgroup: 0 by span (256 up to 512 columns, else 1024), 256, 1024

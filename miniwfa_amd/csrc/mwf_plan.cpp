@@ -805,6 +805,19 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		// (estimate_divergence: batches built from host memory) the lengths are weighed by it: three times as diverged = as if three times as long.
 		// Only upwards of the prior, and a little downwards: a class too narrow costs a second run, one too wide a few per cent.
 		const double div_r = b->div_est > 0 && g->div_aware ? std::min(8.0, std::max(0.7, (double)b->div_est / 0.05)) : 1.0;
+		const double div_lane = b->div_est > 0 && g->div_aware ? std::min(8.0, std::max(0.45, (double)b->div_est / 0.05)) : 1.0;
+		// A batch of reads whose lengths straddle the limit is not split for a few pairs: where most of the pairs up to 10 % beyond the limit lie below it, the rest follow
+		// them (2000 x 300 bp with 28 pairs beyond: 0.37 ms as one lane launch, 0.50 with a launch of their own)
+		int64_t lane_limit = mid_ok ? std::min(g->lane_max_len, 320) : g->lane_max_len;
+		if (lane_ok && !mid_ok && classes) {
+			int64_t n_lo = 0, n_hi = 0;
+			for (int32_t i = 0; i < b->n; ++i) {
+				const int64_t w = (int64_t)((double)std::max(b->h_tl[i], b->h_ql[i]) * div_lane);
+				if (std::abs(b->h_tl[i] - b->h_ql[i]) > 24) continue;
+				n_lo += w <= lane_limit, n_hi += w > lane_limit && w <= lane_limit * 11 / 10;
+			}
+			if (n_hi > 0 && n_lo >= n_hi) lane_limit = lane_limit * 11 / 10;
+		}
 		struct PairInfo { int64_t bound, bound1, exp_win; };
 		std::vector<PairInfo> info((size_t)b->n);
 		std::vector<int8_t> mid_cand;   // large batches: pairs the mid kernel would take if they are few
@@ -840,7 +853,9 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 				if (span_ok && g->band_span == 2) c = 13;
 				// (round 5: the limits leave the mean window at 5 % — 0.27 (tl+ql) — a quarter of margin below each class's widest window; round 4's left 4-18 %,
 				// and 2 kb pairs, just inside the 128-thread class, were re-run at 7.8 %: profiles/r04/chooser_regression.txt)
-				else if (packable && (window <= kBandMicroWindow || lenw + 1 <= 1400)) c = 4;
+				// (... at 5 %.  A batch the sketch puts at 8 % and more outgrows the 64-thread class earlier than its weight says — the sketch reads low up there, and a pair
+				// whose penalty stays below 256 is never shrunk, its window is 2 s + 1: 2000 x 350 bp @ 10 % lost 876 pairs, 20 000 x 380 bp 18 473, to a second run)
+				else if (packable && (window <= kBandMicroWindow || lenw + 1 <= (b->div_est >= 0.06f && g->div_aware ? 1000 : 1400))) c = 4;
 				else if (packable && (window <= kBandTinyWindow || lenw + 1 <= 3600)) c = 3;
 				else if (packable && (window <= kBandSmallWindow || lenw + 1 <= 8200)) c = 2;
 				else if (packable && (lenw + 1 <= 4 * (int64_t)(8 * 3 * 256) || window <= kBandWideWindow)) c = 1;
@@ -854,7 +869,9 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 			// short pairs: a window of 64 diagonals holds them while the penalty stays below ~45 (a 200 bp pair at 5 %)
 			// (in a batch small enough for the mid kernel the lane kernel keeps the pairs of up to 320 bases: 16 x 400 bp 0.31 ms on the lane
 			// kernel — pairs that outgrow its chunks are re-run — against 0.13 on the mid kernel, 1 x 300 bp 56 against 68 us; profiles/r04/lane_vs_mid.txt)
-			const bool to_lane = classes && lane_ok && c >= 1 && c <= 4 && (int64_t)((double)std::max(tl, ql) * div_r) <= (mid_ok ? std::min(g->lane_max_len, 320) : g->lane_max_len) && skew <= 24;
+			// (the lane kernel's limit is a window — its chunks — and a window is proportional to divergence x length: the weight goes further down for it than for the
+			// classes, 2000 x 450 bp @ 2 % 0.14 against 0.27 ms on the 64-thread geometry; profiles/r06/lane_crossover.txt)
+			const bool to_lane = classes && lane_ok && c >= 1 && c <= 4 && (int64_t)((double)std::max(tl, ql) * div_lane) <= lane_limit && skew <= 24;
 			if (to_lane) c = (know_acgt && !b->h_acgt[i]) ? 12 : 10, b->h_class[i] = 4;
 			// a few mid-size pairs: a workgroup each, rings in LDS (a penalty then costs a fraction of what it costs the band kernels).  Admitted
 			// when the span the LDS can hold beside the sequences covers the window of a pair at ~6 % divergence (about 0.3 (tl+ql)) and the gap its lengths
@@ -885,6 +902,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 			return c;
 		};
 		for (int32_t i = 0; i < b->n; ++i) cls[(size_t)i] = (int8_t)classify(i, mid_ok);
+		if (getenv("MWF_DEBUG")) fprintf(stderr, "[libmwf_hip] classes of %d pairs: divergence estimate %.4f (weight %.2f)\n", b->n, (double)b->div_est, div_r);
 		if (n_cand > 0 && n_cand <= mid_cap)
 			for (int32_t i = 0; i < b->n; ++i)
 				if (mid_cand[(size_t)i]) cls[(size_t)i] = (int8_t)classify(i, true);

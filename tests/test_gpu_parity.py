@@ -1627,7 +1627,7 @@ def test_cached_plan_follows_every_tunable(oracle):
     exp = [oracle.align(t, q, make_opt(flag=1)) for t, q in pairs]
     eng = mw.Engine(0)
     b = eng.upload(PackedBatch(pairs))
-    flips = [("lane_max_len", 0), ("lane_max_len", 400), ("mid_max_pairs", 0), ("mid_max_pairs", -1), ("seq2bit", 0), ("seq2bit", 1), ("band_pack", 0), ("band_pack", 1),
+    flips = [("lane_max_len", 0), ("lane_max_len", 325), ("mid_max_pairs", 0), ("mid_max_pairs", -1), ("seq2bit", 0), ("seq2bit", 1), ("band_pack", 0), ("band_pack", 1),
              ("force_kind", 0), ("force_kind", -1), ("block", 256), ("block", 0), ("ring16", 0), ("ring16", 1), ("lane_chunks", 2), ("lane_chunks", 0),
              ("mid_block", 512), ("mid_block", 0), ("band_span", 0), ("band_span", 1), ("wide_slots", 3), ("wide_slots", 0), ("host_results", 0), ("host_results", 1)]
     for name, value in [(None, 0)] + flips:
