@@ -736,8 +736,13 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	if (coop || (g->force_kind < 0 && max_len >= coop_len && coop_supported(P0))) {
 		n_cu_coop = coop_grid_limit(g);
 		const int coop_side_by_side = n_cu_coop > 0 ? std::max(1, n_cu_coop / coop_group_size(n_cu_coop, max_len, false, sys_owned_cols(g->sys_p, 4))) : 1;
-		int64_t coop_max_pairs = std::max<int64_t>(1, std::min<int64_t>(256, std::max<int64_t>(1, max_len * 27 / 1000000) * coop_side_by_side));
-		if (max_len < 65536) coop_max_pairs = std::min<int64_t>(coop_max_pairs, 16); // (measured up to sixteen)
+		// (low-memory mode: the alternative is the generic kernel's two-pass form, three times its high-memory time — 17 x 30 kb @ 5 % 186 ms against 50 ms per round of
+		// sixteen here, 48 x 100 kb @ 3 % 694 ms against 555 ms in six rounds of eight: at least four rounds, where the rule above allowed one round of 30 kb pairs;
+		// profiles/r06/routing_survey_long_before.txt, _after.txt)
+		const bool lowmem_call = (opt->flag & MWF_F_CIGAR) && opt->step > 0;
+		const int64_t coop_rounds = lowmem_call ? std::max<int64_t>(4, max_len * 32 / 1000000) : std::max<int64_t>(1, max_len * 27 / 1000000);
+		int64_t coop_max_pairs = std::max<int64_t>(1, std::min<int64_t>(256, coop_rounds * coop_side_by_side));
+		if (max_len < 65536) coop_max_pairs = std::min<int64_t>(coop_max_pairs, lowmem_call ? 48 : 16); // (measured up to sixteen)
 		coop = coop || b->n <= coop_max_pairs;
 	}
 	if (coop) {
