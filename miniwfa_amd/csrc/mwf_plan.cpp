@@ -776,6 +776,10 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 	// genuinely long pairs go through the two-pass kernel (group 5).
 	const bool low_mem = cigar && opt->step > 0;
 	const bool classes = g->force_kind < 0 && g->block == 0 && band2_supported(P0) && g->band_pack != 0;
+	// Penalties the packed band kernel is not instantiated for (gap extensions other than (2,1), (2,2), (1,1): minimap2's asm5 has 3 and 1) leave the generic kernel for
+	// everything above — but the lane and mid kernels read their penalties at run time: read batches and a few mid-size pairs still get them (20 000 x 150 bp with
+	// e1 = 3: 4.8 ms on the generic kernel, a thirteenth of that on the lane kernel).  What outgrows them goes to the generic kernel.
+	const bool small_only = g->force_kind < 0 && g->block == 0 && !band2_supported(P0) && g->band_pack != 0;
 	// groups 0-4: the size classes, 5: two-pass low-memory pairs, 6-9: classes 1-4 again for the pairs the host knows not to be
 	// plain A/C/G/T (byte-wise sequence copy from the start)
 	// 10: short pairs on the one-diagonal-per-lane kernel (mwf_lane.hip); what outgrows its 64 columns moves to the band classes
@@ -814,7 +818,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 		// A batch of reads whose lengths straddle the limit is not split for a few pairs: where most of the pairs up to 10 % beyond the limit lie below it, the rest follow
 		// them (2000 x 300 bp with 28 pairs beyond: 0.37 ms as one lane launch, 0.50 with a launch of their own)
 		int64_t lane_limit = mid_ok ? std::min(g->lane_max_len, 320) : g->lane_max_len;
-		if (lane_ok && !mid_ok && classes) {
+		if (lane_ok && !mid_ok && (classes || small_only)) {
 			int64_t n_lo = 0, n_hi = 0;
 			for (int32_t i = 0; i < b->n; ++i) {
 				const int64_t w = (int64_t)((double)std::max(b->h_tl[i], b->h_ql[i]) * div_lane);
@@ -871,13 +875,19 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 			}
 			b->h_class[i] = (int8_t)(c == 5 ? 0 : c == 13 ? 5 : c == 14 ? 1 : c);
 			b->h_flags[i] = (int8_t)(step0 ? 1 : 0);
+			// the class the pair's lengths would give it, for the admission to the lane and mid kernels where the band kernel itself cannot serve (their offsets are 16 bits too)
+			int c_adm = c;
+			if (small_only && c == 0 && tl + bound < 32767) {
+				const int64_t window = std::min<int64_t>(len + 1, 2 * bound + 3);
+				c_adm = (window <= kBandMicroWindow || lenw + 1 <= (b->div_est >= 0.06f && g->div_aware ? 1000 : 1400)) ? 4 : (window <= kBandTinyWindow || lenw + 1 <= 3600) ? 3 : 0;
+			}
 			// short pairs: a window of 64 diagonals holds them while the penalty stays below ~45 (a 200 bp pair at 5 %)
 			// (in a batch small enough for the mid kernel the lane kernel keeps the pairs of up to 320 bases: 16 x 400 bp 0.31 ms on the lane
 			// kernel — pairs that outgrow its chunks are re-run — against 0.13 on the mid kernel, 1 x 300 bp 56 against 68 us; profiles/r04/lane_vs_mid.txt)
 			// (the lane kernel's limit is a window — its chunks — and a window is proportional to divergence x length: the weight goes further down for it than for the
 			// classes, 2000 x 450 bp @ 2 % 0.14 against 0.27 ms on the 64-thread geometry; profiles/r06/lane_crossover.txt)
-			const bool to_lane = classes && lane_ok && c >= 1 && c <= 4 && (int64_t)((double)std::max(tl, ql) * div_lane) <= lane_limit && skew <= 24;
-			if (to_lane) c = (know_acgt && !b->h_acgt[i]) ? 12 : 10, b->h_class[i] = 4;
+			const bool to_lane = (classes || small_only) && lane_ok && c_adm >= 1 && c_adm <= 4 && (int64_t)((double)std::max(tl, ql) * div_lane) <= lane_limit && skew <= 24;
+			if (to_lane) c = (know_acgt && !b->h_acgt[i]) ? 12 : 10, b->h_class[i] = (int8_t)(classes ? 4 : 2); // (where an overflow goes: the re-run of "band" pairs takes the mid kernel for a handful, else whatever choose_kernel has for the penalties)
 			// a few mid-size pairs: a workgroup each, rings in LDS (a penalty then costs a fraction of what it costs the band kernels).  Admitted
 			// when the span the LDS can hold beside the sequences covers the window of a pair at ~6 % divergence (about 0.3 (tl+ql)) and the gap its lengths
 			// force — or every column the pair can ever reach; 16-bit offsets.
@@ -895,7 +905,7 @@ int mwf_gpu_batch_align(mwf_gpu_t *g, mwf_gpu_batch_t *b, const mwf_opt_t *opt)
 					if (!allow_mid) {
 						// (a large batch: counted; the pairs move to the mid kernel afterwards if they are few, and only the band kernels' SMALL classes give
 						// pairs away — wide windows are the 512-thread geometry's work whatever their number)
-						if (!mid_cand.empty() && c >= 3 && c <= 4 && !mid_cand[(size_t)i]) mid_cand[(size_t)i] = 1, ++n_cand;
+						if (!mid_cand.empty() && c_adm >= 3 && c_adm <= 4 && !mid_cand[(size_t)i]) mid_cand[(size_t)i] = 1, ++n_cand;
 					} else {
 						b->h_class[i] = (int8_t)((c >= 1 && c <= 4) || (classes && packable) ? 2 : 0); // where an overflow goes: the wide packed band kernel, else generic
 						c = 11;

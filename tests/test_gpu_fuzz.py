@@ -134,6 +134,32 @@ def test_gap_fill_like_batch_few_mid_size_pairs_among_hundreds_of_tiny_ones(orac
     assert got[3].n_retries == 0 and got[3].packed == 33, (got[3].n_retries, got[3].packed)
 
 
+@pytest.mark.parametrize("pen", [dict(x=4, o1=6, e1=3, o2=26, e2=1), dict(x=2, o1=4, e1=4, o2=24, e2=2), dict(x=3, o1=5, e1=3, o2=20, e2=3)])
+def test_penalties_the_band_kernel_is_not_built_for_still_get_the_lane_and_mid_kernels(pen, oracle):
+    """Gap extensions other than (2,1), (2,2), (1,1) — minimap2's asm5 / asm20 use 3 and 4 — leave the generic kernel for long pairs, but the lane and mid kernels read
+    their penalties at run time (the reference has one loop for any penalties, miniwfa.c:261-327): a read batch with a few mid-size pairs among it must come back
+    with the oracle's answers, the reads from the lane kernel (stats.packed 32 of the last launch), nothing on the generic kernel twice."""
+    rng = np.random.default_rng(77)
+    reads = [synth_pair(770000 + i, int(rng.integers(100, 260)), float(rng.choice([0.03, 0.06]))) for i in range(2600)]
+    mids = [synth_pair(771000 + i, int(rng.integers(600, 2400)), 0.05) for i in range(24)] + [synth_pair(772000, 6000, 0.04)]
+    pairs = mids + reads
+    pk = PackedBatch(pairs)
+    for flag in (0, 1):
+        exp = F.oracle_many(oracle, pairs, make_opt(flag=flag, **pen))
+        got = F.run_engine(pk, dict(flag=flag, **pen))
+        bad = []
+        F.compare(got, exp, f"{pen} flag {flag}", pairs, bad, False)
+        no_mismatches(bad)
+        assert got[3].packed == 32, got[3].packed   # the last class launched is the reads': on the lane kernel
+    # a handful of mid-size pairs alone: the mid kernel
+    exp = F.oracle_many(oracle, mids[:8], make_opt(flag=1, **pen))
+    got = F.run_engine(PackedBatch(mids[:8]), dict(flag=1, **pen))
+    bad = []
+    F.compare(got, exp, f"{pen} mid", mids[:8], bad, False)
+    no_mismatches(bad)
+    assert got[3].packed == 33, got[3].packed
+
+
 def test_cached_plan_follows_the_round5_tunables(oracle):
     """test_cached_plan_follows_every_tunable for the tunables it left out: dev_retry, band_fold, div_aware."""
     pairs = [synth_pair(97500 + i, (120, 300, 900, 2500, 6000)[i % 5], (0.03, 0.08)[i % 2]) for i in range(60)]
