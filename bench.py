@@ -199,6 +199,28 @@ def chain_mode(mw, synth_pair, reps=8):
             rec["cpu_reference_ms"] = (time.perf_counter() - t0) / max(2, reps // 2) * 1e3
             rec["matches_reference"] = bool(s == es and (None if cig is None else list(cig)) == ecig)
         out[f"{tl}bp@{p}"] = rec
+    # many records in chain mode (the reference's test program loops mwf_wfa_chain over its records, main.c:67-72): one call per pair against mwf_wfa_chain_batch —
+    # the chaining of the pairs on a few host threads, the gap fills of ALL pairs in one device batch
+    try:
+        for n, tl, p in ((200, 5000, 0.05), (100, 30000, 0.04)):
+            pairs = [synth_pair(9000 + i, tl, p, 2, 800) for i in range(n)]
+            o = mw.opt_init(flag=1)
+            mw.wfa_chain_batch(pairs[:4], o)
+            t0 = time.perf_counter()
+            a = [mw.wfa_chain(t, q, o) for t, q in pairs]
+            t1 = time.perf_counter()
+            b = mw.wfa_chain_batch(pairs, o)
+            t2 = time.perf_counter()
+            rec = {"per_pair_call_ms": (t1 - t0) / n * 1e3, "chain_batch_ms_per_pair": (t2 - t1) / n * 1e3, "same_answers": a == b}
+            if ref is not None:
+                ro = make_opt(flag=1)
+                t0 = time.perf_counter()
+                for t, q in pairs[:20]:
+                    ref.chain(t, q, ro)
+                rec["cpu_reference_ms_per_pair"] = (time.perf_counter() - t0) / 20 * 1e3
+            out[f"batch_{n}x{tl}bp@{p}"] = rec
+    except Exception as e:  # noqa: BLE001
+        out["batch_error"] = repr(e)
     return out
 
 

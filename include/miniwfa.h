@@ -92,6 +92,11 @@ void mwf_wfa_batch(void *km, const mwf_opt_t *opt, int32_t n, const int32_t *tl,
 void mwf_wfa_batch_multi(void *km, const mwf_opt_t *opt, int32_t n, const int32_t *tl, const char *const *ts,
                          const int32_t *ql, const char *const *qs, mwf_rst_t *r, int32_t n_dev, const int32_t *devices);
 
+/* n pairs in chain mode: r[i] is what mwf_wfa_chain would give for pair i (reference miniwfa.c:850-896 once per record, main.c:67-72).  The k-mer chaining of
+ * the pairs runs on a few host threads, the gaps between the anchors of ALL pairs are aligned exactly in one device batch. */
+void mwf_wfa_chain_batch(void *km, const mwf_opt_t *opt, int32_t n, const int32_t *tl, const char *const *ts,
+                         const int32_t *ql, const char *const *qs, mwf_rst_t *r);
+
 /* Batch throughput for callers that keep the reference's one-pair-per-call loop (reference main.c:67-72).
  * mwf_wfa_submit() queues one pair (ts / qs / *opt are read later: they must stay valid until the job has been waited for) and returns at once;
  * a dispatcher thread aligns everything submitted so far as ONE mwf_wfa_batch call per option set — while it runs, the caller may keep submitting.

@@ -13,7 +13,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <atomic>
 #include <chrono>
+#include <climits>
+#include <thread>
 #include "miniwfa.h"
 #include "kalloc.h"
 
@@ -230,22 +233,22 @@ inline int32_t gap_cost(const mwf_opt_t *o, int32_t len)
 	return a < b ? a : b;
 }
 
-} // namespace
-
-extern "C" void mwf_wfa_chain(void *km, const mwf_opt_t *opt, int32_t tl, const char *ts, int32_t ql, const char *qs, mwf_rst_t *r)
-{
-	static const bool timing = getenv("MWF_CHAIN_TIMING") != nullptr; // (diagnostics: where a call's time goes)
-	const auto t_0 = std::chrono::steady_clock::now();
-	std::vector<uint64_t> anchors = chain_anchors(tl, ts, ql, qs, opt->kmer, opt->max_occ);
-	filter_anchors(anchors, tl, ql, opt->kmer, opt->min_len);
-	const auto t_1 = std::chrono::steady_clock::now();
-	const int32_t n_a = (int32_t)anchors.size();
-	const bool want_cigar = (opt->flag & MWF_F_CIGAR) != 0;
-
-	// ---- walk the anchors (reference miniwfa.c:861-891) and collect the gaps that need an exact alignment
+// what the walk over one pair's anchors decided (reference miniwfa.c:861-891), and the gaps it wants aligned exactly
+struct ChainPlan {
 	std::vector<Segment> segs;
 	std::vector<int32_t> ftl, fql;
 	std::vector<const char*> fts, fqs;
+	int32_t n_anchors = 0;
+	double ms_anchors = 0;
+};
+
+void plan_chain(const mwf_opt_t *opt, int32_t tl, const char *ts, int32_t ql, const char *qs, ChainPlan &P)
+{
+	const auto t_0 = std::chrono::steady_clock::now();
+	std::vector<uint64_t> anchors = chain_anchors(tl, ts, ql, qs, opt->kmer, opt->max_occ);
+	filter_anchors(anchors, tl, ql, opt->kmer, opt->min_len);
+	P.ms_anchors = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_0).count();
+	const int32_t n_a = P.n_anchors = (int32_t)anchors.size();
 	int32_t x0 = 0, y0 = 0;
 	for (int32_t i = 0; i <= n_a; ++i) {
 		int32_t x1, y1;
@@ -256,26 +259,23 @@ extern "C" void mwf_wfa_chain(void *km, const mwf_opt_t *opt, int32_t tl, const 
 		else if (x0 < x1 && y0 < y1) {
 			if (x1 - x0 >= 10000 && y1 - y0 >= 10000 && kmer_similarity(x1 - x0, ts + x0, y1 - y0, qs + y0, opt->kmer) < 0.02) sg.kind = 2;
 			else {
-				sg.kind = 1, sg.fill = (int32_t)ftl.size();
-				ftl.push_back(x1 - x0), fql.push_back(y1 - y0), fts.push_back(ts + x0), fqs.push_back(qs + y0);
+				sg.kind = 1, sg.fill = (int32_t)P.ftl.size();
+				P.ftl.push_back(x1 - x0), P.fql.push_back(y1 - y0), P.fts.push_back(ts + x0), P.fqs.push_back(qs + y0);
 			}
 		} else if (x0 < x1) sg.kind = 3;
 		else if (y0 < y1) sg.kind = 4;
-		if (sg.kind >= 0) segs.push_back(sg);
+		if (sg.kind >= 0) P.segs.push_back(sg);
 		x0 = x1, y0 = y1;
 	}
+}
 
-	// ---- every gap fill in one device batch (the reference calls mwf_wfa_exact per gap, miniwfa.c:877)
-	std::vector<mwf_rst_t> fills(ftl.size());
-	const auto t_2 = std::chrono::steady_clock::now();
-	if (!ftl.empty())
-		mwf_wfa_batch(nullptr, opt, (int32_t)ftl.size(), ftl.data(), fts.data(), fql.data(), fqs.data(), fills.data());
-	const auto t_3 = std::chrono::steady_clock::now();
-
-	// ---- stitch
+// the pair's penalty and CIGAR from its segments and the answers of its gap fills (fills[0] is the pair's first)
+void stitch_chain(void *km, const mwf_opt_t *opt, const ChainPlan &P, const mwf_rst_t *fills, mwf_rst_t *r)
+{
+	const bool want_cigar = (opt->flag & MWF_F_CIGAR) != 0;
 	CigarBuf c;
 	int32_t score = 0;
-	for (const Segment &sg : segs) {
+	for (const Segment &sg : P.segs) {
 		switch (sg.kind) {
 		case 0: if (want_cigar) c.push(7, sg.dx); break;
 		case 1:
@@ -290,7 +290,6 @@ extern "C" void mwf_wfa_chain(void *km, const mwf_opt_t *opt, int32_t tl, const 
 		case 4: c.push(1, sg.dy), score += gap_cost(opt, sg.dy); break;
 		}
 	}
-	for (mwf_rst_t &f : fills) free(f.cigar);
 	r->s = score; // n_iter is left as the caller had it (miniwfa.c:850-896 never writes it)
 	r->n_cigar = (int32_t)c.w.size();
 	r->cigar = nullptr;
@@ -298,17 +297,70 @@ extern "C" void mwf_wfa_chain(void *km, const mwf_opt_t *opt, int32_t tl, const 
 		r->cigar = (uint32_t*)kmalloc(km, c.w.size() * sizeof(uint32_t));
 		memcpy(r->cigar, c.w.data(), c.w.size() * sizeof(uint32_t));
 	}
+}
+
+} // namespace
+
+extern "C" void mwf_wfa_chain(void *km, const mwf_opt_t *opt, int32_t tl, const char *ts, int32_t ql, const char *qs, mwf_rst_t *r)
+{
+	static const bool timing = getenv("MWF_CHAIN_TIMING") != nullptr; // (diagnostics: where a call's time goes)
+	const auto t_0 = std::chrono::steady_clock::now();
+	ChainPlan P;
+	plan_chain(opt, tl, ts, ql, qs, P);
+	// ---- every gap fill in one device batch (the reference calls mwf_wfa_exact per gap, miniwfa.c:877)
+	std::vector<mwf_rst_t> fills(P.ftl.size());
+	const auto t_2 = std::chrono::steady_clock::now();
+	if (!P.ftl.empty())
+		mwf_wfa_batch(nullptr, opt, (int32_t)P.ftl.size(), P.ftl.data(), P.fts.data(), P.fql.data(), P.fqs.data(), fills.data());
+	const auto t_3 = std::chrono::steady_clock::now();
+	stitch_chain(km, opt, P, fills.data(), r);
+	for (mwf_rst_t &f : fills) free(f.cigar);
 	if (timing) {
 		auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
 		int64_t fill_bases = 0;
 		int32_t longest = 0, n_100 = 0, n_1000 = 0;
-		for (size_t i = 0; i < ftl.size(); ++i) {
-			fill_bases += ftl[i] + fql[i];
-			const int32_t l = std::max(ftl[i], fql[i]);
+		for (size_t i = 0; i < P.ftl.size(); ++i) {
+			fill_bases += P.ftl[i] + P.fql[i];
+			const int32_t l = std::max(P.ftl[i], P.fql[i]);
 			longest = std::max(longest, l), n_100 += l > 100, n_1000 += l > 1000;
 		}
 		fprintf(stderr, "[libmwf_hip] chain fills: longest %d, %d above 100 bp, %d above 1000 bp\n", longest, n_100, n_1000);
-		fprintf(stderr, "[libmwf_hip] chain %d x %d: anchors %.2f ms (%d kept), gaps %.2f ms, batch of %zu fills (%lld bases) %.2f ms, stitch %.2f ms\n", tl, ql, ms(t_0, t_1), n_a,
-		        ms(t_1, t_2), ftl.size(), (long long)fill_bases, ms(t_2, t_3), ms(t_3, std::chrono::steady_clock::now()));
+		fprintf(stderr, "[libmwf_hip] chain %d x %d: anchors %.2f ms (%d kept), gaps %.2f ms, batch of %zu fills (%lld bases) %.2f ms, stitch %.2f ms\n", tl, ql, P.ms_anchors, P.n_anchors,
+		        ms(t_0, t_2) - P.ms_anchors, P.ftl.size(), (long long)fill_bases, ms(t_2, t_3), ms(t_3, std::chrono::steady_clock::now()));
 	}
+}
+
+// Many pairs in chain mode (the reference's test program loops mwf_wfa_chain over its records, main.c:67-72): the chaining of every pair on a few host threads,
+// then the gap fills of ALL pairs in one device batch, then the stitching on the caller's thread (kalloc arenas are not thread-safe).  Pair by pair the answers of
+// mwf_wfa_chain; a call per pair pays its own launch, copies and the ~800 penalties of its longest fill one after the other.
+extern "C" void mwf_wfa_chain_batch(void *km, const mwf_opt_t *opt, int32_t n, const int32_t *tl, const char *const *ts, const int32_t *ql, const char *const *qs, mwf_rst_t *r)
+{
+	if (n <= 0) return;
+	std::vector<ChainPlan> plans((size_t)n);
+	{
+		const int n_thr = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n, 16), (int64_t)std::thread::hardware_concurrency()));
+		std::atomic<int32_t> next{0};
+		auto work = [&] {
+			for (int32_t i; (i = next.fetch_add(1)) < n;) plan_chain(opt, tl[i], ts[i], ql[i], qs[i], plans[(size_t)i]);
+		};
+		std::vector<std::thread> pool;
+		for (int t = 1; t < n_thr; ++t) pool.emplace_back(work);
+		work();
+		for (std::thread &t : pool) t.join();
+	}
+	std::vector<size_t> first((size_t)n + 1, 0);
+	for (int32_t i = 0; i < n; ++i) first[(size_t)i + 1] = first[(size_t)i] + plans[(size_t)i].ftl.size();
+	const size_t total = first[(size_t)n];
+	if (total > (size_t)INT32_MAX) { fprintf(stderr, "[libmwf_hip] mwf_wfa_chain_batch: more than 2^31 gap fills in one call\n"); abort(); }
+	std::vector<int32_t> ftl(total), fql(total);
+	std::vector<const char*> fts(total), fqs(total);
+	for (int32_t i = 0; i < n; ++i) {
+		const ChainPlan &P = plans[(size_t)i];
+		std::copy(P.ftl.begin(), P.ftl.end(), ftl.begin() + (ptrdiff_t)first[(size_t)i]), std::copy(P.fql.begin(), P.fql.end(), fql.begin() + (ptrdiff_t)first[(size_t)i]);
+		std::copy(P.fts.begin(), P.fts.end(), fts.begin() + (ptrdiff_t)first[(size_t)i]), std::copy(P.fqs.begin(), P.fqs.end(), fqs.begin() + (ptrdiff_t)first[(size_t)i]);
+	}
+	std::vector<mwf_rst_t> fills(total);
+	if (total > 0) mwf_wfa_batch(nullptr, opt, (int32_t)total, ftl.data(), fts.data(), fql.data(), fqs.data(), fills.data());
+	for (int32_t i = 0; i < n; ++i) stitch_chain(km, opt, plans[(size_t)i], fills.data() + first[(size_t)i], &r[i]);
+	for (mwf_rst_t &f : fills) free(f.cigar);
 }

@@ -574,6 +574,32 @@ def test_chain_and_auto_against_reference():
     assert n_auto_chain >= 1 and n_bridge >= 4
 
 
+def test_chain_batch_gives_the_reference_chain_answers_pair_by_pair():
+    """mwf_wfa_chain_batch: the chain mode of every record of a file (reference main.c:67-72 loops mwf_wfa_chain, miniwfa.c:850-896) with the gap fills of ALL pairs
+    in one device batch.  Every chain-mode fixture of chain_fresh.jsonl (answers of the compiled reference), grouped by option set into one call each, must come
+    back pair by pair — and the call must agree with mwf_wfa_chain on pairs that need no fill at all (identical sequences) and on an empty query."""
+    from miniwfa_amd.synth import synth_diverged_block
+    groups = {}
+    for v in load_golden("chain_fresh.jsonl"):
+        if v["entry"] != "chain":
+            continue
+        gen = v["gen"]
+        t, q = synth_pair(*gen["args"]) if gen["kind"] == "synth" else synth_diverged_block(*gen["args"])
+        groups.setdefault(tuple(sorted(v["opt"].items())), []).append((v, t, q))
+    assert sum(len(g) for g in groups.values()) >= 40
+    for key, vs in groups.items():
+        o = mw.opt_init(**dict(key))
+        got = mw.wfa_chain_batch([(t, q) for _, t, q in vs], o)
+        for (v, t, q), (s, _, cig) in zip(vs, got):
+            assert s == v["expect"]["s"], v["id"]
+            assert (None if cig is None else mw.cigar_str(cig)) == v["expect"]["cigar"], v["id"]
+    t, q = synth_pair(4242, 3000, 0.05, 2, 300)
+    odd = [(t, t), (t, q), (t[:40], b""), (b"ACGT" * 10, b"ACGT" * 10), (q, t)]
+    for flag in (0, 1):
+        o = mw.opt_init(flag=flag)
+        assert mw.wfa_chain_batch(odd, o) == [mw.wfa_chain(a, b, o) for a, b in odd]
+
+
 def test_stop_rules(engine, oracle):
     t, q = synth_pair(83000, 2000, 0.1)
     full = oracle.align(t, q, make_opt())

@@ -161,7 +161,10 @@ int main(int argc, char *argv[])
 	for (int32_t k = 0; k < n; ++k) tl[k] = (int32_t)a[k].seq.size(), ql[k] = (int32_t)b[k].seq.size(), ts[k] = a[k].seq.data(), qs[k] = b[k].seq.data();
 	const auto t0 = std::chrono::steady_clock::now();
 	if (mode == 0) mwf_wfa_batch(nullptr, &opt, n, tl.data(), ts.data(), ql.data(), qs.data(), rst.data());
-	else
+	else if (mode == 1) { // chain mode over every record: their gap fills in one device batch
+		for (int32_t k = 0; k < n; ++k) memset(&rst[k], 0, sizeof(mwf_rst_t));
+		mwf_wfa_chain_batch(nullptr, &opt, n, tl.data(), ts.data(), ql.data(), qs.data(), rst.data());
+	} else
 		for (int32_t k = 0; k < n; ++k) {
 			memset(&rst[k], 0, sizeof(mwf_rst_t));
 			if (mode == 1) mwf_wfa_chain(nullptr, &opt, tl[k], ts[k], ql[k], qs[k], &rst[k]);
