@@ -97,6 +97,10 @@ void mwf_wfa_batch_multi(void *km, const mwf_opt_t *opt, int32_t n, const int32_
 void mwf_wfa_chain_batch(void *km, const mwf_opt_t *opt, int32_t n, const int32_t *tl, const char *const *ts,
                          const int32_t *ql, const char *const *qs, mwf_rst_t *r);
 
+/* ... and mwf_wfa_auto of n pairs (reference miniwfa.c:898-908 once per record): the exact branch as one batch, the pairs it gives up on through mwf_wfa_chain_batch. */
+void mwf_wfa_auto_batch(void *km, const mwf_opt_t *opt, int32_t n, const int32_t *tl, const char *const *ts,
+                        const int32_t *ql, const char *const *qs, mwf_rst_t *r);
+
 /* Batch throughput for callers that keep the reference's one-pair-per-call loop (reference main.c:67-72).
  * mwf_wfa_submit() queues one pair (ts / qs / *opt are read later: they must stay valid until the job has been waited for) and returns at once;
  * a dispatcher thread aligns everything submitted so far as ONE mwf_wfa_batch call per option set — while it runs, the caller may keep submitting.

@@ -51,7 +51,7 @@ class KmStat(C.Structure):
 # every symbol include/miniwfa.h and include/kalloc.h declare
 ABI_SYMBOLS = (
     "mwf_opt_init", "mwf_wfa_exact", "mwf_wfa_auto", "mwf_wfa_chain", "mwf_cigar2score", "mwf_assert_cigar",
-    "mwf_wfa_batch", "mwf_wfa_batch_multi", "mwf_wfa_chain_batch", "mwf_wfa_submit", "mwf_wfa_wait", "mwf_wfa_async_stats", "mwf_gpu_batch_dev_status", "mwf_gpu_batch_fetch_cigars", "mwf_gpu_device_count", "mwf_gpu_create", "mwf_gpu_destroy", "mwf_gpu_last_error",
+    "mwf_wfa_batch", "mwf_wfa_batch_multi", "mwf_wfa_chain_batch", "mwf_wfa_auto_batch", "mwf_wfa_submit", "mwf_wfa_wait", "mwf_wfa_async_stats", "mwf_gpu_batch_dev_status", "mwf_gpu_batch_fetch_cigars", "mwf_gpu_device_count", "mwf_gpu_create", "mwf_gpu_destroy", "mwf_gpu_last_error",
     "mwf_gpu_batch_upload", "mwf_gpu_batch_wrap", "mwf_gpu_batch_free", "mwf_gpu_batch_align", "mwf_gpu_batch_results",
     "mwf_gpu_batch_dev_scores", "mwf_gpu_batch_dev_iters", "mwf_gpu_batch_cigar", "mwf_gpu_get_stats", "mwf_gpu_set",
     "mwf_gpu_debug_band",
@@ -89,6 +89,8 @@ def lib() -> C.CDLL:
     L.mwf_wfa_batch_multi.restype = None
     L.mwf_wfa_chain_batch.argtypes = L.mwf_wfa_batch.argtypes
     L.mwf_wfa_chain_batch.restype = None
+    L.mwf_wfa_auto_batch.argtypes = L.mwf_wfa_batch.argtypes
+    L.mwf_wfa_auto_batch.restype = None
     L.mwf_wfa_submit.argtypes = [P(MwfOpt), C.c_int32, C.c_char_p, C.c_int32, C.c_char_p]
     L.mwf_wfa_submit.restype = C.c_void_p
     L.mwf_wfa_wait.argtypes = [C.c_void_p, C.c_void_p, P(MwfRst)]
@@ -194,6 +196,20 @@ def wfa_chain_batch(pairs: Sequence[tuple[bytes, bytes]], opt: MwfOpt, km=None):
     qs = (C.c_char_p * n)(*[q for _, q in pairs])
     r = (MwfRst * n)()
     lib().mwf_wfa_chain_batch(km, C.byref(opt), n, tl, ts, ql, qs, r)
+    return [_take(r[i], km) for i in range(n)]
+
+
+def wfa_auto_batch(pairs: Sequence[tuple[bytes, bytes]], opt: MwfOpt, km=None):
+    """mwf_wfa_auto_batch: mwf_wfa_auto of every pair (exact branch as one batch, chain mode for what it gives up on) -> list of (s, n_iter, cigar)."""
+    n = len(pairs)
+    if n == 0:
+        return []
+    tl = (C.c_int32 * n)(*[len(t) for t, _ in pairs])
+    ql = (C.c_int32 * n)(*[len(q) for _, q in pairs])
+    ts = (C.c_char_p * n)(*[t for t, _ in pairs])
+    qs = (C.c_char_p * n)(*[q for _, q in pairs])
+    r = (MwfRst * n)()
+    lib().mwf_wfa_auto_batch(km, C.byref(opt), n, tl, ts, ql, qs, r)
     return [_take(r[i], km) for i in range(n)]
 
 

@@ -465,5 +465,28 @@ void mwf_wfa_auto(void *km, const mwf_opt_t *opt0, int32_t tl, const char *ts, i
 	}
 }
 
+// mwf_wfa_auto of n records (reference main.c:67-72 loops it): the exact branch of every pair as one batch, and the pairs it gave up on (1e8 cells, miniwfa.c:900-903)
+// through mwf_wfa_chain_batch — r[i].n_iter stays the exact branch's count, as in the reference, which never writes it in chain mode.
+void mwf_wfa_auto_batch(void *km, const mwf_opt_t *opt0, int32_t n, const int32_t *tl, const char *const *ts, const int32_t *ql, const char *const *qs, mwf_rst_t *r)
+{
+	if (n <= 0) return;
+	mwf_opt_t opt = *opt0;
+	opt.step = 0, opt.max_iter = 100000000;
+	mwf_wfa_batch(km, &opt, n, tl, ts, ql, qs, r);
+	std::vector<int32_t> idx;
+	for (int32_t i = 0; i < n; ++i)
+		if (r[i].s < 0) idx.push_back(i);
+	if (idx.empty()) return;
+	if (opt.flag & MWF_F_CIGAR) opt.step = 5000;
+	opt.max_iter = -1;
+	const int32_t m = (int32_t)idx.size();
+	std::vector<int32_t> ctl((size_t)m), cql((size_t)m);
+	std::vector<const char*> cts((size_t)m), cqs((size_t)m);
+	std::vector<mwf_rst_t> cr((size_t)m);
+	for (int32_t j = 0; j < m; ++j) ctl[j] = tl[idx[j]], cql[j] = ql[idx[j]], cts[j] = ts[idx[j]], cqs[j] = qs[idx[j]], cr[j] = r[idx[j]];
+	mwf_wfa_chain_batch(km, &opt, m, ctl.data(), cts.data(), cql.data(), cqs.data(), cr.data());
+	for (int32_t j = 0; j < m; ++j) r[idx[j]] = cr[j];
+}
+
 } // extern "C"
 

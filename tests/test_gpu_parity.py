@@ -600,6 +600,31 @@ def test_chain_batch_gives_the_reference_chain_answers_pair_by_pair():
         assert mw.wfa_chain_batch(odd, o) == [mw.wfa_chain(a, b, o) for a, b in odd]
 
 
+def test_auto_batch_gives_the_reference_auto_answers_pair_by_pair():
+    """mwf_wfa_auto_batch (reference miniwfa.c:898-908 once per record, main.c:67-72): the exact branch of every pair as one batch, chain mode for the pairs it gives
+    up on at 1e8 cells — the `auto` fixtures of chain_fresh.jsonl (answers of the compiled reference, one of them beyond 1e8 cells) and short pairs in one call each per
+    option set; n_iter is the exact branch's count where the chain answered."""
+    from miniwfa_amd.synth import synth_diverged_block
+    groups = {}
+    for v in load_golden("chain_fresh.jsonl"):
+        if v["entry"] != "auto":
+            continue
+        gen = v["gen"]
+        t, q = synth_pair(*gen["args"]) if gen["kind"] == "synth" else synth_diverged_block(*gen["args"])
+        groups.setdefault(tuple(sorted(v["opt"].items())), []).append((v, t, q))
+    assert groups and any(v["expect"]["n_iter"] > 100000000 for g in groups.values() for v, _, _ in g)
+    for key, vs in groups.items():
+        o = mw.opt_init(**dict(key))
+        got = mw.wfa_auto_batch([(t, q) for _, t, q in vs], o)
+        for (v, t, q), (s, it, cig) in zip(vs, got):
+            assert (s, it) == (v["expect"]["s"], v["expect"]["n_iter"]), v["id"]
+            assert (None if cig is None else mw.cigar_str(cig)) == v["expect"]["cigar"], v["id"]
+    small = [synth_pair(61000 + i, 300 + 40 * i, 0.06) for i in range(12)] + [(b"ACGT", b""), (b"", b"")]
+    for flag in (0, 1):
+        o = mw.opt_init(flag=flag)
+        assert mw.wfa_auto_batch(small, o) == [mw.wfa_auto(a, b, o) for a, b in small]
+
+
 def test_stop_rules(engine, oracle):
     t, q = synth_pair(83000, 2000, 0.1)
     full = oracle.align(t, q, make_opt())

@@ -164,12 +164,10 @@ int main(int argc, char *argv[])
 	else if (mode == 1) { // chain mode over every record: their gap fills in one device batch
 		for (int32_t k = 0; k < n; ++k) memset(&rst[k], 0, sizeof(mwf_rst_t));
 		mwf_wfa_chain_batch(nullptr, &opt, n, tl.data(), ts.data(), ql.data(), qs.data(), rst.data());
-	} else
-		for (int32_t k = 0; k < n; ++k) {
-			memset(&rst[k], 0, sizeof(mwf_rst_t));
-			if (mode == 1) mwf_wfa_chain(nullptr, &opt, tl[k], ts[k], ql[k], qs[k], &rst[k]);
-			else mwf_wfa_auto(nullptr, &opt, tl[k], ts[k], ql[k], qs[k], &rst[k]);
-		}
+	} else { // auto: the exact branch of every record as one batch, chain mode for those it gives up on
+		for (int32_t k = 0; k < n; ++k) memset(&rst[k], 0, sizeof(mwf_rst_t));
+		mwf_wfa_auto_batch(nullptr, &opt, n, tl.data(), ts.data(), ql.data(), qs.data(), rst.data());
+	}
 	const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	for (int32_t k = 0; k < n; ++k) {
 		if (opt.flag & MWF_F_CIGAR) mwf_assert_cigar(&opt, rst[k].n_cigar, rst[k].cigar, tl[k], ql[k], rst[k].s);
